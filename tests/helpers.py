@@ -1,0 +1,34 @@
+"""Shared helpers for the test-suite (golden loaders, case builders)."""
+import os
+
+import numpy as np
+
+from oracle import aqc_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-10  # north-star tolerance (complex fp64, absolute)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def ansatz_from(d, key):
+    return orc.Ansatz(
+        int(d[f"{key}/n"]),
+        str(d[f"{key}/ent"]),
+        d[f"{key}/blocks"].astype(np.int64),
+        bool(d[f"{key}/trotter"]),
+        bool(d[f"{key}/second_order"]),
+    )
+
+
+def mps_from(d, key, tag):
+    n = int(d[f"{key}/n"])
+    gam = [(d[f"{key}/{tag}_g0_{q}"], d[f"{key}/{tag}_g1_{q}"]) for q in range(n)]
+    lam = [d[f"{key}/{tag}_lam_{q}"] for q in range(n - 1)]
+    return gam, lam
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0

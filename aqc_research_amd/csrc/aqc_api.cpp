@@ -1,0 +1,707 @@
+// C ABI (include/aqc_hip.h): host runtime around the gfx950 kernels.
+//
+// A context (aqc_ctx) is the immutable gate program of one ansatz.  A workspace (aqc_ws) binds
+// it to one HIP device + one stream and keeps `batch` independent evaluations resident in HBM:
+//   thetas[B][T] -> coef[B][n+L][12]           (coef_kernel, once per theta upload)
+//   Y, Z, X, W, ZW : [B][2^n][pitch] complex128 (pitch = columns padded to a power of two)
+//   partial[B][5*G][ntiles], grads[B][T]        (inner-product partials and their fixed-order sum)
+// Nothing below ever falls back to host arithmetic: if HIP is unusable every call fails loudly.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/aqc_hip.h"
+#include "aqc_device.h"
+#include "aqc_launch.h"
+#include "aqc_plan.h"
+
+using namespace aqc;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+int ceil_log2(int v) {
+    int b = 0;
+    while ((1 << b) < v) ++b;
+    return b;
+}
+
+struct DevPlan {
+    Plan plan;
+    std::vector<DevStage> h_stages;
+    std::vector<DevOp> h_ops;
+    DevStage* d_stages = nullptr;
+    DevOp* d_ops = nullptr;
+    int k = 0, ntiles = 0;
+};
+
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out) {
+    out.plan = plan;
+    out.h_stages.clear();
+    out.h_ops.clear();
+    out.k = (int)plan.stages.front().bits.size();
+    out.ntiles = 1 << (plan.nbits - out.k);
+    for (const Stage& st : plan.stages) {
+        DevStage ds;
+        memset(&ds, 0, sizeof ds);
+        ds.k = (int)st.bits.size();
+        ds.nops = (int)st.ops.size();
+        ds.op_begin = (int)out.h_ops.size();
+        ds.ntiles = 1 << (plan.nbits - ds.k);
+        std::vector<int> local_of(plan.nbits, -1);
+        for (int j = 0; j < ds.k; ++j) local_of[st.bits[j]] = j;
+        for (int b = 0; b < plan.nbits; ++b)
+            if (local_of[b] < 0) ds.ubits[ds.nub++] = b;
+        for (unsigned i = 0; i < 64; ++i) {
+            uint32_t off = 0;
+            for (int j = 0; j < 6 && j < ds.k; ++j)
+                if (i >> j & 1) off |= 1u << st.bits[j];
+            ds.dlo[i] = off;
+        }
+        for (unsigned i = 0; i < 256; ++i) {
+            uint32_t off = 0;
+            for (int j = 0; j < 8 && 6 + j < ds.k; ++j)
+                if (i >> j & 1) off |= 1u << st.bits[6 + j];
+            ds.dhi[i] = off;
+        }
+        for (int gi : st.ops) {
+            const GateGroup& g = prog.groups[gi];
+            DevOp op;
+            op.type = g.type;
+            op.p0 = local_of[plan.col_bits + g.q0];
+            op.p1 = g.q1 >= 0 ? local_of[plan.col_bits + g.q1] : 0;
+            op.flags = g.flags;
+            op.coef = g.coef;
+            op.slot = gi * kSlotsPerGroup;
+            op.jblock = g.jblock;
+            op.pad = 0;
+            out.h_ops.push_back(op);
+        }
+        out.h_stages.push_back(ds);
+    }
+}
+
+}  // namespace
+
+struct aqc_ctx {
+    Program prog;
+    std::mutex mu;
+    std::map<int, aqc_ws*> oneshot;  // ncols -> batch-1 workspace used by the host-pointer entry points
+};
+
+struct aqc_ws {
+    aqc_ctx* ctx = nullptr;
+    int device = 0, batch = 1, ncols = 1, pitch = 1, col_bits = 0, nbits = 0, threads = 256;
+    size_t lane_elems = 0;  // 2^nbits
+    hipStream_t stream = nullptr;
+    DevPlan fwd, inv, sweep;
+    double* d_thetas = nullptr;
+    double* d_coef = nullptr;
+    double2* bufs[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double2* d_partial = nullptr;
+    double2* d_grads = nullptr;
+    double2* d_small = nullptr;  // gather / vdot results
+    double2* d_vdot_part = nullptr;
+    long long* d_index = nullptr;
+    size_t small_cap = 0, index_cap = 0;
+    int* d_theta_slots = nullptr;
+    int* d_slot_ntiles = nullptr;
+    int nslots = 0, vdot_parts = 0;
+    bool coef_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    bool profile = false;
+    int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
+    double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int upload_plan(DevPlan& p) {
+    HIP_OK(hipMalloc((void**)&p.d_stages, p.h_stages.size() * sizeof(DevStage)));
+    HIP_OK(hipMemcpy(p.d_stages, p.h_stages.data(), p.h_stages.size() * sizeof(DevStage), hipMemcpyHostToDevice));
+    const size_t nops = std::max<size_t>(p.h_ops.size(), 1);
+    HIP_OK(hipMalloc((void**)&p.d_ops, nops * sizeof(DevOp)));
+    if (!p.h_ops.empty())
+        HIP_OK(hipMemcpy(p.d_ops, p.h_ops.data(), p.h_ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct ProfScope {  // brackets one launch with events when profiling is on
+    aqc_ws* ws;
+    int kind;
+    ProfScope(aqc_ws* w, int k) : ws(w), kind(k) {
+        if (ws->profile) (void)hipEventRecord(ws->pev0, ws->stream);
+    }
+    ~ProfScope() {
+        if (!ws->profile) return;
+        float ms = 0.f;
+        if (hipEventRecord(ws->pev1, ws->stream) == hipSuccess && hipEventSynchronize(ws->pev1) == hipSuccess &&
+            hipEventElapsedTime(&ms, ws->pev0, ws->pev1) == hipSuccess) {
+            ws->prof_count[kind] += 1;
+            ws->prof_ms[kind] += ms;
+        }
+    }
+};
+
+int check_buf(const aqc_ws* ws, int buf) {
+    if (!ws) return fail("null workspace");
+    if (buf < 0 || buf >= AQC_NUM_BUFS) return fail("invalid buffer id %d", buf);
+    return 0;
+}
+
+int ensure_small(aqc_ws* ws, size_t n_cplx) {
+    if (n_cplx <= ws->small_cap) return 0;
+    if (ws->d_small) HIP_OK(hipFree(ws->d_small));
+    ws->d_small = nullptr;
+    HIP_OK(hipMalloc((void**)&ws->d_small, n_cplx * sizeof(double2)));
+    ws->small_cap = n_cplx;
+    return 0;
+}
+
+int ensure_index(aqc_ws* ws, size_t n) {
+    if (n <= ws->index_cap) return 0;
+    if (ws->d_index) HIP_OK(hipFree(ws->d_index));
+    ws->d_index = nullptr;
+    HIP_OK(hipMalloc((void**)&ws->d_index, n * sizeof(long long)));
+    ws->index_cap = n;
+    return 0;
+}
+
+int ensure_coef(aqc_ws* ws) {
+    if (ws->coef_valid) return 0;
+    return fail("thetas have not been uploaded (aqc_ws_set_thetas)");
+}
+
+// host <-> device copy of [rows][ncols] <-> [rows][pitch]
+int copy_in(aqc_ws* ws, double2* dst, const double* src, size_t rows) {
+    if (ws->pitch == ws->ncols) {
+        HIP_OK(hipMemcpyAsync(dst, src, rows * ws->ncols * sizeof(double2), hipMemcpyHostToDevice, ws->stream));
+    } else {
+        HIP_OK(hipMemsetAsync(dst, 0, rows * ws->pitch * sizeof(double2), ws->stream));
+        HIP_OK(hipMemcpy2DAsync(dst, (size_t)ws->pitch * sizeof(double2), src, (size_t)ws->ncols * sizeof(double2),
+                                (size_t)ws->ncols * sizeof(double2), rows, hipMemcpyHostToDevice, ws->stream));
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+int copy_out(aqc_ws* ws, double* dst, const double2* src, size_t rows) {
+    if (ws->pitch == ws->ncols) {
+        HIP_OK(hipMemcpyAsync(dst, src, rows * ws->ncols * sizeof(double2), hipMemcpyDeviceToHost, ws->stream));
+    } else {
+        HIP_OK(hipMemcpy2DAsync(dst, (size_t)ws->ncols * sizeof(double2), src, (size_t)ws->pitch * sizeof(double2),
+                                (size_t)ws->ncols * sizeof(double2), rows, hipMemcpyDeviceToHost, ws->stream));
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
+    DevPlan& p = inverse ? ws->inv : ws->fwd;
+    const Program& prog = ws->ctx->prog;
+    for (size_t s = 0; s < p.h_stages.size(); ++s) {
+        StageArgs a;
+        memset(&a, 0, sizeof a);
+        a.stage = p.d_stages + s;
+        a.ops = p.d_ops;
+        a.coef = ws->d_coef;
+        a.ncoef = prog.n + prog.num_blocks;
+        a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
+        a.out0 = ws->bufs[dst_buf];
+        a.lane_stride = ws->lane_elems;
+        ProfScope ps(ws, AQC_K_APPLY);
+        HIP_OK(launch_apply(prog.entangler, inverse, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* aqc_version(void) { return "aqc_hip 0.1.0 (gfx950)"; }
+const char* aqc_last_error(void) { return g_error.c_str(); }
+
+int aqc_create(int num_qubits, int entangler, const int32_t* blocks, int num_blocks, int trotter, int second_order,
+               aqc_ctx** out) {
+    if (!out) return fail("out pointer is null");
+    *out = nullptr;
+    aqc_ctx* ctx = new aqc_ctx();
+    const std::string err = build_program(num_qubits, entangler, blocks, num_blocks, trotter != 0, second_order != 0, ctx->prog);
+    if (!err.empty()) {
+        delete ctx;
+        return fail("%s", err.c_str());
+    }
+    *out = ctx;
+    return 0;
+}
+
+int aqc_destroy(aqc_ctx* ctx) {
+    if (!ctx) return 0;
+    for (auto& kv : ctx->oneshot) aqc_ws_destroy(kv.second);
+    delete ctx;
+    return 0;
+}
+
+int aqc_num_thetas(const aqc_ctx* ctx) { return ctx ? ctx->prog.num_thetas() : -1; }
+int aqc_num_gate_groups(const aqc_ctx* ctx) { return ctx ? (int)ctx->prog.groups.size() : -1; }
+
+int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage, int* num_stages,
+                   int* bits_out, int* num_bits, int* ops_out, int* num_ops) {
+    if (!ctx) return fail("null context");
+    if (ncols < 1) return fail("ncols must be positive");
+    const int col_bits = ceil_log2(ncols);
+    if (tile_bits <= 0) tile_bits = which == 1 ? 12 : 13;
+    if (low_bits < 0) low_bits = 3;
+    const Plan plan = make_plan(ctx->prog, col_bits, tile_bits, low_bits, which == 0);
+    const std::string err = check_plan(ctx->prog, plan);
+    if (!err.empty()) return fail("planner produced an invalid plan: %s", err.c_str());
+    if (num_stages) *num_stages = (int)plan.stages.size();
+    if (stage >= 0) {
+        if (stage >= (int)plan.stages.size()) return fail("stage index out of range");
+        const Stage& st = plan.stages[stage];
+        if (num_bits) *num_bits = (int)st.bits.size();
+        if (num_ops) *num_ops = (int)st.ops.size();
+        if (bits_out) for (size_t i = 0; i < st.bits.size(); ++i) bits_out[i] = st.bits[i];
+        if (ops_out) for (size_t i = 0; i < st.ops.size(); ++i) ops_out[i] = st.ops[i];
+    }
+    return 0;
+}
+
+int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_apply, int tile_bits_sweep, aqc_ws** out) {
+    if (!out) return fail("out pointer is null");
+    *out = nullptr;
+    if (!ctx) return fail("null context");
+    if (batch < 1) return fail("batch must be >= 1");
+    if (ncols < 1) return fail("ncols must be >= 1");
+    const Program& prog = ctx->prog;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail("no HIP device available (%s): the aqc_hip path needs an AMD GPU and has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+    HIP_OK(hipSetDevice(device));
+    HIP_OK(init_kernels());
+
+    aqc_ws* ws = new aqc_ws();
+    ws->ctx = ctx;
+    ws->device = device;
+    ws->batch = batch;
+    ws->ncols = ncols;
+    ws->col_bits = ceil_log2(ncols);
+    ws->pitch = 1 << ws->col_bits;
+    ws->nbits = ws->col_bits + prog.n;
+    if (ws->nbits > kMaxBits) { delete ws; return fail("2^%d elements per lane is beyond this build's limit", ws->nbits); }
+    ws->lane_elems = (size_t)1 << ws->nbits;
+    ws->threads = env_int("AQC_THREADS", 256);
+    if (ws->threads < 64 || ws->threads > 512 || ws->threads % 64) { delete ws; return fail("AQC_THREADS must be a multiple of 64 in [64, 512]"); }
+
+    const int low_bits = env_int("AQC_LOW_BITS", 3);
+    int ka = tile_bits_apply > 0 ? tile_bits_apply : env_int("AQC_TILE_BITS_APPLY", 0);
+    int ks = tile_bits_sweep > 0 ? tile_bits_sweep : env_int("AQC_TILE_BITS_SWEEP", 0);
+    // default: the largest tile the 160 KiB LDS takes, shrunk (not below 2^10) while the launch
+    // would leave most of the 256 CUs idle
+    auto pick = [&](int kmax) {
+        int k = std::min(kmax, ws->nbits);
+        while (k > 10 && (size_t)batch * ((size_t)1 << (ws->nbits - k)) < 256) --k;
+        return k;
+    };
+    if (ka <= 0) ka = pick(13);
+    if (ks <= 0) ks = pick(12);
+    ka = std::min(std::min(ka, 13), ws->nbits);
+    ks = std::min(std::min(ks, 12), ws->nbits);
+
+    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep);
+    for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
+        const std::string err = check_plan(prog, p->plan);
+        if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
+    }
+
+    const int T = prog.num_thetas();
+    const int G = (int)prog.groups.size();
+    ws->nslots = G * kSlotsPerGroup;
+    std::vector<int> theta_slots(2 * (size_t)std::max(T, 1), -1), slot_ntiles((size_t)std::max(ws->nslots, 1), ws->sweep.ntiles);
+    auto feed = [&](int theta, int slot) {
+        if (theta_slots[2 * theta] < 0) theta_slots[2 * theta] = slot; else theta_slots[2 * theta + 1] = slot;
+    };
+    for (int gi = 0; gi < G; ++gi) {
+        const GateGroup& g = prog.groups[gi];
+        if (g.type == GROUP_FRONT) {
+            feed(g.theta0 + 2, gi * kSlotsPerGroup + 0);
+            feed(g.theta0 + 1, gi * kSlotsPerGroup + 1);
+            feed(g.theta0 + 0, gi * kSlotsPerGroup + 2);
+        } else {
+            for (int d = 0; d < prog.tpb; ++d) feed(g.theta0 + d, gi * kSlotsPerGroup + d);
+        }
+    }
+
+#define WS_TRY(x) do { if ((x) != 0) { aqc_ws_destroy(ws); return 1; } } while (0)
+#define WS_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail("%s failed: %s", #x, hipGetErrorString(e_)); aqc_ws_destroy(ws); return 1; } } while (0)
+    WS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    WS_HIP(hipEventCreate(&ws->ev0)); WS_HIP(hipEventCreate(&ws->ev1));
+    WS_HIP(hipEventCreate(&ws->pev0)); WS_HIP(hipEventCreate(&ws->pev1));
+    WS_TRY(upload_plan(ws->fwd)); WS_TRY(upload_plan(ws->inv)); WS_TRY(upload_plan(ws->sweep));
+    WS_HIP(hipMalloc((void**)&ws->d_thetas, sizeof(double) * (size_t)batch * std::max(T, 1)));
+    WS_HIP(hipMalloc((void**)&ws->d_coef, sizeof(double) * (size_t)batch * (prog.n + prog.num_blocks) * kCoefStride));
+    for (int b = 0; b < AQC_NUM_BUFS; ++b) {
+        WS_HIP(hipMalloc((void**)&ws->bufs[b], sizeof(double2) * (size_t)batch * ws->lane_elems));
+        WS_HIP(hipMemsetAsync(ws->bufs[b], 0, sizeof(double2) * (size_t)batch * ws->lane_elems, ws->stream));
+    }
+    WS_HIP(hipMalloc((void**)&ws->d_partial, sizeof(double2) * (size_t)batch * std::max(ws->nslots, 1) * ws->sweep.ntiles));
+    WS_HIP(hipMalloc((void**)&ws->d_grads, sizeof(double2) * (size_t)batch * std::max(T, 1)));
+    WS_HIP(hipMalloc((void**)&ws->d_theta_slots, sizeof(int) * theta_slots.size()));
+    WS_HIP(hipMalloc((void**)&ws->d_slot_ntiles, sizeof(int) * slot_ntiles.size()));
+    WS_HIP(hipMemcpy(ws->d_theta_slots, theta_slots.data(), sizeof(int) * theta_slots.size(), hipMemcpyHostToDevice));
+    WS_HIP(hipMemcpy(ws->d_slot_ntiles, slot_ntiles.data(), sizeof(int) * slot_ntiles.size(), hipMemcpyHostToDevice));
+    ws->vdot_parts = (int)std::min<size_t>(1024, std::max<size_t>(1, ws->lane_elems / 1024));
+    WS_HIP(hipMalloc((void**)&ws->d_vdot_part, sizeof(double2) * (size_t)batch * ws->vdot_parts));
+    WS_HIP(hipStreamSynchronize(ws->stream));
+#undef WS_TRY
+#undef WS_HIP
+    *out = ws;
+    return 0;
+}
+
+int aqc_ws_destroy(aqc_ws* ws) {
+    if (!ws) return 0;
+    (void)hipSetDevice(ws->device);
+    if (ws->stream) (void)hipStreamSynchronize(ws->stream);
+    for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
+        if (p->d_stages) (void)hipFree(p->d_stages);
+        if (p->d_ops) (void)hipFree(p->d_ops);
+    }
+    void* ptrs[] = {ws->d_thetas, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
+                    ws->d_theta_slots, ws->d_slot_ntiles};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
+    for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1}) if (ev) (void)hipEventDestroy(ev);
+    if (ws->stream) (void)hipStreamDestroy(ws->stream);
+    delete ws;
+    return 0;
+}
+
+int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas) {
+    if (!ws || !thetas) return fail("null argument");
+    HIP_OK(hipSetDevice(ws->device));
+    const Program& prog = ws->ctx->prog;
+    const int T = prog.num_thetas();
+    HIP_OK(hipMemcpyAsync(ws->d_thetas, thetas, sizeof(double) * (size_t)ws->batch * T, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));  // the host buffer may be reused right away
+    {
+        ProfScope ps(ws, AQC_K_COEF);
+        HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, ws->batch, ws->stream));
+    }
+    ws->coef_valid = true;
+    return 0;
+}
+
+int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
+    if (check_buf(ws, buf)) return 1;
+    if (!src) return fail("null source");
+    HIP_OK(hipSetDevice(ws->device));
+    return copy_in(ws, ws->bufs[buf], src, (size_t)ws->batch << ws->ctx->prog.n);
+}
+
+int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src) {
+    if (check_buf(ws, buf)) return 1;
+    if (!src) return fail("null source");
+    if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
+    HIP_OK(hipSetDevice(ws->device));
+    return copy_in(ws, ws->bufs[buf] + (size_t)lane * ws->lane_elems, src, (size_t)1 << ws->ctx->prog.n);
+}
+
+int aqc_ws_broadcast(aqc_ws* ws, int buf, const double* src) {
+    if (check_buf(ws, buf)) return 1;
+    if (!src) return fail("null source");
+    HIP_OK(hipSetDevice(ws->device));
+    if (copy_in(ws, ws->bufs[buf], src, (size_t)1 << ws->ctx->prog.n)) return 1;
+    for (int b = 1; b < ws->batch; ++b)
+        HIP_OK(hipMemcpyAsync(ws->bufs[buf] + (size_t)b * ws->lane_elems, ws->bufs[buf], ws->lane_elems * sizeof(double2),
+                              hipMemcpyDeviceToDevice, ws->stream));
+    return 0;
+}
+
+int aqc_ws_download(aqc_ws* ws, int buf, double* dst) {
+    if (check_buf(ws, buf)) return 1;
+    if (!dst) return fail("null destination");
+    HIP_OK(hipSetDevice(ws->device));
+    return copy_out(ws, dst, ws->bufs[buf], (size_t)ws->batch << ws->ctx->prog.n);
+}
+
+int aqc_ws_download_lane(aqc_ws* ws, int buf, int lane, double* dst) {
+    if (check_buf(ws, buf)) return 1;
+    if (!dst) return fail("null destination");
+    if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
+    HIP_OK(hipSetDevice(ws->device));
+    return copy_out(ws, dst, ws->bufs[buf] + (size_t)lane * ws->lane_elems, (size_t)1 << ws->ctx->prog.n);
+}
+
+int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
+    if (check_buf(ws, buf)) return 1;
+    if (!index) return fail("null index");
+    HIP_OK(hipSetDevice(ws->device));
+    const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
+    std::vector<long long> elem(ws->batch);
+    for (int b = 0; b < ws->batch; ++b) {
+        if (index[b] < 0 || index[b] >= dim) return fail("basis index out of range");
+        elem[b] = (long long)index[b] << ws->col_bits;
+    }
+    if (ensure_index(ws, ws->batch)) return 1;
+    HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * ws->batch, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    HIP_OK(hipMemsetAsync(ws->bufs[buf], 0, sizeof(double2) * (size_t)ws->batch * ws->lane_elems, ws->stream));
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(launch_scatter_one(ws->bufs[buf], ws->lane_elems, ws->batch, ws->d_index, ws->stream));
+    return 0;
+}
+
+int aqc_ws_set_identity(aqc_ws* ws, int buf) {
+    if (check_buf(ws, buf)) return 1;
+    const int dim = 1 << ws->ctx->prog.n;
+    if (ws->ncols != dim) return fail("identity needs a square workspace (ncols == 2^n)");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipMemsetAsync(ws->bufs[buf], 0, sizeof(double2) * (size_t)ws->batch * ws->lane_elems, ws->stream));
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(launch_set_identity(ws->bufs[buf], ws->lane_elems, dim, ws->pitch, ws->batch, ws->stream));
+    return 0;
+}
+
+int aqc_ws_apply(aqc_ws* ws, int inverse, int src_buf, int dst_buf) {
+    if (check_buf(ws, src_buf) || check_buf(ws, dst_buf)) return 1;
+    if (ensure_coef(ws)) return 1;
+    HIP_OK(hipSetDevice(ws->device));
+    return run_apply(ws, inverse != 0, src_buf, dst_buf);
+}
+
+int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
+    if (!ws) return fail("null workspace");
+    if (ensure_coef(ws)) return 1;
+    const Program& prog = ws->ctx->prog;
+    if (block_from < 0) { block_from = 0; block_to = prog.num_blocks; }
+    if (prog.num_blocks > 0 && !(0 <= block_from && block_from < block_to && block_to <= prog.num_blocks))
+        return fail("invalid block_range [%d, %d)", block_from, block_to);
+    HIP_OK(hipSetDevice(ws->device));
+    DevPlan& p = ws->sweep;
+    for (size_t s = 0; s < p.h_stages.size(); ++s) {
+        StageArgs a;
+        memset(&a, 0, sizeof a);
+        a.stage = p.d_stages + s;
+        a.ops = p.d_ops;
+        a.coef = ws->d_coef;
+        a.ncoef = prog.n + prog.num_blocks;
+        a.in0 = s == 0 ? ws->bufs[AQC_BUF_X] : ws->bufs[AQC_BUF_W];
+        a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
+        a.out0 = ws->bufs[AQC_BUF_W];
+        a.out1 = ws->bufs[AQC_BUF_ZW];
+        a.lane_stride = ws->lane_elems;
+        a.partial = ws->d_partial;
+        a.nslots = ws->nslots;
+        a.ntiles_max = p.ntiles;
+        a.from = block_from;
+        a.to = block_to;
+        a.front = front_layer ? 1 : 0;
+        ProfScope ps(ws, AQC_K_SWEEP);
+        HIP_OK(launch_sweep(prog.entangler, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
+    }
+    ProfScope ps(ws, AQC_K_FINALIZE);
+    HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
+                           p.ntiles, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
+    return 0;
+}
+
+int aqc_ws_get_grads(aqc_ws* ws, double* grads) {
+    if (!ws || !grads) return fail("null argument");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipMemcpyAsync(grads, ws->d_grads, sizeof(double2) * (size_t)ws->batch * ws->ctx->prog.num_thetas(),
+                          hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* out) {
+    if (check_buf(ws, buf)) return 1;
+    if (!index || !out || count < 1) return fail("invalid gather arguments");
+    HIP_OK(hipSetDevice(ws->device));
+    const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
+    std::vector<long long> elem(count);
+    for (int i = 0; i < count; ++i) {
+        if (index[i] < 0 || index[i] >= dim) return fail("gather index out of range");
+        elem[i] = (long long)index[i] << ws->col_bits;
+    }
+    if (ensure_index(ws, count) || ensure_small(ws, (size_t)ws->batch * count)) return 1;
+    HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, count, ws->batch, ws->d_small, ws->stream));
+    }
+    HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch * count, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out) {
+    if (check_buf(ws, buf_a) || check_buf(ws, buf_b)) return 1;
+    if (!out) return fail("null output");
+    HIP_OK(hipSetDevice(ws->device));
+    if (ensure_small(ws, ws->batch)) return 1;
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_vdot(ws->bufs[buf_a], ws->bufs[buf_b], ws->lane_elems, ws->lane_elems, ws->batch, ws->d_vdot_part,
+                           ws->vdot_parts, ws->d_small, ws->stream));
+    }
+    HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_sync(aqc_ws* ws) {
+    if (!ws) return fail("null workspace");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_timer_start(aqc_ws* ws) {
+    if (!ws) return fail("null workspace");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipEventRecord(ws->ev0, ws->stream));
+    return 0;
+}
+
+int aqc_ws_timer_stop(aqc_ws* ws, float* elapsed_ms) {
+    if (!ws || !elapsed_ms) return fail("null argument");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipEventRecord(ws->ev1, ws->stream));
+    HIP_OK(hipEventSynchronize(ws->ev1));
+    HIP_OK(hipEventElapsedTime(elapsed_ms, ws->ev0, ws->ev1));
+    return 0;
+}
+
+int aqc_ws_profile_enable(aqc_ws* ws, int on) {
+    if (!ws) return fail("null workspace");
+    ws->profile = on != 0;
+    return 0;
+}
+
+int aqc_ws_profile_get(aqc_ws* ws, int kind, int64_t* launches, double* total_ms) {
+    if (!ws || kind < 0 || kind >= AQC_NUM_KINDS) return fail("invalid argument");
+    if (launches) *launches = ws->prof_count[kind];
+    if (total_ms) *total_ms = ws->prof_ms[kind];
+    return 0;
+}
+
+int aqc_ws_profile_reset(aqc_ws* ws) {
+    if (!ws) return fail("null workspace");
+    for (int i = 0; i < AQC_NUM_KINDS; ++i) { ws->prof_count[i] = 0; ws->prof_ms[i] = 0.0; }
+    return 0;
+}
+
+int aqc_ws_plan_info(aqc_ws* ws, int which, int* num_stages, int* tile_bits, int* num_tiles) {
+    if (!ws) return fail("null workspace");
+    const DevPlan& p = which == 0 ? ws->inv : (which == 1 ? ws->sweep : ws->fwd);
+    if (num_stages) *num_stages = (int)p.h_stages.size();
+    if (tile_bits) *tile_bits = p.k;
+    if (num_tiles) *num_tiles = p.ntiles;
+    return 0;
+}
+
+// ---- one-shot host-pointer entry points -------------------------------------------------------
+
+static int oneshot_ws(aqc_ctx* ctx, int ncols, aqc_ws** out) {
+    if (!ctx) return fail("null context");
+    auto it = ctx->oneshot.find(ncols);
+    if (it != ctx->oneshot.end()) { *out = it->second; return 0; }
+    aqc_ws* ws = nullptr;
+    if (aqc_ws_create(ctx, env_int("AQC_DEVICE", 0), 1, ncols, 0, 0, &ws)) return 1;
+    ctx->oneshot[ncols] = ws;
+    *out = ws;
+    return 0;
+}
+
+static int oneshot_apply(aqc_ctx* ctx, const double* thetas, const double* src, double* dst, int ncols, int inverse) {
+    if (!thetas || !src || !dst) return fail("null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    aqc_ws* ws = nullptr;
+    if (oneshot_ws(ctx, ncols, &ws)) return 1;
+    if (aqc_ws_set_thetas(ws, thetas)) return 1;
+    if (aqc_ws_upload(ws, AQC_BUF_Y, src)) return 1;
+    if (aqc_ws_apply(ws, inverse, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+    return aqc_ws_download(ws, AQC_BUF_Z, dst);
+}
+
+int aqc_v_mul_vec(aqc_ctx* ctx, const double* thetas, const double* vec, double* out) {
+    if (!ctx) return fail("null context");
+    return oneshot_apply(ctx, thetas, vec, out, 1, 0);
+}
+int aqc_vdag_mul_vec(aqc_ctx* ctx, const double* thetas, const double* vec, double* out) {
+    if (!ctx) return fail("null context");
+    return oneshot_apply(ctx, thetas, vec, out, 1, 1);
+}
+int aqc_v_mul_mat(aqc_ctx* ctx, const double* thetas, double* mat, int ncols) {
+    if (!ctx) return fail("null context");
+    if (ctx->prog.trotter) return fail("matrix path does not support the Trotter ansatz (core_op_matrix.py:480)");
+    return oneshot_apply(ctx, thetas, mat, mat, ncols, 0);
+}
+int aqc_vdag_mul_mat(aqc_ctx* ctx, const double* thetas, double* mat, int ncols) {
+    if (!ctx) return fail("null context");
+    if (ctx->prog.trotter) return fail("matrix path does not support the Trotter ansatz (core_op_matrix.py:562)");
+    return oneshot_apply(ctx, thetas, mat, mat, ncols, 1);
+}
+
+static int oneshot_grad(aqc_ctx* ctx, const double* thetas, const double* x, const double* vh_y, int ncols, int from, int to,
+                        int front, double* grad) {
+    if (!thetas || !x || !vh_y || !grad) return fail("null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    aqc_ws* ws = nullptr;
+    if (oneshot_ws(ctx, ncols, &ws)) return 1;
+    if (aqc_ws_set_thetas(ws, thetas)) return 1;
+    if (aqc_ws_upload(ws, AQC_BUF_X, x)) return 1;
+    if (aqc_ws_upload(ws, AQC_BUF_Z, vh_y)) return 1;
+    if (aqc_ws_grad(ws, from, to, front)) return 1;
+    return aqc_ws_get_grads(ws, grad);
+}
+
+int aqc_grad_dot_vec(aqc_ctx* ctx, const double* thetas, const double* x, const double* vh_y, int block_from, int block_to,
+                     int front_layer, double* grad) {
+    if (!ctx) return fail("null context");
+    return oneshot_grad(ctx, thetas, x, vh_y, 1, block_from, block_to, front_layer, grad);
+}
+int aqc_grad_dot_mat(aqc_ctx* ctx, const double* thetas, const double* x_mat, const double* vh_y_mat, int ncols, double* grad) {
+    if (!ctx) return fail("null context");
+    if (ctx->prog.trotter) return fail("matrix path does not support the Trotter ansatz (core_op_matrix.py:645)");
+    return oneshot_grad(ctx, thetas, x_mat, vh_y_mat, ncols, -1, -1, 1, grad);
+}
+
+}  // extern "C"

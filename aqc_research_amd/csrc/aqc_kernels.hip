@@ -1,0 +1,515 @@
+// gfx950 (MI355X / CDNA4) kernels of the fidelity/gradient path.
+//
+// Stage kernels: one workgroup = one tile of 2^k complex128 amplitudes (those that differ
+// only in the stage's k local address bits) of one batch lane.  The tile is gathered from
+// HBM into LDS in runs of 2^low_bits contiguous elements (16 B per lane, coalesced), every
+// gate group of the stage is applied in LDS, the per-parameter inner products
+// 0.5j<P w|z> are reduced in flight (wave-64 butterfly -> per-wave LDS slot -> fixed-order
+// sum, no float atomics => run-to-run identical), and the tile is scattered back.
+//
+// All arithmetic is complex fp64 on the vector ALU (the path is ~1 flop/byte per gate group
+// before fusion and LDS/VALU bound after it; fp64 MFMA has no higher peak on gfx950).
+#include <hip/hip_runtime.h>
+
+#include "aqc_device.h"
+#include "aqc_launch.h"
+
+namespace aqc {
+
+typedef double2 cplx;  // x = re, y = im
+
+static constexpr double kR = 0.70710678118654752440;  // cos(pi/4) = sin(pi/4)
+
+// ------------------------------------------------------------------------------------------
+// complex helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx cmul(cplx a, double c, double s) {  // a * (c + i s)
+    return make_double2(a.x * c - a.y * s, a.y * c + a.x * s);
+}
+// acc += conj(a) * b
+__device__ __forceinline__ void cmacc(cplx& acc, cplx a, cplx b) {
+    acc.x += a.x * b.x + a.y * b.y;
+    acc.y += a.x * b.y - a.y * b.x;
+}
+// acc -= conj(a) * b
+__device__ __forceinline__ void cmsub(cplx& acc, cplx a, cplx b) {
+    acc.x -= a.x * b.x + a.y * b.y;
+    acc.y -= a.x * b.y - a.y * b.x;
+}
+// Ry = [[c,-s],[s,c]]  (elementary_operations.py:204-210)
+__device__ __forceinline__ void ry2(cplx& a0, cplx& a1, double c, double s) {
+    const cplx t0 = make_double2(c * a0.x - s * a1.x, c * a0.y - s * a1.y);
+    const cplx t1 = make_double2(s * a0.x + c * a1.x, s * a0.y + c * a1.y);
+    a0 = t0;
+    a1 = t1;
+}
+// Rz = diag(c - i s, c + i s)  (elementary_operations.py:246-251)
+__device__ __forceinline__ void rz2(cplx& a0, cplx& a1, double c, double s) {
+    a0 = make_double2(c * a0.x + s * a0.y, c * a0.y - s * a0.x);
+    a1 = make_double2(c * a1.x - s * a1.y, c * a1.y + s * a1.x);
+}
+// Rx = [[c,-is],[-is,c]]  (elementary_operations.py:159-165)
+__device__ __forceinline__ void rx2(cplx& a0, cplx& a1, double c, double s) {
+    const cplx t0 = make_double2(c * a0.x + s * a1.y, c * a0.y - s * a1.x);
+    const cplx t1 = make_double2(s * a0.y + c * a1.x, c * a1.y - s * a0.x);
+    a0 = t0;
+    a1 = t1;
+}
+template <int ENT>
+__device__ __forceinline__ void rs2(cplx& a0, cplx& a1, double c, double s) {
+    if (ENT == 0) rx2(a0, a1, c, s); else rz2(a0, a1, c, s);
+}
+// amplitudes of a 2-qubit group are indexed a[2*cbit + tbit]
+template <int ENT>
+__device__ __forceinline__ void entangle(cplx* a, double c4, double s4) {
+    if (ENT == 0) { const cplx t = a[2]; a[2] = a[3]; a[3] = t; }          // CX
+    else if (ENT == 1) { a[3].x = -a[3].x; a[3].y = -a[3].y; }             // CZ
+    else { a[3] = cmul(a[3], c4, s4); }                                     // CP(theta4)
+}
+
+// Unit block (C (x) T) CG, forward order  (core_operations.py:686-708)
+template <int ENT>
+__device__ __forceinline__ void block_fwd(cplx* a, const double* cf, int flags) {
+    if (flags & 1) { rz2(a[0], a[2], kR, -kR); rz2(a[1], a[3], kR, -kR); }
+    entangle<ENT>(a, cf[8], cf[9]);
+    ry2(a[0], a[2], cf[0], cf[1]); ry2(a[1], a[3], cf[0], cf[1]);
+    rz2(a[0], a[2], cf[2], cf[3]); rz2(a[1], a[3], cf[2], cf[3]);
+    ry2(a[0], a[1], cf[4], cf[5]); ry2(a[2], a[3], cf[4], cf[5]);
+    rs2<ENT>(a[0], a[1], cf[6], cf[7]); rs2<ENT>(a[2], a[3], cf[6], cf[7]);
+    if (flags & 2) { rz2(a[0], a[1], kR, kR); rz2(a[2], a[3], kR, kR); }
+}
+// Conjugate-transposed unit block  (core_operations.py:787-809)
+template <int ENT>
+__device__ __forceinline__ void block_inv(cplx* a, const double* cf, int flags) {
+    if (flags & 2) { rz2(a[0], a[1], kR, -kR); rz2(a[2], a[3], kR, -kR); }
+    rs2<ENT>(a[0], a[1], cf[6], -cf[7]); rs2<ENT>(a[2], a[3], cf[6], -cf[7]);
+    ry2(a[0], a[1], cf[4], -cf[5]); ry2(a[2], a[3], cf[4], -cf[5]);
+    rz2(a[0], a[2], cf[2], -cf[3]); rz2(a[1], a[3], cf[2], -cf[3]);
+    ry2(a[0], a[2], cf[0], -cf[1]); ry2(a[1], a[3], cf[0], -cf[1]);
+    entangle<ENT>(a, cf[8], -cf[9]);
+    if (flags & 1) { rz2(a[0], a[2], kR, kR); rz2(a[1], a[3], kR, kR); }
+}
+
+__device__ __forceinline__ unsigned insert_zero(unsigned g, int pos) {
+    const unsigned lo = g & ((1u << pos) - 1u);
+    return ((g >> pos) << (pos + 1)) | lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct TileCtx {
+    size_t base;      // element offset of the tile inside the lane
+    unsigned* dlo;    // LDS copies of the deposit tables
+    unsigned* dhi;
+};
+
+__device__ __forceinline__ TileCtx tile_setup(const DevStage* st, unsigned* tables) {
+    TileCtx t;
+    t.dlo = tables;
+    t.dhi = tables + 64;
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) t.dlo[i] = st->dlo[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) t.dhi[i] = st->dhi[i];
+    size_t base = 0;
+    const unsigned tile = blockIdx.x;
+    const int nub = st->nub;
+    for (int i = 0; i < nub; ++i) base |= (size_t)((tile >> i) & 1u) << st->ubits[i];
+    t.base = base;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// V / V^H on one vector per lane
+// ------------------------------------------------------------------------------------------
+template <int ENT, bool INV>
+__global__ __launch_bounds__(512) void apply_stage_kernel(StageArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevStage* st = a.stage;
+    const int k = st->k;
+    const unsigned tsize = 1u << k;
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    unsigned* tables = reinterpret_cast<unsigned*>(smem + (size_t)tsize * sizeof(cplx));
+    const TileCtx tc = tile_setup(st, tables);
+    __syncthreads();
+
+    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tc.base;
+    const cplx* src = a.in0 + lane_off;
+    for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x)
+        tile[l] = src[tc.dlo[l & 63u] + tc.dhi[l >> 6]];
+
+    const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
+    const int nops = st->nops;
+    for (int i = 0; i < nops; ++i) {
+        const DevOp op = a.ops[st->op_begin + i];
+        const double* cf = coef + (size_t)op.coef * kCoefStride;
+        __syncthreads();
+        if (op.type == 1) {
+            const int plo = min(op.p0, op.p1), phi = max(op.p0, op.p1);
+            const unsigned ic = 1u << op.p0, it = 1u << op.p1;
+            for (unsigned g = threadIdx.x; g < (tsize >> 2); g += blockDim.x) {
+                const unsigned i0 = insert_zero(insert_zero(g, plo), phi);
+                cplx v[4] = {tile[i0], tile[i0 + it], tile[i0 + ic], tile[i0 + ic + it]};
+                if (INV) block_inv<ENT>(v, cf, op.flags); else block_fwd<ENT>(v, cf, op.flags);
+                tile[i0] = v[0]; tile[i0 + it] = v[1]; tile[i0 + ic] = v[2]; tile[i0 + ic + it] = v[3];
+            }
+        } else {
+            const unsigned h = 1u << op.p0;
+            for (unsigned g = threadIdx.x; g < (tsize >> 1); g += blockDim.x) {
+                const unsigned i0 = insert_zero(g, op.p0);
+                cplx a0 = tile[i0], a1 = tile[i0 + h];
+                if (INV) {  // (Rz Ry Rz)^H  (core_operations.py:812-818)
+                    rz2(a0, a1, cf[0], -cf[1]); ry2(a0, a1, cf[2], -cf[3]); rz2(a0, a1, cf[4], -cf[5]);
+                } else {    // Rz(t0) Ry(t1) Rz(t2), rightmost first  (core_operations.py:671-677)
+                    rz2(a0, a1, cf[4], cf[5]); ry2(a0, a1, cf[2], cf[3]); rz2(a0, a1, cf[0], cf[1]);
+                }
+                tile[i0] = a0; tile[i0 + h] = a1;
+            }
+        }
+    }
+    __syncthreads();
+    cplx* dst = a.out0 + lane_off;
+    for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x)
+        dst[tc.dlo[l & 63u] + tc.dhi[l >> 6]] = tile[l];
+}
+
+// ------------------------------------------------------------------------------------------
+// forward w/z sweep with in-flight inner products  (core_operations.py:918-1019)
+// ------------------------------------------------------------------------------------------
+template <int ENT>
+__global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevStage* st = a.stage;
+    const int k = st->k;
+    const unsigned tsize = 1u << k;
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    cplx* tz = tw + tsize;
+    unsigned* tables = reinterpret_cast<unsigned*>(tz + tsize);
+    cplx* scratch = reinterpret_cast<cplx*>(tables + 320);  // [2][nwaves][kSlotsPerGroup]
+    const TileCtx tc = tile_setup(st, tables);
+    __syncthreads();
+
+    const int nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tc.base;
+    {
+        const cplx* sw = a.in0 + lane_off;
+        const cplx* sz = a.in1 + lane_off;
+        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {
+            const unsigned off = tc.dlo[l & 63u] + tc.dhi[l >> 6];
+            tw[l] = sw[off];
+            tz[l] = sz[off];
+        }
+    }
+    const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
+    cplx* partial = a.partial + (size_t)blockIdx.y * a.nslots * a.ntiles_max;
+    constexpr int ND_BLOCK = (ENT == 2) ? 5 : 4;
+
+    int pend_slot = -1, pend_nd = 0, pend_par = 0;
+    auto flush = [&]() {  // fixed-order cross-wave sum of the previous group's inner products
+        if (pend_slot >= 0 && (int)threadIdx.x < pend_nd) {
+            const cplx* s = scratch + (size_t)pend_par * nwaves * kSlotsPerGroup + threadIdx.x;
+            cplx acc = s[0];
+            for (int w = 1; w < nwaves; ++w) { acc.x += s[w * kSlotsPerGroup].x; acc.y += s[w * kSlotsPerGroup].y; }
+            partial[(size_t)(pend_slot + threadIdx.x) * a.ntiles_max + blockIdx.x] = acc;
+        }
+    };
+
+    const int nops = st->nops;
+    for (int i = 0; i < nops; ++i) {
+        const DevOp op = a.ops[st->op_begin + i];
+        const double* cf = coef + (size_t)op.coef * kCoefStride;
+        __syncthreads();
+        flush();
+        cplx d[kSlotsPerGroup];
+#pragma unroll
+        for (int j = 0; j < kSlotsPerGroup; ++j) d[j] = make_double2(0.0, 0.0);
+        bool dots;
+        int nd;
+        if (op.type == 1) {
+            dots = (op.jblock >= a.from) && (op.jblock < a.to);
+            nd = ND_BLOCK;
+            const int plo = min(op.p0, op.p1), phi = max(op.p0, op.p1);
+            const unsigned ic = 1u << op.p0, it = 1u << op.p1;
+            const int flags = op.flags;
+            for (unsigned g = threadIdx.x; g < (tsize >> 2); g += blockDim.x) {
+                const unsigned i0 = insert_zero(insert_zero(g, plo), phi);
+                cplx w[4] = {tw[i0], tw[i0 + it], tw[i0 + ic], tw[i0 + ic + it]};
+                cplx z[4] = {tz[i0], tz[i0 + it], tz[i0 + ic], tz[i0 + ic + it]};
+                if (flags & 1) {
+                    rz2(w[0], w[2], kR, -kR); rz2(w[1], w[3], kR, -kR);
+                    rz2(z[0], z[2], kR, -kR); rz2(z[1], z[3], kR, -kR);
+                }
+                if (ENT == 2) cmacc(d[4], w[3], z[3]);  // -i<P11 w|z>, pre-gate (core_op_matrix.py:430-477)
+                entangle<ENT>(z, cf[8], cf[9]);
+                entangle<ENT>(w, cf[8], cf[9]);
+                // control qubit: Ry(t0), Rz(t1)
+                ry2(w[0], w[2], cf[0], cf[1]); ry2(w[1], w[3], cf[0], cf[1]);
+                ry2(z[0], z[2], cf[0], cf[1]); ry2(z[1], z[3], cf[0], cf[1]);
+                cmacc(d[0], w[0], z[2]); cmsub(d[0], w[2], z[0]);
+                cmacc(d[0], w[1], z[3]); cmsub(d[0], w[3], z[1]);
+                rz2(w[0], w[2], cf[2], cf[3]); rz2(w[1], w[3], cf[2], cf[3]);
+                rz2(z[0], z[2], cf[2], cf[3]); rz2(z[1], z[3], cf[2], cf[3]);
+                cmacc(d[1], w[0], z[0]); cmsub(d[1], w[2], z[2]);
+                cmacc(d[1], w[1], z[1]); cmsub(d[1], w[3], z[3]);
+                // target qubit: Ry(t2), Rs(t3)
+                ry2(w[0], w[1], cf[4], cf[5]); ry2(w[2], w[3], cf[4], cf[5]);
+                ry2(z[0], z[1], cf[4], cf[5]); ry2(z[2], z[3], cf[4], cf[5]);
+                cmacc(d[2], w[0], z[1]); cmsub(d[2], w[1], z[0]);
+                cmacc(d[2], w[2], z[3]); cmsub(d[2], w[3], z[2]);
+                rs2<ENT>(w[0], w[1], cf[6], cf[7]); rs2<ENT>(w[2], w[3], cf[6], cf[7]);
+                rs2<ENT>(z[0], z[1], cf[6], cf[7]); rs2<ENT>(z[2], z[3], cf[6], cf[7]);
+                if (ENT == 0) {  // <X w|z>
+                    cmacc(d[3], w[1], z[0]); cmacc(d[3], w[0], z[1]);
+                    cmacc(d[3], w[3], z[2]); cmacc(d[3], w[2], z[3]);
+                } else {         // <Z w|z>
+                    cmacc(d[3], w[0], z[0]); cmsub(d[3], w[1], z[1]);
+                    cmacc(d[3], w[2], z[2]); cmsub(d[3], w[3], z[3]);
+                }
+                if (flags & 2) {
+                    rz2(w[0], w[1], kR, kR); rz2(w[2], w[3], kR, kR);
+                    rz2(z[0], z[1], kR, kR); rz2(z[2], z[3], kR, kR);
+                }
+                tw[i0] = w[0]; tw[i0 + it] = w[1]; tw[i0 + ic] = w[2]; tw[i0 + ic + it] = w[3];
+                tz[i0] = z[0]; tz[i0 + it] = z[1]; tz[i0 + ic] = z[2]; tz[i0 + ic + it] = z[3];
+            }
+            // factors: dot_y -> 0.5, dot_z / dot_x -> 0.5j, cphase -> -1j
+            d[0] = make_double2(0.5 * d[0].x, 0.5 * d[0].y);
+            d[1] = make_double2(-0.5 * d[1].y, 0.5 * d[1].x);
+            d[2] = make_double2(0.5 * d[2].x, 0.5 * d[2].y);
+            d[3] = make_double2(-0.5 * d[3].y, 0.5 * d[3].x);
+            d[4] = make_double2(d[4].y, -d[4].x);
+        } else {
+            dots = a.front != 0;
+            nd = 3;
+            const unsigned h = 1u << op.p0;
+            for (unsigned g = threadIdx.x; g < (tsize >> 1); g += blockDim.x) {
+                const unsigned i0 = insert_zero(g, op.p0);
+                cplx w0 = tw[i0], w1 = tw[i0 + h], z0 = tz[i0], z1 = tz[i0 + h];
+                rz2(w0, w1, cf[4], cf[5]); rz2(z0, z1, cf[4], cf[5]);   // Rz(t2)
+                cmacc(d[0], w0, z0); cmsub(d[0], w1, z1);
+                ry2(w0, w1, cf[2], cf[3]); ry2(z0, z1, cf[2], cf[3]);   // Ry(t1)
+                cmacc(d[1], w0, z1); cmsub(d[1], w1, z0);
+                rz2(w0, w1, cf[0], cf[1]); rz2(z0, z1, cf[0], cf[1]);   // Rz(t0)
+                cmacc(d[2], w0, z0); cmsub(d[2], w1, z1);
+                tw[i0] = w0; tw[i0 + h] = w1; tz[i0] = z0; tz[i0 + h] = z1;
+            }
+            d[0] = make_double2(-0.5 * d[0].y, 0.5 * d[0].x);
+            d[1] = make_double2(0.5 * d[1].x, 0.5 * d[1].y);
+            d[2] = make_double2(-0.5 * d[2].y, 0.5 * d[2].x);
+        }
+        if (dots) {
+            cplx* s = scratch + ((size_t)(i & 1) * nwaves + wave) * kSlotsPerGroup;
+#pragma unroll
+            for (int j = 0; j < kSlotsPerGroup; ++j) {
+                if (j < nd) {  // nd is wave-uniform
+                    const double re = wave_sum(d[j].x), im = wave_sum(d[j].y);
+                    if (lane == 0) s[j] = make_double2(re, im);
+                }
+            }
+            pend_slot = op.slot; pend_nd = nd; pend_par = i & 1;
+        } else {
+            pend_slot = -1;
+        }
+    }
+    __syncthreads();
+    flush();
+    {
+        cplx* dw = a.out0 + lane_off;
+        cplx* dz = a.out1 + lane_off;
+        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {
+            const unsigned off = tc.dlo[l & 63u] + tc.dhi[l >> 6];
+            dw[off] = tw[l];
+            dz[off] = tz[l];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------
+// coefficient records from thetas: half-angle (cos, sin) pairs (+ full-angle pair for CP)
+__global__ void coef_kernel(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch) {
+    const int ncoef = n + nblocks;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * ncoef) return;
+    const int b = idx / ncoef, ci = idx % ncoef;
+    const int T = 3 * n + tpb * nblocks;
+    const double* th = thetas + (size_t)b * T;
+    double* cf = coef + (size_t)idx * kCoefStride;
+    double s, c;
+    if (ci < n) {
+        for (int j = 0; j < 3; ++j) { sincos(0.5 * th[3 * ci + j], &s, &c); cf[2 * j] = c; cf[2 * j + 1] = s; }
+        for (int j = 6; j < kCoefStride; ++j) cf[j] = 0.0;
+    } else {
+        const double* t = th + 3 * n + (size_t)tpb * (ci - n);
+        for (int j = 0; j < 4; ++j) { sincos(0.5 * t[j], &s, &c); cf[2 * j] = c; cf[2 * j + 1] = s; }
+        if (tpb == 5) { sincos(t[4], &s, &c); cf[8] = c; cf[9] = s; } else { cf[8] = 1.0; cf[9] = 0.0; }
+        cf[10] = cf[11] = 0.0;
+    }
+}
+
+// grads[b][t] = sum over the (<=2) slots feeding theta t, over tiles, in a fixed order.
+__global__ void finalize_kernel(const cplx* partial, const int* theta_slots, const int* slot_ntiles, cplx* grads,
+                                int T, int nslots, int ntiles_max, int n, int tpb, int from, int to, int front) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const bool on = t < 3 * n ? (front != 0) : ((t - 3 * n) / tpb >= from && (t - 3 * n) / tpb < to);
+    double re = 0.0, im = 0.0;
+    if (on) {
+        for (int s = 0; s < 2; ++s) {
+            const int slot = theta_slots[2 * t + s];
+            if (slot < 0) continue;
+            const cplx* p = partial + ((size_t)b * nslots + slot) * ntiles_max;
+            const int nt = slot_ntiles[slot];
+            for (int i = lane; i < nt; i += 64) { re += p[i].x; im += p[i].y; }
+        }
+    }
+    re = wave_sum(re);
+    im = wave_sum(im);
+    if (lane == 0) grads[(size_t)b * T + t] = make_double2(re, im);
+}
+
+__global__ void scatter_one_kernel(cplx* buf, size_t lane_stride, int batch, const long long* elem) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) buf[(size_t)b * lane_stride + (size_t)elem[b]] = make_double2(1.0, 0.0);
+}
+
+__global__ void set_identity_kernel(cplx* buf, size_t lane_stride, int dim, int pitch, int batch) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)batch * dim) {
+        const size_t b = idx / dim, r = idx % dim;
+        buf[b * lane_stride + r * pitch + r] = make_double2(1.0, 0.0);
+    }
+}
+
+__global__ void gather_kernel(const cplx* buf, size_t lane_stride, const long long* elem, int count, int batch, cplx* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < batch * count) {
+        const int b = idx / count, i = idx % count;
+        out[idx] = buf[(size_t)b * lane_stride + (size_t)elem[i]];
+    }
+}
+
+// <a|b> per lane, stage 1: per-workgroup partials; stage 2 sums them with one wave.
+__global__ __launch_bounds__(256) void vdot_partial_kernel(const cplx* a, const cplx* b, size_t lane_stride, size_t count,
+                                                           cplx* part) {
+    __shared__ cplx sm[4];
+    const cplx* pa = a + (size_t)blockIdx.y * lane_stride;
+    const cplx* pb = b + (size_t)blockIdx.y * lane_stride;
+    cplx acc = make_double2(0.0, 0.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        cmacc(acc, pa[i], pb[i]);
+    const double re = wave_sum(acc.x), im = wave_sum(acc.y);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = make_double2(re, im);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cplx s = sm[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { s.x += sm[w].x; s.y += sm[w].y; }
+        part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
+}
+__global__ void vdot_final_kernel(const cplx* part, int nparts, cplx* out) {
+    const cplx* p = part + (size_t)blockIdx.x * nparts;
+    double re = 0.0, im = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) { re += p[i].x; im += p[i].y; }
+    re = wave_sum(re);
+    im = wave_sum(im);
+    if (threadIdx.x == 0) out[blockIdx.x] = make_double2(re, im);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+size_t apply_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned); }
+size_t sweep_lds_bytes(int k, int threads) {
+    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * (threads / 64) * kSlotsPerGroup * sizeof(cplx);
+}
+
+template <typename K>
+static hipError_t allow_big_lds(K kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t init_kernels() {
+    hipError_t e;
+#define AQC_TRY(x) if ((e = (x)) != hipSuccess) return e
+    AQC_TRY(allow_big_lds(apply_stage_kernel<0, false>)); AQC_TRY(allow_big_lds(apply_stage_kernel<0, true>));
+    AQC_TRY(allow_big_lds(apply_stage_kernel<1, false>)); AQC_TRY(allow_big_lds(apply_stage_kernel<1, true>));
+    AQC_TRY(allow_big_lds(apply_stage_kernel<2, false>)); AQC_TRY(allow_big_lds(apply_stage_kernel<2, true>));
+    AQC_TRY(allow_big_lds(sweep_stage_kernel<0>)); AQC_TRY(allow_big_lds(sweep_stage_kernel<1>));
+    AQC_TRY(allow_big_lds(sweep_stage_kernel<2>));
+#undef AQC_TRY
+    return hipSuccess;
+}
+
+hipError_t launch_apply(int ent, bool inverse, int ntiles, int batch, int threads, int k, hipStream_t s, const StageArgs& a) {
+    const dim3 grid(ntiles, batch), block(threads);
+    const size_t lds = apply_lds_bytes(k);
+    switch (ent * 2 + (inverse ? 1 : 0)) {
+        case 0: apply_stage_kernel<0, false><<<grid, block, lds, s>>>(a); break;
+        case 1: apply_stage_kernel<0, true><<<grid, block, lds, s>>>(a); break;
+        case 2: apply_stage_kernel<1, false><<<grid, block, lds, s>>>(a); break;
+        case 3: apply_stage_kernel<1, true><<<grid, block, lds, s>>>(a); break;
+        case 4: apply_stage_kernel<2, false><<<grid, block, lds, s>>>(a); break;
+        default: apply_stage_kernel<2, true><<<grid, block, lds, s>>>(a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(int ent, int ntiles, int batch, int threads, int k, hipStream_t s, const StageArgs& a) {
+    const dim3 grid(ntiles, batch), block(threads);
+    const size_t lds = sweep_lds_bytes(k, threads);
+    switch (ent) {
+        case 0: sweep_stage_kernel<0><<<grid, block, lds, s>>>(a); break;
+        case 1: sweep_stage_kernel<1><<<grid, block, lds, s>>>(a); break;
+        default: sweep_stage_kernel<2><<<grid, block, lds, s>>>(a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch, hipStream_t s) {
+    const int total = batch * (n + nblocks);
+    coef_kernel<<<(total + 127) / 128, 128, 0, s>>>(thetas, coef, n, nblocks, tpb, batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const void* partial, const int* theta_slots, const int* slot_ntiles, void* grads, int T,
+                           int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, int batch,
+                           hipStream_t s) {
+    finalize_kernel<<<dim3(T, batch), 64, 0, s>>>(static_cast<const cplx*>(partial), theta_slots, slot_ntiles,
+                                                   static_cast<cplx*>(grads), T, nslots, ntiles_max, n, tpb, from, to, front);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_one(void* buf, size_t lane_stride, int batch, const long long* elem, hipStream_t s) {
+    scatter_one_kernel<<<(batch + 63) / 64, 64, 0, s>>>(static_cast<cplx*>(buf), lane_stride, batch, elem);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_identity(void* buf, size_t lane_stride, int dim, int pitch, int batch, hipStream_t s) {
+    const size_t total = (size_t)batch * dim;
+    set_identity_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<cplx*>(buf), lane_stride, dim, pitch, batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* elem, int count, int batch, void* out,
+                         hipStream_t s) {
+    const int total = batch * count;
+    gather_kernel<<<(total + 127) / 128, 128, 0, s>>>(static_cast<const cplx*>(buf), lane_stride, elem, count, batch,
+                                                      static_cast<cplx*>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t count, int batch, void* part, int nparts,
+                       void* out, hipStream_t s) {
+    vdot_partial_kernel<<<dim3(nparts, batch), 256, 0, s>>>(static_cast<const cplx*>(a), static_cast<const cplx*>(b),
+                                                            lane_stride, count, static_cast<cplx*>(part));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    vdot_final_kernel<<<batch, 64, 0, s>>>(static_cast<const cplx*>(part), nparts, static_cast<cplx*>(out));
+    return hipGetLastError();
+}
+
+}  // namespace aqc

@@ -1,0 +1,42 @@
+// Host-visible launch interface of aqc_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+#include "aqc_device.h"
+
+namespace aqc {
+
+struct StageArgs {
+    const DevStage* stage;  // this stage's descriptor (device)
+    const DevOp* ops;       // all ops of the plan (device)
+    const double* coef;     // [batch][ncoef][kCoefStride]
+    int ncoef;
+    const double2* in0;     // apply: src; sweep: w in
+    const double2* in1;     // sweep: z in
+    double2* out0;          // apply: dst; sweep: w out
+    double2* out1;          // sweep: z out
+    size_t lane_stride;     // elements between consecutive batch lanes
+    double2* partial;       // [batch][nslots][ntiles_max] inner-product partials
+    int nslots, ntiles_max;
+    int from, to, front;    // block_range / front_layer (core_operations.py:829-830)
+};
+
+size_t apply_lds_bytes(int k);
+size_t sweep_lds_bytes(int k, int threads);
+hipError_t init_kernels();
+hipError_t launch_apply(int ent, bool inverse, int ntiles, int batch, int threads, int k, hipStream_t s, const StageArgs& a);
+hipError_t launch_sweep(int ent, int ntiles, int batch, int threads, int k, hipStream_t s, const StageArgs& a);
+hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch, hipStream_t s);
+hipError_t launch_finalize(const void* partial, const int* theta_slots, const int* slot_ntiles, void* grads, int T,
+                           int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, int batch,
+                           hipStream_t s);
+hipError_t launch_scatter_one(void* buf, size_t lane_stride, int batch, const long long* elem, hipStream_t s);
+hipError_t launch_set_identity(void* buf, size_t lane_stride, int dim, int pitch, int batch, hipStream_t s);
+hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* elem, int count, int batch, void* out,
+                         hipStream_t s);
+hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t count, int batch, void* part, int nparts,
+                       void* out, hipStream_t s);
+
+}  // namespace aqc

@@ -1,0 +1,191 @@
+#include "aqc_plan.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace aqc {
+
+std::string build_program(int n, int entangler, const int32_t* blocks, int L, bool trotter,
+                          bool second_order, Program& out) {
+    if (n < 2 || n > 30) return "number of qubits must be in [2, 30]";
+    if (entangler < 0 || entangler > 2) return "entangler must be 0 (cx), 1 (cz) or 2 (cp)";
+    if (L < 0) return "negative number of blocks";
+    if (L > 0 && blocks == nullptr) return "blocks pointer is null";
+    if (trotter && entangler != 0) return "Trotter ansatz expects the cx entangler";
+    if (second_order && !trotter) return "second_order needs a Trotter ansatz";
+    for (int i = 0; i < L; ++i) {
+        const int c = blocks[i], t = blocks[L + i];
+        if (c < 0 || c >= n || t < 0 || t >= n || c == t) return "not a valid structure of unit-blocks";
+    }
+    if (trotter && L > 0) {
+        // parametric_circuit.py:391-423: layers of triplets (t,c),(c,t),(t,c) on adjacent qubits.
+        if (L % (3 * (n - 1)) != 0) return "not a valid Trotterized block layout";
+        for (int g = 0; g < L / 3; ++g) {
+            const int c0 = blocks[3 * g], t0 = blocks[L + 3 * g];
+            const int c1 = blocks[3 * g + 1], t1 = blocks[L + 3 * g + 1];
+            const int c2 = blocks[3 * g + 2], t2 = blocks[L + 3 * g + 2];
+            if (!(c0 == c2 && t0 == t2 && c0 == t1 && t0 == c1 && c0 == t0 + 1))
+                return "not a valid Trotterized block layout";
+        }
+        if (second_order) {
+            for (int i = 0; i < n / 2; ++i) {
+                const int c1 = blocks[3 * i + 1], t1 = blocks[L + 3 * i + 1];
+                if (!(c1 == 2 * i && t1 == 2 * i + 1)) return "unexpected layout of the leading half-layer";
+            }
+        }
+    }
+    if (trotter && L == 0 && second_order) return "second-order Trotter ansatz needs at least one layer";
+
+    out = Program();
+    out.n = n;
+    out.entangler = entangler;
+    out.num_blocks = L;
+    out.tpb = entangler == 2 ? 5 : 4;
+    out.trotter = trotter;
+    out.second_order = second_order;
+    out.tail_blocks = (trotter && second_order) ? 3 * (n / 2) : 0;
+    out.blocks.assign(blocks, blocks + 2 * (size_t)L);
+    for (int q = 0; q < n; ++q) out.groups.push_back({GROUP_FRONT, q, -1, q, 3 * q, -1, 0});
+    for (int i = 0; i < L + out.tail_blocks; ++i) {
+        const int j = i % L;
+        int flags = 0;
+        if (trotter && i % 3 == 0) flags |= FLAG_PRE_RZ;
+        if (trotter && i % 3 == 2) flags |= FLAG_POST_RZ;
+        out.groups.push_back({GROUP_BLOCK, blocks[j], blocks[L + j], n + j, 3 * n + out.tpb * j, j, flags});
+    }
+    return "";
+}
+
+namespace {
+
+struct Sim {
+    const Program& prog;
+    const std::vector<int>& order;  // remaining group indices in execution order
+    int col_bits;
+    // Number of groups executable with local set `mask`; optionally collects them and
+    // reports the first group that was skipped although none of its bits was blocked yet.
+    int run(uint64_t mask, std::vector<int>* taken, int* first_missing) const {
+        uint64_t blocked = 0;
+        int count = 0;
+        if (first_missing) *first_missing = -1;
+        for (int gi : order) {
+            const GateGroup& g = prog.groups[gi];
+            uint64_t bits = 1ull << (col_bits + g.q0);
+            if (g.q1 >= 0) bits |= 1ull << (col_bits + g.q1);
+            if (bits & blocked) {
+                blocked |= bits;
+            } else if ((bits & mask) == bits) {
+                ++count;
+                if (taken) taken->push_back(gi);
+            } else {
+                if (first_missing && *first_missing < 0) *first_missing = gi;
+                blocked |= bits;
+            }
+            if ((blocked & mask) == mask) break;  // nothing local is usable any more
+        }
+        return count;
+    }
+};
+
+int popcount64(uint64_t v) { return __builtin_popcountll(v); }
+
+}  // namespace
+
+Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, bool inverse) {
+    Plan plan;
+    plan.nbits = col_bits + prog.n;
+    plan.col_bits = col_bits;
+    plan.inverse = inverse;
+    const int k = std::min(std::max(tile_bits, 2), plan.nbits);
+    plan.tile_bits = k;
+    low_bits = std::max(0, std::min(low_bits, k - 2));
+
+    std::vector<int> order(prog.groups.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = inverse ? (int)(order.size() - 1 - i) : (int)i;
+
+    const uint64_t forced = low_bits ? ((1ull << low_bits) - 1) : 0;
+    while (!order.empty()) {
+        Sim sim{prog, order, col_bits};
+        uint64_t best_mask = 0;
+        int best_count = -1;
+        auto consider = [&](uint64_t m) {
+            const int c = sim.run(m, nullptr, nullptr);
+            if (c > best_count) { best_count = c; best_mask = m; }
+        };
+        if (plan.nbits <= k) {
+            best_mask = (1ull << plan.nbits) - 1;
+            best_count = sim.run(best_mask, nullptr, nullptr);
+        } else {
+            // (a) greedy growth along program order
+            uint64_t m = forced;
+            for (;;) {
+                int miss = -1;
+                sim.run(m, nullptr, &miss);
+                if (miss < 0) break;
+                const GateGroup& g = prog.groups[miss];
+                uint64_t need = 1ull << (col_bits + g.q0);
+                if (g.q1 >= 0) need |= 1ull << (col_bits + g.q1);
+                if (popcount64(m | need) > k) break;
+                m |= need;
+            }
+            consider(m);
+            // (b) forced low bits + a contiguous window of the remaining budget
+            for (int a = 0; a < plan.nbits; ++a) {
+                uint64_t w = forced;
+                for (int b = a; b < plan.nbits && popcount64(w) < k; ++b) w |= 1ull << b;
+                consider(w);
+            }
+        }
+        // pad the set to exactly k bits (deterministic: lowest free bits first)
+        for (int b = 0; b < plan.nbits && popcount64(best_mask) < k; ++b) best_mask |= 1ull << b;
+
+        Stage st;
+        for (int b = 0; b < plan.nbits; ++b)
+            if (best_mask >> b & 1) st.bits.push_back(b);
+        sim.run(best_mask, &st.ops, nullptr);
+        if (st.ops.empty()) {  // cannot happen for k >= low_bits + 2; keep the loop finite anyway
+            st.ops.push_back(order.front());
+        }
+        std::vector<char> done(prog.groups.size(), 0);
+        for (int gi : st.ops) done[gi] = 1;
+        std::vector<int> rest;
+        for (int gi : order)
+            if (!done[gi]) rest.push_back(gi);
+        order.swap(rest);
+        plan.stages.push_back(std::move(st));
+    }
+    if (plan.stages.empty()) {  // empty program: one stage of identity so that copies still happen
+        Stage st;
+        for (int b = 0; b < k; ++b) st.bits.push_back(b);
+        plan.stages.push_back(st);
+    }
+    return plan;
+}
+
+std::string check_plan(const Program& prog, const Plan& plan) {
+    const int G = (int)prog.groups.size();
+    std::vector<int> seen(G, 0);
+    std::vector<int> last_on_bit(plan.nbits, plan.inverse ? G : -1);
+    for (const Stage& st : plan.stages) {
+        uint64_t mask = 0;
+        for (int b : st.bits) mask |= 1ull << b;
+        if ((int)st.bits.size() != std::min(plan.tile_bits, plan.nbits)) return "stage with wrong number of local bits";
+        for (int gi : st.ops) {
+            if (gi < 0 || gi >= G) return "group index out of range";
+            if (seen[gi]++) return "group scheduled twice";
+            const GateGroup& g = prog.groups[gi];
+            int bits[2] = {plan.col_bits + g.q0, g.q1 >= 0 ? plan.col_bits + g.q1 : -1};
+            for (int b : bits) {
+                if (b < 0) continue;
+                if (!(mask >> b & 1)) return "group uses a non-local bit";
+                if (plan.inverse ? gi > last_on_bit[b] : gi < last_on_bit[b]) return "per-qubit order violated";
+                last_on_bit[b] = gi;
+            }
+        }
+    }
+    for (int i = 0; i < G; ++i)
+        if (seen[i] != 1) return "group not scheduled";
+    return "";
+}
+
+}  // namespace aqc

@@ -1,0 +1,207 @@
+"""
+Thin object layer over the C ABI: ``HipContext`` (one per ansatz structure) and
+``Workspace`` (device-resident batch of evaluations).  No arithmetic happens
+here -- every number comes from the HIP kernels.
+"""
+import ctypes
+from ctypes import byref, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import BUF_W, BUF_X, BUF_Y, BUF_Z, BUF_ZW, check, dptr  # noqa: F401
+
+
+def _structure_key(circ) -> tuple:
+    trotter = hasattr(circ, "is_second_order")
+    blocks = np.ascontiguousarray(circ.blocks, dtype=np.int32)
+    return (int(circ.num_qubits), str(circ.entangler), blocks.shape[1], blocks.tobytes(), trotter,
+            bool(circ.is_second_order) if trotter else False)
+
+
+class HipContext:
+    """Immutable gate program of one ansatz (aqc_create / aqc_destroy)."""
+
+    _cache = {}
+
+    def __init__(self, circ):
+        L = _lib.lib()
+        n, ent, nb, _, trotter, second = key = _structure_key(circ)
+        if ent not in _lib.ENTANGLERS:
+            raise ValueError(f"unknown entangler {ent!r}")
+        blocks = np.ascontiguousarray(circ.blocks, dtype=np.int32)
+        handle = c_void_p()
+        status = L.aqc_create(n, _lib.ENTANGLERS[ent], blocks.ctypes.data_as(ctypes.POINTER(c_int32)), nb,
+                              int(trotter), int(second), byref(handle))
+        if status != 0:
+            raise ValueError("aqc_hip: " + L.aqc_last_error().decode())
+        self.handle = handle
+        self.key = key
+        self.num_qubits, self.entangler, self.num_blocks = n, ent, nb
+        self.trotter, self.second_order = trotter, second
+        self.num_thetas = L.aqc_num_thetas(handle)
+        self.num_gate_groups = L.aqc_num_gate_groups(handle)
+        self._ws = {}
+
+    @classmethod
+    def of(cls, circ) -> "HipContext":
+        """Context for the circuit's *current* structure (circuits are mutable:
+        update_structure / insert_unit_blocks)."""
+        key = _structure_key(circ)
+        ctx = cls._cache.get(key)
+        if ctx is None:
+            if len(cls._cache) >= 64:
+                cls._cache.pop(next(iter(cls._cache)))
+            ctx = cls._cache[key] = cls(circ)
+        return ctx
+
+    def workspace(self, batch: int = 1, ncols: int = 1, device: int = 0, **kw) -> "Workspace":
+        """Cached workspace for the given shape (function-level drop-ins reuse it)."""
+        key = (batch, ncols, device, tuple(sorted(kw.items())))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = Workspace(self, batch=batch, ncols=ncols, device=device, **kw)
+        return ws
+
+    def plan(self, which: int = 1, ncols: int = 1, tile_bits: int = 0, low_bits: int = -1):
+        """Host-only planner introspection: list of (local_bits, gate_group_indices)."""
+        L = _lib.lib()
+        ns = c_int()
+        check(L.aqc_plan_query(self.handle, ncols, which, tile_bits, low_bits, -1, byref(ns), None, None, None, None))
+        out = []
+        bits = (c_int * 64)()
+        ops = (c_int * max(1, self.num_gate_groups))()
+        for s in range(ns.value):
+            nb, no = c_int(), c_int()
+            check(L.aqc_plan_query(self.handle, ncols, which, tile_bits, low_bits, s, byref(ns), bits, byref(nb), ops, byref(no)))
+            out.append((list(bits[: nb.value]), list(ops[: no.value])))
+        return out
+
+    def __del__(self):
+        try:
+            for ws in self._ws.values():
+                ws.close()
+            if self.handle:
+                _lib.lib().aqc_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Workspace:
+    """``batch`` independent evaluations resident in HBM (aqc_ws_*)."""
+
+    def __init__(self, ctx: HipContext, batch: int = 1, ncols: int = 1, device: int = 0,
+                 tile_bits_apply: int = 0, tile_bits_sweep: int = 0):
+        self.ctx, self.batch, self.ncols, self.device = ctx, int(batch), int(ncols), int(device)
+        self.dim = 1 << ctx.num_qubits
+        self.T = ctx.num_thetas
+        self._L = _lib.lib()
+        handle = c_void_p()
+        check(self._L.aqc_ws_create(ctx.handle, device, batch, ncols, tile_bits_apply, tile_bits_sweep, byref(handle)))
+        self.handle = handle
+
+    # -- data movement -------------------------------------------------------
+    def _shape(self):
+        return (self.batch, self.dim) if self.ncols == 1 else (self.batch, self.dim, self.ncols)
+
+    def set_thetas(self, thetas) -> None:
+        th = _lib.as_f64(thetas, self.batch * self.T, "thetas")
+        check(self._L.aqc_ws_set_thetas(self.handle, dptr(th)))
+
+    def upload(self, buf: int, data, lane: Optional[int] = None) -> None:
+        if lane is None:
+            a = _lib.as_c128(data)
+            if a.size != self.batch * self.dim * self.ncols:
+                raise ValueError(f"expected {self._shape()} complex values, got shape {a.shape}")
+            check(self._L.aqc_ws_upload(self.handle, buf, dptr(a)))
+        else:
+            a = _lib.as_c128(data)
+            if a.size != self.dim * self.ncols:
+                raise ValueError("lane data has the wrong size")
+            check(self._L.aqc_ws_upload_lane(self.handle, buf, lane, dptr(a)))
+
+    def broadcast(self, buf: int, data) -> None:
+        a = _lib.as_c128(data)
+        if a.size != self.dim * self.ncols:
+            raise ValueError("broadcast data has the wrong size")
+        check(self._L.aqc_ws_broadcast(self.handle, buf, dptr(a)))
+
+    def download(self, buf: int, lane: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if lane is None:
+            res = np.empty(self._shape(), dtype=np.complex128) if out is None else out
+            check(self._L.aqc_ws_download(self.handle, buf, dptr(res)))
+        else:
+            res = np.empty(self._shape()[1:], dtype=np.complex128) if out is None else out
+            check(self._L.aqc_ws_download_lane(self.handle, buf, lane, dptr(res)))
+        return res
+
+    def set_basis(self, buf: int, index) -> None:
+        idx = np.ascontiguousarray(np.broadcast_to(np.asarray(index, dtype=np.int64), (self.batch,)))
+        check(self._L.aqc_ws_set_basis(self.handle, buf, idx.ctypes.data_as(ctypes.POINTER(c_int64))))
+
+    def set_identity(self, buf: int) -> None:
+        check(self._L.aqc_ws_set_identity(self.handle, buf))
+
+    # -- compute -------------------------------------------------------------
+    def apply(self, inverse: bool, src: int = BUF_Y, dst: int = BUF_Z) -> None:
+        check(self._L.aqc_ws_apply(self.handle, int(bool(inverse)), src, dst))
+
+    def grad(self, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        check(self._L.aqc_ws_grad(self.handle, lo, hi, int(bool(front_layer))))
+
+    def get_grads(self) -> np.ndarray:
+        g = np.empty((self.batch, self.T), dtype=np.complex128)
+        check(self._L.aqc_ws_get_grads(self.handle, dptr(g)))
+        return g
+
+    def gather(self, buf: int, index) -> np.ndarray:
+        idx = np.ascontiguousarray(index, dtype=np.int64).ravel()
+        out = np.empty((self.batch, idx.size), dtype=np.complex128)
+        check(self._L.aqc_ws_gather(self.handle, buf, idx.ctypes.data_as(ctypes.POINTER(c_int64)), idx.size, dptr(out)))
+        return out
+
+    def vdot(self, buf_a: int, buf_b: int) -> np.ndarray:
+        out = np.empty(self.batch, dtype=np.complex128)
+        check(self._L.aqc_ws_vdot(self.handle, buf_a, buf_b, dptr(out)))
+        return out
+
+    def sync(self) -> None:
+        check(self._L.aqc_ws_sync(self.handle))
+
+    # -- measurement ---------------------------------------------------------
+    def timer_start(self) -> None:
+        check(self._L.aqc_ws_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = c_float()
+        check(self._L.aqc_ws_timer_stop(self.handle, byref(ms)))
+        return float(ms.value)
+
+    def profile(self, on: bool) -> None:
+        check(self._L.aqc_ws_profile_enable(self.handle, int(on)))
+        if on:
+            check(self._L.aqc_ws_profile_reset(self.handle))
+
+    def profile_get(self, kind: int) -> Tuple[int, float]:
+        n, ms = c_int64(), c_double()
+        check(self._L.aqc_ws_profile_get(self.handle, kind, byref(n), byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def plan_info(self, which: int) -> Tuple[int, int, int]:
+        a, b, c = c_int(), c_int(), c_int()
+        check(self._L.aqc_ws_plan_info(self.handle, which, byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._L.aqc_ws_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

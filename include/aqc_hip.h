@@ -1,0 +1,122 @@
+/*
+ * aqc_hip.h -- C ABI of the MI355X-native fidelity/gradient path of aqc-research.
+ *
+ * The reference (qiskit-community/aqc-research v0.1.0) has no FFI: the boundary
+ * of this path is a set of Python functions and duck-typed objective objects.
+ * Each entry point below names the reference interface it replaces (file:line
+ * relative to the reference tree); INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - complex128 arrays travel as interleaved (re, im) doubles;
+ *   - qubit q is bit q of the amplitude index (Qiskit order,
+ *     core_operations.py:34-43); a (d, k) matrix is row-major
+ *     (core_op_matrix.py:56);
+ *   - blocks is int32[2][L] row-major: row 0 = control, row 1 = target
+ *     (parametric_circuit.py:24-70);
+ *   - every function returns 0 on success; on failure a non-zero code is
+ *     returned and aqc_last_error() gives the message (the ABI never throws
+ *     and never calls back into the host language);
+ *   - a context is immutable after creation and may be shared; a workspace
+ *     owns one HIP device + one stream and is NOT thread-safe (one workspace
+ *     per thread / process, exactly like the reference's one-objective-per-
+ *     process model, job_executor.py:141).
+ */
+#ifndef AQC_HIP_H
+#define AQC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aqc_ctx aqc_ctx; /* ansatz description + gate program (host only) */
+typedef struct aqc_ws aqc_ws;   /* device-resident batch workspace            */
+
+enum { AQC_CX = 0, AQC_CZ = 1, AQC_CP = 2 };
+/* device buffers of a workspace, each [batch][2^n][ncols] complex128 */
+enum { AQC_BUF_Y = 0, AQC_BUF_Z = 1, AQC_BUF_X = 2, AQC_BUF_W = 3, AQC_BUF_ZW = 4, AQC_NUM_BUFS = 5 };
+/* kernel families for aqc_ws_profile_get */
+enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC_K_MISC = 4, AQC_NUM_KINDS = 5 };
+
+const char* aqc_version(void);
+const char* aqc_last_error(void);
+
+/* ---- ansatz description: ParametricCircuit / TrotterAnsatz
+ *      (parametric_circuit.py:24-70,267-320; validity rules :234-254,391-423) */
+int aqc_create(int num_qubits, int entangler, const int32_t* blocks, int num_blocks,
+               int trotter, int second_order, aqc_ctx** out);
+int aqc_destroy(aqc_ctx* ctx);
+int aqc_num_thetas(const aqc_ctx* ctx);          /* parametric_circuit.py:108-112 */
+int aqc_num_gate_groups(const aqc_ctx* ctx);     /* G = n + L_eff     */
+
+/* ---- one-shot, host-pointer entry points (function-level drop-ins).
+ * vec/out/x/vh_y: complex128[2^n]; grad: complex128[num_thetas]. */
+/* core_operations.py:606  v_mul_vec(circ, thetas, vec, out, workspace) */
+int aqc_v_mul_vec(aqc_ctx* ctx, const double* thetas, const double* vec, double* out);
+/* core_operations.py:713  v_dagger_mul_vec(circ, thetas, vec, out, workspace) */
+int aqc_vdag_mul_vec(aqc_ctx* ctx, const double* thetas, const double* vec, double* out);
+/* core_operations.py:823  grad_of_dot_product(circ, thetas, x_vec, vh_y_vec, workspace,
+ *                          block_range, front_layer); block_from<0 => full range */
+int aqc_grad_dot_vec(aqc_ctx* ctx, const double* thetas, const double* x, const double* vh_y,
+                     int block_from, int block_to, int front_layer, double* grad);
+/* core_op_matrix.py:480 / :562  v_mul_mat / v_dagger_mul_mat(circ, thetas, mat, workspace);
+ * mat: complex128[2^n][ncols], updated in place */
+int aqc_v_mul_mat(aqc_ctx* ctx, const double* thetas, double* mat, int ncols);
+int aqc_vdag_mul_mat(aqc_ctx* ctx, const double* thetas, double* mat, int ncols);
+/* core_op_matrix.py:645  grad_of_matrix_dot_product(circ, thetas, x_mat, vh_y_mat, workspace);
+ * unlike the reference the inputs are left intact (the Python shim reproduces the clobbering
+ * contract where callers rely on it) */
+int aqc_grad_dot_mat(aqc_ctx* ctx, const double* thetas, const double* x_mat, const double* vh_y_mat,
+                     int ncols, double* grad);
+
+/* ---- device-resident batch workspace: `batch` independent evaluations
+ * (own thetas, own target) advance together in every launch.  This is what the
+ * objective objects (objective_lhs_sur_max.py:82-191, sk_core.py:167-222) and
+ * the job executor (job_executor.py:96) sit on.
+ * ncols = 1 for state vectors, k for (2^n x k) matrices.
+ * tile_bits_* = 0 selects the default LDS tile size. */
+int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_apply,
+                  int tile_bits_sweep, aqc_ws** out);
+int aqc_ws_destroy(aqc_ws* ws);
+int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas /* [batch][T] */);
+int aqc_ws_upload(aqc_ws* ws, int buf, const double* src /* [batch][2^n][ncols] c128 */);
+int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src);
+int aqc_ws_broadcast(aqc_ws* ws, int buf, const double* src /* [2^n][ncols] c128, same for all lanes */);
+int aqc_ws_download(aqc_ws* ws, int buf, double* dst);
+int aqc_ws_download_lane(aqc_ws* ws, int buf, int lane, double* dst);
+/* X_lane <- one-hot basis state |index[lane]>  (ThinStateHandler.init_state, objective_base.py:99-116) */
+int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index /* [batch] */);
+/* X <- identity matrix (FullRangeSketchingVectors.generate, sk_core.py:317-326); needs ncols == 2^n */
+int aqc_ws_set_identity(aqc_ws* ws, int buf);
+/* dst <- V src (inverse=0) or V^H src (inverse=1), per lane, with the lane's thetas */
+int aqc_ws_apply(aqc_ws* ws, int inverse, int src_buf, int dst_buf);
+/* grads <- complex gradient of <V X|Y> from X and Z = V^H Y (kept intact); W/ZW are scratch */
+int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer);
+int aqc_ws_get_grads(aqc_ws* ws, double* grads /* [batch][T] c128 */);
+/* out[lane][i] = buf[lane][index[i]]  (ThinStateHandler.state_dot_vector, objective_base.py:166-177) */
+int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* out);
+/* out[lane] = <a_lane|b_lane> (np.vdot; GenericStateHandler.state_dot_vector, sk_core.py:192) */
+int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out /* [batch] c128 */);
+int aqc_ws_sync(aqc_ws* ws);
+
+/* ---- measurement hooks (bench.py): HIP events on the workspace's own stream */
+int aqc_ws_timer_start(aqc_ws* ws);
+int aqc_ws_timer_stop(aqc_ws* ws, float* elapsed_ms); /* synchronises */
+/* per-kernel-family timing: when enabled every launch is bracketed by events */
+int aqc_ws_profile_enable(aqc_ws* ws, int on);
+int aqc_ws_profile_get(aqc_ws* ws, int kind, int64_t* launches, double* total_ms);
+int aqc_ws_profile_reset(aqc_ws* ws);
+/* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
+int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,
+                     int* num_stages, int* tile_bits, int* num_tiles);
+/* host-only planner introspection (no GPU needed): stage s of plan `which` for the given tiling;
+ * ops_out receives gate-group indices (forward program order), bits_out the local address bits */
+int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage,
+                   int* num_stages, int* bits_out, int* num_bits, int* ops_out, int* num_ops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQC_HIP_H */

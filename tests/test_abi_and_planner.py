@@ -1,0 +1,111 @@
+"""CPU-only: the C-ABI library loads and exports every symbol of include/aqc_hip.h; the
+host-side planner produces valid stage plans; host-side validation raises like the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import aqc_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    from aqc_research_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "aqc_hip.h")).read()
+    declared = set(re.findall(r"\b(aqc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()  # resolves every symbol or raises
+    assert L.aqc_version().startswith(b"aqc_hip")
+
+
+def _circ(n, ent, blocks, trotter=False, order2=False):
+    from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+
+    return TrotterAnsatz(n, blocks, order2) if trotter else ParametricCircuit(n, ent, blocks)
+
+
+@pytest.mark.parametrize("n,depth", [(2, 1), (3, 4), (6, 11), (12, 40), (16, 40), (20, 64)])
+def test_planner_valid_plans(n, depth):
+    from aqc_research_amd.engine import HipContext
+
+    rng = np.random.default_rng(n)
+    layouts = [orc.spin_blocks(n, depth), np.stack([rng.permutation(n)[:2] for _ in range(depth)], axis=1)]
+    for blocks in layouts:
+        ctx = HipContext.of(_circ(n, "cx", blocks.astype(np.int64)))
+        G = ctx.num_gate_groups
+        assert G == n + depth
+        for which in (0, 1, 2):
+            for k in (2, 4, 7, 10, 12, 13):
+                for low in (0, 2, 3):
+                    plan = ctx.plan(which, 1, k, low)  # library validates (check_plan) or raises
+                    ops = [g for _, o in plan for g in o]
+                    assert sorted(ops) == list(range(G))
+                    for bits, o in plan:
+                        assert len(bits) == min(k, n) and bits == sorted(bits)
+                        if low and k - 2 >= low and n > k:
+                            assert bits[:low] == list(range(low))
+
+
+def test_planner_matrix_and_trotter():
+    from aqc_research_amd.engine import HipContext
+
+    ctx = HipContext.of(_circ(10, "cx", orc.spin_blocks(10, 40)))
+    plan = ctx.plan(1, 1024, 12, 2)  # config 5: all ten qubits + 2 column bits in one LDS tile
+    assert len(plan) == 1 and plan[0][0] == [0, 1] + list(range(10, 20))
+    t = HipContext.of(_circ(12, "cx", orc.trotter_blocks(12, 2), True, True))
+    assert t.num_gate_groups == 12 + 66 + 18 and t.num_thetas == 36 + 4 * 66
+    assert len(t.plan(1, 1, 12, 3)) == 1  # 12 qubits: the whole sweep is one launch
+
+
+def test_validation_errors():
+    from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+
+    with pytest.raises(ValueError):
+        ParametricCircuit(3, "cx", np.array([[0, 1], [0, 2]]))  # ctrl == targ
+    with pytest.raises(ValueError):
+        ParametricCircuit(3, "cx", np.array([[0, 3], [1, 2]]))  # out of range
+    with pytest.raises(ValueError):
+        ParametricCircuit(3, "xx", np.array([[0], [1]]))
+    with pytest.raises(ValueError):
+        TrotterAnsatz(4, orc.spin_blocks(4, 9), second_order=False)  # not triplets
+    tb = orc.trotter_blocks(5, 1)
+    circ = TrotterAnsatz(5, tb, second_order=True)
+    assert circ.num_layers == 1 and circ.bpl == 12 and circ.half_layer_num_blocks == 6
+    with pytest.raises(ValueError):
+        circ.insert_unit_blocks(3, tb)  # not aligned at a layer boundary
+    th, idx = circ.insert_unit_blocks(12, tb, np.ones(circ.num_thetas))
+    assert circ.num_blocks == 24 and th.size == circ.num_thetas and np.all(th[idx] == 0) and idx[0] == 15 + 48
+    # C ABI rejects what the Python layer would (defence in depth)
+    from aqc_research_amd import _lib
+    import ctypes
+
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    bad = np.array([0, 0], dtype=np.int32)
+    assert L.aqc_create(3, 0, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 1, 0, 0, ctypes.byref(h)) != 0
+    assert b"unit-blocks" in L.aqc_last_error()
+
+
+def test_fails_loudly_without_gpu():
+    """On a box without an AMD GPU the product path must raise, never fall back."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "from aqc_research_amd import ParametricCircuit\n"
+        "import aqc_research_amd.core_operations as cop\n"
+        "c = ParametricCircuit(2, 'cx', np.array([[0],[1]]))\n"
+        "v = np.zeros(4, complex); v[0] = 1\n"
+        "try:\n"
+        "    cop.v_mul_vec(c, np.zeros(c.num_thetas), v, np.zeros(4, complex), None)\n"
+        "    print('COMPUTED')\n"
+        "except RuntimeError as e:\n"
+        "    print('RAISED', e)\n" % ROOT
+    )
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300).stdout
+    assert "RAISED" in out and "no CPU fallback" in out, out

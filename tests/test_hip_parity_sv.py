@@ -1,0 +1,150 @@
+"""GPU parity: HIP state-vector path vs golden vectors (reference outputs) and vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import aqc_oracle as orc
+from tests.helpers import TOL, ansatz_from, load, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+SV = load("state_vector.npz")
+
+
+def make_circ(a: orc.Ansatz):
+    from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+
+    if a.trotter:
+        return TrotterAnsatz(a.n, a.blocks, second_order=a.second_order)
+    return ParametricCircuit(a.n, a.entangler, a.blocks)
+
+
+@pytest.mark.parametrize("key", [str(k) for k in SV["names"]])
+def test_golden_function_level(key):
+    import aqc_research_amd.core_operations as cop
+
+    a = ansatz_from(SV, key)
+    circ = make_circ(a)
+    th, x, y = SV[f"{key}/thetas"], SV[f"{key}/x"].copy(), SV[f"{key}/y"].copy()
+    dim = 1 << a.n
+    ws = np.zeros((3, dim), np.complex128)
+    out = np.zeros(dim, np.complex128)
+    res = cop.v_mul_vec(circ, th, x, out, ws[:2])
+    assert res is out and maxdiff(out, SV[f"{key}/v_x"]) < TOL
+    vhy = cop.v_dagger_mul_vec(circ, th, y, np.zeros(dim, np.complex128), ws[:2])
+    assert maxdiff(vhy, SV[f"{key}/vh_y"]) < TOL
+    x0, v0 = x.copy(), vhy.copy()
+    g = cop.grad_of_dot_product(circ, th, x, vhy, ws)
+    assert g.dtype == np.complex128 and g.shape == (a.num_thetas,)
+    assert maxdiff(g, SV[f"{key}/grad_full"]) < TOL
+    assert np.array_equal(x, x0) and np.array_equal(vhy, v0)  # inputs intact (core_operations.py:892-893)
+    br = tuple(int(v) for v in SV[f"{key}/block_range"])
+    gp = cop.grad_of_dot_product(circ, th, x, vhy, ws, block_range=br, front_layer=False)
+    assert maxdiff(gp, SV[f"{key}/grad_part"]) < TOL
+    # out aliasing vec (test_core_operations.py:270)
+    buf = y.copy()
+    cop.v_dagger_mul_vec(circ, th, buf, buf, ws[:2])
+    assert maxdiff(buf, SV[f"{key}/vh_y"]) < TOL
+
+
+CASES = [
+    # n, entangler/kind, depth, tile_bits_apply, tile_bits_sweep, batch
+    (7, "cx", 12, 4, 4, 1),
+    (8, "cz", 15, 5, 6, 3),
+    (9, "cp", 14, 6, 5, 2),
+    (10, "cx", 30, 7, 7, 2),
+    (11, "cp", 20, 11, 11, 1),
+    (12, "cz", 25, 8, 9, 1),
+    (13, "cx", 40, 13, 12, 2),
+    (14, "cx", 40, 10, 10, 1),
+]
+
+
+@pytest.mark.parametrize("n,ent,depth,ka,ks,batch", CASES)
+def test_oracle_multistage_batched(n, ent, depth, ka, ks, batch):
+    """Random generic circuits; small tiles force many stages and many tiles; lanes carry
+    different thetas / targets."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    rng = np.random.default_rng(100 * n + depth)
+    blocks = np.stack([rng.permutation(n)[:2] for _ in range(depth)], axis=1).astype(np.int64)
+    a = orc.Ansatz(n, ent, blocks)
+    ctx = HipContext.of(make_circ(a))
+    ws = Workspace(ctx, batch=batch, tile_bits_apply=ka, tile_bits_sweep=ks)
+    th = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(batch)])
+    x = np.stack([orc.rand_state(n, rng) for _ in range(batch)])
+    y = np.stack([orc.rand_state(n, rng) for _ in range(batch)])
+    ws.set_thetas(th)
+    ws.upload(BUF_Y, y)
+    ws.upload(BUF_X, x)
+    ws.apply(True, BUF_Y, BUF_Z)
+    z = ws.download(BUF_Z)
+    ws.grad(None, True)
+    g = ws.get_grads()
+    hs = ws.vdot(BUF_X, BUF_Z)
+    for b in range(batch):
+        zr = orc.v_dagger_mul_vec(a, th[b], y[b])
+        assert maxdiff(z[b], zr) < TOL
+        assert maxdiff(g[b], orc.grad_of_dot_product(a, th[b], x[b], zr)) < TOL
+        assert abs(hs[b] - np.vdot(x[b], zr)) < TOL
+    # forward apply and V V^H = I
+    ws.apply(False, BUF_Z, BUF_Y)
+    assert maxdiff(ws.download(BUF_Y), y) < TOL
+    ws.close()
+
+
+@pytest.mark.parametrize("n,layers,order2", [(6, 2, True), (9, 2, True), (12, 2, True), (12, 1, False)])
+def test_trotter_vs_oracle(n, layers, order2):
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    rng = np.random.default_rng(7 * n + layers)
+    a = orc.Ansatz(n, "cx", orc.trotter_blocks(n, layers), True, order2)
+    ctx = HipContext.of(make_circ(a))
+    for ka, ks in ((0, 0), (6, 5)):
+        ws = Workspace(ctx, batch=1, tile_bits_apply=ka, tile_bits_sweep=ks)
+        th, y = orc.rand_thetas(a.num_thetas, rng), orc.rand_state(n, rng)
+        ws.set_thetas(th)
+        ws.upload(BUF_Y, y)
+        ws.apply(True, BUF_Y, BUF_Z)
+        zr = orc.v_dagger_mul_vec(a, th, y)
+        assert maxdiff(ws.download(BUF_Z)[0], zr) < TOL
+        idx = int(rng.integers(0, 1 << n))
+        ws.set_basis(BUF_X, idx)
+        x = np.zeros(1 << n, complex); x[idx] = 1
+        bpl = 3 * (n - 1)
+        for br, front in ((None, True), ((0, bpl), False), ((bpl, 2 * bpl) if layers > 1 else (1, bpl - 1), False)):
+            ws.grad(br, front)
+            assert maxdiff(ws.get_grads()[0], orc.grad_of_dot_product(a, th, x, zr, br, front)) < TOL
+        got = ws.gather(BUF_Z, [0, idx, (1 << n) - 1])[0]
+        assert maxdiff(got, zr[[0, idx, (1 << n) - 1]]) == 0.0
+        ws.close()
+
+
+def test_headline_size_properties():
+    """n=16, L=40 (BASELINE configs[2] geometry): parity vs the oracle plus size-independent
+    properties (unitarity, linearity of the gradient in x)."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n, L = 16, 40
+    rng = np.random.default_rng(16)
+    a = orc.Ansatz(n, "cx", orc.spin_blocks(n, L))
+    ws = Workspace(HipContext.of(make_circ(a)), batch=2)
+    th = np.stack([orc.rand_thetas(a.num_thetas, rng)] * 2)
+    y = orc.rand_state(n, rng)
+    x1, x2 = orc.rand_state(n, rng), orc.rand_state(n, rng)
+    ws.set_thetas(th)
+    ws.broadcast(BUF_Y, y)
+    ws.apply(True, BUF_Y, BUF_Z)
+    z = ws.download(BUF_Z)
+    zr = orc.v_dagger_mul_vec(a, th[0], y)
+    assert maxdiff(z[0], zr) < TOL and np.array_equal(z[0], z[1])
+    assert abs(np.linalg.norm(z[0]) - 1) < 1e-12
+    ws.upload(BUF_X, np.stack([x1, x2]))
+    ws.grad()
+    g = ws.get_grads()
+    assert maxdiff(g[0], orc.grad_of_dot_product(a, th[0], x1, zr)) < TOL
+    ws.upload(BUF_X, np.stack([x1 + 2j * x2, x1]))
+    ws.grad()
+    g2 = ws.get_grads()
+    assert maxdiff(g2[0], g[0] - 2j * g[1]) < 1e-9  # <V x|y> is anti-linear in x
+    assert maxdiff(g2[1], g[0]) == 0.0  # bitwise reproducible
+    ws.close()

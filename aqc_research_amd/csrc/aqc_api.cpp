@@ -124,7 +124,10 @@ struct aqc_ws {
     size_t lane_elems = 0;  // 2^nbits
     hipStream_t stream = nullptr;
     DevPlan fwd, inv, sweep;
-    double* d_thetas = nullptr;
+    double* d_thetas = nullptr;       // parameters in use (own buffer or a slice of the bank)
+    double* d_thetas_own = nullptr;
+    double* d_theta_bank = nullptr;
+    int bank_sets = 0, gather_count = 0;
     double* d_coef = nullptr;
     double2* bufs[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double2* d_partial = nullptr;
@@ -372,7 +375,8 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     WS_HIP(hipEventCreate(&ws->ev0)); WS_HIP(hipEventCreate(&ws->ev1));
     WS_HIP(hipEventCreate(&ws->pev0)); WS_HIP(hipEventCreate(&ws->pev1));
     WS_TRY(upload_plan(ws->fwd)); WS_TRY(upload_plan(ws->inv)); WS_TRY(upload_plan(ws->sweep));
-    WS_HIP(hipMalloc((void**)&ws->d_thetas, sizeof(double) * (size_t)batch * std::max(T, 1)));
+    WS_HIP(hipMalloc((void**)&ws->d_thetas_own, sizeof(double) * (size_t)batch * std::max(T, 1)));
+    ws->d_thetas = ws->d_thetas_own;
     WS_HIP(hipMalloc((void**)&ws->d_coef, sizeof(double) * (size_t)batch * (prog.n + prog.num_blocks) * kCoefStride));
     for (int b = 0; b < AQC_NUM_BUFS; ++b) {
         WS_HIP(hipMalloc((void**)&ws->bufs[b], sizeof(double2) * (size_t)batch * ws->lane_elems));
@@ -401,7 +405,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_stages) (void)hipFree(p->d_stages);
         if (p->d_ops) (void)hipFree(p->d_ops);
     }
-    void* ptrs[] = {ws->d_thetas, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
+    void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
                     ws->d_theta_slots, ws->d_slot_ntiles};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
@@ -416,6 +420,7 @@ int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas) {
     HIP_OK(hipSetDevice(ws->device));
     const Program& prog = ws->ctx->prog;
     const int T = prog.num_thetas();
+    ws->d_thetas = ws->d_thetas_own;
     HIP_OK(hipMemcpyAsync(ws->d_thetas, thetas, sizeof(double) * (size_t)ws->batch * T, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));  // the host buffer may be reused right away
     {
@@ -478,6 +483,7 @@ int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
         elem[b] = (long long)index[b] << ws->col_bits;
     }
     if (ensure_index(ws, ws->batch)) return 1;
+    ws->gather_count = 0;
     HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * ws->batch, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     HIP_OK(hipMemsetAsync(ws->bufs[buf], 0, sizeof(double2) * (size_t)ws->batch * ws->lane_elems, ws->stream));
@@ -560,6 +566,7 @@ int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* 
         elem[i] = (long long)index[i] << ws->col_bits;
     }
     if (ensure_index(ws, count) || ensure_small(ws, (size_t)ws->batch * count)) return 1;
+    ws->gather_count = 0;
     HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     {
@@ -576,12 +583,76 @@ int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out) {
     if (!out) return fail("null output");
     HIP_OK(hipSetDevice(ws->device));
     if (ensure_small(ws, ws->batch)) return 1;
+    ws->gather_count = 0;
     {
         ProfScope ps(ws, AQC_K_MISC);
         HIP_OK(launch_vdot(ws->bufs[buf_a], ws->bufs[buf_b], ws->lane_elems, ws->lane_elems, ws->batch, ws->d_vdot_part,
                            ws->vdot_parts, ws->d_small, ws->stream));
     }
     HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_theta_bank(aqc_ws* ws, const double* thetas, int nsets) {
+    if (!ws || !thetas || nsets < 1) return fail("invalid theta bank arguments");
+    HIP_OK(hipSetDevice(ws->device));
+    const size_t bytes = sizeof(double) * (size_t)nsets * ws->batch * std::max(ws->ctx->prog.num_thetas(), 1);
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (ws->d_theta_bank) HIP_OK(hipFree(ws->d_theta_bank));
+    ws->d_theta_bank = nullptr;
+    ws->bank_sets = 0;
+    ws->d_thetas = ws->d_thetas_own;
+    HIP_OK(hipMalloc((void**)&ws->d_theta_bank, bytes));
+    HIP_OK(hipMemcpyAsync(ws->d_theta_bank, thetas, bytes, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    ws->bank_sets = nsets;
+    return 0;
+}
+
+int aqc_ws_use_theta_set(aqc_ws* ws, int set_index) {
+    if (!ws) return fail("null workspace");
+    if (set_index < 0 || set_index >= ws->bank_sets) return fail("theta set %d out of range (%d loaded)", set_index, ws->bank_sets);
+    HIP_OK(hipSetDevice(ws->device));
+    const Program& prog = ws->ctx->prog;
+    ws->d_thetas = ws->d_theta_bank + (size_t)set_index * ws->batch * prog.num_thetas();
+    ProfScope ps(ws, AQC_K_COEF);
+    HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, ws->batch, ws->stream));
+    ws->coef_valid = true;
+    return 0;
+}
+
+int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count) {
+    if (!ws || !index || count < 1) return fail("invalid gather arguments");
+    HIP_OK(hipSetDevice(ws->device));
+    const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
+    std::vector<long long> elem(count);
+    for (int i = 0; i < count; ++i) {
+        if (index[i] < 0 || index[i] >= dim) return fail("gather index out of range");
+        elem[i] = (long long)index[i] << ws->col_bits;
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (ensure_index(ws, count) || ensure_small(ws, (size_t)ws->batch * count)) return 1;
+    HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    ws->gather_count = count;
+    return 0;
+}
+
+int aqc_ws_gather_launch(aqc_ws* ws, int buf) {
+    if (check_buf(ws, buf)) return 1;
+    if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
+    HIP_OK(hipSetDevice(ws->device));
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream));
+    return 0;
+}
+
+int aqc_ws_gather_fetch(aqc_ws* ws, double* out) {
+    if (!ws || !out) return fail("null argument");
+    if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch * ws->gather_count, hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     return 0;
 }

@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import BUF_W, BUF_X, BUF_Y, BUF_Z, BUF_ZW, check, dptr  # noqa: F401
+from ._lib import BUF_W, BUF_X, BUF_Y, BUF_Z, BUF_ZW, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, check, dptr  # noqa: F401
 
 
 def _structure_key(circ) -> tuple:
@@ -166,6 +166,31 @@ class Workspace:
     def vdot(self, buf_a: int, buf_b: int) -> np.ndarray:
         out = np.empty(self.batch, dtype=np.complex128)
         check(self._L.aqc_ws_vdot(self.handle, buf_a, buf_b, dptr(out)))
+        return out
+
+    # -- asynchronous, HBM-resident variants ------------------------------------
+    def theta_bank(self, thetas) -> int:
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        if th.size % (self.batch * self.T):
+            raise ValueError("theta bank must have shape (nsets, batch, T)")
+        nsets = th.size // (self.batch * self.T)
+        check(self._L.aqc_ws_theta_bank(self.handle, dptr(th), nsets))
+        return nsets
+
+    def use_theta_set(self, i: int) -> None:
+        check(self._L.aqc_ws_use_theta_set(self.handle, int(i)))
+
+    def gather_setup(self, index) -> None:
+        idx = np.ascontiguousarray(index, dtype=np.int64).ravel()
+        self._gather_count = idx.size
+        check(self._L.aqc_ws_gather_setup(self.handle, idx.ctypes.data_as(ctypes.POINTER(c_int64)), idx.size))
+
+    def gather_launch(self, buf: int) -> None:
+        check(self._L.aqc_ws_gather_launch(self.handle, buf))
+
+    def gather_fetch(self) -> np.ndarray:
+        out = np.empty((self.batch, self._gather_count), dtype=np.complex128)
+        check(self._L.aqc_ws_gather_fetch(self.handle, dptr(out)))
         return out
 
     def sync(self) -> None:

@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""
+bench.py -- objective+gradient evaluations/sec of the HIP fidelity/gradient path.
+
+One *step* = one full objective+gradient evaluation for each of the `batch`
+independent (theta, target) lanes resident on the GPU:
+    coefficient kernel (sin/cos of the lane's thetas)
+  + V^H |target>                      (objective: hs = <state_i|V^H|target>)
+  + gather of the n+1 flip-state amplitudes
+  + forward w/z sweep with all inner products + fixed-order finalize  (gradient)
+Thetas change every step (bank of K+W parameter sets resident in HBM), so nothing is
+served from a cache.  Default workload = BASELINE.json's headline: 16 qubits, 40 blocks
+(cx, spin layout, T = 208), state-vector path.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload NAME]
+For N > 1 launch with torch.distributed.run (one rank per GPU); ranks process their own
+lanes (weak scaling) and only the final result records are gathered (RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (n, layout, L, kind)
+    "sv16_l40": dict(n=16, blocks=40, kind="generic", desc="16-qubit, 40-block cx spin ansatz, state-vector objective+gradient"),
+    "sv12_trotter2": dict(n=12, layers=2, kind="trotter2", desc="12-qubit ASP, 2nd-order Trotter ansatz (2 layers), state-vector objective+gradient"),
+    "sv20_l40": dict(n=20, blocks=40, kind="generic", desc="20-qubit, 40-block cx spin ansatz, state-vector objective+gradient"),
+}
+
+
+def build_circuit(w):
+    from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+    from aqc_research_amd.circuit_structures import create_ansatz_structure, make_trotter_like_circuit
+
+    if w["kind"] == "generic":
+        return ParametricCircuit(w["n"], "cx", create_ansatz_structure(w["n"], "spin", "full", w["blocks"]))
+    return TrotterAnsatz(w["n"], make_trotter_like_circuit(w["n"], w["layers"]), second_order=True)
+
+
+def cpu_baseline(circ, seconds=12.0):
+    """Reference algorithm restated in NumPy (oracle/aqc_oracle.py), timed on the host cores
+    of this box on a bounded sample of the same workload (1 thread)."""
+    from oracle import aqc_oracle as orc
+
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        limiter = None
+    rng = np.random.default_rng(7)
+    a = orc.as_ansatz(circ)
+    target = orc.rand_state(a.n, rng)
+    x = np.zeros(a.dim, complex)
+    x[0] = 1
+
+    def one():
+        th = orc.rand_thetas(a.num_thetas, rng)
+        vh = orc.v_dagger_mul_vec(a, th, target)
+        orc.grad_of_dot_product(a, th, x, vh)
+
+    one()  # warm-up
+    t0, count = time.perf_counter(), 0
+    while count < 3 or (time.perf_counter() - t0 < seconds and count < 200):
+        one()
+        count += 1
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return {
+        "value": count / dt,
+        "unit": "evals/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{count} objective+gradient evaluations of the same ansatz (NumPy restatement of the reference, 1 thread, {dt:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="independent evaluations resident per GPU")
+    ap.add_argument("--workload", default="sv16_l40", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(args.gpus, world) if world > 1 else args.gpus
+    if world == 1 and args.gpus > 1:
+        print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU); running 1 GPU", file=sys.stderr)
+        n_gpus = 1
+
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, HipContext, Workspace
+    from oracle import aqc_oracle as orc
+
+    w = WORKLOADS[args.workload]
+    circ = build_circuit(w)
+    n, T = circ.num_qubits, circ.num_thetas
+    ctx = HipContext.of(circ)
+    G = ctx.num_gate_groups
+    N = 1 << n
+    B, K, W = args.batch, args.steps, args.warmup
+
+    rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule
+    ws = Workspace(ctx, batch=B, device=local_rank)
+    targets = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    ws.upload(BUF_Y, targets)
+    ws.set_basis(BUF_X, 0)  # x = |0>
+    flip_idx = orc.flip_state_indices(n, 1)
+    ws.gather_setup(flip_idx)
+    nsets = K + W
+    bank = np.pi * (2 * rng.random((nsets, B, T)) - 1)
+    ws.theta_bank(bank)
+
+    def step(i):
+        ws.use_theta_set(i)
+        ws.apply(True, BUF_Y, BUF_Z)
+        ws.gather_launch(BUF_Z)
+        ws.grad(None, True)
+
+    def barrier():
+        ws.sync()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    ws.timer_start()
+    for i in range(W, W + K):
+        step(i)
+    ev_ms = ws.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # result record of the last step (checked + gathered: the only inter-GPU traffic)
+    hs = ws.gather_fetch()
+    grads = ws.get_grads()
+    record = np.array([np.abs(hs[:, 0]).mean() ** 2, np.linalg.norm(grads.real)], dtype=np.float64)
+    if dist is not None:
+        import torch
+
+        rec = torch.from_numpy(record).to(f"cuda:{local_rank}")
+        allrec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations on this stream (HIP events around every launch) ----------
+        ws.profile(True)
+        prof_steps = min(K, 10)
+        for i in range(W, W + prof_steps):
+            step(i)
+        ws.sync()
+        kinds = {"apply": K_APPLY, "sweep": K_SWEEP, "coef": K_COEF, "finalize": K_FINALIZE, "misc": K_MISC}
+        prof = {k: ws.profile_get(v) for k, v in kinds.items()}
+        ws.profile(False)
+        sweep_launches, sweep_ms = prof["sweep"]
+        apply_launches, apply_ms = prof["apply"]
+        # algorithmic bytes: one gate group = read+write of each live vector
+        sweep_bytes_per_step = 4 * 16 * N * G * B   # two vectors
+        apply_bytes_per_step = 2 * 16 * N * G * B   # one vector
+        sweep_avg_ms = sweep_ms / max(sweep_launches, 1)
+        sweep_bytes_per_launch = sweep_bytes_per_step * prof_steps / max(sweep_launches, 1)
+        achieved = sweep_bytes_per_launch / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
+        stages_inv, k_inv, tiles_inv = ws.plan_info(0)
+        stages_sw, k_sw, tiles_sw = ws.plan_info(1)
+
+        # ---- single-evaluation latency (batch 1, host-visible result each call) ---------------
+        latency = None
+        if not args.no_latency:
+            ws1 = Workspace(ctx, batch=1, device=local_rank)
+            ws1.upload(BUF_Y, targets[0])
+            ws1.set_basis(BUF_X, 0)
+            ths = np.pi * (2 * rng.random((30, T)) - 1)
+            for i in range(5):
+                ws1.set_thetas(ths[i]); ws1.apply(True, BUF_Y, BUF_Z); ws1.gather(BUF_Z, flip_idx); ws1.grad(); ws1.get_grads()
+            t1 = time.perf_counter()
+            for i in range(5, 30):
+                ws1.set_thetas(ths[i]); ws1.apply(True, BUF_Y, BUF_Z); ws1.gather(BUF_Z, flip_idx); ws1.grad(); ws1.get_grads()
+            latency = (time.perf_counter() - t1) / 25 * 1e3
+            ws1.close()
+
+        evals = K * B * n_gpus
+        value = evals / wall
+        out = {
+            "metric": "objective+gradient evals/sec",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": n_gpus,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": wall / K * 1e3,
+            "ms_per_eval": wall / (K * B) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": w["desc"],
+                "n_qubits": n,
+                "num_thetas": T,
+                "gate_groups": G,
+                "batch_per_gpu": B,
+                "path": "state-vector (core_operations)",
+                "tile_bits": {"vdag": k_inv, "sweep": k_sw},
+                "launches_per_eval_step": {"vdag": stages_inv, "sweep": stages_sw},
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "sweep_stage_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": sweep_avg_ms,
+                "algorithmic_bytes_per_launch": sweep_bytes_per_launch,
+                "note": "algorithmic bytes = 64 B x 2^n x gate groups x lanes per launch (SURVEY 8d); a launch fuses "
+                        "many gate groups in LDS, so achieved may exceed what HBM itself could stream",
+            },
+            "kernel_ms_per_step": {k: v[1] / prof_steps for k, v in prof.items()},
+            "device_ms_per_step_events": ev_ms / K,
+            "latency_batch1_ms": latency,
+            "algorithmic_GBps_whole_eval": (sweep_bytes_per_step + apply_bytes_per_step) * K / wall / 1e9,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(circ)
+        print(json.dumps(out))
+    ws.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

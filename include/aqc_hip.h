@@ -101,6 +101,15 @@ int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* 
 int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out /* [batch] c128 */);
 int aqc_ws_sync(aqc_ws* ws);
 
+/* ---- fully asynchronous variants: inputs stay resident in HBM, nothing below synchronises.
+ * A theta bank holds `nsets` parameter sets [nsets][batch][T]; selecting one only launches the
+ * coefficient kernel.  Gathered amplitudes stay on the device until fetched. */
+int aqc_ws_theta_bank(aqc_ws* ws, const double* thetas, int nsets);
+int aqc_ws_use_theta_set(aqc_ws* ws, int set_index);
+int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count);
+int aqc_ws_gather_launch(aqc_ws* ws, int buf);
+int aqc_ws_gather_fetch(aqc_ws* ws, double* out /* [batch][count] c128 */);
+
 /* ---- measurement hooks (bench.py): HIP events on the workspace's own stream */
 int aqc_ws_timer_start(aqc_ws* ws);
 int aqc_ws_timer_stop(aqc_ws* ws, float* elapsed_ms); /* synchronises */

@@ -1,0 +1,73 @@
+"""
+Matrix entry points with the reference signatures (core_op_matrix.py:480,562,645,765),
+executed by the HIP kernels.  A row-major (2^n, k) matrix is a flat array in which qubit q
+has stride k*2^q, so the same fused stage kernels run with the column index as extra
+low-order ("batch") address bits; k is padded to a power of two on the device.
+"""
+from typing import Optional
+
+import numpy as np
+
+from .engine import BUF_X, BUF_Y, BUF_Z, HipContext
+from .parametric_circuit import TrotterAnsatz
+
+
+def _check(circ, thetas, mat: np.ndarray, name: str) -> np.ndarray:
+    if isinstance(circ, TrotterAnsatz):
+        raise ValueError("the matrix path takes a plain ParametricCircuit (core_op_matrix.py:480-559)")
+    th = np.asarray(thetas)
+    if th.ndim != 1 or th.size != circ.num_thetas or not np.issubdtype(th.dtype, np.floating):
+        raise ValueError("thetas: expects a float vector of size circ.num_thetas")
+    if not (isinstance(mat, np.ndarray) and mat.dtype == np.complex128 and mat.ndim == 2 and mat.flags.c_contiguous):
+        raise ValueError(f"{name}: expects a C-contiguous complex128 matrix")
+    if mat.shape[0] != circ.dimension or mat.shape[1] > mat.shape[0] or mat.shape[1] < 1:
+        raise ValueError(f"{name}: expects shape (2^n, k) with 1 <= k <= 2^n")
+    return np.ascontiguousarray(th, dtype=np.float64)
+
+
+def _no_overlap(a, workspace) -> None:
+    if isinstance(workspace, np.ndarray) and np.may_share_memory(a, workspace):
+        raise ValueError("matrix must not overlap the workspace")
+
+
+def _apply(circ, thetas, mat, workspace, inverse: bool) -> np.ndarray:
+    th = _check(circ, thetas, mat, "mat")
+    _no_overlap(mat, workspace)
+    ws = HipContext.of(circ).workspace(1, mat.shape[1])
+    ws.set_thetas(th)
+    ws.upload(BUF_Y, mat)
+    ws.apply(inverse, BUF_Y, BUF_Z)
+    ws.download(BUF_Z, lane=0, out=mat)
+    return mat
+
+
+def v_mul_mat(circ, thetas: np.ndarray, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """mat <- V(thetas) @ mat in place; returns ``mat`` (core_op_matrix.py:480)."""
+    return _apply(circ, thetas, mat, workspace, False)
+
+
+def v_dagger_mul_mat(circ, thetas: np.ndarray, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """mat <- V(thetas)^H @ mat in place; returns ``mat`` (core_op_matrix.py:562)."""
+    return _apply(circ, thetas, mat, workspace, True)
+
+
+def grad_of_matrix_dot_product(
+    circ, thetas: np.ndarray, x_mat: np.ndarray, vh_y_mat: np.ndarray, workspace: Optional[np.ndarray] = None
+) -> np.ndarray:
+    """Complex gradient of <V X|Y>_F given vh_y = V^H Y (core_op_matrix.py:645).  The
+    reference clobbers both inputs; here they are left intact (their final content is
+    never consumed by any reference caller: sk_core.py:190-193 regenerates them)."""
+    th = _check(circ, thetas, x_mat, "x_mat")
+    _check(circ, thetas, vh_y_mat, "vh_y_mat")
+    if x_mat.shape != vh_y_mat.shape:
+        raise ValueError("x_mat and vh_y_mat must have the same shape")
+    if np.may_share_memory(x_mat, vh_y_mat):
+        raise ValueError("x_mat and vh_y_mat must not overlap")
+    _no_overlap(x_mat, workspace)
+    _no_overlap(vh_y_mat, workspace)
+    ws = HipContext.of(circ).workspace(1, x_mat.shape[1])
+    ws.set_thetas(th)
+    ws.upload(BUF_X, x_mat)
+    ws.upload(BUF_Z, vh_y_mat)
+    ws.grad(None, True)
+    return ws.get_grads()[0]

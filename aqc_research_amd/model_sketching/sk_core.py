@@ -1,0 +1,148 @@
+"""
+Full / sketched unitary-AQC objective ``1 - Re<X|V^H|Y>/k`` on the GPU: drop-in for
+SketchingObjectiveEx + FullRangeSketchingVectors (sk_core.py:34-326).
+"""
+from time import perf_counter
+from typing import Optional, Tuple, Union
+
+import numpy as np
+
+from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext
+from ..parametric_circuit import ParametricCircuit
+
+
+class SketchingVectorsBase:
+    """Generator of X (2^n x k) and Y = U X (sk_core.py:34-91)."""
+
+    def __init__(self, num_skvecs: int, target_mat: np.ndarray):
+        if not (isinstance(target_mat, np.ndarray) and target_mat.ndim == 2 and target_mat.shape[0] == target_mat.shape[1]
+                and target_mat.dtype == np.complex128):
+            raise ValueError("target_mat must be a square complex128 matrix")
+        num_skvecs = min(max(int(num_skvecs), 1), target_mat.shape[0])
+        if num_skvecs & (num_skvecs - 1):
+            raise ValueError("'num_skvecs' must be a power of 2 number")
+        self._num_skvecs, self._target_mat = num_skvecs, target_mat
+
+    num_skvecs = property(lambda self: self._num_skvecs)
+    target_matrix = property(lambda self: self._target_mat)
+
+    def generate(self, circ=None, thetas=None) -> Tuple[np.ndarray, np.ndarray]:
+        raise NotImplementedError("abstract method")
+
+
+class FullRangeSketchingVectors(SketchingVectorsBase):
+    """X = I, Y = U (sk_core.py:300-326).  ``device_resident`` tells the objective that X
+    and Y never change, so they are placed in HBM once instead of per call."""
+
+    device_resident = True
+
+    def __init__(self, target_mat: np.ndarray):
+        super().__init__(target_mat.shape[0], target_mat)
+
+    def generate(self, _=None, __=None) -> Tuple[np.ndarray, np.ndarray]:
+        return np.eye(self._target_mat.shape[0], dtype=np.complex128), np.array(self._target_mat, dtype=np.complex128)
+
+
+class SketchingObjectiveEx:
+    """fobj = 1 - Re Tr<V Q, U Q>/k and its gradient (sk_core.py:94-297); stoppers and the
+    gradient amplifier are duck-typed host objects."""
+
+    def __init__(self, circ: ParametricCircuit, skvecs: SketchingVectorsBase, *, enable_stats: bool = False,
+                 grad_scaler=None, stop_timeout=None, stop_stagnant=None, stop_small_fobj=None, logger=None, device: int = 0):
+        if not isinstance(skvecs, SketchingVectorsBase):
+            raise TypeError("skvecs must derive from SketchingVectorsBase")
+        if skvecs.target_matrix.shape[0] != circ.dimension:
+            raise ValueError("target matrix does not match the circuit dimension")
+        self._circ, self._skvecs, self._target = circ, skvecs, skvecs.target_matrix
+        self._enable_stats, self._grad_scaler, self._logger = enable_stats, grad_scaler, logger
+        self._stop_timeout, self._stop_stagnant, self._stop_small_fobj = stop_timeout, stop_stagnant, stop_small_fobj
+        self._fobj_best = float(np.inf)
+        self._thetas_best = np.zeros(circ.num_thetas)
+        self._nit = 0
+        self._fobj_profile = []
+        self._fobj_latest = float(1e30)
+        self._grad_latest = np.empty(0)
+        self._thetas_latest = np.empty(0)
+        self._elapsed_time = perf_counter()
+        self._period = int(round(10 + 60.0 / (1 + 2.0 ** (6 - circ.num_qubits))))
+        self._structure = None
+        self._device = device
+        self._ws = None
+
+    def _workspace(self):
+        """Workspace for the circuit's current structure (blocks may be edited between calls)."""
+        ctx = HipContext.of(self._circ)
+        if self._ws is None or self._structure != ctx.key:
+            self._ws = ctx.workspace(1, self._skvecs.num_skvecs, self._device)
+            self._structure = ctx.key
+            if getattr(self._skvecs, "device_resident", False):
+                self._ws.set_identity(BUF_X)
+                self._ws.upload(BUF_Y, np.ascontiguousarray(self._target, dtype=np.complex128))
+        return self._ws
+
+    def objective_and_gradient(self, thetas: np.ndarray) -> Tuple[float, np.ndarray]:
+        now = perf_counter()
+        if self._elapsed_time + self._period < now:
+            print(".", end="", flush=True)
+            self._elapsed_time = now
+        k = self._skvecs.num_skvecs
+        ws = self._workspace()
+        if not getattr(self._skvecs, "device_resident", False):
+            x, y = self._skvecs.generate(self._circ, thetas)
+            ws.upload(BUF_X, x)
+            ws.upload(BUF_Y, y)
+        ws.set_thetas(thetas)
+        ws.apply(True, BUF_Y, BUF_Z)                      # V^H Y            (sk_core.py:191)
+        fobj = float(1 - np.real(ws.vdot(BUF_X, BUF_Z)[0]) / k)   # 1 - Re<X|V^H Y>/k (:192)
+        ws.grad(None, True)                               # sweep            (:193)
+        grad = -np.real(ws.get_grads()[0]) / k
+        if self._grad_scaler:
+            grad *= self._grad_scaler.estimate(fobj)
+        if fobj < self._fobj_best:
+            self._fobj_best = fobj
+            np.copyto(self._thetas_best, thetas)
+        self._nit += 1
+        if self._enable_stats:
+            self._fobj_profile.append(float(fobj))
+        if self._logger is not None:
+            print(f"\riter: {self._nit:4d}, fobj: {fobj:0.4f}, |grad|: {np.linalg.norm(grad):0.5f}")
+        if self._stop_timeout:
+            self._stop_timeout.check()
+        if self._stop_stagnant:
+            self._stop_stagnant.check(fobj=fobj, iter_no=self._nit)
+        if self._stop_small_fobj:
+            self._stop_small_fobj.check(fobj=fobj)
+        return fobj, grad
+
+    def objective(self, thetas: np.ndarray) -> float:
+        self._thetas_latest = np.array(thetas, dtype=np.float64)
+        self._fobj_latest, self._grad_latest = self.objective_and_gradient(thetas)
+        return self._fobj_latest
+
+    def gradient(self, thetas: np.ndarray) -> np.ndarray:
+        tol = float(10.0 * np.finfo(np.float64).eps)
+        last = self._thetas_latest
+        if last.size == 0 or not np.allclose(thetas, last, atol=tol, rtol=tol):
+            self.objective(thetas)
+        return self._grad_latest
+
+    @property
+    def statistics(self) -> dict:
+        return {"convergence_profile": np.asarray(self._fobj_profile, dtype=np.float32), "nit": self._nit}
+
+    num_iterations = property(lambda self: int(self._nit))
+
+    @property
+    def optim_results(self) -> dict:
+        return {
+            "cost": float(self._fobj_best),
+            "num_fun_ev": int(self._nit),
+            "num_grad_ev": int(self._nit),
+            "num_iters": int(self._nit),
+            "thetas": self._thetas_best,
+            "entangler": self._circ.entangler,
+            "blocks": self._circ.blocks.copy(),
+        }
+
+    def set_status_trackers(self, timeout, stopper):
+        """Compatibility with AqcOptimizer.optimize (optimizer.py:561-563)."""

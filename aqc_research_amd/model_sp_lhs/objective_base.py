@@ -1,0 +1,230 @@
+"""
+Host-side glue of the state-preparation (ASP) objectives: flip-state bookkeeping,
+statistics / early-stop service and the common base class.  Mirrors the public surface of
+model_sp_lhs/objective_base.py:42-255,437-834; all vector arithmetic is delegated to the
+HIP workspace, only scalars live here.
+"""
+import itertools
+from typing import Callable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+from ..parametric_circuit import ParametricCircuit
+
+
+class ThinStateHandler:
+    """|0>, X_i|0>, X_i X_j|0>, ... kept as the index of their single non-zero amplitude
+    (objective_base.py:42-255).  ``base_index`` XORs a computational-basis preparation
+    (e.g. the Neel pattern, trotter.py:389-398) on top of every state."""
+
+    def __init__(self, num_qubits: int, max_flips: int, verbose: bool = False, base_index: int = 0):
+        if not (isinstance(num_qubits, (int, np.integer)) and num_qubits >= 2):
+            raise ValueError("num_qubits must be an integer >= 2")
+        if not (isinstance(max_flips, (int, np.integer)) and 0 <= max_flips <= num_qubits):
+            raise ValueError("max_flips must be in [0, num_qubits]")
+        self._n = int(num_qubits)
+        self._comb_labels: List[List[Tuple]] = [
+            list(itertools.combinations(range(num_qubits), f)) for f in range(1, max_flips + 1)
+        ]
+        idx = [0]
+        for combos in self._comb_labels:
+            for sub in combos:
+                v = 0
+                for q in sub:
+                    v ^= 1 << q  # Qiskit bit order (core_operations.py:34-43)
+                idx.append(v)
+        self._state_idx = np.asarray(idx, dtype=np.int64) ^ np.int64(base_index)
+
+    @property
+    def num_states(self) -> int:
+        return int(self._state_idx.size)
+
+    @property
+    def state_indices(self) -> np.ndarray:
+        return self._state_idx
+
+    @property
+    def flip_qubit_positions(self) -> List[List[Tuple]]:
+        return self._comb_labels
+
+    def init_state(self, state_no: int) -> np.ndarray:
+        """Dense copy of a state (host convenience / tests only)."""
+        s = np.zeros(1 << self._n, dtype=np.complex128)
+        s[self._state_idx[state_no]] = 1
+        return s
+
+    @property
+    def state0(self) -> np.ndarray:
+        return self.init_state(0)
+
+    def state_dot_vector(self, state_no: int, vec: np.ndarray) -> np.complex128:
+        return vec[self._state_idx[state_no]]
+
+
+class DenseStateHandler:
+    """States given explicitly as rows of a (num_states, 2^n) array -- the HIP-side
+    counterpart of GenericStateHandler (objective_base.py:258-342), whose Qiskit circuit
+    simulation is outside this path."""
+
+    def __init__(self, states: np.ndarray):
+        st = np.ascontiguousarray(states, dtype=np.complex128)
+        if st.ndim != 2 or st.shape[1] & (st.shape[1] - 1):
+            raise ValueError("states must have shape (num_states, 2^n)")
+        self._states = st
+
+    num_states = property(lambda self: int(self._states.shape[0]))
+    state0 = property(lambda self: self._states[0])
+
+    def init_state(self, state_no: int) -> np.ndarray:
+        return self._states[state_no]
+
+
+class SpService:
+    """Counters, statistics and early-termination hooks (objective_base.py:437-622).
+    Stoppers are duck-typed (TimeoutChecker / EarlyStopper of the reference's optimizer.py
+    work unchanged) and always run on the host, outside native calls, so the exceptions
+    they raise propagate to the optimizer."""
+
+    def __init__(self, user_parameters: dict, circuit, num_states: int, verbose: bool = False):
+        self._params, self._circuit, self._num_states, self._verbose = user_parameters, circuit, num_states, verbose
+        self._num_fun_ev = 0
+        self._num_grad_ev = 0
+        self._timeout_checker = None
+        self._early_stopper = None
+        self._stats = {}
+        if user_parameters.get("enable_optim_stats", False):
+            self._stats = {
+                "hs2": np.empty((0, num_states), dtype=np.float16),
+                "weight": np.empty(0, dtype=np.float16),
+                "fobj": np.empty(0, dtype=np.float32),
+                "grad": np.empty(0, dtype=np.float32),
+                "num_fun_ev": 0,
+                "num_grad_ev": 0,
+            }
+
+    def set_status_trackers(self, timeout=None, stopper=None):
+        self._timeout_checker, self._early_stopper = timeout, stopper
+
+    statistics = property(lambda self: self._stats)
+
+    def _on_stop(self, fobj: float, thetas: np.ndarray) -> dict:
+        return {
+            "cost": fobj,
+            "num_fun_ev": self._num_fun_ev,
+            "num_grad_ev": self._num_grad_ev,
+            "num_iters": self._num_grad_ev,
+            "thetas": thetas.copy(),
+            "blocks": self._circuit.blocks.copy(),
+        }
+
+    def on_begin_gradient(self, fobj: float, thetas: np.ndarray, fidelity: Optional[float] = None):
+        if self._timeout_checker:
+            self._timeout_checker.check(fobj, thetas, self._on_stop)
+        if self._early_stopper:
+            self._early_stopper.check(fobj=fobj, fidelity=fidelity, thetas=thetas, iter_no=self._num_grad_ev, on_stop=self._on_stop)
+
+    def on_end_gradient(self, fobj: float, fidelity: float, grad: np.ndarray, hs2: np.ndarray, weight: float):
+        self._num_grad_ev += 1
+        if self._stats:
+            s = self._stats
+            s["hs2"] = np.vstack((s["hs2"], hs2.astype(np.float16)[None, :]))
+            s["weight"] = np.append(s["weight"], np.float16(weight))
+            s["fobj"] = np.append(s["fobj"], np.float32(fobj))
+            s["grad"] = np.append(s["grad"], np.float32(np.linalg.norm(grad)))
+            s["num_fun_ev"], s["num_grad_ev"], s["num_iters"] = self._num_fun_ev, self._num_grad_ev, self._num_grad_ev
+        if self._params.get("verbose", 0) and self._num_grad_ev % max(1, self._params.get("maxiter", 50) // 50) == 0:
+            print(".", end="", flush=True)
+
+    def on_end_objective(self):
+        self._num_fun_ev += 1
+
+    def on_epoch_end(self):
+        if self._stats:
+            s = self._stats
+            s["hs2"] = np.vstack((s["hs2"], np.full((1, self._num_states), np.nan, dtype=np.float16)))
+            s["weight"] = np.append(s["weight"], np.float16(np.nan))
+            s["fobj"] = np.append(s["fobj"], np.float32(np.nan))
+            s["grad"] = np.append(s["grad"], np.float32(np.nan))
+
+
+class SpLHSObjectiveBase:
+    """Base of the local-Hilbert-Schmidt state-preparation objectives
+    (objective_base.py:630-834).  ``user_parameters`` keys: num_qubits, max_flips, optional
+    state_prep_func, enable_optim_stats, verbose, maxiter, device.
+
+    ``state_prep_func(num_qubits)`` may return an ``int`` (bit mask of a computational-basis
+    preparation, e.g. the Neel state) or a dense (num_states, 2^n) array of prepared states;
+    Qiskit circuits are outside this path."""
+
+    def __init__(self, user_parameters: dict, circuit: ParametricCircuit, use_mps: bool = False, verbose: bool = False):
+        if not isinstance(user_parameters, dict):
+            raise TypeError("user_parameters must be a dict")
+        self._params, self._circuit, self._verbose, self._use_mps = user_parameters, circuit, verbose, bool(use_mps)
+        self._target = None
+        self._last_thetas = np.empty(0)
+        n = int(user_parameters["num_qubits"])
+        if n != circuit.num_qubits:
+            raise ValueError("user_parameters['num_qubits'] differs from the circuit")
+        max_flips = int(user_parameters["max_flips"])
+        prep = user_parameters.get("state_prep_func", None)
+        prepared = prep(n) if callable(prep) else prep
+        if prepared is None:
+            self._state_handler = ThinStateHandler(n, max_flips, verbose)
+        elif isinstance(prepared, (int, np.integer)):
+            self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=int(prepared))
+        elif isinstance(prepared, np.ndarray):
+            self._state_handler = DenseStateHandler(prepared)
+        else:
+            raise NotImplementedError(
+                "state_prep_func must return a basis-state bit mask (int) or a dense array of states; "
+                "Qiskit circuits are not simulated by the HIP path"
+            )
+        self._num_states = self._state_handler.num_states
+        self._service = SpService(user_parameters, circuit, self._num_states, verbose=verbose)
+        self._hs2 = np.zeros(self._num_states)
+        self._fobj = 1.0
+        self._weight = 1.0
+        # device side: one lane; Y = target, Z = V^H target, X = lhs state
+        self._ws: Workspace = HipContext.of(circuit).workspace(1, 1, int(user_parameters.get("device", 0)))
+
+    def _store_latest_thetas(self, thetas: np.ndarray):
+        self._last_thetas = np.array(thetas, dtype=np.float64)
+
+    def _calc_objective_before_gradient(self, thetas: np.ndarray):
+        """objective_base.py:715-734: optimizers may ask for the gradient first (ADAM)."""
+        tol = float(np.sqrt(np.finfo(np.float64).eps))
+        last = self._last_thetas
+        if last.size == 0 or not np.allclose(thetas, last, atol=tol, rtol=tol):
+            self.objective(thetas)
+
+    def objective(self, thetas: np.ndarray) -> float:
+        raise NotImplementedError()
+
+    def gradient(self, thetas: np.ndarray) -> np.ndarray:
+        raise NotImplementedError()
+
+    def set_status_trackers(self, timeout=None, stopper=None):
+        self._service.set_status_trackers(timeout, stopper)
+
+    num_thetas = property(lambda self: self._circuit.num_thetas)
+    num_states = property(lambda self: self._num_states)
+    target = property(lambda self: self._target)
+    statistics = property(lambda self: self._service.statistics)
+
+    def set_target(self, target) -> None:
+        """Uploads the state to approximate (objective_base.py:804-819)."""
+        if isinstance(target, np.ndarray):
+            if target.dtype != np.complex128 or target.shape != (self._circuit.dimension,):
+                raise ValueError("target: expects a complex128 vector of size 2^n")
+            self._target = target
+            self._ws.upload(BUF_Y, target)
+        else:
+            self._set_mps_target(target)
+        self._last_thetas = np.empty(0)
+
+    def _set_mps_target(self, target) -> None:
+        raise ValueError("this objective expects a dense target vector")
+
+    def on_epoch_end(self):
+        self._service.on_epoch_end()

@@ -1,0 +1,106 @@
+"""
+Surrogate state-preparation objective ``1 - (1-w)|h_0|^2 - w|h_max|^2`` on state vectors:
+drop-in for SpSurrogateObjectiveMax (objective_lhs_sur_max.py:32-196).  ``objective`` runs
+V^H|target> on the GPU and reads back the n+1 flip-state amplitudes; ``gradient`` runs one
+(or two) w/z sweeps; the hysteresis / weight-smoothing state machine stays on the host.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+
+from ..engine import BUF_X, BUF_Y, BUF_Z
+from ..parametric_circuit import ParametricCircuit
+from .objective_base import DenseStateHandler, SpLHSObjectiveBase
+
+
+class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
+    _gamma = 0.1  # exponential smoothing of the weight (objective_lhs_sur_max.py:40)
+
+    def __init__(
+        self,
+        *,
+        user_parameters: dict,
+        circ: ParametricCircuit,
+        block_range: Optional[Tuple[int, int]] = None,
+        front_layer: bool = False,
+        verbose: bool = False,
+        grad_scaler=None,
+    ):
+        super().__init__(user_parameters, circ, verbose=verbose)
+        block_range = (0, circ.num_blocks) if block_range is None else block_range
+        if not (isinstance(block_range, tuple) and len(block_range) == 2
+                and 0 <= block_range[0] < block_range[1] <= circ.num_blocks):
+            raise ValueError("block_range must be a tuple (from, to) with 0 <= from < to <= num_blocks")
+        if not isinstance(front_layer, (bool, np.bool_)):
+            raise TypeError("front_layer must be bool")
+        self._block_range = (int(block_range[0]), int(block_range[1]))
+        self._front_layer = bool(front_layer)
+        self._fidelity = float(-1)
+        self._grad_scaler = grad_scaler
+        self._hs = np.zeros(self._num_states, dtype=np.complex128)
+        self._max_no = 0
+        self._dense = isinstance(self._state_handler, DenseStateHandler)
+
+    def _projections(self) -> np.ndarray:
+        """hs[i] = <state_i|V^H|target> for every state."""
+        ws = self._ws
+        if not self._dense:
+            return ws.gather(BUF_Z, self._state_handler.state_indices)[0]
+        out = np.empty(self._num_states, dtype=np.complex128)
+        for i in range(self._num_states):
+            ws.upload(BUF_X, self._state_handler.init_state(i))
+            out[i] = ws.vdot(BUF_X, BUF_Z)[0]
+        return out
+
+    def _load_lhs(self, state_no: int) -> None:
+        if self._dense:
+            self._ws.upload(BUF_X, self._state_handler.init_state(state_no))
+        else:
+            self._ws.set_basis(BUF_X, int(self._state_handler.state_indices[state_no]))
+
+    def objective(self, thetas: np.ndarray) -> float:
+        if self._target is None:
+            raise RuntimeError("set_target() has not been called")
+        self._store_latest_thetas(thetas)
+        ws = self._ws
+        ws.set_thetas(thetas)
+        ws.apply(True, BUF_Y, BUF_Z)  # V^H |target>   (objective_lhs_sur_max.py:96-102)
+        self._hs[:] = self._projections()
+        np.copyto(self._hs2, np.absolute(self._hs) ** 2)
+        # hysteresis: the leading state changes only for a 10 % better candidate (:113-117)
+        max_proj = self._hs2[self._max_no]
+        for i in range(self._num_states):
+            if 1.1 * max_proj < self._hs2[i]:
+                max_proj = self._hs2[i]
+                self._max_no = i
+        wgh = self._weight
+        self._fobj = float(1.0 - (1.0 - wgh) * self._hs2[0] - wgh * self._hs2[self._max_no])
+        self._fidelity = float(self._hs2[0])
+        self._service.on_end_objective()
+        return self._fobj
+
+    def _sweep(self, state_no: int, front: bool) -> np.ndarray:
+        self._load_lhs(state_no)
+        self._ws.grad(self._block_range, front)
+        return self._ws.get_grads()[0]
+
+    def gradient(self, thetas: np.ndarray) -> np.ndarray:
+        self._service.on_begin_gradient(self._fobj, thetas, self._fidelity)  # may raise (stoppers)
+        self._calc_objective_before_gradient(thetas)
+        front = bool(self._front_layer or self._block_range == (0, self._circuit.num_blocks))
+        grad_0 = self._sweep(0, front)
+        if self._max_no == 0:
+            full_grad = (grad_0 * (-2 * np.conj(self._hs[0]))).real.copy()
+        else:
+            full_grad = (grad_0 * (-2 * (1 - self._weight) * np.conj(self._hs[0]))).real.copy()
+            grad_max = self._sweep(self._max_no, front)
+            full_grad += (grad_max * (-2 * self._weight * np.conj(self._hs[self._max_no]))).real
+        if self._grad_scaler:
+            full_grad *= self._grad_scaler.estimate(self._fobj)
+        self._weight += self._gamma * (float(np.sqrt(abs(self._fobj))) - self._weight)
+        self._service.on_end_gradient(self._fobj, self._fidelity, full_grad, self._hs2, self._weight)
+        return full_grad
+
+    @property
+    def fidelity(self) -> float:
+        return self._fidelity

@@ -140,6 +140,13 @@ struct aqc_ws {
     int* d_slot_ntiles = nullptr;
     int nslots = 0, vdot_parts = 0;
     bool coef_valid = false;
+    struct MpsSlot {
+        std::vector<int> dims;          // n + 1 bond dimensions
+        std::vector<size_t> offset;     // element offset of site q inside d_t
+        double2* d_t = nullptr;         // [q][2][dims[q]][dims[q+1]], lambda folded in
+    } mps[AQC_MPS_SLOTS];
+    double2* d_mps_scratch = nullptr;
+    size_t mps_scratch_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     bool profile = false;
     int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
@@ -409,6 +416,8 @@ int aqc_ws_destroy(aqc_ws* ws) {
                     ws->d_theta_slots, ws->d_slot_ntiles};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
+    for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
+    if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1}) if (ev) (void)hipEventDestroy(ev);
     if (ws->stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
@@ -653,6 +662,125 @@ int aqc_ws_gather_fetch(aqc_ws* ws, double* out) {
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
     HIP_OK(hipSetDevice(ws->device));
     HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch * ws->gather_count, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+// ---- MPS helpers ------------------------------------------------------------------------------
+
+static int mps_scratch(aqc_ws* ws, size_t n_cplx) {
+    if (n_cplx <= ws->mps_scratch_cap) return 0;
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (ws->d_mps_scratch) HIP_OK(hipFree(ws->d_mps_scratch));
+    ws->d_mps_scratch = nullptr;
+    ws->mps_scratch_cap = 0;
+    HIP_OK(hipMalloc((void**)&ws->d_mps_scratch, n_cplx * sizeof(double2)));
+    ws->mps_scratch_cap = n_cplx;
+    return 0;
+}
+
+static int check_mps_slot(const aqc_ws* ws, int slot, bool need_data) {
+    if (!ws) return fail("null workspace");
+    if (ws->ncols != 1) return fail("MPS helpers need a state-vector workspace (ncols == 1)");
+    if (slot < 0 || slot >= AQC_MPS_SLOTS) return fail("MPS slot %d out of range", slot);
+    if (need_data && !ws->mps[slot].d_t) return fail("MPS slot %d is empty", slot);
+    return 0;
+}
+
+int aqc_ws_mps_upload(aqc_ws* ws, int slot, const int32_t* dims, const double* gammas, const double* lambdas) {
+    if (check_mps_slot(ws, slot, false)) return 1;
+    const int n = ws->ctx->prog.n;
+    if (!dims || !gammas || (n > 1 && !lambdas)) return fail("null MPS argument");
+    if (dims[0] != 1 || dims[n] != 1) return fail("MPS boundary bond dimensions must be 1");
+    HIP_OK(hipSetDevice(ws->device));
+    aqc_ws::MpsSlot& m = ws->mps[slot];
+    m.dims.assign(dims, dims + n + 1);
+    m.offset.assign(n + 1, 0);
+    size_t total = 0, lam_total = 0;
+    for (int q = 0; q < n; ++q) {
+        if (dims[q] < 1 || dims[q + 1] < 1) return fail("MPS bond dimensions must be positive");
+        m.offset[q] = total;
+        total += (size_t)2 * dims[q] * dims[q + 1];
+        if (q < n - 1) lam_total += dims[q + 1];
+    }
+    m.offset[n] = total;
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (m.d_t) HIP_OK(hipFree(m.d_t));
+    m.d_t = nullptr;
+    HIP_OK(hipMalloc((void**)&m.d_t, total * sizeof(double2)));
+    double* d_lam = nullptr;
+    HIP_OK(hipMalloc((void**)&d_lam, std::max<size_t>(lam_total, 1) * sizeof(double)));
+    HIP_OK(hipMemcpyAsync(m.d_t, gammas, total * sizeof(double2), hipMemcpyHostToDevice, ws->stream));
+    if (lam_total) HIP_OK(hipMemcpyAsync(d_lam, lambdas, lam_total * sizeof(double), hipMemcpyHostToDevice, ws->stream));
+    size_t lo = 0;
+    for (int q = 0; q < n - 1; ++q) {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_mps_scale(m.d_t + m.offset[q], d_lam + lo, 2 * dims[q], dims[q + 1], ws->stream));
+        lo += dims[q + 1];
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    HIP_OK(hipFree(d_lam));
+    return 0;
+}
+
+int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
+    if (check_mps_slot(ws, slot, true) || check_buf(ws, buf)) return 1;
+    if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
+    HIP_OK(hipSetDevice(ws->device));
+    const aqc_ws::MpsSlot& m = ws->mps[slot];
+    const int n = ws->ctx->prog.n;
+    size_t need = 0;
+    for (int q = 0; q < n - 1; ++q) need = std::max(need, ((size_t)2 << q) * m.dims[q + 1]);
+    if (mps_scratch(ws, 2 * need)) return 1;
+    double2* ping = ws->d_mps_scratch;
+    double2* pong = ws->d_mps_scratch + need;
+    double2* out = ws->bufs[buf] + (size_t)lane * ws->lane_elems;
+    const double2* acc = m.d_t;  // site 0: (2 x chi_0), rows = bit 0
+    for (int q = 1; q < n; ++q) {
+        double2* dst = (q == n - 1) ? out : ((q & 1) ? ping : pong);
+        const int rows = 1 << q, kk = m.dims[q], nn = m.dims[q + 1];
+        for (int b = 0; b < 2; ++b) {  // new index = idx + 2^q b  (mps_operations.py:178-186)
+            ProfScope ps(ws, AQC_K_MISC);
+            HIP_OK(launch_zgemm(false, false, rows, nn, kk, acc, kk, m.d_t + m.offset[q] + (size_t)b * kk * nn, nn,
+                                dst + (size_t)b * rows * nn, nn, ws->stream));
+        }
+        acc = dst;
+    }
+    return 0;
+}
+
+int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out) {
+    if (check_mps_slot(ws, slot_a, true) || check_mps_slot(ws, slot_b, true)) return 1;
+    if (!out) return fail("null output");
+    HIP_OK(hipSetDevice(ws->device));
+    const aqc_ws::MpsSlot& a = ws->mps[slot_a];
+    const aqc_ws::MpsSlot& b = ws->mps[slot_b];
+    const int n = ws->ctx->prog.n;
+    size_t need = 1;
+    for (int q = 0; q <= n; ++q) need = std::max(need, (size_t)a.dims[q] * b.dims[q]);
+    for (int q = 0; q < n; ++q) need = std::max(need, (size_t)a.dims[q] * b.dims[q + 1]);
+    if (mps_scratch(ws, 3 * need)) return 1;
+    double2* e0 = ws->d_mps_scratch;
+    double2* e1 = e0 + need;
+    double2* t = e1 + need;
+    {   // E[x][y] = sum_b conj(A0[b][x]) B0[b][y]
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_zgemm(true, false, a.dims[1], b.dims[1], 2, a.d_t, a.dims[1], b.d_t, b.dims[1], e0, b.dims[1], ws->stream));
+    }
+    double2* e = e0;
+    double2* en = e1;
+    for (int q = 1; q < n; ++q) {
+        const int xa = a.dims[q], ua = a.dims[q + 1], yb = b.dims[q], vb = b.dims[q + 1];
+        for (int bit = 0; bit < 2; ++bit) {
+            ProfScope ps(ws, AQC_K_MISC);
+            // T = E B_q[bit]            (xa x vb)
+            HIP_OK(launch_zgemm(false, false, xa, vb, yb, e, yb, b.d_t + b.offset[q] + (size_t)bit * yb * vb, vb, t, vb, ws->stream));
+            // E' (+)= A_q[bit]^H T      (ua x vb)
+            HIP_OK(launch_zgemm(true, bit == 1, ua, vb, xa, a.d_t + a.offset[q] + (size_t)bit * xa * ua, ua, t, vb, en, vb, ws->stream));
+        }
+        std::swap(e, en);
+    }
+    HIP_OK(hipMemcpyAsync(out, e, sizeof(double2), hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     return 0;
 }

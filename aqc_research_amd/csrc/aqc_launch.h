@@ -39,4 +39,9 @@ hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* e
 hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t count, int batch, void* part, int nparts,
                        void* out, hipStream_t s);
 
+// aqc_mps.hip
+hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);
+hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                        void* C, int ldc, hipStream_t s);
+
 }  // namespace aqc

@@ -230,3 +230,45 @@ class Workspace:
             self.close()
         except Exception:
             pass
+
+
+def _pack_mps(mps, n: int):
+    """QiskitMPS tuple -> (dims int32[n+1], gammas c128 packed, lambdas f64 packed); pure marshaling."""
+    gam, lam = mps
+    if len(gam) != n or len(lam) != n - 1:
+        raise ValueError("MPS does not match the number of qubits")
+    dims = [1]
+    parts = []
+    for q in range(n):
+        g0 = np.asarray(gam[q][0], dtype=np.complex128)
+        g1 = np.asarray(gam[q][1], dtype=np.complex128)
+        if g0.ndim != 2 or g0.shape != g1.shape or g0.shape[0] != dims[-1]:
+            raise ValueError(f"inconsistent Gamma shapes at site {q}")
+        dims.append(g0.shape[1])
+        parts.append(np.stack((g0, g1)).ravel())
+    lams = [np.asarray(l, dtype=np.float64).ravel() for l in lam]
+    for q, l in enumerate(lams):
+        if l.size != dims[q + 1]:
+            raise ValueError(f"lambda {q} does not match the bond dimension")
+    return (np.asarray(dims, dtype=np.int32), np.ascontiguousarray(np.concatenate(parts)),
+            np.ascontiguousarray(np.concatenate(lams)) if lams else np.zeros(1))
+
+
+def _ws_mps_upload(self, slot: int, mps) -> None:
+    dims, gam, lam = _pack_mps(mps, self.ctx.num_qubits)
+    check(self._L.aqc_ws_mps_upload(self.handle, slot, dims.ctypes.data_as(ctypes.POINTER(c_int32)), dptr(gam), dptr(lam)))
+
+
+def _ws_mps_to_vec(self, slot: int, buf: int, lane: int = 0) -> None:
+    check(self._L.aqc_ws_mps_to_vec(self.handle, slot, buf, lane))
+
+
+def _ws_mps_dot(self, slot_a: int, slot_b: int) -> complex:
+    out = np.empty(1, dtype=np.complex128)
+    check(self._L.aqc_ws_mps_dot(self.handle, slot_a, slot_b, dptr(out)))
+    return complex(out[0])
+
+
+Workspace.mps_upload = _ws_mps_upload
+Workspace.mps_to_vec = _ws_mps_to_vec
+Workspace.mps_dot = _ws_mps_dot

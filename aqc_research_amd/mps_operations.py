@@ -1,0 +1,130 @@
+"""
+MPS helpers with the reference signatures (mps_operations.py:33-371) on the GPU.
+
+The reference delegates gate application on MPS to qiskit-aer's matrix_product_state
+simulator (third party).  This path works at the level the reference's own tests pin it
+-- exact (no truncation) dense semantics: an MPS is contracted to its 2^n amplitudes on the
+device (chain of zgemm), the state-vector kernels do the work, and results that must be
+MPS again are returned as an *exact* MPS (bond dimension <= 2^(n/2), all lambdas = 1).
+Truncated-SVD MPS gates (trunc_thr > 0, n > ~26) are not provided.
+"""
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .engine import BUF_X, BUF_Y, BUF_Z, HipContext
+
+_NO_TRUNCATION_THR = 1e-16
+QiskitMPS = Tuple[List[Tuple[np.ndarray, np.ndarray]], List[np.ndarray]]
+
+
+def no_truncation_threshold() -> float:
+    return _NO_TRUNCATION_THR
+
+
+def check_mps(qiskit_mps) -> bool:
+    """Structural check of a (gammas, lambdas) tuple (mps_operations.py:87-123)."""
+    if not (isinstance(qiskit_mps, tuple) and len(qiskit_mps) == 2):
+        return False
+    gam, lam = qiskit_mps
+    n = len(gam)
+    if len(lam) != n - 1:
+        return False
+    for q in range(n):
+        g = gam[q]
+        if len(g) != 2 or np.ndim(g[0]) != 2 or np.shape(g[0]) != np.shape(g[1]):
+            return False
+        if q < n - 1:
+            l = np.asarray(lam[q])
+            if not (l.ndim == 1 or (l.ndim == 2 and min(l.shape) == 1)):
+                return False
+            l = l.ravel()
+            if not np.all(l[:-1] >= l[1:]):
+                return False
+    return True
+
+
+class _Circ:
+    """Gate-free n-qubit descriptor: MPS helpers only need a device workspace of size 2^n."""
+
+    entangler = "cx"
+
+    def __init__(self, n):
+        self.num_qubits, self.blocks = n, np.zeros((2, 0), dtype=np.int64)
+
+
+def _workspace(n: int):
+    return HipContext.of(_Circ(n)).workspace(1, 1)
+
+
+def mps_to_vector(qiskit_mps) -> np.ndarray:
+    """Dense state of an MPS; index bit q <-> site q (mps_operations.py:159-189)."""
+    if not check_mps(qiskit_mps):
+        raise ValueError("not a valid MPS in Qiskit format")
+    ws = _workspace(len(qiskit_mps[0]))
+    ws.mps_upload(0, qiskit_mps)
+    ws.mps_to_vec(0, BUF_Y, 0)
+    return ws.download(BUF_Y, lane=0)
+
+
+def mps_dot(qiskit_mps1, qiskit_mps2) -> np.complex128:
+    """<mps1|mps2> by transfer matrices (mps_operations.py:192-213)."""
+    if not (check_mps(qiskit_mps1) and check_mps(qiskit_mps2)):
+        raise ValueError("not a valid MPS in Qiskit format")
+    if len(qiskit_mps1[0]) != len(qiskit_mps2[0]):
+        raise ValueError("MPS with different numbers of qubits")
+    ws = _workspace(len(qiskit_mps1[0]))
+    ws.mps_upload(0, qiskit_mps1)
+    ws.mps_upload(1, qiskit_mps2)
+    return np.complex128(ws.mps_dot(0, 1))
+
+
+def vector_to_exact_mps(vec: np.ndarray) -> QiskitMPS:
+    """Exact MPS of a dense state without any SVD: index-routing (0/1) tensors on both
+    halves, all amplitudes in the middle site, lambdas = 1.  Pure data movement."""
+    vec = np.asarray(vec, dtype=np.complex128).ravel()
+    n = int(round(np.log2(vec.size)))
+    if vec.size != 1 << n or n < 2:
+        raise ValueError("expects a vector of size 2^n, n >= 2")
+    h = n // 2
+    gam, lam = [], []
+    for q in range(h):  # left half: new bond index j = i + 2^q b
+        g = np.zeros((2, 1 << q, 2 << q), dtype=np.complex128)
+        i = np.arange(1 << q)
+        g[0, i, i] = 1
+        g[1, i, i + (1 << q)] = 1
+        gam.append((g[0], g[1]))
+    rest = n - 1 - h  # bits above the middle site
+    mid = vec.reshape(1 << rest, 2, 1 << h)  # [r, b, j]
+    gam.append((np.ascontiguousarray(mid[:, 0, :].T), np.ascontiguousarray(mid[:, 1, :].T)))
+    for q in range(h + 1, n):  # right half: left bond l = b + 2 r
+        r = 1 << (n - 1 - q)
+        g = np.zeros((2, 2 * r, r), dtype=np.complex128)
+        j = np.arange(r)
+        g[0, 2 * j, j] = 1
+        g[1, 2 * j + 1, j] = 1
+        gam.append((g[0], g[1]))
+    for q in range(n - 1):
+        lam.append(np.ones(gam[q][0].shape[1]))
+    return gam, lam
+
+
+def _apply_to_mps(circ, thetas, mps_vec, inverse: bool) -> QiskitMPS:
+    if not check_mps(mps_vec) or len(mps_vec[0]) != circ.num_qubits:
+        raise ValueError("MPS does not match the circuit")
+    ws = HipContext.of(circ).workspace(1, 1)
+    ws.set_thetas(thetas)
+    ws.mps_upload(0, mps_vec)
+    ws.mps_to_vec(0, BUF_Y, 0)
+    ws.apply(inverse, BUF_Y, BUF_Z)
+    return vector_to_exact_mps(ws.download(BUF_Z, lane=0))
+
+
+def v_mul_mps(circ, thetas: np.ndarray, mps_vec, *, trunc_thr: Optional[float] = _NO_TRUNCATION_THR) -> QiskitMPS:
+    """V |mps> as an exact MPS (mps_operations.py:326-346; no truncation is applied)."""
+    return _apply_to_mps(circ, thetas, mps_vec, False)
+
+
+def v_dagger_mul_mps(circ, thetas: np.ndarray, mps_vec, *, trunc_thr: Optional[float] = _NO_TRUNCATION_THR) -> QiskitMPS:
+    """V^H |mps> as an exact MPS (mps_operations.py:349-371; no truncation is applied)."""
+    return _apply_to_mps(circ, thetas, mps_vec, True)

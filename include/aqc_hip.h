@@ -110,6 +110,20 @@ int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count);
 int aqc_ws_gather_launch(aqc_ws* ws, int buf);
 int aqc_ws_gather_fetch(aqc_ws* ws, double* out /* [batch][count] c128 */);
 
+/* ---- MPS helpers (state-vector workspaces only).  An MPS arrives in the reference's QiskitMPS
+ * layout (mps_operations.py:33,87-123): site q has Gamma^0, Gamma^1 of shape (dims[q], dims[q+1]),
+ * dims[0] = dims[n] = 1, and lambda_q (float64[dims[q+1]]) for q < n-1.
+ *   gammas : per site [2][dims[q]][dims[q+1]] complex128, sites concatenated
+ *   lambdas: per site [dims[q+1]] float64, sites 0..n-2 concatenated
+ * Upload folds lambda into the right bond of Gamma on the device (_preprocess_mps, :126-156). */
+enum { AQC_MPS_SLOTS = 4 };
+int aqc_ws_mps_upload(aqc_ws* ws, int slot, const int32_t* dims /* [n+1] */, const double* gammas,
+                      const double* lambdas);
+/* buf[lane] <- dense state of the MPS; index bit q <-> site q   (mps_to_vector, :159-189) */
+int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane);
+/* out <- <mps_a|mps_b> by transfer matrices                      (mps_dot, :192-213) */
+int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out /* 1 c128 */);
+
 /* ---- measurement hooks (bench.py): HIP events on the workspace's own stream */
 int aqc_ws_timer_start(aqc_ws* ws);
 int aqc_ws_timer_stop(aqc_ws* ws, float* elapsed_ms); /* synchronises */

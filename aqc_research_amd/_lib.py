@@ -50,6 +50,7 @@ SIGNATURES = {
     "aqc_ws_gather": (c_int, [_P, c_int, POINTER(c_int64), c_int, _D]),
     "aqc_ws_vdot": (c_int, [_P, c_int, c_int, _D]),
     "aqc_ws_sync": (c_int, [_P]),
+    "aqc_ws_cd_sweep": (c_int, [_P, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),
     "aqc_ws_mps_dot": (c_int, [_P, c_int, c_int, _D]),

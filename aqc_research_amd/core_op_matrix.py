@@ -71,3 +71,26 @@ def grad_of_matrix_dot_product(
     ws.upload(BUF_Z, vh_y_mat)
     ws.grad(None, True)
     return ws.get_grads()[0]
+
+
+def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray, workspace: Optional[np.ndarray] = None) -> float:
+    """One Gauss-Seidel sweep over all parameters of ``1 - |<V,U>|^2 / d^2``
+    (core_op_matrix.py:765-917).  ``thetas`` is updated in place; returns the objective at the
+    end of the sweep.  The whole sweep (2 launches per parameter) runs on the device."""
+    from . import _lib
+    from ._lib import check, dptr
+
+    if circ.entangler == "cp":
+        raise NotImplementedError("CPhase entangler is not supported yet")
+    if not (isinstance(thetas, np.ndarray) and thetas.dtype == np.float64 and thetas.ndim == 1
+            and thetas.size == circ.num_thetas and thetas.flags.c_contiguous):
+        raise ValueError("thetas: expects a contiguous float64 vector of size circ.num_thetas (updated in place)")
+    _check(circ, thetas, target, "target")
+    if target.shape[0] != target.shape[1]:
+        raise ValueError("target must be square")
+    _no_overlap(target, workspace)
+    ws = HipContext.of(circ).workspace(1, target.shape[1])
+    ws.upload(BUF_Y, target)
+    fobj = np.zeros(1)
+    check(_lib.lib().aqc_ws_cd_sweep(ws.handle, dptr(thetas), dptr(fobj)))
+    return float(fobj[0])

@@ -8,6 +8,7 @@
 // Nothing below ever falls back to host arithmetic: if HIP is unusable every call fails loudly.
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -664,6 +665,66 @@ int aqc_ws_gather_fetch(aqc_ws* ws, double* out) {
     HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch * ws->gather_count, hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     return 0;
+}
+
+static int mps_scratch(aqc_ws* ws, size_t n_cplx);
+
+// ---- coordinate descent ------------------------------------------------------------------------
+
+int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io, double* fobj) {
+    if (!ws || !thetas_io || !fobj) return fail("null argument");
+    const Program& prog = ws->ctx->prog;
+    const int dim = 1 << prog.n;
+    if (ws->ncols != dim || ws->batch != 1) return fail("coordinate descent needs a square, single-lane workspace");
+    if (prog.entangler == AQC_CP) return fail("CPhase entangler is not supported yet");
+    if (prog.trotter) return fail("matrix path does not support the Trotter ansatz");
+    HIP_OK(hipSetDevice(ws->device));
+    const int T = prog.num_thetas();
+    if (aqc_ws_set_thetas(ws, thetas_io)) return 1;                  // theta_in = d_thetas_own
+    if (aqc_ws_apply(ws, 1, AQC_BUF_Y, AQC_BUF_Z)) return 1;          // z = V^H U      (core_op_matrix.py:806-810)
+    if (aqc_ws_set_identity(ws, AQC_BUF_X)) return 1;                 // w = I
+    double* d_theta_out = nullptr;
+    HIP_OK(hipMalloc((void**)&d_theta_out, sizeof(double) * T));
+    HIP_OK(hipMemcpyAsync(d_theta_out, ws->d_thetas_own, sizeof(double) * T, hipMemcpyDeviceToDevice, ws->stream));
+    double2* w = ws->bufs[AQC_BUF_X];
+    double2* z = ws->bufs[AQC_BUF_Z];
+    const size_t npairs = ws->lane_elems >> 1, ngroups = ws->lane_elems >> 2;
+    const int nparts = cd_num_parts(npairs);
+    if (mps_scratch(ws, 2 * (size_t)nparts)) { (void)hipFree(d_theta_out); return 1; }
+    double2* part = ws->d_mps_scratch;
+    int rc = 0;
+    auto step = [&](int qubit, int kind, int tindex) -> int {
+        const int hbit = ws->col_bits + qubit;
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_cd_dot(w, z, npairs, hbit, kind, part, ws->stream));
+        HIP_OK(launch_cd_update(w, z, npairs, hbit, kind, part, nparts, ws->d_thetas_own, d_theta_out, tindex, (double)dim, ws->stream));
+        return 0;
+    };
+    for (const GateGroup& g : prog.groups) {
+        if (g.type == GROUP_FRONT) {
+            rc = step(g.q0, 1, g.theta0 + 2) || step(g.q0, 0, g.theta0 + 1) || step(g.q0, 1, g.theta0 + 0);
+        } else {
+            hipError_t e = launch_cd_entangle(w, z, ngroups, ws->col_bits + g.q0, ws->col_bits + g.q1, prog.entangler, ws->stream);
+            if (e != hipSuccess) { rc = fail("cd_entangle launch failed: %s", hipGetErrorString(e)); }
+            else rc = step(g.q0, 0, g.theta0) || step(g.q0, 1, g.theta0 + 1) || step(g.q1, 0, g.theta0 + 2) ||
+                      step(g.q1, prog.entangler == AQC_CX ? 2 : 1, g.theta0 + 3);
+        }
+        if (rc) break;
+    }
+    if (!rc) {
+        double prod[2] = {0, 0};
+        rc = aqc_ws_vdot(ws, AQC_BUF_X, AQC_BUF_Z, prod);
+        if (!rc) {
+            const double a = std::hypot(prod[0], prod[1]) / dim;
+            *fobj = 1.0 - a * a;
+            hipError_t e = hipMemcpyAsync(thetas_io, d_theta_out, sizeof(double) * T, hipMemcpyDeviceToHost, ws->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
+            if (e != hipSuccess) rc = fail("theta download failed: %s", hipGetErrorString(e));
+        }
+    }
+    (void)hipStreamSynchronize(ws->stream);
+    (void)hipFree(d_theta_out);
+    return rc;
 }
 
 // ---- MPS helpers ------------------------------------------------------------------------------

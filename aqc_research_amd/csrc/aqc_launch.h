@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 
 #include "aqc_device.h"
@@ -43,5 +44,12 @@ hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t 
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);
 hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                         void* C, int ldc, hipStream_t s);
+
+// aqc_cd.hip
+int cd_num_parts(size_t npairs);
+hipError_t launch_cd_dot(const void* w, const void* z, size_t npairs, int hbit, int kind, void* part, hipStream_t s);
+hipError_t launch_cd_update(void* w, void* z, size_t npairs, int hbit, int kind, const void* part, int nparts,
+                            const double* theta_in, double* theta_out, int tindex, double dim, hipStream_t s);
+hipError_t launch_cd_entangle(void* w, void* z, size_t ngroups, int cbit, int tbit, int ent, hipStream_t s);
 
 }  // namespace aqc

@@ -124,6 +124,12 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane);
 /* out <- <mps_a|mps_b> by transfer matrices                      (mps_dot, :192-213) */
 int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out /* 1 c128 */);
 
+/* ---- coordinate descent (core_op_matrix.py:765  coord_descent_single_sweep(circ, thetas, target,
+ * workspace)).  Square workspace (ncols == 2^n) with the target unitary in AQC_BUF_Y.  One
+ * Gauss-Seidel sweep over all parameters of 1 - |<V,U>|^2/d^2; thetas are updated in place and
+ * the objective at the end of the sweep is returned.  cx / cz entanglers only (:818-827). */
+int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io /* [T] */, double* fobj);
+
 /* ---- measurement hooks (bench.py): HIP events on the workspace's own stream */
 int aqc_ws_timer_start(aqc_ws* ws);
 int aqc_ws_timer_stop(aqc_ws* ws, float* elapsed_ms); /* synchronises */

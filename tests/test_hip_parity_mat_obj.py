@@ -126,3 +126,31 @@ def test_sur_max_neel_and_stoppers():
     obj.set_status_trackers(timeout=None, stopper=Stop())
     with pytest.raises(StopIteration):
         obj.gradient(th)
+
+
+MATCD = [str(k) for k in MAT["names"] if str(k).endswith("_cd")]
+
+
+@pytest.mark.parametrize("key", MATCD)
+def test_golden_coord_descent(key):
+    """Two consecutive sweeps vs the reference (sequential Newton steps amplify rounding, hence 1e-8)."""
+    import aqc_research_amd.core_op_matrix as com
+
+    a = ansatz_from(MAT, key)
+    circ = make_circ(a)
+    th = MAT[f"{key}/thetas"].copy()
+    target = MAT[f"{key}/target"].copy()
+    f1 = com.coord_descent_single_sweep(circ, th, target, None)
+    assert maxdiff(th, MAT[f"{key}/thetas_1"]) < 1e-9 and abs(f1 - float(MAT[f"{key}/fobj_1"])) < 1e-9
+    f2 = com.coord_descent_single_sweep(circ, th, target, None)
+    assert maxdiff(th, MAT[f"{key}/thetas_2"]) < 1e-8 and abs(f2 - float(MAT[f"{key}/fobj_2"])) < 1e-8
+    assert f2 <= f1 + 1e-12  # descent
+
+
+def test_coord_descent_rejects_cp():
+    import aqc_research_amd.core_op_matrix as com
+    from aqc_research_amd import ParametricCircuit
+
+    circ = ParametricCircuit(2, "cp", np.array([[0], [1]]))
+    with pytest.raises(NotImplementedError):
+        com.coord_descent_single_sweep(circ, np.zeros(circ.num_thetas), np.eye(4, dtype=complex), None)

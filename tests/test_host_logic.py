@@ -1,0 +1,129 @@
+"""CPU-only tests of host logic: job executor (incl. world_size-2 gloo), stoppers, optimizer wrapper."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _job(idx, cfg):
+    if cfg.get("fail"):
+        raise ValueError("boom")
+    return {"value": cfg["a"] * 2 + np.random.rand(), "idx_echo": idx}
+
+
+def test_run_jobs_serial_contract():
+    from aqc_research_amd.job_executor import run_jobs
+
+    cfgs = [{"a": i} for i in range(5)] + [{"a": 0, "fail": True}]
+    res = run_jobs(cfgs, 100, _job)
+    assert [r["job_index"] for r in res] == list(range(6))
+    assert [r["seed"] for r in res] == [100 + 7 * (i + 1) for i in range(6)]
+    assert all(r["status"] == "ok" for r in res[:5]) and "ValueError" in res[5]["status"] and res[5]["time"] == -1.0
+    np.random.seed(107)
+    assert res[0]["value"] == 0 + np.random.rand()  # per-job seeding (job_executor.py:64-65)
+    assert len(run_jobs(cfgs, 100, _job, tolerate_failure=True)) == 5
+    with pytest.raises(RuntimeError):
+        run_jobs([{"a": 1, "fail": True}], 0, _job)
+    with pytest.raises(ValueError):
+        run_jobs([], 0, _job)
+
+
+def test_run_jobs_gloo_world2(tmp_path):
+    """Two ranks shard 7 jobs, gather the padded records; every rank ends with the same ordered list."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, json
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np, torch.distributed as dist
+        from aqc_research_amd.job_executor import run_jobs
+        dist.init_process_group(backend="gloo")
+        def job(i, cfg):
+            return {{"value": cfg["a"] + np.random.rand(), "rank": dist.get_rank(), "arr": np.arange(cfg["a"] + 1)}}
+        res = run_jobs([{{"a": i}} for i in range(7)], 5, job)
+        out = [(r["job_index"], r["seed"], r["rank"], float(r["value"]), int(r["arr"].sum())) for r in res]
+        open(os.path.join({str(tmp_path)!r}, f"out{{dist.get_rank()}}.json"), "w").write(json.dumps(out))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+
+    a = json.loads((tmp_path / "out0.json").read_text())
+    b = json.loads((tmp_path / "out1.json").read_text())
+    assert a == b and [r[0] for r in a] == list(range(7))
+    assert [r[2] for r in a] == [i % 2 for i in range(7)]  # job j ran on rank j % world
+    for i, r in enumerate(a):
+        np.random.seed(5 + 7 * (i + 1))
+        assert r[1] == 5 + 7 * (i + 1) and abs(r[3] - (i + np.random.rand())) < 1e-15 and r[4] == i * (i + 1) // 2
+
+
+class _Quad:
+    """Duck-typed objective: f = |x - c|^2."""
+
+    def __init__(self, c):
+        self.c, self.trackers, self.nf = np.asarray(c, float), None, 0
+
+    def objective(self, x):
+        self.nf += 1
+        return float(np.sum((x - self.c) ** 2))
+
+    def gradient(self, x):
+        return 2 * (x - self.c)
+
+    def set_status_trackers(self, timeout=None, stopper=None):
+        self.trackers = (timeout, stopper)
+
+    fidelity = property(lambda self: 0.5)
+    statistics = property(lambda self: {"n": self.nf})
+
+
+class _Circ:
+    blocks = np.array([[0], [1]])
+    entangler = "cx"
+
+
+def test_optimizer_wrapper_and_stoppers():
+    from aqc_research_amd import optimizer as opt
+
+    obj = _Quad([1.0, -2.0, 0.5])
+    res = opt.AqcOptimizer(optimizer_name="lbfgs", maxiter=50).optimize(obj, _Circ(), np.zeros(3))
+    assert res["cost"] < 1e-10 and np.allclose(res["thetas"], obj.c, atol=1e-5)
+    for key in ("num_iters", "num_fun_ev", "num_grad_ev", "ini_thetas", "blocks", "entangler", "stats", "is_timeout", "fidelity"):
+        assert key in res
+    assert res["is_timeout"] is False and res["stats"]["is_timeout"] is False and np.all(res["ini_thetas"] == 0)
+    res = opt.AqcOptimizer(optimizer_name="adam", maxiter=2000, learn_rate=0.05).optimize(_Quad([0.3, 0.1]), _Circ(), np.zeros(2))
+    assert res["cost"] < 1e-6
+
+    # stoppers
+    with pytest.raises(StopIteration):
+        opt.SmallObjectiveStopper(fobj_thr=0.1).check(0.05)
+    s = opt.NotImproveStopper(num_iters=2)
+    s.check(1.0, 0); s.check(1.0, 1); s.check(1.0, 2)
+    with pytest.raises(opt.StagnantOptimizationWarning):
+        s.check(1.0, 3)
+    es = opt.EarlyStopper(fidelity_thr=0.9)
+    with pytest.raises(StopIteration):
+        es.check(0.2, 0.95, np.zeros(2), 3, lambda f, t: {"cost": f, "thetas": t})
+    assert es.optim_results["cost"] == 0.2
+    tc = opt.TimeoutChecker(time_limit=-1)
+    tc.check(1.0, np.zeros(1))  # no limit => no raise
+    ga = opt.GradientAmplifier(history=3)
+    assert ga.estimate(0.5) == 1.0 and ga.estimate(0.5) == 1.0 and ga.estimate(0.5) > 1.0
+
+    # early stop propagates through the wrapper with the stored result
+    class StopObj(_Quad):
+        def gradient(self, x):
+            raise StopIteration("stop")
+
+        optim_results = property(lambda self: {"cost": 0.123, "thetas": np.ones(3)})
+
+    res = opt.AqcOptimizer(maxiter=5).optimize(StopObj([0, 0, 0]), _Circ(), np.zeros(3))
+    assert res["cost"] == 0.123 and res["is_timeout"] is False

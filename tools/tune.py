@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of workspace configurations (threads, tile bits, low bits) in ONE process."""
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aqc_research_amd import ParametricCircuit, TrotterAnsatz  # noqa: E402
+from aqc_research_amd.circuit_structures import create_ansatz_structure, make_trotter_like_circuit  # noqa: E402
+from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_SWEEP, HipContext, Workspace  # noqa: E402
+
+
+def run(n=16, L=40, B=64, configs=None, steps=20, rounds=3, trotter_layers=0, grad_args=(None, True)):
+    if trotter_layers:
+        circ = TrotterAnsatz(n, make_trotter_like_circuit(n, trotter_layers), second_order=True)
+    else:
+        circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", L))
+    ctx = HipContext.of(circ)
+    rng = np.random.default_rng(0)
+    T = circ.num_thetas
+    wss = []
+    for cfg in configs:
+        for k, v in cfg.get("env", {}).items():
+            os.environ[k] = str(v)
+        ws = Workspace(ctx, batch=B, tile_bits_apply=cfg.get("ka", 0), tile_bits_sweep=cfg.get("ks", 0))
+        tg = rng.random((B, 1 << n)) + 1j * rng.random((B, 1 << n))
+        ws.upload(BUF_Y, tg / np.linalg.norm(tg, axis=1, keepdims=True))
+        ws.set_basis(BUF_X, 0)
+        ws.gather_setup(np.arange(n + 1))
+        ws.theta_bank(np.pi * (2 * rng.random((4, B, T)) - 1))
+        wss.append(ws)
+    res = [[] for _ in configs]
+    for r in range(rounds):
+        for ci, ws in enumerate(wss):
+            for i in range(3):
+                ws.use_theta_set(i % 4); ws.apply(True, BUF_Y, BUF_Z); ws.gather_launch(BUF_Z); ws.grad(*grad_args)
+            ws.sync()
+            ws.timer_start()
+            for i in range(steps):
+                ws.use_theta_set(i % 4); ws.apply(True, BUF_Y, BUF_Z); ws.gather_launch(BUF_Z); ws.grad(*grad_args)
+            res[ci].append(ws.timer_stop() / steps)
+    for ci, (cfg, ws) in enumerate(zip(configs, wss)):
+        ws.profile(True)
+        for i in range(5):
+            ws.use_theta_set(i % 4); ws.apply(True, BUF_Y, BUF_Z); ws.gather_launch(BUF_Z); ws.grad(*grad_args)
+        ws.sync()
+        a, s = ws.profile_get(K_APPLY), ws.profile_get(K_SWEEP)
+        ws.profile(False)
+        ms = min(res[ci])
+        print(f"{cfg}: step {ms:.4f} ms (med {np.median(res[ci]):.4f}) -> {B / ms * 1e3:,.0f} evals/s | "
+              f"apply {a[1] / 5:.3f} ms/{a[0] // 5} launches, sweep {s[1] / 5:.3f} ms/{s[0] // 5} launches | "
+              f"plan inv{ws.plan_info(0)} sweep{ws.plan_info(1)}", flush=True)
+        ws.close()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if which == "a":
+        cfgs = []
+        for thr, ks, low in itertools.product((256, 512), (10, 11, 12), (2, 3)):
+            cfgs.append({"env": {"AQC_THREADS": thr, "AQC_LOW_BITS": low}, "ks": ks, "ka": min(ks + 1, 13)})
+        run(configs=cfgs)
+    elif which == "nodots":
+        cfgs = [{"env": {"AQC_THREADS": 256, "AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}]
+        print("with dots"); run(configs=cfgs)
+        print("dots only for block 0"); run(configs=cfgs, grad_args=((0, 1), False))
+    elif which == "b1":
+        cfgs = []
+        for thr, ks in itertools.product((256, 512), (8, 9, 10, 11, 12)):
+            cfgs.append({"env": {"AQC_THREADS": thr, "AQC_LOW_BITS": 2}, "ks": ks, "ka": ks})
+        run(B=1, configs=cfgs, steps=50)

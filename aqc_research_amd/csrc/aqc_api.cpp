@@ -60,18 +60,71 @@ struct DevPlan {
     Plan plan;
     std::vector<DevStage> h_stages;
     std::vector<DevOp> h_ops;
+    std::vector<DevSub> h_subs;   // register-blocked kernels
+    std::vector<DevMop> h_mops;
     DevStage* d_stages = nullptr;
     DevOp* d_ops = nullptr;
-    int k = 0, ntiles = 0;
+    DevSub* d_subs = nullptr;
+    DevMop* d_mops = nullptr;
+    int k = 0, ntiles = 0, reg_bits = 0;
+    bool v2 = false;              // run the register-blocked kernels
 };
 
-void lower_plan(const Program& prog, const Plan& plan, DevPlan& out) {
+// Micro-ops of one gate group on register bits (pc, pt); forward or conjugate-transposed order.
+void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, std::vector<DevMop>& out) {
+    const GateGroup& g = prog.groups[gi];
+    const int rec = g.coef * kCoefStride;
+    const int konst = (prog.n + prog.num_blocks) * kCoefStride;  // (cos, sin)(pi/4)
+    const int neg = inverse ? MOPF_NEG_S : 0;
+    auto rot = [&](int kind, int p, int coef, int flags, int slot) {
+        out.push_back({kind, p, 0, flags, coef, inverse ? -1 : slot, g.jblock, 0});
+    };
+    const int slot0 = gi * kSlotsPerGroup;
+    if (g.type == GROUP_FRONT) {
+        if (!inverse) {  // Rz(t2), Ry(t1), Rz(t0), rightmost first (core_operations.py:671-677,921-935)
+            rot(MOP_RZ, pc, rec + 4, 0, slot0 + 0);
+            rot(MOP_RY, pc, rec + 2, 0, slot0 + 1);
+            rot(MOP_RZ, pc, rec + 0, 0, slot0 + 2);
+        } else {         // (Rz Ry Rz)^H (core_operations.py:812-818)
+            rot(MOP_RZ, pc, rec + 0, neg, -1);
+            rot(MOP_RY, pc, rec + 2, neg, -1);
+            rot(MOP_RZ, pc, rec + 4, neg, -1);
+        }
+        return;
+    }
+    const int ekind = prog.entangler == 0 ? MOP_CX : (prog.entangler == 1 ? MOP_CZ : MOP_CP);
+    const int rs = prog.entangler == 0 ? MOP_RX : MOP_RZ;
+    if (!inverse) {  // core_operations.py:956-1017
+        if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, konst, MOPF_NEG_S, -1);   // Rz(-pi/2) on control
+        out.push_back({ekind, pc, pt, 0, rec + 8, prog.entangler == 2 ? slot0 + 4 : -1, g.jblock, 0});
+        rot(MOP_RY, pc, rec + 0, 0, slot0 + 0);
+        rot(MOP_RZ, pc, rec + 2, 0, slot0 + 1);
+        rot(MOP_RY, pt, rec + 4, 0, slot0 + 2);
+        rot(rs, pt, rec + 6, 0, slot0 + 3);
+        if (g.flags & FLAG_POST_RZ) rot(MOP_RZ, pt, konst, 0, -1);           // Rz(+pi/2) on target
+    } else {         // core_operations.py:787-809
+        if (g.flags & FLAG_POST_RZ) rot(MOP_RZ, pt, konst, MOPF_NEG_S, -1);
+        rot(rs, pt, rec + 6, neg, -1);
+        rot(MOP_RY, pt, rec + 4, neg, -1);
+        rot(MOP_RZ, pc, rec + 2, neg, -1);
+        rot(MOP_RY, pc, rec + 0, neg, -1);
+        out.push_back({ekind, pc, pt, neg, rec + 8, -1, g.jblock, 0});
+        if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, konst, 0, -1);
+    }
+}
+
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits) {
     out.plan = plan;
     out.h_stages.clear();
     out.h_ops.clear();
+    out.h_subs.clear();
+    out.h_mops.clear();
+    out.reg_bits = reg_bits;
+    out.v2 = reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
+    if (out.v2) split_substages(prog, out.plan, reg_bits, 12);
     out.k = (int)plan.stages.front().bits.size();
     out.ntiles = 1 << (plan.nbits - out.k);
-    for (const Stage& st : plan.stages) {
+    for (const Stage& st : out.plan.stages) {
         DevStage ds;
         memset(&ds, 0, sizeof ds);
         ds.k = (int)st.bits.size();
@@ -106,6 +159,27 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out) {
             op.jblock = g.jblock;
             op.pad = 0;
             out.h_ops.push_back(op);
+        }
+        ds.sub_begin = (int)out.h_subs.size();
+        ds.nsubs = 0;
+        if (out.v2) {
+            for (const SubStage& sub : st.subs) {
+                DevSub dsub;
+                memset(&dsub, 0, sizeof dsub);
+                dsub.nbits = (int)sub.bits.size();
+                std::vector<int> reg_of(ds.k, -1);
+                for (int j = 0; j < dsub.nbits; ++j) { dsub.bits[j] = sub.bits[j]; reg_of[sub.bits[j]] = j; }
+                dsub.mop_begin = (int)out.h_mops.size();
+                for (int gi : sub.ops) {
+                    const GateGroup& g = prog.groups[gi];
+                    const int pc = reg_of[local_of[plan.col_bits + g.q0]];
+                    const int pt = g.q1 >= 0 ? reg_of[local_of[plan.col_bits + g.q1]] : 0;
+                    emit_mops(prog, gi, pc, pt, plan.inverse, out.h_mops);
+                }
+                dsub.nmops = (int)out.h_mops.size() - dsub.mop_begin;
+                out.h_subs.push_back(dsub);
+                ++ds.nsubs;
+            }
         }
         out.h_stages.push_back(ds);
     }
@@ -163,6 +237,12 @@ int upload_plan(DevPlan& p) {
     HIP_OK(hipMalloc((void**)&p.d_ops, nops * sizeof(DevOp)));
     if (!p.h_ops.empty())
         HIP_OK(hipMemcpy(p.d_ops, p.h_ops.data(), p.h_ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void**)&p.d_subs, std::max<size_t>(p.h_subs.size(), 1) * sizeof(DevSub)));
+    HIP_OK(hipMalloc((void**)&p.d_mops, std::max<size_t>(p.h_mops.size(), 1) * sizeof(DevMop)));
+    if (!p.h_subs.empty())
+        HIP_OK(hipMemcpy(p.d_subs, p.h_subs.data(), p.h_subs.size() * sizeof(DevSub), hipMemcpyHostToDevice));
+    if (!p.h_mops.empty())
+        HIP_OK(hipMemcpy(p.d_mops, p.h_mops.data(), p.h_mops.size() * sizeof(DevMop), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -243,13 +323,16 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
         memset(&a, 0, sizeof a);
         a.stage = p.d_stages + s;
         a.ops = p.d_ops;
+        a.subs = p.d_subs;
+        a.mops = p.d_mops;
         a.coef = ws->d_coef;
-        a.ncoef = prog.n + prog.num_blocks;
+        a.ncoef = prog.n + prog.num_blocks + 1;
         a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
         a.out0 = ws->bufs[dst_buf];
         a.lane_stride = ws->lane_elems;
         ProfScope ps(ws, AQC_K_APPLY);
-        HIP_OK(launch_apply(prog.entangler, inverse, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
+        if (p.v2) HIP_OK(launch_apply2(prog.entangler, p.ntiles, ws->batch, p.k, ws->stream, a));
+        else HIP_OK(launch_apply(prog.entangler, inverse, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
     }
     return 0;
 }
@@ -322,6 +405,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
     HIP_OK(hipSetDevice(device));
     HIP_OK(init_kernels());
+    HIP_OK(init_kernels2());
 
     aqc_ws* ws = new aqc_ws();
     ws->ctx = ctx;
@@ -351,9 +435,10 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     ka = std::min(std::min(ka, 13), ws->nbits);
     ks = std::min(std::min(ks, 12), ws->nbits);
 
-    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd);
-    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv);
-    lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep);
+    const bool want_v2 = env_int("AQC_KERNEL_V2", 1) != 0;
+    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd, want_v2 ? 4 : 0);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv, want_v2 ? 4 : 0);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep, want_v2 ? 4 : 0);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -385,7 +470,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     WS_TRY(upload_plan(ws->fwd)); WS_TRY(upload_plan(ws->inv)); WS_TRY(upload_plan(ws->sweep));
     WS_HIP(hipMalloc((void**)&ws->d_thetas_own, sizeof(double) * (size_t)batch * std::max(T, 1)));
     ws->d_thetas = ws->d_thetas_own;
-    WS_HIP(hipMalloc((void**)&ws->d_coef, sizeof(double) * (size_t)batch * (prog.n + prog.num_blocks) * kCoefStride));
+    WS_HIP(hipMalloc((void**)&ws->d_coef, sizeof(double) * (size_t)batch * (prog.n + prog.num_blocks + 1) * kCoefStride));
     for (int b = 0; b < AQC_NUM_BUFS; ++b) {
         WS_HIP(hipMalloc((void**)&ws->bufs[b], sizeof(double2) * (size_t)batch * ws->lane_elems));
         WS_HIP(hipMemsetAsync(ws->bufs[b], 0, sizeof(double2) * (size_t)batch * ws->lane_elems, ws->stream));
@@ -412,6 +497,8 @@ int aqc_ws_destroy(aqc_ws* ws) {
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         if (p->d_stages) (void)hipFree(p->d_stages);
         if (p->d_ops) (void)hipFree(p->d_ops);
+        if (p->d_subs) (void)hipFree(p->d_subs);
+        if (p->d_mops) (void)hipFree(p->d_mops);
     }
     void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
                     ws->d_theta_slots, ws->d_slot_ntiles};
@@ -534,8 +621,10 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
         memset(&a, 0, sizeof a);
         a.stage = p.d_stages + s;
         a.ops = p.d_ops;
+        a.subs = p.d_subs;
+        a.mops = p.d_mops;
         a.coef = ws->d_coef;
-        a.ncoef = prog.n + prog.num_blocks;
+        a.ncoef = prog.n + prog.num_blocks + 1;
         a.in0 = s == 0 ? ws->bufs[AQC_BUF_X] : ws->bufs[AQC_BUF_W];
         a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
         a.out0 = ws->bufs[AQC_BUF_W];
@@ -548,7 +637,8 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
         a.to = block_to;
         a.front = front_layer ? 1 : 0;
         ProfScope ps(ws, AQC_K_SWEEP);
-        HIP_OK(launch_sweep(prog.entangler, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
+        if (p.v2) HIP_OK(launch_sweep2(prog.entangler, p.ntiles, ws->batch, p.k, ws->stream, a));
+        else HIP_OK(launch_sweep(prog.entangler, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
     }
     ProfScope ps(ws, AQC_K_FINALIZE);
     HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,

@@ -28,10 +28,38 @@ struct DevStage {
     int32_t op_begin;     // first DevOp
     int32_t ntiles;       // 2^(nbits-k)
     int32_t nub;          // number of non-local bits
-    int32_t pad[3];
+    int32_t sub_begin;    // first DevSub (register-blocked kernels)
+    int32_t nsubs;
+    int32_t pad;
     int32_t ubits[32];    // non-local address bits, ascending
     uint32_t dlo[64];     // element offset of local index low 6 bits
     uint32_t dhi[256];    // element offset of local index bits 6..13
 };
+
+// ---- register-blocked ("v2") kernels ------------------------------------------------------------
+// A sub-stage keeps 2^r amplitudes per thread in registers (r register bits out of the tile's local
+// bits) and runs a list of micro-ops on them before going back to LDS.
+enum MopKind { MOP_RY = 0, MOP_RZ = 1, MOP_RX = 2, MOP_CX = 3, MOP_CZ = 4, MOP_CP = 5 };
+enum MopFlags { MOPF_NEG_S = 1 };  // use (c, -s): inverse rotation / Rz(-pi/2) decoration
+
+struct DevMop {
+    int32_t kind;    // MopKind
+    int32_t p;       // register bit (rotations) or control register bit (entanglers)
+    int32_t p2;      // target register bit (entanglers)
+    int32_t flags;   // MopFlags
+    int32_t coef;    // offset (in doubles) of the (c, s) pair inside the lane's coefficient array
+    int32_t slot;    // inner-product slot fed by this micro-op, -1 if none
+    int32_t jblock;  // block index mod L for the block_range test, -1 = front layer
+    int32_t pad;
+};
+
+struct DevSub {
+    int32_t bits[5];    // register bits as local bit positions, ascending
+    int32_t nbits;
+    int32_t nmops;
+    int32_t mop_begin;
+};
+
+constexpr int kMaxMopsPerSub = 96;
 
 }  // namespace aqc

@@ -13,48 +13,10 @@
 
 #include "aqc_device.h"
 #include "aqc_launch.h"
+#include "aqc_math.h"
 
 namespace aqc {
 
-typedef double2 cplx;  // x = re, y = im
-
-static constexpr double kR = 0.70710678118654752440;  // cos(pi/4) = sin(pi/4)
-
-// ------------------------------------------------------------------------------------------
-// complex helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ cplx cmul(cplx a, double c, double s) {  // a * (c + i s)
-    return make_double2(a.x * c - a.y * s, a.y * c + a.x * s);
-}
-// acc += conj(a) * b
-__device__ __forceinline__ void cmacc(cplx& acc, cplx a, cplx b) {
-    acc.x += a.x * b.x + a.y * b.y;
-    acc.y += a.x * b.y - a.y * b.x;
-}
-// acc -= conj(a) * b
-__device__ __forceinline__ void cmsub(cplx& acc, cplx a, cplx b) {
-    acc.x -= a.x * b.x + a.y * b.y;
-    acc.y -= a.x * b.y - a.y * b.x;
-}
-// Ry = [[c,-s],[s,c]]  (elementary_operations.py:204-210)
-__device__ __forceinline__ void ry2(cplx& a0, cplx& a1, double c, double s) {
-    const cplx t0 = make_double2(c * a0.x - s * a1.x, c * a0.y - s * a1.y);
-    const cplx t1 = make_double2(s * a0.x + c * a1.x, s * a0.y + c * a1.y);
-    a0 = t0;
-    a1 = t1;
-}
-// Rz = diag(c - i s, c + i s)  (elementary_operations.py:246-251)
-__device__ __forceinline__ void rz2(cplx& a0, cplx& a1, double c, double s) {
-    a0 = make_double2(c * a0.x + s * a0.y, c * a0.y - s * a0.x);
-    a1 = make_double2(c * a1.x - s * a1.y, c * a1.y + s * a1.x);
-}
-// Rx = [[c,-is],[-is,c]]  (elementary_operations.py:159-165)
-__device__ __forceinline__ void rx2(cplx& a0, cplx& a1, double c, double s) {
-    const cplx t0 = make_double2(c * a0.x + s * a1.y, c * a0.y - s * a1.x);
-    const cplx t1 = make_double2(s * a0.y + c * a1.x, c * a1.y - s * a0.x);
-    a0 = t0;
-    a1 = t1;
-}
 template <int ENT>
 __device__ __forceinline__ void rs2(cplx& a0, cplx& a1, double c, double s) {
     if (ENT == 0) rx2(a0, a1, c, s); else rz2(a0, a1, c, s);
@@ -88,17 +50,6 @@ __device__ __forceinline__ void block_inv(cplx* a, const double* cf, int flags) 
     ry2(a[0], a[2], cf[0], -cf[1]); ry2(a[1], a[3], cf[0], -cf[1]);
     entangle<ENT>(a, cf[8], -cf[9]);
     if (flags & 1) { rz2(a[0], a[2], kR, kR); rz2(a[1], a[3], kR, kR); }
-}
-
-__device__ __forceinline__ unsigned insert_zero(unsigned g, int pos) {
-    const unsigned lo = g & ((1u << pos) - 1u);
-    return ((g >> pos) << (pos + 1)) | lo;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 struct TileCtx {
@@ -332,7 +283,7 @@ __global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
 // ------------------------------------------------------------------------------------------
 // coefficient records from thetas: half-angle (cos, sin) pairs (+ full-angle pair for CP)
 __global__ void coef_kernel(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch) {
-    const int ncoef = n + nblocks;
+    const int ncoef = n + nblocks + 1;  // + one constant record: (cos, sin)(pi/4) for the Trotter Rz(+-pi/2)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * ncoef) return;
     const int b = idx / ncoef, ci = idx % ncoef;
@@ -340,7 +291,10 @@ __global__ void coef_kernel(const double* thetas, double* coef, int n, int nbloc
     const double* th = thetas + (size_t)b * T;
     double* cf = coef + (size_t)idx * kCoefStride;
     double s, c;
-    if (ci < n) {
+    if (ci == n + nblocks) {
+        cf[0] = kR; cf[1] = kR;
+        for (int j = 2; j < kCoefStride; ++j) cf[j] = 0.0;
+    } else if (ci < n) {
         for (int j = 0; j < 3; ++j) { sincos(0.5 * th[3 * ci + j], &s, &c); cf[2 * j] = c; cf[2 * j + 1] = s; }
         for (int j = 6; j < kCoefStride; ++j) cf[j] = 0.0;
     } else {
@@ -470,7 +424,7 @@ hipError_t launch_sweep(int ent, int ntiles, int batch, int threads, int k, hipS
 }
 
 hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch, hipStream_t s) {
-    const int total = batch * (n + nblocks);
+    const int total = batch * (n + nblocks + 1);
     coef_kernel<<<(total + 127) / 128, 128, 0, s>>>(thetas, coef, n, nblocks, tpb, batch);
     return hipGetLastError();
 }

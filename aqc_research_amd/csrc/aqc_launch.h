@@ -12,6 +12,8 @@ namespace aqc {
 struct StageArgs {
     const DevStage* stage;  // this stage's descriptor (device)
     const DevOp* ops;       // all ops of the plan (device)
+    const DevSub* subs;     // register-blocked kernels: sub-stages of the plan
+    const DevMop* mops;     // ... and their micro-ops
     const double* coef;     // [batch][ncoef][kCoefStride]
     int ncoef;
     const double2* in0;     // apply: src; sweep: w in
@@ -39,6 +41,11 @@ hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* e
                          hipStream_t s);
 hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t count, int batch, void* part, int nparts,
                        void* out, hipStream_t s);
+
+// aqc_kernels2.hip (register-blocked kernels)
+hipError_t init_kernels2();
+hipError_t launch_apply2(int ent, int ntiles, int batch, int k, hipStream_t s, const StageArgs& a);
+hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, hipStream_t s, const StageArgs& a);
 
 // aqc_mps.hip
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);

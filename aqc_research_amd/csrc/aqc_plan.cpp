@@ -62,6 +62,14 @@ struct Sim {
     const Program& prog;
     const std::vector<int>& order;  // remaining group indices in execution order
     int col_bits;
+    const std::vector<int>* remap = nullptr;  // optional address bit -> position map (sub-stage planning)
+    int max_take = 1 << 30;
+    uint64_t group_bits(const GateGroup& g) const {
+        auto pos = [&](int q) { const int b = col_bits + q; return remap ? (*remap)[b] : b; };
+        uint64_t bits = 1ull << pos(g.q0);
+        if (g.q1 >= 0) bits |= 1ull << pos(g.q1);
+        return bits;
+    }
     // Number of groups executable with local set `mask`; optionally collects them and
     // reports the first group that was skipped although none of its bits was blocked yet.
     int run(uint64_t mask, std::vector<int>* taken, int* first_missing) const {
@@ -70,8 +78,8 @@ struct Sim {
         if (first_missing) *first_missing = -1;
         for (int gi : order) {
             const GateGroup& g = prog.groups[gi];
-            uint64_t bits = 1ull << (col_bits + g.q0);
-            if (g.q1 >= 0) bits |= 1ull << (col_bits + g.q1);
+            const uint64_t bits = group_bits(g);
+            if (count >= max_take) break;
             if (bits & blocked) {
                 blocked |= bits;
             } else if ((bits & mask) == bits) {
@@ -162,6 +170,57 @@ Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, b
     return plan;
 }
 
+void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops) {
+    for (Stage& st : plan.stages) {
+        st.subs.clear();
+        const int k = (int)st.bits.size();
+        const int r = std::min(reg_bits, k);
+        std::vector<int> local_of(plan.nbits, 0);
+        for (int j = 0; j < k; ++j) local_of[st.bits[j]] = j;
+        std::vector<int> order = st.ops;
+        while (!order.empty()) {
+            Sim sim{prog, order, plan.col_bits, &local_of, max_ops};
+            uint64_t best = 0;
+            int best_count = -1;
+            auto consider = [&](uint64_t m) {
+                const int c = sim.run(m, nullptr, nullptr);
+                if (c > best_count) { best_count = c; best = m; }
+            };
+            if (k <= r) {
+                consider((1ull << k) - 1);
+            } else {
+                uint64_t m = 0;
+                for (;;) {  // greedy growth along program order
+                    int miss = -1;
+                    sim.run(m, nullptr, &miss);
+                    if (miss < 0) break;
+                    const uint64_t need = sim.group_bits(prog.groups[miss]);
+                    if (popcount64(m | need) > r) break;
+                    m |= need;
+                }
+                consider(m);
+                for (int a = 0; a + r <= k; ++a) consider(((1ull << r) - 1) << a);  // contiguous windows
+            }
+            for (int b = 0; b < k && popcount64(best) < r; ++b) best |= 1ull << b;
+            SubStage sub;
+            for (int b = 0; b < k; ++b)
+                if (best >> b & 1) sub.bits.push_back(b);
+            sim.run(best, &sub.ops, nullptr);
+            if (sub.ops.empty()) sub.ops.push_back(order.front());  // unreachable for r >= 2
+            std::vector<char> done(prog.groups.size(), 0);
+            for (int gi : sub.ops) done[gi] = 1;
+            std::vector<int> rest;
+            for (int gi : order)
+                if (!done[gi]) rest.push_back(gi);
+            order.swap(rest);
+            st.subs.push_back(std::move(sub));
+        }
+        // execution order of the stage is now the concatenation of its sub-stages
+        st.ops.clear();
+        for (const SubStage& sub : st.subs) st.ops.insert(st.ops.end(), sub.ops.begin(), sub.ops.end());
+    }
+}
+
 std::string check_plan(const Program& prog, const Plan& plan) {
     const int G = (int)prog.groups.size();
     std::vector<int> seen(G, 0);
@@ -185,6 +244,23 @@ std::string check_plan(const Program& prog, const Plan& plan) {
     }
     for (int i = 0; i < G; ++i)
         if (seen[i] != 1) return "group not scheduled";
+    for (const Stage& st : plan.stages) {
+        if (st.subs.empty()) continue;
+        std::vector<int> local_of(plan.nbits, -1);
+        for (size_t j = 0; j < st.bits.size(); ++j) local_of[st.bits[j]] = (int)j;
+        std::vector<int> flat;
+        for (const SubStage& sub : st.subs) {
+            uint64_t m = 0;
+            for (int b : sub.bits) m |= 1ull << b;
+            for (int gi : sub.ops) {
+                const GateGroup& g = prog.groups[gi];
+                const int p0 = local_of[plan.col_bits + g.q0], p1 = g.q1 >= 0 ? local_of[plan.col_bits + g.q1] : p0;
+                if (!(m >> p0 & 1) || !(m >> p1 & 1)) return "sub-stage group uses a non-register bit";
+                flat.push_back(gi);
+            }
+        }
+        if (flat != st.ops) return "sub-stages do not reproduce the stage order";
+    }
     return "";
 }
 

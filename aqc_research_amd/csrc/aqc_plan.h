@@ -40,9 +40,15 @@ struct Program {
 std::string build_program(int n, int entangler, const int32_t* blocks, int L, bool trotter,
                           bool second_order, Program& out);
 
+struct SubStage {
+    std::vector<int> bits;  // register bits as LOCAL bit positions of the stage (ascending, <= 4)
+    std::vector<int> ops;   // indices into Program::groups, in execution order
+};
+
 struct Stage {
     std::vector<int> bits;  // local address bits, ascending; local index bit j <-> bits[j]
     std::vector<int> ops;   // indices into Program::groups, in execution order
+    std::vector<SubStage> subs;  // register-blocked partition of `ops` (same overall order per qubit)
 };
 
 struct Plan {
@@ -58,6 +64,10 @@ struct Plan {
 // tile_bits local bits; the lowest `low_bits` address bits are always local so that
 // every HBM access is a run of 2^low_bits contiguous complex128.
 Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, bool inverse);
+
+// Partitions every stage into sub-stages: each sub-stage touches at most `reg_bits` of the stage's
+// local bits (held in registers by one thread: 2^reg_bits amplitudes) and at most `max_ops` groups.
+void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops);
 
 // Throws nothing; returns "" if the plan executes every group exactly once, in an order
 // compatible with per-qubit program order, using only local bits.

@@ -71,49 +71,71 @@ struct DevPlan {
 };
 
 // Micro-ops of one gate group on register bits (pc, pt); forward or conjugate-transposed order.
-void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, std::vector<DevMop>& out) {
+// with_dots: the sweep; every group ends with a MOP_REDUCE that folds its inner products.
+void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, bool with_dots, std::vector<DevMop>& out) {
     const GateGroup& g = prog.groups[gi];
     const int rec = g.coef * kCoefStride;
-    const int konst = (prog.n + prog.num_blocks) * kCoefStride;  // (cos, sin)(pi/4)
+    const int konst = (prog.n + prog.num_blocks) * kCoefStride + kLiftOffset;  // Rz(pi/2) in lifting form
     const int neg = inverse ? MOPF_NEG_S : 0;
-    auto rot = [&](int kind, int p, int coef, int flags, int slot) {
-        out.push_back({kind, p, 0, flags, coef, inverse ? -1 : slot, g.jblock, 0});
+    std::vector<std::pair<int, int>> dots;  // (slot, producer kind), oldest first
+    auto rot = [&](int kind, int p, int pair, int flags, int slot) {
+        const int coef = pair < 0 ? konst : rec + kLiftOffset + 2 * pair;
+        const bool has = with_dots && slot >= 0;
+        out.push_back({kind, p, 0, flags, coef, has ? slot : -1, g.jblock, 0});
+        if (has) dots.push_back({slot, kind});
+    };
+    auto reduce = [&]() {
+        if (dots.empty()) return;
+        DevMop m = {MOP_REDUCE, -1, -1, 0, -1, -1, g.jblock, 0};
+        int kinds = 0;
+        for (size_t j = 0; j < dots.size(); ++j) {  // newest first
+            const auto& d = dots[dots.size() - 1 - j];
+            kinds |= d.second << (4 * j);
+            (j == 0 ? m.slot : j == 1 ? m.p : j == 2 ? m.p2 : m.coef) = d.first;
+        }
+        m.flags = kinds;
+        out.push_back(m);
+        dots.clear();
     };
     const int slot0 = gi * kSlotsPerGroup;
     if (g.type == GROUP_FRONT) {
         if (!inverse) {  // Rz(t2), Ry(t1), Rz(t0), rightmost first (core_operations.py:671-677,921-935)
-            rot(MOP_RZ, pc, rec + 4, 0, slot0 + 0);
-            rot(MOP_RY, pc, rec + 2, 0, slot0 + 1);
-            rot(MOP_RZ, pc, rec + 0, 0, slot0 + 2);
+            rot(MOP_RZ, pc, 2, 0, slot0 + 0);
+            rot(MOP_RY, pc, 1, 0, slot0 + 1);
+            rot(MOP_RZ, pc, 0, 0, slot0 + 2);
+            reduce();
         } else {         // (Rz Ry Rz)^H (core_operations.py:812-818)
-            rot(MOP_RZ, pc, rec + 0, neg, -1);
-            rot(MOP_RY, pc, rec + 2, neg, -1);
-            rot(MOP_RZ, pc, rec + 4, neg, -1);
+            rot(MOP_RZ, pc, 0, neg, -1);
+            rot(MOP_RY, pc, 1, neg, -1);
+            rot(MOP_RZ, pc, 2, neg, -1);
         }
         return;
     }
     const int ekind = prog.entangler == 0 ? MOP_CX : (prog.entangler == 1 ? MOP_CZ : MOP_CP);
     const int rs = prog.entangler == 0 ? MOP_RX : MOP_RZ;
     if (!inverse) {  // core_operations.py:956-1017
-        if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, konst, MOPF_NEG_S, -1);   // Rz(-pi/2) on control
-        out.push_back({ekind, pc, pt, 0, rec + 8, prog.entangler == 2 ? slot0 + 4 : -1, g.jblock, 0});
-        rot(MOP_RY, pc, rec + 0, 0, slot0 + 0);
-        rot(MOP_RZ, pc, rec + 2, 0, slot0 + 1);
-        rot(MOP_RY, pt, rec + 4, 0, slot0 + 2);
-        rot(rs, pt, rec + 6, 0, slot0 + 3);
-        if (g.flags & FLAG_POST_RZ) rot(MOP_RZ, pt, konst, 0, -1);           // Rz(+pi/2) on target
+        if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, -1, MOPF_NEG_S, -1);   // Rz(-pi/2) on control
+        const bool cpdot = with_dots && prog.entangler == 2;
+        out.push_back({ekind, pc, pt, 0, rec + 8, cpdot ? slot0 + 4 : -1, g.jblock, 0});
+        if (cpdot) { dots.push_back({slot0 + 4, MOP_CP}); reduce(); }
+        rot(MOP_RY, pc, 0, 0, slot0 + 0);
+        rot(MOP_RZ, pc, 1, 0, slot0 + 1);
+        rot(MOP_RY, pt, 2, 0, slot0 + 2);
+        rot(rs, pt, 3, 0, slot0 + 3);
+        reduce();
+        if (g.flags & FLAG_POST_RZ) rot(MOP_RZ, pt, -1, 0, -1);           // Rz(+pi/2) on target
     } else {         // core_operations.py:787-809
-        if (g.flags & FLAG_POST_RZ) rot(MOP_RZ, pt, konst, MOPF_NEG_S, -1);
-        rot(rs, pt, rec + 6, neg, -1);
-        rot(MOP_RY, pt, rec + 4, neg, -1);
-        rot(MOP_RZ, pc, rec + 2, neg, -1);
-        rot(MOP_RY, pc, rec + 0, neg, -1);
+        if (g.flags & FLAG_POST_RZ) rot(MOP_RZ, pt, -1, MOPF_NEG_S, -1);
+        rot(rs, pt, 3, neg, -1);
+        rot(MOP_RY, pt, 2, neg, -1);
+        rot(MOP_RZ, pc, 1, neg, -1);
+        rot(MOP_RY, pc, 0, neg, -1);
         out.push_back({ekind, pc, pt, neg, rec + 8, -1, g.jblock, 0});
-        if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, konst, 0, -1);
+        if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, -1, 0, -1);
     }
 }
 
-void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits) {
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots) {
     out.plan = plan;
     out.h_stages.clear();
     out.h_ops.clear();
@@ -121,7 +143,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
     out.h_mops.clear();
     out.reg_bits = reg_bits;
     out.v2 = reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
-    if (out.v2) split_substages(prog, out.plan, reg_bits, 12);
+    if (out.v2) split_substages(prog, out.plan, reg_bits, kMaxOpsPerSub);
     out.k = (int)plan.stages.front().bits.size();
     out.ntiles = 1 << (plan.nbits - out.k);
     for (const Stage& st : out.plan.stages) {
@@ -174,7 +196,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
                     const GateGroup& g = prog.groups[gi];
                     const int pc = reg_of[local_of[plan.col_bits + g.q0]];
                     const int pt = g.q1 >= 0 ? reg_of[local_of[plan.col_bits + g.q1]] : 0;
-                    emit_mops(prog, gi, pc, pt, plan.inverse, out.h_mops);
+                    emit_mops(prog, gi, pc, pt, plan.inverse, with_dots, out.h_mops);
                 }
                 dsub.nmops = (int)out.h_mops.size() - dsub.mop_begin;
                 out.h_subs.push_back(dsub);
@@ -330,6 +352,7 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
         a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
         a.out0 = ws->bufs[dst_buf];
         a.lane_stride = ws->lane_elems;
+        a.final_stage = (s + 1 == p.h_stages.size()) ? 1 : 0;
         ProfScope ps(ws, AQC_K_APPLY);
         if (p.v2) HIP_OK(launch_apply2(prog.entangler, p.ntiles, ws->batch, p.k, ws->stream, a));
         else HIP_OK(launch_apply(prog.entangler, inverse, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
@@ -436,9 +459,9 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     ks = std::min(std::min(ks, 12), ws->nbits);
 
     const bool want_v2 = env_int("AQC_KERNEL_V2", 1) != 0;
-    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd, want_v2 ? 4 : 0);
-    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv, want_v2 ? 4 : 0);
-    lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep, want_v2 ? 4 : 0);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd, want_v2 ? 4 : 0, false);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv, want_v2 ? 4 : 0, false);
+    lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep, want_v2 ? 4 : 0, true);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -522,7 +545,7 @@ int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas) {
     HIP_OK(hipStreamSynchronize(ws->stream));  // the host buffer may be reused right away
     {
         ProfScope ps(ws, AQC_K_COEF);
-        HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, ws->batch, ws->stream));
+        HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
     }
     ws->coef_valid = true;
     return 0;
@@ -717,7 +740,7 @@ int aqc_ws_use_theta_set(aqc_ws* ws, int set_index) {
     const Program& prog = ws->ctx->prog;
     ws->d_thetas = ws->d_theta_bank + (size_t)set_index * ws->batch * prog.num_thetas();
     ProfScope ps(ws, AQC_K_COEF);
-    HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, ws->batch, ws->stream));
+    HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
     ws->coef_valid = true;
     return 0;
 }

@@ -4,7 +4,14 @@
 
 namespace aqc {
 
-constexpr int kCoefStride = 12;     // doubles per coefficient record
+// Coefficient record (doubles): [0..9] five (cos, sin) pairs -- half angles of t0..t3, full angle of the
+// CP phase; [12..21] the same rotations in lifting form (-tan(phi/2), sin(phi)) after normalising to
+// cos(phi) >= 0 (a rotation by phi equals minus the rotation by phi -+ pi); [22] product of the signs
+// dropped by that normalisation.  Record n+L is constant: Rz(+-pi/2) of the Trotter decoration, and
+// [2] of it holds the lane's overall sign.
+constexpr int kCoefStride = 24;     // doubles per coefficient record
+constexpr int kLiftOffset = 12;
+constexpr int kSignOffset = 22;
 constexpr int kSlotsPerGroup = 5;   // inner-product slots reserved per gate group
 constexpr int kMaxTileBits = 14;    // dlo: 6 bits, dhi: 8 bits
 constexpr int kMaxBits = 31;
@@ -39,7 +46,7 @@ struct DevStage {
 // ---- register-blocked ("v2") kernels ------------------------------------------------------------
 // A sub-stage keeps 2^r amplitudes per thread in registers (r register bits out of the tile's local
 // bits) and runs a list of micro-ops on them before going back to LDS.
-enum MopKind { MOP_RY = 0, MOP_RZ = 1, MOP_RX = 2, MOP_CX = 3, MOP_CZ = 4, MOP_CP = 5 };
+enum MopKind { MOP_RY = 0, MOP_RZ = 1, MOP_RX = 2, MOP_CX = 3, MOP_CZ = 4, MOP_CP = 5, MOP_REDUCE = 6 };
 enum MopFlags { MOPF_NEG_S = 1 };  // use (c, -s): inverse rotation / Rz(-pi/2) decoration
 
 struct DevMop {
@@ -51,6 +58,9 @@ struct DevMop {
     int32_t slot;    // inner-product slot fed by this micro-op, -1 if none
     int32_t jblock;  // block index mod L for the block_range test, -1 = front layer
     int32_t pad;
+    // MOP_REDUCE: reduces the (up to 4) most recent inner products of the thread; `slot` is the slot of
+    // the newest one, p / p2 / coef those of the 2nd / 3rd / 4th newest (-1 = none); `flags` packs the
+    // MopKind of each producer (4 bits each, newest first) for the 0.5 / 0.5j / -1j factor.
 };
 
 struct DevSub {
@@ -61,5 +71,7 @@ struct DevSub {
 };
 
 constexpr int kMaxMopsPerSub = 96;
+constexpr int kMaxReducePerSub = 16;
+constexpr int kMaxOpsPerSub = 8;
 
 }  // namespace aqc

@@ -281,28 +281,51 @@ __global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
 // ------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------
-// coefficient records from thetas: half-angle (cos, sin) pairs (+ full-angle pair for CP)
+// coefficient records from thetas: half-angle (cos, sin) pairs (+ full-angle pair for CP) and their
+// lifting form (see aqc_device.h)
+__device__ __forceinline__ double put_pair(double* cf, int j, double angle) {
+    double s, c;
+    sincos(angle, &s, &c);
+    cf[2 * j] = c;
+    cf[2 * j + 1] = s;
+    double sg = 1.0;
+    if (c < 0.0) { c = -c; s = -s; sg = -1.0; }
+    cf[kLiftOffset + 2 * j] = -s / (1.0 + c);
+    cf[kLiftOffset + 2 * j + 1] = s;
+    return sg;
+}
 __global__ void coef_kernel(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch) {
-    const int ncoef = n + nblocks + 1;  // + one constant record: (cos, sin)(pi/4) for the Trotter Rz(+-pi/2)
+    const int ncoef = n + nblocks + 1;  // + one constant record: Rz(+-pi/2) of the Trotter decoration
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * ncoef) return;
     const int b = idx / ncoef, ci = idx % ncoef;
     const int T = 3 * n + tpb * nblocks;
     const double* th = thetas + (size_t)b * T;
     double* cf = coef + (size_t)idx * kCoefStride;
-    double s, c;
+    for (int j = 0; j < kCoefStride; ++j) cf[j] = 0.0;
+    double sg = 1.0;
     if (ci == n + nblocks) {
-        cf[0] = kR; cf[1] = kR;
-        for (int j = 2; j < kCoefStride; ++j) cf[j] = 0.0;
+        put_pair(cf, 0, 0.78539816339744831);  // pi/4
+        cf[2] = 1.0;
     } else if (ci < n) {
-        for (int j = 0; j < 3; ++j) { sincos(0.5 * th[3 * ci + j], &s, &c); cf[2 * j] = c; cf[2 * j + 1] = s; }
-        for (int j = 6; j < kCoefStride; ++j) cf[j] = 0.0;
+        for (int j = 0; j < 3; ++j) sg *= put_pair(cf, j, 0.5 * th[3 * ci + j]);
     } else {
         const double* t = th + 3 * n + (size_t)tpb * (ci - n);
-        for (int j = 0; j < 4; ++j) { sincos(0.5 * t[j], &s, &c); cf[2 * j] = c; cf[2 * j + 1] = s; }
-        if (tpb == 5) { sincos(t[4], &s, &c); cf[8] = c; cf[9] = s; } else { cf[8] = 1.0; cf[9] = 0.0; }
-        cf[10] = cf[11] = 0.0;
+        for (int j = 0; j < 4; ++j) sg *= put_pair(cf, j, 0.5 * t[j]);
+        if (tpb == 5) put_pair(cf, 4, t[4]); else { cf[8] = 1.0; cf[9] = 0.0; }
     }
+    cf[kSignOffset] = sg;
+}
+// lane sign = product of the record signs over the gate groups actually executed (the virtual trailing
+// half-layer of a 2nd-order Trotter ansatz re-uses the first `tail` block records: their signs square away)
+__global__ void sign_kernel(double* coef, int n, int nblocks, int tail) {
+    const int ncoef = n + nblocks + 1, lane = threadIdx.x;
+    double* base = coef + (size_t)blockIdx.x * ncoef * kCoefStride;
+    int neg = 0;
+    for (int ci = lane; ci < n + nblocks; ci += 64)
+        if (!(ci >= n && ci < n + tail) && base[(size_t)ci * kCoefStride + kSignOffset] < 0.0) ++neg;
+    for (int o = 32; o > 0; o >>= 1) neg += __shfl_xor(neg, o, 64);
+    if (lane == 0) base[(size_t)(n + nblocks) * kCoefStride + 2] = (neg & 1) ? -1.0 : 1.0;
 }
 
 // grads[b][t] = sum over the (<=2) slots feeding theta t, over tiles, in a fixed order.
@@ -423,9 +446,10 @@ hipError_t launch_sweep(int ent, int ntiles, int batch, int threads, int k, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch, hipStream_t s) {
+hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int tail, int batch, hipStream_t s) {
     const int total = batch * (n + nblocks + 1);
     coef_kernel<<<(total + 127) / 128, 128, 0, s>>>(thetas, coef, n, nblocks, tpb, batch);
+    sign_kernel<<<batch, 64, 0, s>>>(coef, n, nblocks, tail);
     return hipGetLastError();
 }
 

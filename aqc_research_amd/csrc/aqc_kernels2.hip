@@ -18,134 +18,199 @@
 #include "aqc_launch.h"
 #include "aqc_math.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace aqc {
 
 __device__ __forceinline__ unsigned swz(unsigned l) { return l ^ ((l >> 4) & 15u); }
 
+// ---- in-place arithmetic --------------------------------------------------------------------------
+// Every update below is a v_fma_f64 whose destination is tied to its addend ("+v"), so the 64 doubles
+// of a chunk stay in the registers they were loaded into: without the tie the compiler materialises
+// each micro-op's results in fresh registers and copies them back at the dispatch merge point
+// (v_mov_b64 count ~ fp64 op count in the first version of this kernel).
+__device__ __forceinline__ void fma_ip(double& acc, double a, double b) {   // acc += a * b
+    asm("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fnma_ip(double& acc, double a, double b) {  // acc -= a * b
+    asm("v_fma_f64 %0, -%1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// Plane rotation by phi, |phi| <= pi/2, as three shears: (x, y) <- (c x - s y, s x + c y) with
+// nt = -tan(phi/2), s = sin(phi).  3 FMAs instead of 2 mul + 2 fma, and no temporaries.
+__device__ __forceinline__ void lift_pos(double& x, double& y, double nt, double s) {
+    fma_ip(x, nt, y); fma_ip(y, s, x); fma_ip(x, nt, y);
+}
+__device__ __forceinline__ void lift_neg(double& x, double& y, double nt, double s) {  // rotation by -phi
+    fnma_ip(x, nt, y); fnma_ip(y, s, x); fnma_ip(x, nt, y);
+}
+template <int KIND>
+__device__ __forceinline__ void rot_pair_ip(cplx& a0, cplx& a1, double nt, double s) {
+    if (KIND == MOP_RY) {          // [[c,-s],[s,c]] on real and imaginary parts
+        lift_pos(a0.x, a1.x, nt, s); lift_pos(a0.y, a1.y, nt, s);
+    } else if (KIND == MOP_RZ) {   // a0 *= e^{-i phi}, a1 *= e^{+i phi}
+        lift_neg(a0.x, a0.y, nt, s); lift_pos(a1.x, a1.y, nt, s);
+    } else {                       // Rx: (a0.x, a1.y) rotate by -phi, (a0.y, a1.x) by +phi
+        lift_neg(a0.x, a1.y, nt, s); lift_pos(a0.y, a1.x, nt, s);
+    }
+}
+__device__ __forceinline__ void cmacc_ip(cplx& d, const cplx& a, const cplx& b) {  // d += conj(a) b
+    fma_ip(d.x, a.x, b.x); fma_ip(d.x, a.y, b.y); fma_ip(d.y, a.x, b.y); fnma_ip(d.y, a.y, b.x);
+}
+__device__ __forceinline__ void cmsub_ip(cplx& d, const cplx& a, const cplx& b) {  // d -= conj(a) b
+    fnma_ip(d.x, a.x, b.x); fnma_ip(d.x, a.y, b.y); fnma_ip(d.y, a.x, b.y); fma_ip(d.y, a.y, b.x);
+}
+__device__ __forceinline__ void swap_ip(cplx& a, cplx& b) { const cplx t = a; a = b; b = t; }
+
+// Compile-time loop: the index arrives as an integral_constant, so every array subscript is a constant
+// in the very first IR and the arrays are promoted to SSA values before any CFG transformation runs
+// (with `#pragma unroll` loops the promotion has to wait for the unroller, and by then SimplifyCFG may
+// have merged look-alike arms through pointer phis, which pins the arrays in scratch memory).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // ---- micro-ops on register-resident amplitudes ---------------------------------------------------
 // one vector
 template <int R, int P, int KIND>
-__device__ __forceinline__ void rot_regs1(cplx (&v)[1 << R], double c, double s) {
-#pragma unroll
-    for (int g = 0; g < (1 << (R - 1)); ++g) {
-        const int i0 = ((g >> P) << (P + 1)) | (g & ((1 << P) - 1)), i1 = i0 | (1 << P);
-        if (KIND == MOP_RY) ry2(v[i0], v[i1], c, s);
-        else if (KIND == MOP_RZ) rz2(v[i0], v[i1], c, s);
-        else rx2(v[i0], v[i1], c, s);
-    }
+__device__ __forceinline__ void rot_regs1(cplx (&v)[1 << R], double nt, double s) {
+    static_for<(1 << (R - 1))>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int i0 = ((g >> P) << (P + 1)) | (g & ((1 << P) - 1)), i1 = i0 | (1 << P);
+        rot_pair_ip<KIND>(v[i0], v[i1], nt, s);
+    });
 }
 template <int R, int PC, int PT, int KIND>
 __device__ __forceinline__ void ent_regs1(cplx (&v)[1 << R], double c, double s) {
     constexpr int LO = PC < PT ? PC : PT, HI = PC < PT ? PT : PC;
-#pragma unroll
-    for (int g = 0; g < (1 << (R - 2)); ++g) {
-        int b = ((g >> LO) << (LO + 1)) | (g & ((1 << LO) - 1));
-        b = ((b >> HI) << (HI + 1)) | (b & ((1 << HI) - 1));
-        const int i2 = b | (1 << PC), i3 = i2 | (1 << PT);
-        if (KIND == MOP_CX) { const cplx t = v[i2]; v[i2] = v[i3]; v[i3] = t; }
+    static_for<(1 << (R - 2))>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int b0 = ((g >> LO) << (LO + 1)) | (g & ((1 << LO) - 1));
+        constexpr int b = ((b0 >> HI) << (HI + 1)) | (b0 & ((1 << HI) - 1));
+        constexpr int i2 = b | (1 << PC), i3 = i2 | (1 << PT);
+        if (KIND == MOP_CX) swap_ip(v[i2], v[i3]);
         else if (KIND == MOP_CZ) { v[i3].x = -v[i3].x; v[i3].y = -v[i3].y; }
         else v[i3] = cmul(v[i3], c, s);
-    }
+    });
 }
 // two vectors + inner product
 template <int R, int P, int KIND, bool DOT>
-__device__ __forceinline__ void rot_regs2(cplx (&w)[1 << R], cplx (&z)[1 << R], double c, double s, cplx& d) {
-#pragma unroll
-    for (int g = 0; g < (1 << (R - 1)); ++g) {
-        const int i0 = ((g >> P) << (P + 1)) | (g & ((1 << P) - 1)), i1 = i0 | (1 << P);
-        if (KIND == MOP_RY) {
-            ry2(w[i0], w[i1], c, s); ry2(z[i0], z[i1], c, s);
-            if (DOT) { cmacc(d, w[i0], z[i1]); cmsub(d, w[i1], z[i0]); }   // <Y w|z> / i
-        } else if (KIND == MOP_RZ) {
-            rz2(w[i0], w[i1], c, s); rz2(z[i0], z[i1], c, s);
-            if (DOT) { cmacc(d, w[i0], z[i0]); cmsub(d, w[i1], z[i1]); }   // <Z w|z>
-        } else {
-            rx2(w[i0], w[i1], c, s); rx2(z[i0], z[i1], c, s);
-            if (DOT) { cmacc(d, w[i1], z[i0]); cmacc(d, w[i0], z[i1]); }   // <X w|z>
+__device__ __forceinline__ void rot_regs2(cplx (&w)[1 << R], cplx (&z)[1 << R], double nt, double s, cplx& d) {
+    static_for<(1 << (R - 1))>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int i0 = ((g >> P) << (P + 1)) | (g & ((1 << P) - 1)), i1 = i0 | (1 << P);
+        rot_pair_ip<KIND>(w[i0], w[i1], nt, s);
+        rot_pair_ip<KIND>(z[i0], z[i1], nt, s);
+        if (DOT) {
+            if (KIND == MOP_RY) { cmacc_ip(d, w[i0], z[i1]); cmsub_ip(d, w[i1], z[i0]); }        // <Y w|z> / i
+            else if (KIND == MOP_RZ) { cmacc_ip(d, w[i0], z[i0]); cmsub_ip(d, w[i1], z[i1]); }   // <Z w|z>
+            else { cmacc_ip(d, w[i1], z[i0]); cmacc_ip(d, w[i0], z[i1]); }                       // <X w|z>
         }
-    }
+    });
 }
 template <int R, int PC, int PT, int KIND, bool DOT>
 __device__ __forceinline__ void ent_regs2(cplx (&w)[1 << R], cplx (&z)[1 << R], double c, double s, cplx& d) {
     constexpr int LO = PC < PT ? PC : PT, HI = PC < PT ? PT : PC;
-#pragma unroll
-    for (int g = 0; g < (1 << (R - 2)); ++g) {
-        int b = ((g >> LO) << (LO + 1)) | (g & ((1 << LO) - 1));
-        b = ((b >> HI) << (HI + 1)) | (b & ((1 << HI) - 1));
-        const int i2 = b | (1 << PC), i3 = i2 | (1 << PT);
+    static_for<(1 << (R - 2))>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int b0 = ((g >> LO) << (LO + 1)) | (g & ((1 << LO) - 1));
+        constexpr int b = ((b0 >> HI) << (HI + 1)) | (b0 & ((1 << HI) - 1));
+        constexpr int i2 = b | (1 << PC), i3 = i2 | (1 << PT);
         if (KIND == MOP_CX) {
-            cplx t = w[i2]; w[i2] = w[i3]; w[i3] = t;
-            t = z[i2]; z[i2] = z[i3]; z[i3] = t;
+            swap_ip(w[i2], w[i3]); swap_ip(z[i2], z[i3]);
         } else if (KIND == MOP_CZ) {
             w[i3].x = -w[i3].x; w[i3].y = -w[i3].y; z[i3].x = -z[i3].x; z[i3].y = -z[i3].y;
         } else {
-            if (DOT) cmacc(d, w[i3], z[i3]);  // -i<P11 w|z>, pre-gate (core_op_matrix.py:430-477)
+            if (DOT) cmacc_ip(d, w[i3], z[i3]);  // -i<P11 w|z>, pre-gate (core_op_matrix.py:430-477)
             w[i3] = cmul(w[i3], c, s); z[i3] = cmul(z[i3], c, s);
         }
-    }
+    });
 }
 
-#define AQC_ROT1_CASE(K, P) case (K) * 8 + (P): if ((P) < R) rot_regs1<R, (P) < R ? (P) : 0, K>(v, c, s); break;
-#define AQC_ENT1_CASE(K, PC, PT) case (PC) * 8 + (PT): if ((PC) < R && (PT) < R) ent_regs1<R, (PC) < R ? (PC) : 0, (PT) < R ? (PT) : 1, K>(v, c, s); break;
+// Sums eight per-thread doubles over the wave with a transposing butterfly: after the three exchange
+// steps lane l owns value (l & 7), after three more every lane holds the wave total of its value.
+__device__ __forceinline__ double reduce8(const double (&v)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    double r[4], q[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        r[i] = keep + dpp_mov<0xB1, 0xf>(send);  // lane ^ 1
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b1 ? r[2 * i + 1] : r[2 * i], send = b1 ? r[2 * i] : r[2 * i + 1];
+        q[i] = keep + dpp_mov<0x4E, 0xf>(send);  // lane ^ 2
+    }
+    const double keep = b2 ? q[1] : q[0], send = b2 ? q[0] : q[1];
+    double u = keep + __shfl_xor(send, 4, 64);
+    u += __shfl_xor(u, 8, 64);
+    u += __shfl_xor(u, 16, 64);
+    u += __shfl_xor(u, 32, 64);
+    return u;
+}
+
+// ---- dispatch -----------------------------------------------------------------------------------------
+// The dispatch is a sequence of ONE-SIDED, wave-uniform ifs.  A switch (or if/else chain) is lowered
+// to a multi-exit region that StructurizeCFG linearises with "Flow" blocks; the phis of those blocks
+// keep the pre-dispatch copy of every live value alive across each arm, so every arm starts by copying
+// the whole register tile (measured: ~1 v_mov_b64 per fp64 op).  Guarded in-place updates have no such
+// problem: each arm is a simple diamond and the values never leave their registers.
+// Conditions are single-bit tests of ONE-HOT masks (kind, position, target, dot): the compiler cannot
+// prove two bit tests exclusive, so it cannot fold the sequence back into a switch / if-else chain.
+#define AQC_ROT1_ARM(K, P) if ((P) < R && (pm & (1 << (P)))) rot_regs1<R, (P) < R ? (P) : 0, K>(v, c, s);
+#define AQC_ENT1_ARM(K, PC, PT) if (tm & (1 << (PT))) ent_regs1<R, PC, PT, K>(v, c, s);
 
 template <int R, int ENT>
-__device__ __forceinline__ void run_mop1(int code, cplx (&v)[1 << R], double c, double s) {
-    if (code < 64) {
-        switch (code) {
-            AQC_ROT1_CASE(MOP_RY, 0) AQC_ROT1_CASE(MOP_RY, 1) AQC_ROT1_CASE(MOP_RY, 2) AQC_ROT1_CASE(MOP_RY, 3) AQC_ROT1_CASE(MOP_RY, 4)
-            AQC_ROT1_CASE(MOP_RZ, 0) AQC_ROT1_CASE(MOP_RZ, 1) AQC_ROT1_CASE(MOP_RZ, 2) AQC_ROT1_CASE(MOP_RZ, 3) AQC_ROT1_CASE(MOP_RZ, 4)
-            AQC_ROT1_CASE(MOP_RX, 0) AQC_ROT1_CASE(MOP_RX, 1) AQC_ROT1_CASE(MOP_RX, 2) AQC_ROT1_CASE(MOP_RX, 3) AQC_ROT1_CASE(MOP_RX, 4)
-            default: break;
-        }
-    } else {
-        constexpr int K = ENT == 0 ? MOP_CX : (ENT == 1 ? MOP_CZ : MOP_CP);
-        switch (code - 64) {
-            AQC_ENT1_CASE(K, 0, 1) AQC_ENT1_CASE(K, 0, 2) AQC_ENT1_CASE(K, 0, 3) AQC_ENT1_CASE(K, 0, 4)
-            AQC_ENT1_CASE(K, 1, 0) AQC_ENT1_CASE(K, 1, 2) AQC_ENT1_CASE(K, 1, 3) AQC_ENT1_CASE(K, 1, 4)
-            AQC_ENT1_CASE(K, 2, 0) AQC_ENT1_CASE(K, 2, 1) AQC_ENT1_CASE(K, 2, 3) AQC_ENT1_CASE(K, 2, 4)
-            AQC_ENT1_CASE(K, 3, 0) AQC_ENT1_CASE(K, 3, 1) AQC_ENT1_CASE(K, 3, 2) AQC_ENT1_CASE(K, 3, 4)
-            AQC_ENT1_CASE(K, 4, 0) AQC_ENT1_CASE(K, 4, 1) AQC_ENT1_CASE(K, 4, 2) AQC_ENT1_CASE(K, 4, 3)
-            default: break;
-        }
+__device__ __forceinline__ void run_mop1(int km, int pm, int tm, cplx (&v)[1 << R], double c, double s) {
+    if (km & (1 << MOP_RY)) { AQC_ROT1_ARM(MOP_RY, 0) AQC_ROT1_ARM(MOP_RY, 1) AQC_ROT1_ARM(MOP_RY, 2) AQC_ROT1_ARM(MOP_RY, 3) }
+    if (km & (1 << MOP_RZ)) { AQC_ROT1_ARM(MOP_RZ, 0) AQC_ROT1_ARM(MOP_RZ, 1) AQC_ROT1_ARM(MOP_RZ, 2) AQC_ROT1_ARM(MOP_RZ, 3) }
+    if (ENT == 0 && (km & (1 << MOP_RX))) { AQC_ROT1_ARM(MOP_RX, 0) AQC_ROT1_ARM(MOP_RX, 1) AQC_ROT1_ARM(MOP_RX, 2) AQC_ROT1_ARM(MOP_RX, 3) }
+    constexpr int K = ENT == 0 ? MOP_CX : (ENT == 1 ? MOP_CZ : MOP_CP);
+    if (km & (1 << K)) {
+        if (pm & 1) { AQC_ENT1_ARM(K, 0, 1) AQC_ENT1_ARM(K, 0, 2) AQC_ENT1_ARM(K, 0, 3) }
+        if (pm & 2) { AQC_ENT1_ARM(K, 1, 0) AQC_ENT1_ARM(K, 1, 2) AQC_ENT1_ARM(K, 1, 3) }
+        if (pm & 4) { AQC_ENT1_ARM(K, 2, 0) AQC_ENT1_ARM(K, 2, 1) AQC_ENT1_ARM(K, 2, 3) }
+        if (pm & 8) { AQC_ENT1_ARM(K, 3, 0) AQC_ENT1_ARM(K, 3, 1) AQC_ENT1_ARM(K, 3, 2) }
     }
 }
 
-#define AQC_ROT2_CASE(K, P) \
-    case (K) * 16 + (P) * 2: rot_regs2<4, P, K, false>(w, z, c, s, d); break; \
-    case (K) * 16 + (P) * 2 + 1: rot_regs2<4, P, K, true>(w, z, c, s, d); break;
-#define AQC_ENT2_CASE(K, PC, PT) \
-    case ((PC) * 4 + (PT)) * 2: ent_regs2<4, PC, PT, K, false>(w, z, c, s, d); break; \
-    case ((PC) * 4 + (PT)) * 2 + 1: ent_regs2<4, PC, PT, K, true>(w, z, c, s, d); break;
+// dm: one-hot {1: no inner product, 2: inner product}
+#define AQC_ROT2_ARM(K, P) \
+    if (pm & (1 << (P))) { if (dm & 2) rot_regs2<4, P, K, true>(w, z, c, s, d); if (dm & 1) rot_regs2<4, P, K, false>(w, z, c, s, d); }
+#define AQC_ENT2_ARM(K, PC, PT) \
+    if (tm & (1 << (PT))) { if (dm & 2) ent_regs2<4, PC, PT, K, true>(w, z, c, s, d); if (dm & 1) ent_regs2<4, PC, PT, K, false>(w, z, c, s, d); }
 
 template <int ENT>
-__device__ __forceinline__ void run_mop2(int code, cplx (&w)[16], cplx (&z)[16], double c, double s, cplx& d) {
-    if (code < 64) {
-        switch (code) {
-            AQC_ROT2_CASE(MOP_RY, 0) AQC_ROT2_CASE(MOP_RY, 1) AQC_ROT2_CASE(MOP_RY, 2) AQC_ROT2_CASE(MOP_RY, 3)
-            AQC_ROT2_CASE(MOP_RZ, 0) AQC_ROT2_CASE(MOP_RZ, 1) AQC_ROT2_CASE(MOP_RZ, 2) AQC_ROT2_CASE(MOP_RZ, 3)
-            AQC_ROT2_CASE(MOP_RX, 0) AQC_ROT2_CASE(MOP_RX, 1) AQC_ROT2_CASE(MOP_RX, 2) AQC_ROT2_CASE(MOP_RX, 3)
-            default: break;
-        }
-    } else {
-        constexpr int K = ENT == 0 ? MOP_CX : (ENT == 1 ? MOP_CZ : MOP_CP);
-        switch (code - 64) {
-            AQC_ENT2_CASE(K, 0, 1) AQC_ENT2_CASE(K, 0, 2) AQC_ENT2_CASE(K, 0, 3)
-            AQC_ENT2_CASE(K, 1, 0) AQC_ENT2_CASE(K, 1, 2) AQC_ENT2_CASE(K, 1, 3)
-            AQC_ENT2_CASE(K, 2, 0) AQC_ENT2_CASE(K, 2, 1) AQC_ENT2_CASE(K, 2, 3)
-            AQC_ENT2_CASE(K, 3, 0) AQC_ENT2_CASE(K, 3, 1) AQC_ENT2_CASE(K, 3, 2)
-            default: break;
-        }
+__device__ __forceinline__ void run_mop2(int km, int pm, int tm, int dm, cplx (&w)[16], cplx (&z)[16], double c, double s, cplx& d) {
+    if (km & (1 << MOP_RY)) { AQC_ROT2_ARM(MOP_RY, 0) AQC_ROT2_ARM(MOP_RY, 1) AQC_ROT2_ARM(MOP_RY, 2) AQC_ROT2_ARM(MOP_RY, 3) }
+    if (km & (1 << MOP_RZ)) { AQC_ROT2_ARM(MOP_RZ, 0) AQC_ROT2_ARM(MOP_RZ, 1) AQC_ROT2_ARM(MOP_RZ, 2) AQC_ROT2_ARM(MOP_RZ, 3) }
+    if (ENT == 0 && (km & (1 << MOP_RX))) { AQC_ROT2_ARM(MOP_RX, 0) AQC_ROT2_ARM(MOP_RX, 1) AQC_ROT2_ARM(MOP_RX, 2) AQC_ROT2_ARM(MOP_RX, 3) }
+    constexpr int K = ENT == 0 ? MOP_CX : (ENT == 1 ? MOP_CZ : MOP_CP);
+    if (km & (1 << K)) {
+        if (pm & 1) { AQC_ENT2_ARM(K, 0, 1) AQC_ENT2_ARM(K, 0, 2) AQC_ENT2_ARM(K, 0, 3) }
+        if (pm & 2) { AQC_ENT2_ARM(K, 1, 0) AQC_ENT2_ARM(K, 1, 2) AQC_ENT2_ARM(K, 1, 3) }
+        if (pm & 4) { AQC_ENT2_ARM(K, 2, 0) AQC_ENT2_ARM(K, 2, 1) AQC_ENT2_ARM(K, 2, 3) }
+        if (pm & 8) { AQC_ENT2_ARM(K, 3, 0) AQC_ENT2_ARM(K, 3, 1) AQC_ENT2_ARM(K, 3, 2) }
     }
 }
 
 // Micro-op as the inner loop sees it: decoded once per sub-stage into LDS (one thread per micro-op)
 // so that the per-micro-op dispatch costs one LDS broadcast read instead of two dependent global loads.
 struct __attribute__((aligned(16))) SMop {
-    int code;      // dispatch code (kind / register bits / dot flag folded in)
-    int kind;      // MopKind (for the inner-product factor)
-    double c, s;   // rotation coefficients, sign already applied
-    int slot;      // enabled inner-product slot or -1
-    int pad;
+    int km;        // one-hot: 1 << MopKind
+    int pm;        // one-hot: 1 << register bit (control bit); MOP_REDUCE: producer kinds, 4 bits each, newest first
+    int tm;        // one-hot: 1 << target bit (entanglers); MOP_REDUCE: index of this reduction inside the sub-stage
+    int dm;        // one-hot: 2 if the inner product(s) of this micro-op are wanted, else 1
+    union {
+        struct { double c, s; };  // rotation: (-tan(phi/2), sin(phi)); CP: (cos, sin); sign applied
+        int slots[4];             // MOP_REDUCE: enabled slots of the 4 newest inner products (-1 = none)
+    };
 };
 
 struct Tile2 {
@@ -201,12 +266,10 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
         for (int t = threadIdx.x; t < sub.nmops; t += blockDim.x) {
             const DevMop m = a.mops[sub.mop_begin + t];
             SMop sm;
-            sm.kind = m.kind;
-            sm.code = m.kind <= MOP_RX ? m.kind * 8 + m.p : 64 + m.p * 8 + m.p2;
-            sm.c = coef[m.coef];
-            sm.s = (m.flags & MOPF_NEG_S) ? -coef[m.coef + 1] : coef[m.coef + 1];
-            sm.slot = -1;
-            sm.pad = 0;
+            sm.km = 1 << m.kind; sm.pm = 1 << m.p; sm.tm = 1 << m.p2; sm.dm = 1;
+            const double sg = (m.flags & MOPF_NEG_S) ? -1.0 : 1.0;
+            sm.c = m.kind <= MOP_RX ? sg * coef[m.coef] : coef[m.coef];   // rotations: (-t, s) flip together
+            sm.s = sg * coef[m.coef + 1];
             smops[(si & 1) * kMaxMopsPerSub + t] = sm;
         }
     };
@@ -228,14 +291,24 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
 #pragma unroll
             for (int j = 0; j < (1 << R); ++j) v[j] = tile[swz(b | amp_offset<R>(j, sub))];
             const SMop* sm = smops + (si & 1) * kMaxMopsPerSub;
-            for (int i = 0; i < sub.nmops; ++i) run_mop1<R, ENT>(sm[i].code, v, sm[i].c, sm[i].s);
+            for (int i = 0; i < sub.nmops; ++i) {
+                const SMop m = sm[i];
+                run_mop1<R, ENT>(__builtin_amdgcn_readfirstlane(m.km), __builtin_amdgcn_readfirstlane(m.pm),
+                                 __builtin_amdgcn_readfirstlane(m.tm), v, m.c, m.s);
+            }
 #pragma unroll
             for (int j = 0; j < (1 << R); ++j) tile[swz(b | amp_offset<R>(j, sub))] = v[j];
         }
     }
     __syncthreads();
     cplx* dst = a.out0 + lane_off;
-    for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) dst[tc.dlo[l & 63u] + tc.dhi[l >> 6]] = tile[swz(l)];
+    // rotations with cos(phi) < 0 were applied as minus the rotation by phi -+ pi: undo the lane's sign
+    const double sign = a.final_stage ? coef[(size_t)(a.ncoef - 1) * kCoefStride + 2] : 1.0;
+    for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {
+        cplx v = tile[swz(l)];
+        v.x *= sign; v.y *= sign;
+        dst[tc.dlo[l & 63u] + tc.dhi[l >> 6]] = v;
+    }
 }
 
 // ---- forward w/z sweep with in-flight inner products, r = 4 -----------------------------------------
@@ -249,26 +322,34 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
     cplx* tz = tw + tsize;
     unsigned* tables = reinterpret_cast<unsigned*>(tz + tsize);
     const int nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    cplx* scratch = reinterpret_cast<cplx*>(tables + 320);  // [2][kMaxMopsPerSub][nwaves]
-    SMop* smops = reinterpret_cast<SMop*>(scratch + (size_t)2 * kMaxMopsPerSub * nwaves);  // [2][kMaxMopsPerSub]
+    double* scratch = reinterpret_cast<double*>(tables + 320);  // [2][kMaxReducePerSub][nwaves][8]
+    SMop* smops = reinterpret_cast<SMop*>(scratch + (size_t)2 * kMaxReducePerSub * nwaves * 8);  // [2][kMaxMopsPerSub]
     const Tile2 tc = tile_setup2(st, tables);
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
-    auto enabled = [&](const DevMop& m) {
-        return m.slot >= 0 && (m.jblock < 0 ? (a.front != 0) : (m.jblock >= a.from && m.jblock < a.to));
-    };
+    auto enabled = [&](int jblock) { return jblock < 0 ? (a.front != 0) : (jblock >= a.from && jblock < a.to); };
     auto stage_mops = [&](int si) {  // decode sub-stage si into smops[si & 1]
         if (si >= st->nsubs) return;
         const DevSub sub = a.subs[st->sub_begin + si];
         for (int t = threadIdx.x; t < sub.nmops; t += blockDim.x) {
             const DevMop m = a.mops[sub.mop_begin + t];
-            const bool dot = enabled(m);
+            const bool on = enabled(m.jblock);
             SMop sm;
-            sm.kind = m.kind;
-            sm.code = m.kind <= MOP_RX ? m.kind * 16 + m.p * 2 + (dot ? 1 : 0) : 64 + (m.p * 4 + m.p2) * 2 + (dot ? 1 : 0);
-            sm.c = coef[m.coef];
-            sm.s = (m.flags & MOPF_NEG_S) ? -coef[m.coef + 1] : coef[m.coef + 1];
-            sm.slot = dot ? m.slot : -1;
-            sm.pad = 0;
+            sm.km = 1 << m.kind;
+            if (m.kind == MOP_REDUCE) {
+                sm.pm = m.flags;
+                sm.slots[0] = on ? m.slot : -1; sm.slots[1] = on ? m.p : -1;
+                sm.slots[2] = on ? m.p2 : -1;   sm.slots[3] = on ? m.coef : -1;
+                sm.dm = on ? 2 : 1;
+                int r = 0;  // index among the reductions of this sub-stage
+                for (int u = 0; u < t; ++u) r += a.mops[sub.mop_begin + u].kind == MOP_REDUCE;
+                sm.tm = r;
+            } else {
+                sm.pm = 1 << m.p; sm.tm = 1 << m.p2;
+                sm.dm = (on && m.slot >= 0) ? 2 : 1;
+                const double sg = (m.flags & MOPF_NEG_S) ? -1.0 : 1.0;
+                sm.c = m.kind <= MOP_RX ? sg * coef[m.coef] : coef[m.coef];
+                sm.s = sg * coef[m.coef + 1];
+            }
             smops[(si & 1) * kMaxMopsPerSub + t] = sm;
         }
     };
@@ -289,14 +370,23 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
     const bool active = threadIdx.x < nchunks;
 
     int prev_n = 0;
-    auto flush = [&](int par) {  // fixed-order cross-wave sum of the previous sub-stage's inner products
+    auto flush = [&](int par) {  // fixed-order cross-wave sums of the previous sub-stage's reductions
         for (int t = threadIdx.x; t < prev_n; t += blockDim.x) {
-            const int slot = smops[par * kMaxMopsPerSub + t].slot;
-            if (slot < 0) continue;
-            const cplx* sc = scratch + ((size_t)par * kMaxMopsPerSub + t) * nwaves;
-            cplx acc = sc[0];
-            for (int wv = 1; wv < nwaves; ++wv) { acc.x += sc[wv].x; acc.y += sc[wv].y; }
-            partial[(size_t)slot * a.ntiles_max + blockIdx.x] = acc;
+            const SMop m = smops[par * kMaxMopsPerSub + t];
+            if (!(m.km & (1 << MOP_REDUCE)) || !(m.dm & 2)) continue;
+            const double* sc = scratch + ((size_t)par * kMaxReducePerSub + m.tm) * nwaves * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (m.slots[q] < 0) continue;
+                double re = 0.0, im = 0.0;
+                for (int wv = 0; wv < nwaves; ++wv) { re += sc[wv * 8 + 2 * q]; im += sc[wv * 8 + 2 * q + 1]; }
+                const int kind = (m.pm >> (4 * q)) & 15;
+                cplx r;  // factors: Ry -> 0.5, Rz / Rx -> 0.5j, CP -> -1j  (core_operations.py:267-351,972-975)
+                if (kind == MOP_RY) r = make_double2(0.5 * re, 0.5 * im);
+                else if (kind == MOP_CP) r = make_double2(im, -re);
+                else r = make_double2(-0.5 * im, 0.5 * re);
+                partial[(size_t)m.slots[q] * a.ntiles_max + blockIdx.x] = r;
+            }
         }
     };
 
@@ -305,7 +395,7 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
         const int par = si & 1;
         __syncthreads();
         flush(par ^ 1);
-        __syncthreads();          // the slots of smops[par ^ 1] are consumed before they are overwritten
+        __syncthreads();          // smops[par ^ 1] / scratch[par ^ 1] are consumed before they are rewritten
         stage_mops(si + 1);
         cplx w[16], z[16];
         const unsigned b = chunk_base<R>(threadIdx.x, sub);
@@ -317,20 +407,24 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
             for (int j = 0; j < 16; ++j) { w[j] = make_double2(0.0, 0.0); z[j] = make_double2(0.0, 0.0); }
         }
         const SMop* smp = smops + par * kMaxMopsPerSub;
+        cplx d0 = make_double2(0.0, 0.0), d1 = d0, d2 = d0, d3 = d0;  // newest ... oldest pending inner products
         for (int i = 0; i < sub.nmops; ++i) {
             const SMop m = smp[i];
-            const bool dot = m.slot >= 0;
-            cplx d = make_double2(0.0, 0.0);
-            run_mop2<ENT>(m.code, w, z, m.c, m.s, d);   // idle lanes carry zeros: harmless and keeps the wave uniform
-            if (dot) {
-                const double re = wave_sum_dpp(d.x), im = wave_sum_dpp(d.y);
-                if (lane == 63) {
-                    cplx r;  // factors: Ry -> 0.5, Rz / Rx -> 0.5j, CP -> -1j
-                    if (m.kind == MOP_RY) r = make_double2(0.5 * re, 0.5 * im);
-                    else if (m.kind == MOP_CP) r = make_double2(im, -re);
-                    else r = make_double2(-0.5 * im, 0.5 * re);
-                    scratch[((size_t)par * kMaxMopsPerSub + i) * nwaves + wave] = r;
+            const int km = __builtin_amdgcn_readfirstlane(m.km);  // wave-uniform by construction
+            const int mp = __builtin_amdgcn_readfirstlane(m.pm), mp2 = __builtin_amdgcn_readfirstlane(m.tm);
+            const int dm = __builtin_amdgcn_readfirstlane(m.dm);
+            if (km & (1 << MOP_REDUCE)) {
+                if (dm & 2) {
+                    const double v[8] = {d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
+                    const double tot = reduce8(v, lane);
+                    if (lane < 8) scratch[(((size_t)par * kMaxReducePerSub + mp2) * nwaves + wave) * 8 + lane] = tot;
                 }
+                d0 = d1 = d2 = d3 = make_double2(0.0, 0.0);
+            }
+            if (km & ((1 << MOP_REDUCE) - 1)) {
+                cplx d = make_double2(0.0, 0.0);
+                run_mop2<ENT>(km, mp, mp2, dm, w, z, m.c, m.s, d);   // idle lanes carry zeros: harmless
+                if (dm & 2) { d3 = d2; d2 = d1; d1 = d0; d0 = d; }
             }
         }
         if (active) {
@@ -355,7 +449,7 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
 // ---- launchers -----------------------------------------------------------------------------------------
 size_t apply2_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxMopsPerSub * sizeof(SMop); }
 size_t sweep2_lds_bytes(int k, int threads) {
-    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxMopsPerSub * (threads / 64) * sizeof(cplx) +
+    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxReducePerSub * (threads / 64) * 8 * sizeof(double) +
            (size_t)2 * kMaxMopsPerSub * sizeof(SMop);
 }
 int apply2_threads(int k) { return std::max(64, 1 << (k - 4)); }

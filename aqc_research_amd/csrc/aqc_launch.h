@@ -24,6 +24,7 @@ struct StageArgs {
     double2* partial;       // [batch][nslots][ntiles_max] inner-product partials
     int nslots, ntiles_max;
     int from, to, front;    // block_range / front_layer (core_operations.py:829-830)
+    int final_stage;        // register-blocked V / V^H: last launch applies the lane's overall sign
 };
 
 size_t apply_lds_bytes(int k);
@@ -31,7 +32,7 @@ size_t sweep_lds_bytes(int k, int threads);
 hipError_t init_kernels();
 hipError_t launch_apply(int ent, bool inverse, int ntiles, int batch, int threads, int k, hipStream_t s, const StageArgs& a);
 hipError_t launch_sweep(int ent, int ntiles, int batch, int threads, int k, hipStream_t s, const StageArgs& a);
-hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int batch, hipStream_t s);
+hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int tail, int batch, hipStream_t s);
 hipError_t launch_finalize(const void* partial, const int* theta_slots, const int* slot_ntiles, void* grads, int T,
                            int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, int batch,
                            hipStream_t s);

@@ -143,7 +143,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
     out.h_mops.clear();
     out.reg_bits = reg_bits;
     out.v2 = reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
-    if (out.v2) split_substages(prog, out.plan, reg_bits, kMaxOpsPerSub);
+    if (out.v2) split_substages(prog, out.plan, reg_bits, prog.entangler == 2 ? kMaxOpsPerSub / 2 : kMaxOpsPerSub);
     out.k = (int)plan.stages.front().bits.size();
     out.ntiles = 1 << (plan.nbits - out.k);
     for (const Stage& st : out.plan.stages) {
@@ -656,6 +656,7 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
         a.partial = ws->d_partial;
         a.nslots = ws->nslots;
         a.ntiles_max = p.ntiles;
+        a.debug = env_int("AQC_DEBUG_SKIP", 0);
         a.from = block_from;
         a.to = block_to;
         a.front = front_layer ? 1 : 0;

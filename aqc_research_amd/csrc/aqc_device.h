@@ -70,8 +70,8 @@ struct DevSub {
     int32_t mop_begin;
 };
 
-constexpr int kMaxMopsPerSub = 96;
-constexpr int kMaxReducePerSub = 16;
-constexpr int kMaxOpsPerSub = 8;
+constexpr int kMaxMopsPerSub = 64;   // 8 gate groups x (7 micro-ops + 1 reduction)
+constexpr int kMaxReducePerSub = 8;
+constexpr int kMaxOpsPerSub = 8;     // (CP entangler: 2 reductions per block => 4 groups per sub-stage)
 
 }  // namespace aqc

@@ -21,6 +21,16 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef AQC_OPT_PREFETCH
+#define AQC_OPT_PREFETCH 1
+#endif
+#ifndef AQC_OPT_UNROLL
+#define AQC_OPT_UNROLL 1
+#endif
+#ifndef AQC_OPT_DPPRED
+#define AQC_OPT_DPPRED 1
+#endif
+
 namespace aqc {
 
 __device__ __forceinline__ unsigned swz(unsigned l) { return l ^ ((l >> 4) & 15u); }
@@ -132,9 +142,10 @@ __device__ __forceinline__ void ent_regs2(cplx (&w)[1 << R], cplx (&z)[1 << R], 
     });
 }
 
-// Sums eight per-thread doubles over the wave with a transposing butterfly: after the three exchange
-// steps lane l owns value (l & 7), after three more every lane holds the wave total of its value.
-__device__ __forceinline__ double reduce8(const double (&v)[8], int lane) {
+// Sums eight per-thread doubles over each ROW of 16 lanes with a transposing butterfly made of DPP moves
+// only (no LDS traffic, no ds_bpermute latency): after the three exchange steps lane l owns value (l & 7),
+// one more step folds the two halves of the row.  Lanes 0..7 of every row then hold the row totals.
+__device__ __forceinline__ double reduce8_row(const double (&v)[8], int lane) {
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
     double r[4], q[2];
 #pragma unroll
@@ -148,10 +159,13 @@ __device__ __forceinline__ double reduce8(const double (&v)[8], int lane) {
         q[i] = keep + dpp_mov<0x4E, 0xf>(send);  // lane ^ 2
     }
     const double keep = b2 ? q[1] : q[0], send = b2 ? q[0] : q[1];
+#if AQC_OPT_DPPRED
+    double u = keep + dpp_xor4(send);             // lane ^ 4
+    u += dpp_mov<0x128, 0xf>(u);                  // row_ror:8 = lane ^ 8
+#else
     double u = keep + __shfl_xor(send, 4, 64);
     u += __shfl_xor(u, 8, 64);
-    u += __shfl_xor(u, 16, 64);
-    u += __shfl_xor(u, 32, 64);
+#endif
     return u;
 }
 
@@ -277,6 +291,9 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
     __syncthreads();
     const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tc.base;
     const cplx* src = a.in0 + lane_off;
+#if AQC_OPT_UNROLL
+#pragma unroll 8
+#endif
     for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) tile[swz(l)] = src[tc.dlo[l & 63u] + tc.dhi[l >> 6]];
 
     const unsigned nchunks = tsize >> R;
@@ -291,8 +308,10 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
 #pragma unroll
             for (int j = 0; j < (1 << R); ++j) v[j] = tile[swz(b | amp_offset<R>(j, sub))];
             const SMop* sm = smops + (si & 1) * kMaxMopsPerSub;
+            SMop mnext = sm[0];
             for (int i = 0; i < sub.nmops; ++i) {
-                const SMop m = sm[i];
+                const SMop m = mnext;
+                mnext = sm[i + 1 < sub.nmops ? i + 1 : i];
                 run_mop1<R, ENT>(__builtin_amdgcn_readfirstlane(m.km), __builtin_amdgcn_readfirstlane(m.pm),
                                  __builtin_amdgcn_readfirstlane(m.tm), v, m.c, m.s);
             }
@@ -322,8 +341,8 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
     cplx* tz = tw + tsize;
     unsigned* tables = reinterpret_cast<unsigned*>(tz + tsize);
     const int nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* scratch = reinterpret_cast<double*>(tables + 320);  // [2][kMaxReducePerSub][nwaves][8]
-    SMop* smops = reinterpret_cast<SMop*>(scratch + (size_t)2 * kMaxReducePerSub * nwaves * 8);  // [2][kMaxMopsPerSub]
+    double* scratch = reinterpret_cast<double*>(tables + 320);  // [2][kMaxReducePerSub][nwaves * 4 rows][8]
+    SMop* smops = reinterpret_cast<SMop*>(scratch + (size_t)2 * kMaxReducePerSub * nwaves * 32);  // [2][kMaxMopsPerSub]
     const Tile2 tc = tile_setup2(st, tables);
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
     auto enabled = [&](int jblock) { return jblock < 0 ? (a.front != 0) : (jblock >= a.from && jblock < a.to); };
@@ -335,6 +354,8 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
             const bool on = enabled(m.jblock);
             SMop sm;
             sm.km = 1 << m.kind;
+            if ((a.debug & 1) && m.kind != MOP_REDUCE) sm.km = 1 << 20;
+            if ((a.debug & 2) && m.kind == MOP_REDUCE) sm.km = 1 << 20;
             if (m.kind == MOP_REDUCE) {
                 sm.pm = m.flags;
                 sm.slots[0] = on ? m.slot : -1; sm.slots[1] = on ? m.p : -1;
@@ -359,7 +380,10 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
     {
         const cplx* sw = a.in0 + lane_off;
         const cplx* sz = a.in1 + lane_off;
-        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {
+#if AQC_OPT_UNROLL
+#pragma unroll 8
+#endif
+        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {   // 16 HBM loads in flight per thread
             const unsigned off = tc.dlo[l & 63u] + tc.dhi[l >> 6], p = swz(l);
             tw[p] = sw[off];
             tz[p] = sz[off];
@@ -374,12 +398,12 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
         for (int t = threadIdx.x; t < prev_n; t += blockDim.x) {
             const SMop m = smops[par * kMaxMopsPerSub + t];
             if (!(m.km & (1 << MOP_REDUCE)) || !(m.dm & 2)) continue;
-            const double* sc = scratch + ((size_t)par * kMaxReducePerSub + m.tm) * nwaves * 8;
+            const double* sc = scratch + ((size_t)par * kMaxReducePerSub + m.tm) * nwaves * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (m.slots[q] < 0) continue;
                 double re = 0.0, im = 0.0;
-                for (int wv = 0; wv < nwaves; ++wv) { re += sc[wv * 8 + 2 * q]; im += sc[wv * 8 + 2 * q + 1]; }
+                for (int rw = 0; rw < nwaves * 4; ++rw) { re += sc[rw * 8 + 2 * q]; im += sc[rw * 8 + 2 * q + 1]; }
                 const int kind = (m.pm >> (4 * q)) & 15;
                 cplx r;  // factors: Ry -> 0.5, Rz / Rx -> 0.5j, CP -> -1j  (core_operations.py:267-351,972-975)
                 if (kind == MOP_RY) r = make_double2(0.5 * re, 0.5 * im);
@@ -408,16 +432,24 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
         }
         const SMop* smp = smops + par * kMaxMopsPerSub;
         cplx d0 = make_double2(0.0, 0.0), d1 = d0, d2 = d0, d3 = d0;  // newest ... oldest pending inner products
+        SMop mnext = smp[0];
         for (int i = 0; i < sub.nmops; ++i) {
-            const SMop m = smp[i];
+            const SMop m = mnext;
+#if AQC_OPT_PREFETCH
+            mnext = smp[i + 1 < sub.nmops ? i + 1 : i];   // fetch the next descriptor under this micro-op's arithmetic
+#else
+            if (i + 1 < sub.nmops) mnext = smp[i + 1];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             const int km = __builtin_amdgcn_readfirstlane(m.km);  // wave-uniform by construction
             const int mp = __builtin_amdgcn_readfirstlane(m.pm), mp2 = __builtin_amdgcn_readfirstlane(m.tm);
             const int dm = __builtin_amdgcn_readfirstlane(m.dm);
             if (km & (1 << MOP_REDUCE)) {
                 if (dm & 2) {
                     const double v[8] = {d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
-                    const double tot = reduce8(v, lane);
-                    if (lane < 8) scratch[(((size_t)par * kMaxReducePerSub + mp2) * nwaves + wave) * 8 + lane] = tot;
+                    const double tot = reduce8_row(v, lane);
+                    if ((lane & 15) < 8)
+                        scratch[(((size_t)par * kMaxReducePerSub + mp2) * nwaves * 4 + wave * 4 + (lane >> 4)) * 8 + (lane & 7)] = tot;
                 }
                 d0 = d1 = d2 = d3 = make_double2(0.0, 0.0);
             }
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
 // ---- launchers -----------------------------------------------------------------------------------------
 size_t apply2_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxMopsPerSub * sizeof(SMop); }
 size_t sweep2_lds_bytes(int k, int threads) {
-    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxReducePerSub * (threads / 64) * 8 * sizeof(double) +
+    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxReducePerSub * (threads / 64) * 32 * sizeof(double) +
            (size_t)2 * kMaxMopsPerSub * sizeof(SMop);
 }
 int apply2_threads(int k) { return std::max(64, 1 << (k - 4)); }

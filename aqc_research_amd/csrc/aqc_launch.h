@@ -25,6 +25,7 @@ struct StageArgs {
     int nslots, ntiles_max;
     int from, to, front;    // block_range / front_layer (core_operations.py:829-830)
     int final_stage;        // register-blocked V / V^H: last launch applies the lane's overall sign
+    int debug;              // AQC_DEBUG_SKIP bits (timing experiments only): 1 skip micro-op bodies, 2 skip reductions
 };
 
 size_t apply_lds_bytes(int k);

@@ -60,6 +60,15 @@ __device__ __forceinline__ double dpp_mov(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+// lane ^ 4 inside a row of 16: banks 0/2 read 4 lanes up (row_shl:4), banks 1/3 read 4 lanes down (row_shr:4)
+__device__ __forceinline__ double dpp_xor4(double v) {
+    const long long bits = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), 0x104, 0xf, 0x5, false);
+    lo = __builtin_amdgcn_update_dpp(lo, (int)(bits & 0xffffffffll), 0x114, 0xf, 0xa, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), 0x104, 0xf, 0x5, false);
+    hi = __builtin_amdgcn_update_dpp(hi, (int)(bits >> 32), 0x114, 0xf, 0xa, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 // Sum over the 64 lanes with DPP only (no LDS traffic); the total lands in lane 63.
 __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += dpp_mov<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]

@@ -67,6 +67,16 @@ if __name__ == "__main__":
         cfgs = [{"env": {"AQC_THREADS": 256, "AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}]
         print("with dots"); run(configs=cfgs)
         print("dots only for block 0"); run(configs=cfgs, grad_args=((0, 1), False))
+    elif which == "k":
+        cfgs = [{"env": {"AQC_LOW_BITS": low}, "ks": ks, "ka": ka} for low in (2, 3) for ks, ka in ((10, 11), (11, 12), (11, 13), (12, 13), (12, 12))]
+        run(configs=cfgs)
+    elif which == "one":
+        run(configs=[{"env": {"AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}])
+    elif which == "skip":
+        cfgs = [{"env": {"AQC_THREADS": 256, "AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}]
+        for dbg in (0, 2, 1, 3):
+            os.environ["AQC_DEBUG_SKIP"] = str(dbg)
+            print("AQC_DEBUG_SKIP =", dbg); run(configs=cfgs)
     elif which == "b1":
         cfgs = []
         for thr, ks in itertools.product((256, 512), (8, 9, 10, 11, 12)):

@@ -440,25 +440,30 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     ws->nbits = ws->col_bits + prog.n;
     if (ws->nbits > kMaxBits) { delete ws; return fail("2^%d elements per lane is beyond this build's limit", ws->nbits); }
     ws->lane_elems = (size_t)1 << ws->nbits;
-    ws->threads = env_int("AQC_THREADS", 256);
-    if (ws->threads < 64 || ws->threads > 512 || ws->threads % 64) { delete ws; return fail("AQC_THREADS must be a multiple of 64 in [64, 512]"); }
-
+    // Kernel family and tile size.  Throughput regime (enough tiles x lanes to give every CU >= 1 workgroup of
+    // the largest tile): register-blocked kernels on 2^12 / 2^13 tiles.  Latency regime (few lanes): the
+    // per-gate-group kernels on small tiles, where all threads of a workgroup share every gate group and the
+    // serial chain per launch is short.  AQC_KERNEL_V2 = 0 / 1 forces a family, AQC_TILE_BITS_* a tile size.
     const int low_bits = env_int("AQC_LOW_BITS", 3);
     int ka = tile_bits_apply > 0 ? tile_bits_apply : env_int("AQC_TILE_BITS_APPLY", 0);
     int ks = tile_bits_sweep > 0 ? tile_bits_sweep : env_int("AQC_TILE_BITS_SWEEP", 0);
-    // default: the largest tile the 160 KiB LDS takes, shrunk (not below 2^10) while the launch
-    // would leave most of the 256 CUs idle
+    const int force_v2 = env_int("AQC_KERNEL_V2", -1);
+    const size_t big_tiles = (size_t)batch << std::max(0, ws->nbits - 12);
+    const bool want_v2 = force_v2 >= 0 ? force_v2 != 0 : big_tiles >= 256;
     auto pick = [&](int kmax) {
         int k = std::min(kmax, ws->nbits);
-        while (k > 10 && (size_t)batch * ((size_t)1 << (ws->nbits - k)) < 256) --k;
+        if (!want_v2)
+            while (k > 8 && ((size_t)batch << (ws->nbits - k)) < 256) --k;
         return k;
     };
     if (ka <= 0) ka = pick(13);
     if (ks <= 0) ks = pick(12);
     ka = std::min(std::min(ka, 13), ws->nbits);
     ks = std::min(std::min(ks, 12), ws->nbits);
+    ws->threads = env_int("AQC_THREADS", 0);
+    if (ws->threads <= 0) ws->threads = std::min(256, std::max(64, 1 << (std::min(ka, ks) - 2)));
+    if (ws->threads < 64 || ws->threads > 512 || ws->threads % 64) { delete ws; return fail("AQC_THREADS must be a multiple of 64 in [64, 512]"); }
 
-    const bool want_v2 = env_int("AQC_KERNEL_V2", 1) != 0;
     lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd, want_v2 ? 4 : 0, false);
     lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv, want_v2 ? 4 : 0, false);
     lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep, want_v2 ? 4 : 0, true);

@@ -34,9 +34,14 @@ def test_golden_matrix(key):
     assert maxdiff(g, MAT[f"{key}/grad"]) < TOL
 
 
+@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
 @pytest.mark.parametrize("n,ent,depth,k", [(6, "cx", 15, 64), (7, "cp", 12, 5), (8, "cz", 20, 32), (9, "cx", 24, 512)])
-def test_matrix_vs_oracle(n, ent, depth, k):
+def test_matrix_vs_oracle(n, ent, depth, k, family, monkeypatch):
     import aqc_research_amd.core_op_matrix as com
+    from aqc_research_amd.engine import HipContext
+
+    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
+    HipContext._cache.clear()  # function-level entry points cache their workspace per structure
 
     rng = np.random.default_rng(n * 31 + k)
     blocks = np.stack([rng.permutation(n)[:2] for _ in range(depth)], axis=1).astype(np.int64)

@@ -59,11 +59,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
 @pytest.mark.parametrize("n,ent,depth,ka,ks,batch", CASES)
-def test_oracle_multistage_batched(n, ent, depth, ka, ks, batch):
+def test_oracle_multistage_batched(n, ent, depth, ka, ks, batch, family, monkeypatch):
     """Random generic circuits; small tiles force many stages and many tiles; lanes carry
-    different thetas / targets."""
+    different thetas / targets.  Both kernel families (aqc_kernels.hip / aqc_kernels2.hip)."""
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
 
     rng = np.random.default_rng(100 * n + depth)
     blocks = np.stack([rng.permutation(n)[:2] for _ in range(depth)], axis=1).astype(np.int64)
@@ -92,9 +95,12 @@ def test_oracle_multistage_batched(n, ent, depth, ka, ks, batch):
     ws.close()
 
 
+@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
 @pytest.mark.parametrize("n,layers,order2", [(6, 2, True), (9, 2, True), (12, 2, True), (12, 1, False)])
-def test_trotter_vs_oracle(n, layers, order2):
+def test_trotter_vs_oracle(n, layers, order2, family, monkeypatch):
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
 
     rng = np.random.default_rng(7 * n + layers)
     a = orc.Ansatz(n, "cx", orc.trotter_blocks(n, layers), True, order2)
@@ -120,10 +126,13 @@ def test_trotter_vs_oracle(n, layers, order2):
         ws.close()
 
 
-def test_headline_size_properties():
+@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
+def test_headline_size_properties(family, monkeypatch):
     """n=16, L=40 (BASELINE configs[2] geometry): parity vs the oracle plus size-independent
     properties (unitarity, linearity of the gradient in x)."""
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
 
     n, L = 16, 40
     rng = np.random.default_rng(16)

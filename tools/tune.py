@@ -79,6 +79,8 @@ if __name__ == "__main__":
             print("AQC_DEBUG_SKIP =", dbg); run(configs=cfgs)
     elif which == "b1":
         cfgs = []
-        for thr, ks in itertools.product((256, 512), (8, 9, 10, 11, 12)):
-            cfgs.append({"env": {"AQC_THREADS": thr, "AQC_LOW_BITS": 2}, "ks": ks, "ka": ks})
-        run(B=1, configs=cfgs, steps=50)
+        for v2, thr, ks in itertools.product((0, 1), (64, 128, 256), (7, 8, 9, 10, 11, 12)):
+            if v2 and thr != 256:
+                continue
+            cfgs.append({"env": {"AQC_KERNEL_V2": v2, "AQC_THREADS": thr, "AQC_LOW_BITS": 2}, "ks": ks, "ka": ks})
+        run(B=int(sys.argv[2]) if len(sys.argv) > 2 else 1, configs=cfgs, steps=50)

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQC_HIP_LIB", os.path.join(_HERE, "libaqc_hip.so"))
 
-BUF_Y, BUF_Z, BUF_X, BUF_W, BUF_ZW = range(5)
+BUF_Y, BUF_Z, BUF_X, BUF_W, BUF_ZW, BUF_X2 = range(6)
 K_APPLY, K_SWEEP, K_COEF, K_FINALIZE, K_MISC = range(5)
 ENTANGLERS = {"cx": 0, "cz": 1, "cp": 2}
 
@@ -50,6 +50,8 @@ SIGNATURES = {
     "aqc_ws_gather": (c_int, [_P, c_int, POINTER(c_int64), c_int, _D]),
     "aqc_ws_vdot": (c_int, [_P, c_int, c_int, _D]),
     "aqc_ws_sync": (c_int, [_P]),
+    "aqc_ws_eval": (c_int, [_P, _D, c_int, _D, c_int, c_int, c_int, c_int, _D]),
+    "aqc_ws_grad_from": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "aqc_ws_cd_sweep": (c_int, [_P, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),

@@ -226,12 +226,15 @@ struct aqc_ws {
     double* d_theta_bank = nullptr;
     int bank_sets = 0, gather_count = 0;
     double* d_coef = nullptr;
-    double2* bufs[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double2* bufs[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* h_pin = nullptr;           // pinned staging: thetas | grads | gathered
+    size_t pin_thetas = 0, pin_grads = 0, pin_small = 0;
     double2* d_partial = nullptr;
     double2* d_grads = nullptr;
     double2* d_small = nullptr;  // gather / vdot results
     double2* d_vdot_part = nullptr;
     long long* d_index = nullptr;
+    long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
     size_t small_cap = 0, index_cap = 0;
     int* d_theta_slots = nullptr;
     int* d_slot_ntiles = nullptr;
@@ -509,6 +512,10 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     WS_HIP(hipMalloc((void**)&ws->d_slot_ntiles, sizeof(int) * slot_ntiles.size()));
     WS_HIP(hipMemcpy(ws->d_theta_slots, theta_slots.data(), sizeof(int) * theta_slots.size(), hipMemcpyHostToDevice));
     WS_HIP(hipMemcpy(ws->d_slot_ntiles, slot_ntiles.data(), sizeof(int) * slot_ntiles.size(), hipMemcpyHostToDevice));
+    ws->pin_thetas = (size_t)batch * std::max(T, 1);
+    ws->pin_grads = 2 * (size_t)batch * std::max(T, 1);
+    ws->pin_small = 2 * (size_t)batch * 64;
+    WS_HIP(hipHostMalloc((void**)&ws->h_pin, sizeof(double) * (ws->pin_thetas + ws->pin_grads + ws->pin_small), hipHostMallocDefault));
     ws->vdot_parts = (int)std::min<size_t>(1024, std::max<size_t>(1, ws->lane_elems / 1024));
     WS_HIP(hipMalloc((void**)&ws->d_vdot_part, sizeof(double2) * (size_t)batch * ws->vdot_parts));
     WS_HIP(hipStreamSynchronize(ws->stream));
@@ -529,9 +536,10 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_mops) (void)hipFree(p->d_mops);
     }
     void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
-                    ws->d_theta_slots, ws->d_slot_ntiles};
+                    ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
+    if (ws->h_pin) (void)hipHostFree(ws->h_pin);
     for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1}) if (ev) (void)hipEventDestroy(ev);
@@ -607,13 +615,12 @@ int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
         if (index[b] < 0 || index[b] >= dim) return fail("basis index out of range");
         elem[b] = (long long)index[b] << ws->col_bits;
     }
-    if (ensure_index(ws, ws->batch)) return 1;
-    ws->gather_count = 0;
-    HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * ws->batch, hipMemcpyHostToDevice, ws->stream));
+    if (!ws->d_basis_index) HIP_OK(hipMalloc((void**)&ws->d_basis_index, sizeof(long long) * ws->batch));
+    HIP_OK(hipMemcpyAsync(ws->d_basis_index, elem.data(), sizeof(long long) * ws->batch, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     HIP_OK(hipMemsetAsync(ws->bufs[buf], 0, sizeof(double2) * (size_t)ws->batch * ws->lane_elems, ws->stream));
     ProfScope ps(ws, AQC_K_MISC);
-    HIP_OK(launch_scatter_one(ws->bufs[buf], ws->lane_elems, ws->batch, ws->d_index, ws->stream));
+    HIP_OK(launch_scatter_one(ws->bufs[buf], ws->lane_elems, ws->batch, ws->d_basis_index, ws->stream));
     return 0;
 }
 
@@ -636,7 +643,12 @@ int aqc_ws_apply(aqc_ws* ws, int inverse, int src_buf, int dst_buf) {
 }
 
 int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
-    if (!ws) return fail("null workspace");
+    return aqc_ws_grad_from(ws, AQC_BUF_X, block_from, block_to, front_layer);
+}
+
+int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer) {
+    if (check_buf(ws, x_buf)) return 1;
+    if (x_buf == AQC_BUF_W || x_buf == AQC_BUF_ZW || x_buf == AQC_BUF_Z) return fail("lhs buffer must not be Z, W or ZW");
     if (ensure_coef(ws)) return 1;
     const Program& prog = ws->ctx->prog;
     if (block_from < 0) { block_from = 0; block_to = prog.num_blocks; }
@@ -653,7 +665,7 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
         a.mops = p.d_mops;
         a.coef = ws->d_coef;
         a.ncoef = prog.n + prog.num_blocks + 1;
-        a.in0 = s == 0 ? ws->bufs[AQC_BUF_X] : ws->bufs[AQC_BUF_W];
+        a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
         a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
         a.out0 = ws->bufs[AQC_BUF_W];
         a.out1 = ws->bufs[AQC_BUF_ZW];
@@ -672,6 +684,42 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
     ProfScope ps(ws, AQC_K_FINALIZE);
     HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
                            p.ntiles, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
+    return 0;
+}
+
+int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered, int x_buf, int block_from, int block_to,
+                int front_layer, double* grads) {
+    if (!ws) return fail("null workspace");
+    HIP_OK(hipSetDevice(ws->device));
+    const Program& prog = ws->ctx->prog;
+    const size_t nth = (size_t)ws->batch * prog.num_thetas();
+    double* pin_th = ws->h_pin;
+    double* pin_gr = ws->h_pin + ws->pin_thetas;
+    double* pin_sm = pin_gr + ws->pin_grads;
+    if (thetas) {
+        memcpy(pin_th, thetas, sizeof(double) * nth);
+        ws->d_thetas = ws->d_thetas_own;
+        HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
+        ProfScope ps(ws, AQC_K_COEF);
+        HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
+        ws->coef_valid = true;
+    }
+    if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+    size_t nsm = 0;
+    if (gathered) {
+        if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
+        nsm = (size_t)ws->batch * ws->gather_count;
+        if (2 * nsm > ws->pin_small) return fail("too many gathered amplitudes for the staging buffer");
+        if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
+    }
+    if (grads) {
+        if (aqc_ws_grad_from(ws, x_buf, block_from, block_to, front_layer)) return 1;
+        HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (gathered) memcpy(gathered, pin_sm, sizeof(double2) * nsm);
+    if (grads) memcpy(grads, pin_gr, sizeof(double2) * nth);
     return 0;
 }
 

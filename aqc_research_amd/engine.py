@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import BUF_W, BUF_X, BUF_Y, BUF_Z, BUF_ZW, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, check, dptr  # noqa: F401
+from ._lib import BUF_W, BUF_X, BUF_X2, BUF_Y, BUF_Z, BUF_ZW, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, check, dptr  # noqa: F401
 
 
 def _structure_key(circ) -> tuple:
@@ -101,6 +101,7 @@ class Workspace:
         handle = c_void_p()
         check(self._L.aqc_ws_create(ctx.handle, device, batch, ncols, tile_bits_apply, tile_bits_sweep, byref(handle)))
         self.handle = handle
+        self._gather_count = 0
 
     # -- data movement -------------------------------------------------------
     def _shape(self):
@@ -151,6 +152,23 @@ class Workspace:
     def grad(self, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
         check(self._L.aqc_ws_grad(self.handle, lo, hi, int(bool(front_layer))))
+
+    def eval(self, thetas=None, vdag: bool = True, gather: bool = False, grad: bool = True, x_buf: int = BUF_X,
+             block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True):
+        """One native call, one host synchronisation: [thetas ->] [Z = V^H Y] [gather from Z] [sweep].
+        Returns (gathered or None, grads or None)."""
+        th = None if thetas is None else _lib.as_f64(thetas, self.batch * self.T, "thetas")
+        hs = np.empty((self.batch, self._gather_count), dtype=np.complex128) if gather else None
+        g = np.empty((self.batch, self.T), dtype=np.complex128) if grad else None
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        check(self._L.aqc_ws_eval(self.handle, None if th is None else dptr(th), int(bool(vdag)),
+                                  None if hs is None else dptr(hs), x_buf, lo, hi, int(bool(front_layer)),
+                                  None if g is None else dptr(g)))
+        return hs, g
+
+    def grad_from(self, x_buf: int, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        check(self._L.aqc_ws_grad_from(self.handle, x_buf, lo, hi, int(bool(front_layer))))
 
     def get_grads(self) -> np.ndarray:
         g = np.empty((self.batch, self.T), dtype=np.complex128)

@@ -185,8 +185,8 @@ class SpLHSObjectiveBase:
         self._hs2 = np.zeros(self._num_states)
         self._fobj = 1.0
         self._weight = 1.0
-        # device side: one lane; Y = target, Z = V^H target, X = lhs state
-        self._ws: Workspace = HipContext.of(circuit).workspace(1, 1, int(user_parameters.get("device", 0)))
+        # device side: a private one-lane workspace; Y = target, Z = V^H target, X / X2 = lhs states
+        self._ws: Workspace = Workspace(HipContext.of(circuit), batch=1, ncols=1, device=int(user_parameters.get("device", 0)))
 
     def _store_latest_thetas(self, thetas: np.ndarray):
         self._last_thetas = np.array(thetas, dtype=np.float64)

@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from ..engine import BUF_X, BUF_Y, BUF_Z
+from ..engine import BUF_X, BUF_X2, BUF_Y, BUF_Z
 from ..parametric_circuit import ParametricCircuit
 from .objective_base import DenseStateHandler, SpLHSObjectiveBase
 
@@ -40,6 +40,15 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         self._hs = np.zeros(self._num_states, dtype=np.complex128)
         self._max_no = 0
         self._dense = isinstance(self._state_handler, DenseStateHandler)
+        # One native call per objective(): V^H|target>, the flip-state amplitudes AND (speculatively) the sweep
+        # for |state_0>, so that the gradient() call that optimizers issue right after costs no extra GPU
+        # round trip.  Pure caching: values are exactly those of separate calls.
+        self._speculative = bool(user_parameters.get("speculative_gradient", True)) and not self._dense
+        self._grad0 = None       # cached complex gradient of the |state_0> term at self._last_thetas
+        self._x2_state = -1      # state currently held in BUF_X2
+        if not self._dense:
+            self._ws.set_basis(BUF_X, int(self._state_handler.state_indices[0]))
+            self._ws.gather_setup(self._state_handler.state_indices)
 
     def _projections(self) -> np.ndarray:
         """hs[i] = <state_i|V^H|target> for every state."""
@@ -63,9 +72,17 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
             raise RuntimeError("set_target() has not been called")
         self._store_latest_thetas(thetas)
         ws = self._ws
-        ws.set_thetas(thetas)
-        ws.apply(True, BUF_Y, BUF_Z)  # V^H |target>   (objective_lhs_sur_max.py:96-102)
-        self._hs[:] = self._projections()
+        front = bool(self._front_layer or self._block_range == (0, self._circuit.num_blocks))
+        if self._dense:
+            ws.set_thetas(thetas)
+            ws.apply(True, BUF_Y, BUF_Z)  # V^H |target>   (objective_lhs_sur_max.py:96-102)
+            self._hs[:] = self._projections()
+            self._grad0 = None
+        else:
+            hs, g = ws.eval(thetas, vdag=True, gather=True, grad=self._speculative, x_buf=BUF_X,
+                            block_range=self._block_range, front_layer=front)
+            self._hs[:] = hs[0]
+            self._grad0 = g[0] if self._speculative else None
         np.copyto(self._hs2, np.absolute(self._hs) ** 2)
         # hysteresis: the leading state changes only for a 10 % better candidate (:113-117)
         max_proj = self._hs2[self._max_no]
@@ -80,9 +97,20 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         return self._fobj
 
     def _sweep(self, state_no: int, front: bool) -> np.ndarray:
-        self._load_lhs(state_no)
-        self._ws.grad(self._block_range, front)
-        return self._ws.get_grads()[0]
+        ws = self._ws
+        if self._dense:
+            self._load_lhs(state_no)
+            ws.grad(self._block_range, front)
+            return ws.get_grads()[0]
+        if state_no == 0:
+            if self._grad0 is not None:
+                g, self._grad0 = self._grad0, None
+                return g
+            return ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X, block_range=self._block_range, front_layer=front)[1][0]
+        if self._x2_state != state_no:
+            ws.set_basis(BUF_X2, int(self._state_handler.state_indices[state_no]))
+            self._x2_state = state_no
+        return ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=self._block_range, front_layer=front)[1][0]
 
     def gradient(self, thetas: np.ndarray) -> np.ndarray:
         self._service.on_begin_gradient(self._fobj, thetas, self._fidelity)  # may raise (stoppers)

@@ -205,13 +205,14 @@ def main():
             ws1 = Workspace(ctx, batch=1, device=local_rank)
             ws1.upload(BUF_Y, targets[0])
             ws1.set_basis(BUF_X, 0)
-            ths = np.pi * (2 * rng.random((30, T)) - 1)
-            for i in range(5):
-                ws1.set_thetas(ths[i]); ws1.apply(True, BUF_Y, BUF_Z); ws1.gather(BUF_Z, flip_idx); ws1.grad(); ws1.get_grads()
+            ws1.gather_setup(flip_idx)
+            ths = np.pi * (2 * rng.random((60, T)) - 1)
+            for i in range(10):  # thetas from host, amplitudes + gradient back to host: one native call
+                ws1.eval(ths[i], vdag=True, gather=True, grad=True)
             t1 = time.perf_counter()
-            for i in range(5, 30):
-                ws1.set_thetas(ths[i]); ws1.apply(True, BUF_Y, BUF_Z); ws1.gather(BUF_Z, flip_idx); ws1.grad(); ws1.get_grads()
-            latency = (time.perf_counter() - t1) / 25 * 1e3
+            for i in range(10, 60):
+                ws1.eval(ths[i], vdag=True, gather=True, grad=True)
+            latency = (time.perf_counter() - t1) / 50 * 1e3
             ws1.close()
 
         evals = K * B * n_gpus

@@ -36,7 +36,7 @@ typedef struct aqc_ws aqc_ws;   /* device-resident batch workspace            */
 
 enum { AQC_CX = 0, AQC_CZ = 1, AQC_CP = 2 };
 /* device buffers of a workspace, each [batch][2^n][ncols] complex128 */
-enum { AQC_BUF_Y = 0, AQC_BUF_Z = 1, AQC_BUF_X = 2, AQC_BUF_W = 3, AQC_BUF_ZW = 4, AQC_NUM_BUFS = 5 };
+enum { AQC_BUF_Y = 0, AQC_BUF_Z = 1, AQC_BUF_X = 2, AQC_BUF_W = 3, AQC_BUF_ZW = 4, AQC_BUF_X2 = 5, AQC_NUM_BUFS = 6 };
 /* kernel families for aqc_ws_profile_get */
 enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC_K_MISC = 4, AQC_NUM_KINDS = 5 };
 
@@ -100,6 +100,18 @@ int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* 
 /* out[lane] = <a_lane|b_lane> (np.vdot; GenericStateHandler.state_dot_vector, sk_core.py:192) */
 int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out /* [batch] c128 */);
 int aqc_ws_sync(aqc_ws* ws);
+
+/* ---- one-call evaluation: what objective(thetas) + gradient(thetas) of the objective objects need
+ * (objective_lhs_sur_max.py:82-191), with a single host synchronisation:
+ *   thetas -> device, coefficients, [Z = V^H Y], [gather of the amplitudes selected by
+ *   aqc_ws_gather_setup from Z], [sweep with lhs buffer x_buf -> grads], results -> host.
+ * Any of gathered / grads may be NULL to skip that part.  Host buffers are staged through pinned
+ * memory owned by the workspace. */
+int aqc_ws_eval(aqc_ws* ws, const double* thetas /* [batch][T] or NULL = keep */, int do_vdag,
+                double* gathered /* [batch][count] c128 */, int x_buf, int block_from, int block_to,
+                int front_layer, double* grads /* [batch][T] c128 */);
+/* sweep with an explicit lhs buffer (aqc_ws_grad uses AQC_BUF_X) */
+int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer);
 
 /* ---- fully asynchronous variants: inputs stay resident in HBM, nothing below synchronises.
  * A theta bank holds `nsets` parameter sets [nsets][batch][T]; selecting one only launches the

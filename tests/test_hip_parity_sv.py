@@ -158,3 +158,31 @@ def test_headline_size_properties(family, monkeypatch):
     assert maxdiff(g2[0], g[0] - 2j * g[1]) < 1e-9  # <V x|y> is anti-linear in x
     assert maxdiff(g2[1], g[0]) == 0.0  # bitwise reproducible
     ws.close()
+
+
+def test_fused_eval_matches_separate_calls():
+    """aqc_ws_eval (one synchronisation) == set_thetas + apply + gather + grad."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.engine import BUF_X, BUF_X2, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n = 11
+    rng = np.random.default_rng(77)
+    a = orc.Ansatz(n, "cz", orc.spin_blocks(n, 25))
+    ws = Workspace(HipContext.of(ParametricCircuit(n, "cz", a.blocks)), batch=2)
+    th = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(2)])
+    y = np.stack([orc.rand_state(n, rng) for _ in range(2)])
+    idx = orc.flip_state_indices(n, 1)
+    ws.upload(BUF_Y, y)
+    ws.set_basis(BUF_X, 0)
+    ws.set_basis(BUF_X2, [5, 9])
+    ws.gather_setup(idx)
+    hs, g = ws.eval(th, vdag=True, gather=True, grad=True, block_range=(2, 20), front_layer=False)
+    _, g2 = ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2)
+    for b in range(2):
+        zr = orc.v_dagger_mul_vec(a, th[b], y[b])
+        assert maxdiff(hs[b], zr[idx]) < TOL
+        x0 = np.zeros(1 << n, complex); x0[0] = 1
+        assert maxdiff(g[b], orc.grad_of_dot_product(a, th[b], x0, zr, (2, 20), False)) < TOL
+        x2 = np.zeros(1 << n, complex); x2[[5, 9][b]] = 1
+        assert maxdiff(g2[b], orc.grad_of_dot_product(a, th[b], x2, zr)) < TOL
+    ws.close()

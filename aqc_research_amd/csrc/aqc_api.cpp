@@ -260,6 +260,7 @@ int upload_plan(DevPlan& p) {
     HIP_OK(hipMemcpy(p.d_stages, p.h_stages.data(), p.h_stages.size() * sizeof(DevStage), hipMemcpyHostToDevice));
     const size_t nops = std::max<size_t>(p.h_ops.size(), 1);
     HIP_OK(hipMalloc((void**)&p.d_ops, nops * sizeof(DevOp)));
+    HIP_OK(hipMemset(p.d_ops, 0, nops * sizeof(DevOp)));
     if (!p.h_ops.empty())
         HIP_OK(hipMemcpy(p.d_ops, p.h_ops.data(), p.h_ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc((void**)&p.d_subs, std::max<size_t>(p.h_subs.size(), 1) * sizeof(DevSub)));

@@ -93,9 +93,21 @@ __global__ __launch_bounds__(512) void apply_stage_kernel(StageArgs a) {
 
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
     const int nops = st->nops;
+    DevOp op_next = a.ops[nops > 0 ? st->op_begin : 0];
+    if (nops == 0) op_next.coef = 0;   // empty stage (pure copy): keep the prefetch in bounds
+    double cf_next[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
     for (int i = 0; i < nops; ++i) {
-        const DevOp op = a.ops[st->op_begin + i];
-        const double* cf = coef + (size_t)op.coef * kCoefStride;
+        const DevOp op = op_next;
+        double cf[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) cf[j] = cf_next[j];
+        if (i + 1 < nops) {
+            op_next = a.ops[st->op_begin + i + 1];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
+        }
         __syncthreads();
         if (op.type == 1) {
             const int plo = min(op.p0, op.p1), phi = max(op.p0, op.p1);
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
     cplx* tw = reinterpret_cast<cplx*>(smem);
     cplx* tz = tw + tsize;
     unsigned* tables = reinterpret_cast<unsigned*>(tz + tsize);
-    cplx* scratch = reinterpret_cast<cplx*>(tables + 320);  // [2][nwaves][kSlotsPerGroup]
+    double* scratch = reinterpret_cast<double*>(tables + 320);  // [2][nwaves * 4 rows][10]: row partials of <=5 inner products
     const TileCtx tc = tile_setup(st, tables);
     __syncthreads();
 
@@ -159,19 +171,31 @@ __global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
     constexpr int ND_BLOCK = (ENT == 2) ? 5 : 4;
 
     int pend_slot = -1, pend_nd = 0, pend_par = 0;
-    auto flush = [&]() {  // fixed-order cross-wave sum of the previous group's inner products
+    auto flush = [&]() {  // fixed-order sum over the row partials of the previous group's inner products
         if (pend_slot >= 0 && (int)threadIdx.x < pend_nd) {
-            const cplx* s = scratch + (size_t)pend_par * nwaves * kSlotsPerGroup + threadIdx.x;
-            cplx acc = s[0];
-            for (int w = 1; w < nwaves; ++w) { acc.x += s[w * kSlotsPerGroup].x; acc.y += s[w * kSlotsPerGroup].y; }
-            partial[(size_t)(pend_slot + threadIdx.x) * a.ntiles_max + blockIdx.x] = acc;
+            const double* s = scratch + (size_t)pend_par * nwaves * 40 + 2 * threadIdx.x;
+            double re = 0.0, im = 0.0;
+            for (int r = 0; r < nwaves * 4; ++r) { re += s[r * 10]; im += s[r * 10 + 1]; }
+            partial[(size_t)(pend_slot + threadIdx.x) * a.ntiles_max + blockIdx.x] = make_double2(re, im);
         }
     };
 
     const int nops = st->nops;
+    DevOp op_next = a.ops[nops > 0 ? st->op_begin : 0];
+    if (nops == 0) op_next.coef = 0;   // empty stage (pure copy): keep the prefetch in bounds
+    double cf_next[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
     for (int i = 0; i < nops; ++i) {
-        const DevOp op = a.ops[st->op_begin + i];
-        const double* cf = coef + (size_t)op.coef * kCoefStride;
+        const DevOp op = op_next;   // descriptor and coefficients were fetched under the previous group's arithmetic
+        double cf[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) cf[j] = cf_next[j];
+        if (i + 1 < nops) {
+            op_next = a.ops[st->op_begin + i + 1];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
+        }
         __syncthreads();
         flush();
         cplx d[kSlotsPerGroup];
@@ -252,13 +276,15 @@ __global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
             d[2] = make_double2(-0.5 * d[2].y, 0.5 * d[2].x);
         }
         if (dots) {
-            cplx* s = scratch + ((size_t)(i & 1) * nwaves + wave) * kSlotsPerGroup;
-#pragma unroll
-            for (int j = 0; j < kSlotsPerGroup; ++j) {
-                if (j < nd) {  // nd is wave-uniform
-                    const double re = wave_sum(d[j].x), im = wave_sum(d[j].y);
-                    if (lane == 0) s[j] = make_double2(re, im);
-                }
+            // transposing DPP butterfly over each row of 16 lanes; lanes 0..7 of a row hold its totals
+            double* s = scratch + ((size_t)(i & 1) * nwaves * 4 + wave * 4 + (lane >> 4)) * 10;
+            const double v[8] = {d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
+            const double tot = reduce8_row(v, lane);
+            if ((lane & 15) < 8) s[lane & 7] = tot;
+            if (ENT == 2 && nd == 5) {   // CP: fifth inner product
+                const double w8[8] = {d[4].x, d[4].y, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                const double t2 = reduce8_row(w8, lane);
+                if ((lane & 15) < 2) s[8 + (lane & 7)] = t2;
             }
             pend_slot = op.slot; pend_nd = nd; pend_par = i & 1;
         } else {
@@ -401,7 +427,7 @@ __global__ void vdot_final_kernel(const cplx* part, int nparts, cplx* out) {
 // ------------------------------------------------------------------------------------------
 size_t apply_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned); }
 size_t sweep_lds_bytes(int k, int threads) {
-    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * (threads / 64) * kSlotsPerGroup * sizeof(cplx);
+    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * (threads / 64) * 4 * 10 * sizeof(double);
 }
 
 template <typename K>

@@ -142,33 +142,6 @@ __device__ __forceinline__ void ent_regs2(cplx (&w)[1 << R], cplx (&z)[1 << R], 
     });
 }
 
-// Sums eight per-thread doubles over each ROW of 16 lanes with a transposing butterfly made of DPP moves
-// only (no LDS traffic, no ds_bpermute latency): after the three exchange steps lane l owns value (l & 7),
-// one more step folds the two halves of the row.  Lanes 0..7 of every row then hold the row totals.
-__device__ __forceinline__ double reduce8_row(const double (&v)[8], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-    double r[4], q[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
-        r[i] = keep + dpp_mov<0xB1, 0xf>(send);  // lane ^ 1
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double keep = b1 ? r[2 * i + 1] : r[2 * i], send = b1 ? r[2 * i] : r[2 * i + 1];
-        q[i] = keep + dpp_mov<0x4E, 0xf>(send);  // lane ^ 2
-    }
-    const double keep = b2 ? q[1] : q[0], send = b2 ? q[0] : q[1];
-#if AQC_OPT_DPPRED
-    double u = keep + dpp_xor4(send);             // lane ^ 4
-    u += dpp_mov<0x128, 0xf>(u);                  // row_ror:8 = lane ^ 8
-#else
-    double u = keep + __shfl_xor(send, 4, 64);
-    u += __shfl_xor(u, 8, 64);
-#endif
-    return u;
-}
-
 // ---- dispatch -----------------------------------------------------------------------------------------
 // The dispatch is a sequence of ONE-SIDED, wave-uniform ifs.  A switch (or if/else chain) is lowered
 // to a multi-exit region that StructurizeCFG linearises with "Flow" blocks; the phis of those blocks

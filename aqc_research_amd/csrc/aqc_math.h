@@ -80,4 +80,26 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return v;
 }
 
+// Sums eight per-thread doubles over each ROW of 16 lanes with a transposing butterfly made of DPP moves
+// only (no LDS traffic, no ds_bpermute latency): after the three exchange steps lane l owns value (l & 7),
+// one more step folds the two halves of the row.  Lanes 0..7 of every row then hold the row totals.
+__device__ __forceinline__ double reduce8_row(const double (&v)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    double r[4], q[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        r[i] = keep + dpp_mov<0xB1, 0xf>(send);  // lane ^ 1
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b1 ? r[2 * i + 1] : r[2 * i], send = b1 ? r[2 * i] : r[2 * i + 1];
+        q[i] = keep + dpp_mov<0x4E, 0xf>(send);  // lane ^ 2
+    }
+    const double keep = b2 ? q[1] : q[0], send = b2 ? q[0] : q[1];
+    double u = keep + dpp_xor4(send);             // lane ^ 4
+    u += dpp_mov<0x128, 0xf>(u);                  // row_ror:8 = lane ^ 8
+    return u;
+}
+
 }  // namespace aqc

@@ -61,6 +61,8 @@ SIGNATURES = {
     "aqc_ws_gather_setup": (c_int, [_P, POINTER(c_int64), c_int]),
     "aqc_ws_gather_launch": (c_int, [_P, c_int]),
     "aqc_ws_gather_fetch": (c_int, [_P, _D]),
+    "aqc_ws_vdot_launch": (c_int, [_P, c_int, c_int]),
+    "aqc_ws_vdot_fetch": (c_int, [_P, _D]),
     "aqc_ws_timer_start": (c_int, [_P]),
     "aqc_ws_timer_stop": (c_int, [_P, POINTER(c_float)]),
     "aqc_ws_profile_enable": (c_int, [_P, c_int]),

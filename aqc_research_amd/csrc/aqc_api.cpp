@@ -233,6 +233,7 @@ struct aqc_ws {
     double2* d_grads = nullptr;
     double2* d_small = nullptr;  // gather / vdot results
     double2* d_vdot_part = nullptr;
+    double2* d_vdot_out = nullptr;
     long long* d_index = nullptr;
     long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
     size_t small_cap = 0, index_cap = 0;
@@ -468,9 +469,18 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     if (ws->threads <= 0) ws->threads = std::min(256, std::max(64, 1 << (std::min(ka, ks) - 2)));
     if (ws->threads < 64 || ws->threads > 512 || ws->threads % 64) { delete ws; return fail("AQC_THREADS must be a multiple of 64 in [64, 512]"); }
 
-    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, false), ws->fwd, want_v2 ? 4 : 0, false);
-    lower_plan(prog, make_plan(prog, ws->col_bits, ka, low_bits, true), ws->inv, want_v2 ? 4 : 0, false);
-    lower_plan(prog, make_plan(prog, ws->col_bits, ks, low_bits, false), ws->sweep, want_v2 ? 4 : 0, true);
+    // fewest launches wins; among equals prefer the longer contiguous HBM runs (more forced low bits)
+    auto best_plan = [&](int k, bool inverse) {
+        Plan best = make_plan(prog, ws->col_bits, k, low_bits, inverse);
+        for (int lb = low_bits - 1; lb >= 2; --lb) {
+            Plan cand = make_plan(prog, ws->col_bits, k, lb, inverse);
+            if (cand.stages.size() < best.stages.size()) best = cand;
+        }
+        return best;
+    };
+    lower_plan(prog, best_plan(ka, false), ws->fwd, want_v2 ? 4 : 0, false);
+    lower_plan(prog, best_plan(ka, true), ws->inv, want_v2 ? 4 : 0, false);
+    lower_plan(prog, best_plan(ks, false), ws->sweep, want_v2 ? 4 : 0, true);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -537,7 +547,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_mops) (void)hipFree(p->d_mops);
     }
     void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
-                    ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index};
+                    ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
@@ -1010,6 +1020,25 @@ int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out) {
         std::swap(e, en);
     }
     HIP_OK(hipMemcpyAsync(out, e, sizeof(double2), hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_vdot_launch(aqc_ws* ws, int buf_a, int buf_b) {
+    if (check_buf(ws, buf_a) || check_buf(ws, buf_b)) return 1;
+    HIP_OK(hipSetDevice(ws->device));
+    if (!ws->d_vdot_out) HIP_OK(hipMalloc((void**)&ws->d_vdot_out, sizeof(double2) * ws->batch));
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(launch_vdot(ws->bufs[buf_a], ws->bufs[buf_b], ws->lane_elems, ws->lane_elems, ws->batch, ws->d_vdot_part,
+                       ws->vdot_parts, ws->d_vdot_out, ws->stream));
+    return 0;
+}
+
+int aqc_ws_vdot_fetch(aqc_ws* ws, double* out) {
+    if (!ws || !out) return fail("null argument");
+    if (!ws->d_vdot_out) return fail("aqc_ws_vdot_launch has not been called");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipMemcpyAsync(out, ws->d_vdot_out, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     return 0;
 }

@@ -211,6 +211,14 @@ class Workspace:
         check(self._L.aqc_ws_gather_fetch(self.handle, dptr(out)))
         return out
 
+    def vdot_launch(self, buf_a: int, buf_b: int) -> None:
+        check(self._L.aqc_ws_vdot_launch(self.handle, buf_a, buf_b))
+
+    def vdot_fetch(self) -> np.ndarray:
+        out = np.empty(self.batch, dtype=np.complex128)
+        check(self._L.aqc_ws_vdot_fetch(self.handle, dptr(out)))
+        return out
+
     def sync(self) -> None:
         check(self._L.aqc_ws_sync(self.handle))
 

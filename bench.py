@@ -35,6 +35,9 @@ WORKLOADS = {
     "sv16_l40": dict(n=16, blocks=40, kind="generic", desc="16-qubit, 40-block cx spin ansatz, state-vector objective+gradient"),
     "sv12_trotter2": dict(n=12, layers=2, kind="trotter2", desc="12-qubit ASP, 2nd-order Trotter ansatz (2 layers), state-vector objective+gradient"),
     "sv20_l40": dict(n=20, blocks=40, kind="generic", desc="20-qubit, 40-block cx spin ansatz, state-vector objective+gradient"),
+    "sv20_trotter2": dict(n=20, layers=2, kind="trotter2", desc="20-qubit ASP, 2nd-order Trotter ansatz (2 layers), state-vector objective+gradient"),
+    "mat10_l40": dict(n=10, blocks=40, kind="generic", ncols=1024, desc="10-qubit full-unitary AQC (1024x1024 target), cx spin ansatz L=40, matrix objective+gradient"),
+    "mat5_cyc180": dict(n=5, blocks=180, kind="cyclic", ncols=32, desc="5-qubit full AQC (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks), matrix objective+gradient"),
 }
 
 
@@ -44,10 +47,12 @@ def build_circuit(w):
 
     if w["kind"] == "generic":
         return ParametricCircuit(w["n"], "cx", create_ansatz_structure(w["n"], "spin", "full", w["blocks"]))
+    if w["kind"] == "cyclic":
+        return ParametricCircuit(w["n"], "cx", create_ansatz_structure(w["n"], "cyclic_spin", "full", w["blocks"]))
     return TrotterAnsatz(w["n"], make_trotter_like_circuit(w["n"], w["layers"]), second_order=True)
 
 
-def cpu_baseline(circ, seconds=12.0):
+def cpu_baseline(circ, ncols=1, seconds=12.0):
     """Reference algorithm restated in NumPy (oracle/aqc_oracle.py), timed on the host cores
     of this box on a bounded sample of the same workload (1 thread)."""
     from oracle import aqc_oracle as orc
@@ -60,18 +65,25 @@ def cpu_baseline(circ, seconds=12.0):
         limiter = None
     rng = np.random.default_rng(7)
     a = orc.as_ansatz(circ)
-    target = orc.rand_state(a.n, rng)
-    x = np.zeros(a.dim, complex)
-    x[0] = 1
+    if ncols == 1:
+        target = orc.rand_state(a.n, rng)
+        x = np.zeros(a.dim, complex)
+        x[0] = 1
 
-    def one():
-        th = orc.rand_thetas(a.num_thetas, rng)
-        vh = orc.v_dagger_mul_vec(a, th, target)
-        orc.grad_of_dot_product(a, th, x, vh)
+        def one():
+            th = orc.rand_thetas(a.num_thetas, rng)
+            vh = orc.v_dagger_mul_vec(a, th, target)
+            orc.grad_of_dot_product(a, th, x, vh)
+    else:
+        u = np.linalg.qr(rng.standard_normal((a.dim, ncols)) + 1j * rng.standard_normal((a.dim, ncols)))[0]
+        eye = np.eye(a.dim, ncols, dtype=complex)
+
+        def one():
+            orc.sketching_objective_and_gradient(a, orc.rand_thetas(a.num_thetas, rng), eye, u)
 
     one()  # warm-up
     t0, count = time.perf_counter(), 0
-    while count < 3 or (time.perf_counter() - t0 < seconds and count < 200):
+    while count < 2 or (time.perf_counter() - t0 < seconds and count < 200):
         one()
         count += 1
     dt = time.perf_counter() - t0
@@ -91,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="independent evaluations resident per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="independent evaluations resident per GPU (default: 64 state vectors / 8 matrices)")
     ap.add_argument("--workload", default="sv16_l40", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -121,16 +133,24 @@ def main():
     n, T = circ.num_qubits, circ.num_thetas
     ctx = HipContext.of(circ)
     G = ctx.num_gate_groups
-    N = 1 << n
-    B, K, W = args.batch, args.steps, args.warmup
+    ncols = w.get("ncols", 1)
+    N = (1 << n) * ncols          # complex128 elements per lane
+    B = args.batch if args.batch > 0 else (64 if ncols == 1 else (8 if ncols >= 256 else 64))
+    K, W = args.steps, args.warmup
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule
-    ws = Workspace(ctx, batch=B, device=local_rank)
-    targets = np.stack([orc.rand_state(n, rng) for _ in range(B)])
-    ws.upload(BUF_Y, targets)
-    ws.set_basis(BUF_X, 0)  # x = |0>
+    ws = Workspace(ctx, batch=B, ncols=ncols, device=local_rank)
     flip_idx = orc.flip_state_indices(n, 1)
-    ws.gather_setup(flip_idx)
+    if ncols == 1:
+        targets = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+        ws.upload(BUF_Y, targets)
+        ws.set_basis(BUF_X, 0)  # x = |0>
+        ws.gather_setup(flip_idx)
+    else:  # X = I, Y = random unitary per lane (FullRangeSketchingVectors, sk_core.py:317-326)
+        targets = np.stack([np.linalg.qr(rng.standard_normal((1 << n, ncols)) + 1j * rng.standard_normal((1 << n, ncols)))[0]
+                            for _ in range(B)])
+        ws.upload(BUF_Y, targets)
+        ws.set_identity(BUF_X)
     nsets = K + W
     bank = np.pi * (2 * rng.random((nsets, B, T)) - 1)
     ws.theta_bank(bank)
@@ -138,7 +158,10 @@ def main():
     def step(i):
         ws.use_theta_set(i)
         ws.apply(True, BUF_Y, BUF_Z)
-        ws.gather_launch(BUF_Z)
+        if ncols == 1:
+            ws.gather_launch(BUF_Z)       # hs = <state_i|V^H|target>
+        else:
+            ws.vdot_launch(BUF_X, BUF_Z)  # <X|V^H Y>  (sk_core.py:192)
         ws.grad(None, True)
 
     def barrier():
@@ -167,7 +190,7 @@ def main():
         wall = float(t.item())
 
     # result record of the last step (checked + gathered: the only inter-GPU traffic)
-    hs = ws.gather_fetch()
+    hs = ws.gather_fetch() if ncols == 1 else ws.vdot_fetch().reshape(B, 1)
     grads = ws.get_grads()
     record = np.array([np.abs(hs[:, 0]).mean() ** 2, np.linalg.norm(grads.real)], dtype=np.float64)
     if dist is not None:
@@ -201,7 +224,7 @@ def main():
 
         # ---- single-evaluation latency (batch 1, host-visible result each call) ---------------
         latency = None
-        if not args.no_latency:
+        if not args.no_latency and ncols == 1:
             ws1 = Workspace(ctx, batch=1, device=local_rank)
             ws1.upload(BUF_Y, targets[0])
             ws1.set_basis(BUF_X, 0)
@@ -215,6 +238,17 @@ def main():
             latency = (time.perf_counter() - t1) / 50 * 1e3
             ws1.close()
 
+        # measured HBM traffic of the dominant kernel (rocprofv3 --pmc passes, tools/pmc_summary.py), if the
+        # committed profile was taken on this workload / batch
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pj.get("workload") == args.workload and pj.get("batch_per_gpu") == B:
+                for kname, kv in pj["kernels"].items():
+                    if "sweep_stage_kernel" in kname:
+                        traffic = kv["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         evals = K * B * n_gpus
         value = evals / wall
         out = {
@@ -237,22 +271,23 @@ def main():
                 "num_thetas": T,
                 "gate_groups": G,
                 "batch_per_gpu": B,
-                "path": "state-vector (core_operations)",
+                "path": "state-vector (core_operations)" if ncols == 1 else "matrix (core_op_matrix)",
+                "columns": ncols,
                 "tile_bits": {"vdag": k_inv, "sweep": k_sw},
                 "launches_per_eval_step": {"vdag": stages_inv, "sweep": stages_sw},
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "sweep_stage_kernel",
+                "kernel": "sweep_stage_kernel2" if stages_sw and ws.plan_info(1)[1] >= 4 and B * (N >> 12) >= 256 else "sweep_stage_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": sweep_avg_ms,
                 "algorithmic_bytes_per_launch": sweep_bytes_per_launch,
-                "note": "algorithmic bytes = 64 B x 2^n x gate groups x lanes per launch (SURVEY 8d); a launch fuses "
-                        "many gate groups in LDS, so achieved may exceed what HBM itself could stream",
+                "note": "algorithmic bytes = 64 B x 2^n x columns x gate groups x lanes per launch (SURVEY 8d); a launch "
+                        "fuses many gate groups in LDS, so achieved may exceed what HBM itself could stream",
             },
             "kernel_ms_per_step": {k: v[1] / prof_steps for k, v in prof.items()},
             "device_ms_per_step_events": ev_ms / K,
@@ -260,7 +295,7 @@ def main():
             "algorithmic_GBps_whole_eval": (sweep_bytes_per_step + apply_bytes_per_step) * K / wall / 1e9,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(circ)
+            out["cpu_baseline"] = cpu_baseline(circ, ncols)
         print(json.dumps(out))
     ws.close()
     if dist is not None:

@@ -121,6 +121,8 @@ int aqc_ws_use_theta_set(aqc_ws* ws, int set_index);
 int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count);
 int aqc_ws_gather_launch(aqc_ws* ws, int buf);
 int aqc_ws_gather_fetch(aqc_ws* ws, double* out /* [batch][count] c128 */);
+int aqc_ws_vdot_launch(aqc_ws* ws, int buf_a, int buf_b);
+int aqc_ws_vdot_fetch(aqc_ws* ws, double* out /* [batch] c128 */);
 
 /* ---- MPS helpers (state-vector workspaces only).  An MPS arrives in the reference's QiskitMPS
  * layout (mps_operations.py:33,87-123): site q has Gamma^0, Gamma^1 of shape (dims[q], dims[q+1]),

@@ -70,6 +70,11 @@ if __name__ == "__main__":
     elif which == "k":
         cfgs = [{"env": {"AQC_LOW_BITS": low}, "ks": ks, "ka": ka} for low in (2, 3) for ks, ka in ((10, 11), (11, 12), (11, 13), (12, 13), (12, 12))]
         run(configs=cfgs)
+    elif which == "n12":
+        cfgs = []
+        for v2, ks in ((0, 6), (0, 8), (0, 10), (0, 12), (1, 8), (1, 10), (1, 12)):
+            cfgs.append({"env": {"AQC_KERNEL_V2": v2, "AQC_THREADS": 0}, "ks": ks, "ka": ks})
+        run(n=12, B=int(sys.argv[2]) if len(sys.argv) > 2 else 1, configs=cfgs, steps=50, trotter_layers=2)
     elif which == "one":
         run(configs=[{"env": {"AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}])
     elif which == "skip":

@@ -143,7 +143,11 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
     out.h_mops.clear();
     out.reg_bits = reg_bits;
     out.v2 = reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
-    if (out.v2) split_substages(prog, out.plan, reg_bits, prog.entangler == 2 ? kMaxOpsPerSub / 2 : kMaxOpsPerSub);
+    if (out.v2) {
+        int max_ops = reg_bits == 4 ? kMaxOpsPerSub : kMaxOpsPerSub / 2;
+        if (prog.entangler == 2) max_ops /= 2;   // CP: two reductions per block
+        split_substages(prog, out.plan, reg_bits, max_ops);
+    }
     out.k = (int)plan.stages.front().bits.size();
     out.ntiles = 1 << (plan.nbits - out.k);
     for (const Stage& st : out.plan.stages) {
@@ -480,7 +484,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     };
     lower_plan(prog, best_plan(ka, false), ws->fwd, want_v2 ? 4 : 0, false);
     lower_plan(prog, best_plan(ka, true), ws->inv, want_v2 ? 4 : 0, false);
-    lower_plan(prog, best_plan(ks, false), ws->sweep, want_v2 ? 4 : 0, true);
+    lower_plan(prog, best_plan(ks, false), ws->sweep, want_v2 ? (env_int("AQC_SWEEP_REG_BITS", 4) == 3 ? 3 : 4) : 0, true);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -689,7 +693,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
         a.to = block_to;
         a.front = front_layer ? 1 : 0;
         ProfScope ps(ws, AQC_K_SWEEP);
-        if (p.v2) HIP_OK(launch_sweep2(prog.entangler, p.ntiles, ws->batch, p.k, ws->stream, a));
+        if (p.v2) HIP_OK(launch_sweep2(prog.entangler, p.ntiles, ws->batch, p.k, p.reg_bits, ws->stream, a));
         else HIP_OK(launch_sweep(prog.entangler, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
     }
     ProfScope ps(ws, AQC_K_FINALIZE);

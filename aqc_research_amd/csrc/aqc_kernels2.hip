@@ -169,12 +169,16 @@ __device__ __forceinline__ void run_mop1(int km, int pm, int tm, cplx (&v)[1 << 
 
 // dm: one-hot {1: no inner product, 2: inner product}
 #define AQC_ROT2_ARM(K, P) \
-    if (pm & (1 << (P))) { if (dm & 2) rot_regs2<4, P, K, true>(w, z, c, s, d); if (dm & 1) rot_regs2<4, P, K, false>(w, z, c, s, d); }
+    if ((P) < R && (pm & (1 << (P)))) { \
+        if (dm & 2) rot_regs2<R, (P) < R ? (P) : 0, K, true>(w, z, c, s, d); \
+        if (dm & 1) rot_regs2<R, (P) < R ? (P) : 0, K, false>(w, z, c, s, d); }
 #define AQC_ENT2_ARM(K, PC, PT) \
-    if (tm & (1 << (PT))) { if (dm & 2) ent_regs2<4, PC, PT, K, true>(w, z, c, s, d); if (dm & 1) ent_regs2<4, PC, PT, K, false>(w, z, c, s, d); }
+    if ((PC) < R && (PT) < R && (tm & (1 << (PT)))) { \
+        if (dm & 2) ent_regs2<R, (PC) < R ? (PC) : 0, (PT) < R ? (PT) : 1, K, true>(w, z, c, s, d); \
+        if (dm & 1) ent_regs2<R, (PC) < R ? (PC) : 0, (PT) < R ? (PT) : 1, K, false>(w, z, c, s, d); }
 
-template <int ENT>
-__device__ __forceinline__ void run_mop2(int km, int pm, int tm, int dm, cplx (&w)[16], cplx (&z)[16], double c, double s, cplx& d) {
+template <int ENT, int R>
+__device__ __forceinline__ void run_mop2(int km, int pm, int tm, int dm, cplx (&w)[1 << R], cplx (&z)[1 << R], double c, double s, cplx& d) {
     if (km & (1 << MOP_RY)) { AQC_ROT2_ARM(MOP_RY, 0) AQC_ROT2_ARM(MOP_RY, 1) AQC_ROT2_ARM(MOP_RY, 2) AQC_ROT2_ARM(MOP_RY, 3) }
     if (km & (1 << MOP_RZ)) { AQC_ROT2_ARM(MOP_RZ, 0) AQC_ROT2_ARM(MOP_RZ, 1) AQC_ROT2_ARM(MOP_RZ, 2) AQC_ROT2_ARM(MOP_RZ, 3) }
     if (ENT == 0 && (km & (1 << MOP_RX))) { AQC_ROT2_ARM(MOP_RX, 0) AQC_ROT2_ARM(MOP_RX, 1) AQC_ROT2_ARM(MOP_RX, 2) AQC_ROT2_ARM(MOP_RX, 3) }
@@ -304,9 +308,10 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
 }
 
 // ---- forward w/z sweep with in-flight inner products, r = 4 -----------------------------------------
-template <int ENT>
-__global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
-    constexpr int R = 4;
+template <int ENT, int R>
+__global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageArgs a) {
+    constexpr int NA = 1 << R;  // amplitudes per thread and vector
+    constexpr int kMaxReducePerSub = R == 4 ? aqc::kMaxReducePerSub : aqc::kMaxReducePerSub / 2;  // shadows: 8 waves at R = 3
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevStage* st = a.stage;
     const unsigned tsize = 1u << st->k;
@@ -387,21 +392,22 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
         }
     };
 
-    for (int si = 0; si < st->nsubs; ++si) {
+    const int nsubs_run = (a.debug & 4) ? 0 : st->nsubs;   // timing experiment: memory phases only
+    for (int si = 0; si < nsubs_run; ++si) {
         const DevSub sub = a.subs[st->sub_begin + si];
         const int par = si & 1;
         __syncthreads();
         flush(par ^ 1);
         __syncthreads();          // smops[par ^ 1] / scratch[par ^ 1] are consumed before they are rewritten
         stage_mops(si + 1);
-        cplx w[16], z[16];
+        cplx w[NA], z[NA];
         const unsigned b = chunk_base<R>(threadIdx.x, sub);
         if (active) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); w[j] = tw[p]; z[j] = tz[p]; }
+            for (int j = 0; j < NA; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); w[j] = tw[p]; z[j] = tz[p]; }
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { w[j] = make_double2(0.0, 0.0); z[j] = make_double2(0.0, 0.0); }
+            for (int j = 0; j < NA; ++j) { w[j] = make_double2(0.0, 0.0); z[j] = make_double2(0.0, 0.0); }
         }
         const SMop* smp = smops + par * kMaxMopsPerSub;
         cplx d0 = make_double2(0.0, 0.0), d1 = d0, d2 = d0, d3 = d0;  // newest ... oldest pending inner products
@@ -428,18 +434,18 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
             }
             if (km & ((1 << MOP_REDUCE) - 1)) {
                 cplx d = make_double2(0.0, 0.0);
-                run_mop2<ENT>(km, mp, mp2, dm, w, z, m.c, m.s, d);   // idle lanes carry zeros: harmless
+                run_mop2<ENT, R>(km, mp, mp2, dm, w, z, m.c, m.s, d);   // idle lanes carry zeros: harmless
                 if (dm & 2) { d3 = d2; d2 = d1; d1 = d0; d0 = d; }
             }
         }
         if (active) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); tw[p] = w[j]; tz[p] = z[j]; }
+            for (int j = 0; j < NA; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); tw[p] = w[j]; tz[p] = z[j]; }
         }
         prev_n = sub.nmops;
     }
     __syncthreads();
-    flush((st->nsubs - 1) & 1);
+    if (nsubs_run) flush((st->nsubs - 1) & 1);
     {
         cplx* dw = a.out0 + lane_off;
         cplx* dz = a.out1 + lane_off;
@@ -453,12 +459,13 @@ __global__ __launch_bounds__(256) void sweep_stage_kernel2(StageArgs a) {
 
 // ---- launchers -----------------------------------------------------------------------------------------
 size_t apply2_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxMopsPerSub * sizeof(SMop); }
-size_t sweep2_lds_bytes(int k, int threads) {
-    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxReducePerSub * (threads / 64) * 32 * sizeof(double) +
+size_t sweep2_lds_bytes(int k, int threads, int reg_bits) {
+    const int maxr = reg_bits == 4 ? kMaxReducePerSub : kMaxReducePerSub / 2;
+    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * maxr * (threads / 64) * 32 * sizeof(double) +
            (size_t)2 * kMaxMopsPerSub * sizeof(SMop);
 }
 int apply2_threads(int k) { return std::max(64, 1 << (k - 4)); }
-int sweep2_threads(int k) { return std::max(64, 1 << (k - 4)); }
+int sweep2_threads(int k, int r) { return std::max(64, 1 << (k - r)); }
 
 template <typename K>
 static hipError_t allow_big_lds2(K kernel) {
@@ -468,7 +475,8 @@ hipError_t init_kernels2() {
     hipError_t e;
 #define AQC_TRY(x) if ((e = (x)) != hipSuccess) return e
     AQC_TRY(allow_big_lds2(apply_stage_kernel2<0>)); AQC_TRY(allow_big_lds2(apply_stage_kernel2<1>)); AQC_TRY(allow_big_lds2(apply_stage_kernel2<2>));
-    AQC_TRY(allow_big_lds2(sweep_stage_kernel2<0>)); AQC_TRY(allow_big_lds2(sweep_stage_kernel2<1>)); AQC_TRY(allow_big_lds2(sweep_stage_kernel2<2>));
+    AQC_TRY(allow_big_lds2(sweep_stage_kernel2<0, 4>)); AQC_TRY(allow_big_lds2(sweep_stage_kernel2<1, 4>)); AQC_TRY(allow_big_lds2(sweep_stage_kernel2<2, 4>));
+    AQC_TRY(allow_big_lds2(sweep_stage_kernel2<0, 3>)); AQC_TRY(allow_big_lds2(sweep_stage_kernel2<1, 3>)); AQC_TRY(allow_big_lds2(sweep_stage_kernel2<2, 3>));
 #undef AQC_TRY
     return hipSuccess;
 }
@@ -483,14 +491,17 @@ hipError_t launch_apply2(int ent, int ntiles, int batch, int k, hipStream_t s, c
     }
     return hipGetLastError();
 }
-hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, hipStream_t s, const StageArgs& a) {
-    const int threads = sweep2_threads(k);
+hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, int reg_bits, hipStream_t s, const StageArgs& a) {
+    const int threads = sweep2_threads(k, reg_bits);
     const dim3 grid(ntiles, batch), block(threads);
-    const size_t lds = sweep2_lds_bytes(k, threads);
-    switch (ent) {
-        case 0: sweep_stage_kernel2<0><<<grid, block, lds, s>>>(a); break;
-        case 1: sweep_stage_kernel2<1><<<grid, block, lds, s>>>(a); break;
-        default: sweep_stage_kernel2<2><<<grid, block, lds, s>>>(a); break;
+    const size_t lds = sweep2_lds_bytes(k, threads, reg_bits);
+    switch (ent * 2 + (reg_bits == 3 ? 1 : 0)) {
+        case 0: sweep_stage_kernel2<0, 4><<<grid, block, lds, s>>>(a); break;
+        case 1: sweep_stage_kernel2<0, 3><<<grid, block, lds, s>>>(a); break;
+        case 2: sweep_stage_kernel2<1, 4><<<grid, block, lds, s>>>(a); break;
+        case 3: sweep_stage_kernel2<1, 3><<<grid, block, lds, s>>>(a); break;
+        case 4: sweep_stage_kernel2<2, 4><<<grid, block, lds, s>>>(a); break;
+        default: sweep_stage_kernel2<2, 3><<<grid, block, lds, s>>>(a); break;
     }
     return hipGetLastError();
 }

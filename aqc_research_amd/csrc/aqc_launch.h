@@ -47,7 +47,7 @@ hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t 
 // aqc_kernels2.hip (register-blocked kernels)
 hipError_t init_kernels2();
 hipError_t launch_apply2(int ent, int ntiles, int batch, int k, hipStream_t s, const StageArgs& a);
-hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, hipStream_t s, const StageArgs& a);
+hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, int reg_bits, hipStream_t s, const StageArgs& a);
 
 // aqc_mps.hip
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);

@@ -109,11 +109,15 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: anything libraries print there (RCCL prints a version banner when a
+    # communicator is created) is diverted to stderr until the result is written
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AQC_BENCH_FORCE_DIST") == "1":  # one rank per GPU under torch.distributed.run
         import torch
         import torch.distributed as dist
 
@@ -296,7 +300,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(circ, ncols)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ws.close()
     if dist is not None:
         dist.barrier()

@@ -186,3 +186,78 @@ def test_fused_eval_matches_separate_calls():
         x2 = np.zeros(1 << n, complex); x2[[5, 9][b]] = 1
         assert maxdiff(g2[b], orc.grad_of_dot_product(a, th[b], x2, zr)) < TOL
     ws.close()
+
+
+def test_edge_cases_minimal_and_empty():
+    """n = 2 (smallest system), zero blocks (front layer only), a single block, and the validation
+    the reference does with asserts (core_operations.py:626-630,869-879)."""
+    import aqc_research_amd.core_operations as cop
+    from aqc_research_amd import ParametricCircuit
+
+    rng = np.random.default_rng(2)
+    for n, blocks in ((2, np.zeros((2, 0), dtype=np.int64)), (2, np.array([[1], [0]])), (5, np.zeros((2, 0), dtype=np.int64))):
+        circ = ParametricCircuit(n, "cp", blocks)
+        a = orc.as_ansatz(circ)
+        th = orc.rand_thetas(circ.num_thetas, rng)
+        x, y = orc.rand_state(n, rng), orc.rand_state(n, rng)
+        out = np.zeros(1 << n, np.complex128)
+        assert maxdiff(cop.v_mul_vec(circ, th, x, out, None), orc.v_mul_vec(a, th, x)) < TOL
+        vhy = cop.v_dagger_mul_vec(circ, th, y, np.zeros(1 << n, np.complex128), None)
+        assert maxdiff(vhy, orc.v_dagger_mul_vec(a, th, y)) < TOL
+        if circ.num_blocks:
+            assert maxdiff(cop.grad_of_dot_product(circ, th, x, vhy, None), orc.grad_of_dot_product(a, th, x, vhy)) < TOL
+    circ = ParametricCircuit(3, "cx", np.array([[0, 1], [1, 2]]))
+    th = np.zeros(circ.num_thetas)
+    v = np.zeros(8, np.complex128)
+    with pytest.raises(ValueError):
+        cop.v_mul_vec(circ, th[:-1], v, v.copy(), None)            # wrong number of thetas
+    with pytest.raises(ValueError):
+        cop.v_mul_vec(circ, th, v[:4], v.copy(), None)             # wrong vector size
+    with pytest.raises(ValueError):
+        cop.v_mul_vec(circ, th, v.astype(np.complex64), v.copy(), None)
+    with pytest.raises(ValueError):
+        cop.grad_of_dot_product(circ, th, v, v.copy(), None, block_range=(1, 1))
+    with pytest.raises(ValueError):
+        cop.grad_of_dot_product(circ, th, v, v.copy(), None, block_range=(0, 3))
+    ws = np.zeros((3, 8), np.complex128)
+    with pytest.raises(ValueError):
+        cop.v_mul_vec(circ, th, ws[0], v.copy(), ws)               # vec overlaps the workspace
+
+
+def test_20_qubit_properties():
+    """BASELINE configs[3] size (2^20 amplitudes, 2nd-order Trotter ansatz): size-independent properties
+    instead of a full oracle run -- unitarity, V V^H = 1, gradient == central finite differences of the
+    objective computed by the same path, repeatability."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n = 20
+    rng = np.random.default_rng(20)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 1), second_order=True)
+    ws = Workspace(HipContext.of(circ), batch=1)
+    th = 0.4 * orc.rand_thetas(circ.num_thetas, rng)
+    y = orc.rand_state(n, rng)
+    ws.upload(BUF_Y, y)
+    ws.set_thetas(th)
+    ws.apply(True, BUF_Y, BUF_Z)
+    z = ws.download(BUF_Z)[0]
+    assert abs(np.linalg.norm(z) - 1) < 1e-12
+    ws.set_basis(BUF_X, 0)
+    ws.grad()
+    g = ws.get_grads()[0]
+    ws.grad()
+    assert np.array_equal(g, ws.get_grads()[0])          # bit-reproducible
+    for t in rng.choice(circ.num_thetas, 6, replace=False):  # <V e0|y> = (V^H y)[0]
+        f = []
+        for sgn in (+1, -1):
+            e = np.zeros_like(th); e[t] = sgn * 1e-5
+            ws.set_thetas(th + e)
+            ws.apply(True, BUF_Y, BUF_Z)
+            f.append(ws.gather(BUF_Z, [0])[0, 0])
+        assert abs((f[0] - f[1]) / 2e-5 - g[t]) < 1e-8
+    ws.set_thetas(th)
+    ws.apply(True, BUF_Y, BUF_Z)
+    ws.apply(False, BUF_Z, BUF_X)
+    assert maxdiff(ws.download(BUF_X)[0], y) < 1e-12      # V V^H y = y
+    ws.close()

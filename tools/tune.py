@@ -75,11 +75,13 @@ if __name__ == "__main__":
         for v2, ks in ((0, 6), (0, 8), (0, 10), (0, 12), (1, 8), (1, 10), (1, 12)):
             cfgs.append({"env": {"AQC_KERNEL_V2": v2, "AQC_THREADS": 0}, "ks": ks, "ka": ks})
         run(n=12, B=int(sys.argv[2]) if len(sys.argv) > 2 else 1, configs=cfgs, steps=50, trotter_layers=2)
+    elif which == "r3":
+        run(configs=[{"env": {"AQC_SWEEP_REG_BITS": r}, "ks": 12, "ka": 13} for r in (4, 3)])
     elif which == "one":
         run(configs=[{"env": {"AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}])
     elif which == "skip":
         cfgs = [{"env": {"AQC_THREADS": 256, "AQC_LOW_BITS": 3}, "ks": 12, "ka": 13}]
-        for dbg in (0, 2, 1, 3):
+        for dbg in (0, 3, 4):
             os.environ["AQC_DEBUG_SKIP"] = str(dbg)
             print("AQC_DEBUG_SKIP =", dbg); run(configs=cfgs)
     elif which == "b1":

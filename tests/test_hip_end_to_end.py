@@ -59,3 +59,25 @@ def test_full_aqc_lbfgs_and_run_jobs():
     assert [r["status"] for r in results] == ["ok"] * 3
     for r in results:
         assert r["cost"] < 1e-6 and r["overlap"] > 1 - 1e-6
+
+
+def test_asp_time_evolution_driver():
+    """Two horizons of the ASP driver on 8 qubits: device-synthesised Trotter targets, Trotter initial point,
+    L-BFGS on the HIP objective; the optimised ansatz must not be worse than its Trotter start."""
+    from scipy.linalg import expm
+
+    from aqc_research_amd.model_sp_lhs.time_evol import UserOptions, run_simulation
+    from aqc_research_amd.model_sp_lhs.trotter import make_hamiltonian, neel_state_index, trotter_state
+
+    n = 8
+    # device Trotter state vs exact evolution
+    ini = np.zeros(1 << n, complex); ini[neel_state_index(n)] = 1
+    exact = expm(-1j * 1.2 * make_hamiltonian(n, 1.0)) @ ini
+    tgt = trotter_state(n, evol_time=1.2, num_steps=12, with_global_phase=True)
+    assert np.linalg.norm(tgt - exact) < 2e-3
+    opts = UserOptions(num_qubits=n, num_horizons=2, num_layers_inc=1, trotter_steps_per_horizon=6, maxiter=30)
+    res = run_simulation(opts)
+    assert [r["status"] for r in res] == ["ok", "ok"] and [r["horizon"] for r in res] == [1, 2]
+    for r in res:
+        assert r["fidelity"] >= r["fidelity_trotter_init"] - 1e-9 and r["fidelity"] > 0.9
+        assert r["thetas"].shape == (r["num_thetas"],)

@@ -127,3 +127,33 @@ def test_optimizer_wrapper_and_stoppers():
 
     res = opt.AqcOptimizer(maxiter=5).optimize(StopObj([0, 0, 0]), _Circ(), np.zeros(3))
     assert res["cost"] == 0.123 and res["is_timeout"] is False
+
+
+def test_trotter_initialisation_matches_exact_evolution():
+    """init_ansatz_to_trotter reproduces the XXZ evolution: the Trotter state (CPU oracle applies the
+    ansatz) converges to exp(-iHt)|neel> with the 2nd-order rate (test_trotter.py:88-96 asks > 0.9)."""
+    from scipy.linalg import expm
+
+    from aqc_research_amd.model_sp_lhs.trotter import (init_ansatz_to_trotter, make_hamiltonian, neel_state_index,
+                                                       trotter_alphas, trotter_ansatz, trotter_global_phase)
+    from oracle import aqc_oracle as orc
+
+    n, t, delta = 5, 1.0, 1.0
+    ini = np.zeros(1 << n, complex); ini[neel_state_index(n)] = 1
+    exact = expm(-1j * t * make_hamiltonian(n, delta)) @ ini
+    errs = []
+    for steps in (2, 4, 8):
+        circ = trotter_ansatz(n, steps, True)
+        th = init_ansatz_to_trotter(circ, np.ones(circ.num_thetas), evol_time=t, delta=delta)
+        assert np.count_nonzero(th) <= 3 * (circ.num_blocks // 3) and np.all(th[: 3 * n] == 0)
+        v = orc.v_mul_vec(circ, th, ini) * np.exp(1j * trotter_global_phase(n, steps, True))
+        errs.append(np.linalg.norm(v - exact))
+        assert abs(np.vdot(exact, v)) ** 2 > 0.99
+    assert errs[1] < errs[0] / 3 and errs[2] < errs[1] / 3      # ~ dt^2
+    a = trotter_alphas(0.3, 1.5)
+    assert np.allclose(a, [np.pi / 2 - 0.225, 0.15 - np.pi / 2, np.pi / 2 - 0.15])
+    # partial range leaves the other layers alone
+    circ = trotter_ansatz(4, 3, False)
+    th = init_ansatz_to_trotter(circ, np.full(circ.num_thetas, 7.0), evol_time=1.0, delta=1.0, layer_range=(1, 2))
+    v2 = circ.subset2q(th).reshape(3, 3, 12)
+    assert np.all(v2[0] == 7.0) and np.all(v2[2] == 7.0) and np.all(th[: 12] == 7.0) and np.count_nonzero(v2[1]) == 9

@@ -53,6 +53,7 @@ SIGNATURES = {
     "aqc_ws_eval": (c_int, [_P, _D, c_int, _D, c_int, c_int, c_int, c_int, _D]),
     "aqc_ws_grad_from": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "aqc_ws_cd_sweep": (c_int, [_P, _D, _D]),
+    "aqc_zgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, _D, c_int, _D, c_int, _D, c_int]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),
     "aqc_ws_mps_dot": (c_int, [_P, c_int, c_int, _D]),

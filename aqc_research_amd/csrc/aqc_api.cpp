@@ -851,6 +851,36 @@ int aqc_ws_gather_fetch(aqc_ws* ws, double* out) {
 
 static int mps_scratch(aqc_ws* ws, size_t n_cplx);
 
+// ---- dense zgemm with host pointers ---------------------------------------------------------------
+
+int aqc_zgemm(int device, int conj_trans_a, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+              double* C, int ldc) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1) return fail("invalid zgemm arguments");
+    const int a_rows = conj_trans_a ? K : M, a_cols = conj_trans_a ? M : K;
+    if (lda < a_cols || ldb < N || ldc < N) return fail("invalid leading dimension");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: the aqc_hip path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("device out of range");
+    HIP_OK(hipSetDevice(device));
+    double2 *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    const size_t na = (size_t)a_rows * lda, nb = (size_t)K * ldb, nc = (size_t)M * ldc;
+    int rc = 0;
+    hipError_t e = hipMalloc((void**)&dA, na * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void**)&dB, nb * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void**)&dC, nc * sizeof(double2));
+    if (e == hipSuccess) e = hipMemcpy(dA, A, na * sizeof(double2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dB, B, nb * sizeof(double2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ldc != N) e = hipMemcpy(dC, C, nc * sizeof(double2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_zgemm(conj_trans_a != 0, false, M, N, K, dA, lda, dB, ldb, dC, ldc, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(C, dC, nc * sizeof(double2), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail("aqc_zgemm failed: %s", hipGetErrorString(e));
+    if (dA) (void)hipFree(dA);
+    if (dB) (void)hipFree(dB);
+    if (dC) (void)hipFree(dC);
+    return rc;
+}
+
 // ---- coordinate descent ------------------------------------------------------------------------
 
 int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io, double* fobj) {

@@ -298,3 +298,17 @@ def _ws_mps_dot(self, slot_a: int, slot_b: int) -> complex:
 Workspace.mps_upload = _ws_mps_upload
 Workspace.mps_to_vec = _ws_mps_to_vec
 Workspace.mps_dot = _ws_mps_dot
+
+
+def zgemm(a: np.ndarray, b: np.ndarray, conj_trans_a: bool = False, device: int = 0) -> np.ndarray:
+    """op(a) @ b on the device (aqc_zgemm); op(a) = a or a^H."""
+    a = _lib.as_c128(a)
+    b = _lib.as_c128(b)
+    if a.ndim != 2 or b.ndim != 2:
+        raise ValueError("zgemm expects two matrices")
+    m, k = (a.shape[1], a.shape[0]) if conj_trans_a else a.shape
+    if b.shape[0] != k:
+        raise ValueError("inner dimensions differ")
+    c = np.empty((m, b.shape[1]), dtype=np.complex128)
+    check(_lib.lib().aqc_zgemm(device, int(conj_trans_a), m, b.shape[1], k, dptr(a), a.shape[1], dptr(b), b.shape[1], dptr(c), c.shape[1]))
+    return c

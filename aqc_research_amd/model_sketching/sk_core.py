@@ -7,7 +7,7 @@ from typing import Optional, Tuple, Union
 
 import numpy as np
 
-from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext
+from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext, zgemm
 from ..parametric_circuit import ParametricCircuit
 
 
@@ -41,6 +41,79 @@ class FullRangeSketchingVectors(SketchingVectorsBase):
 
     def generate(self, _=None, __=None) -> Tuple[np.ndarray, np.ndarray]:
         return np.eye(self._target_mat.shape[0], dtype=np.complex128), np.array(self._target_mat, dtype=np.complex128)
+
+
+class RandomSketchingVectors(SketchingVectorsBase):
+    """Fresh random orthonormal X on every request, Y = U X (sk_core.py:329-356).  The random draw and the
+    QR are input generation on the host (same np.random call order as the reference); U X runs on the GPU."""
+
+    def __init__(self, num_skvecs: int, target_mat: np.ndarray):
+        super().__init__(num_skvecs, target_mat)
+        if target_mat.shape[0] % self.num_skvecs:
+            raise ValueError("the dimension must be divisible by num_skvecs")
+
+    def generate(self, _=None, __=None) -> Tuple[np.ndarray, np.ndarray]:
+        dim, k = self.target_matrix.shape[0], self.num_skvecs
+        x_vecs, _r = np.linalg.qr(np.random.rand(dim, k) + 1j * np.random.rand(dim, k))
+        x_vecs = np.ascontiguousarray(x_vecs)
+        return x_vecs, zgemm(self.target_matrix, x_vecs)
+
+
+class AlternatingSketchingVectors(SketchingVectorsBase):
+    """Random subset of unit vectors / target columns per request (sk_core.py:359-401)."""
+
+    def __init__(self, num_skvecs: int, target_mat: np.ndarray):
+        super().__init__(num_skvecs, target_mat)
+        dim = target_mat.shape[0]
+        if dim % self.num_skvecs:
+            raise ValueError("the dimension must be divisible by num_skvecs")
+        self._offset = 0
+        self._indices = np.random.permutation(dim)
+
+    def generate(self, _=None, __=None) -> Tuple[np.ndarray, np.ndarray]:
+        target, dim, k = self.target_matrix, self.target_matrix.shape[0], self.num_skvecs
+        if self._offset >= dim:
+            self._offset = 0
+            self._indices = np.random.permutation(dim)
+        idx = self._indices[self._offset : self._offset + k]
+        x_vecs = np.zeros((dim, k), dtype=np.complex128)
+        x_vecs[idx, np.arange(idx.size)] = 1
+        y_vecs = np.ascontiguousarray(target[:, idx])
+        self._offset += k
+        return x_vecs, y_vecs
+
+
+class EigenSketchingVectors(SketchingVectorsBase):
+    """Randomised range finder of (V^H - U^H) (sk_core.py:404-464): X = qr((V^H - U^H) Omega), Y = U X.
+    V^H Omega and both GEMMs run on the GPU."""
+
+    def generate(self, circ=None, thetas=None) -> Tuple[np.ndarray, np.ndarray]:
+        from ..core_op_matrix import v_dagger_mul_mat
+
+        if circ is None or thetas is None or np.size(thetas) != circ.num_thetas:
+            raise ValueError("EigenSketchingVectors needs the circuit and its thetas")
+        dim, k, target = circ.dimension, self.num_skvecs, self.target_matrix
+        omega = np.random.randn(dim, k).astype(np.complex128)
+        omega = omega * 1j
+        omega += np.random.randn(dim, k)
+        uh_omega = zgemm(target, omega, conj_trans_a=True)                 # U^H Omega
+        vh_omega = v_dagger_mul_mat(circ, np.asarray(thetas, dtype=np.float64), np.ascontiguousarray(omega.copy()), None)
+        x_vecs, _r = np.linalg.qr(vh_omega - uh_omega)
+        x_vecs = np.ascontiguousarray(x_vecs)
+        return x_vecs, zgemm(target, x_vecs)
+
+
+def skvecs_generator(skvecs_type: str, num_skvecs: int, target_mat: np.ndarray) -> SketchingVectorsBase:
+    """Factory of sk_core.py:467-494."""
+    if skvecs_type == "full" or num_skvecs == target_mat.shape[0]:
+        return FullRangeSketchingVectors(target_mat)
+    if skvecs_type == "rand":
+        return RandomSketchingVectors(num_skvecs, target_mat)
+    if skvecs_type == "alt":
+        return AlternatingSketchingVectors(num_skvecs, target_mat)
+    if skvecs_type == "eigen":
+        return EigenSketchingVectors(num_skvecs, target_mat)
+    raise ValueError(f"unknown type of sketching vectors generator, expects one of: ['full', 'rand', 'alt', 'eigen'], got {skvecs_type}")
 
 
 class SketchingObjectiveEx:

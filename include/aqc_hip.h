@@ -138,6 +138,12 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane);
 /* out <- <mps_a|mps_b> by transfer matrices                      (mps_dot, :192-213) */
 int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out /* 1 c128 */);
 
+/* ---- dense complex GEMM on the device: C (M x N) = op(A) B with op(A) = A (M x K) or A^H (A stored K x M),
+ * row-major, host pointers.  Used by the sketching-vector generators (Y = U X, sk_core.py:357,463) and by
+ * the MPS contractions internally. */
+int aqc_zgemm(int device, int conj_trans_a, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+              double* C, int ldc);
+
 /* ---- coordinate descent (core_op_matrix.py:765  coord_descent_single_sweep(circ, thetas, target,
  * workspace)).  Square workspace (ncols == 2^n) with the target unitary in AQC_BUF_Y.  One
  * Gauss-Seidel sweep over all parameters of 1 - |<V,U>|^2/d^2; thetas are updated in place and

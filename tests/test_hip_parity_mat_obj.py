@@ -159,3 +159,48 @@ def test_coord_descent_rejects_cp():
     circ = ParametricCircuit(2, "cp", np.array([[0], [1]]))
     with pytest.raises(NotImplementedError):
         com.coord_descent_single_sweep(circ, np.zeros(circ.num_thetas), np.eye(4, dtype=complex), None)
+
+
+@pytest.mark.parametrize("kind", ["rand", "alt", "eigen"])
+def test_sketched_objective_generators(kind):
+    """Sketched AQC (k < d columns): the generators draw from np.random in the reference's order, so replaying the
+    seed on the CPU gives the same (X, Y); objective and gradient must match the oracle on them."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.model_sketching.sk_core import SketchingObjectiveEx, skvecs_generator
+
+    n, k = 5, 8
+    rng = np.random.default_rng(8)
+    circ = ParametricCircuit(n, "cz", orc.spin_blocks(n, 12))
+    d = 1 << n
+    u = np.ascontiguousarray(np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0])
+    th = orc.rand_thetas(circ.num_thetas, rng)
+
+    np.random.seed(321)
+    gen = skvecs_generator(kind, k, u)
+    f, g = SketchingObjectiveEx(circ, gen).objective_and_gradient(th)
+
+    np.random.seed(321)                       # replay the draws with plain NumPy
+    if kind == "rand":
+        x = np.linalg.qr(np.random.rand(d, k) + 1j * np.random.rand(d, k))[0]
+    elif kind == "alt":
+        idx = np.random.permutation(d)[:k]
+        x = np.zeros((d, k), complex); x[idx, np.arange(k)] = 1
+    else:
+        omega = np.random.randn(d, k) * 1j
+        omega = omega + np.random.randn(d, k)
+        x = np.linalg.qr(orc.v_dagger_mul_mat(circ, th, omega) - u.conj().T @ omega)[0]
+    y = u @ x
+    fr, gr = orc.sketching_objective_and_gradient(circ, th, x, y)
+    assert abs(f - fr) < 1e-9 and maxdiff(g, gr) < 1e-9
+    assert maxdiff(np.conj(x.T) @ x, np.eye(k)) < 1e-12
+
+
+def test_zgemm_entry_point():
+    from aqc_research_amd.engine import zgemm
+
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((70, 33)) + 1j * rng.standard_normal((70, 33))
+    b = rng.standard_normal((33, 130)) + 1j * rng.standard_normal((33, 130))
+    assert maxdiff(zgemm(a, b), a @ b) < 1e-12
+    c = rng.standard_normal((70, 5)) + 1j * rng.standard_normal((70, 5))
+    assert maxdiff(zgemm(a, c, conj_trans_a=True), a.conj().T @ c) < 1e-12

@@ -251,20 +251,29 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
     SMop* smops = reinterpret_cast<SMop*>(tables + 320);  // [2][kMaxMopsPerSub]
     const Tile2 tc = tile_setup2(st, tables);
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
-    auto stage_mops = [&](int si) {  // decode sub-stage si into smops[si & 1]
+    // Decoding sub-stage si+1 (one thread per micro-op: two dependent global loads) is split into `fetch`, issued
+    // at the start of sub-stage si, and `commit` (the LDS write) after si's micro-op loop: the ~1 us of load
+    // latency hides behind the arithmetic instead of stalling every sub-stage.
+    SMop pend;
+    bool pend_valid = false;
+    auto fetch_mop = [&](int si) {
+        pend_valid = false;
         if (si >= st->nsubs) return;
         const DevSub sub = a.subs[st->sub_begin + si];
-        for (int t = threadIdx.x; t < sub.nmops; t += blockDim.x) {
-            const DevMop m = a.mops[sub.mop_begin + t];
-            SMop sm;
-            sm.km = 1 << m.kind; sm.pm = 1 << m.p; sm.tm = 1 << m.p2; sm.dm = 1;
+        if ((int)threadIdx.x < sub.nmops) {
+            const DevMop m = a.mops[sub.mop_begin + threadIdx.x];
+            pend.km = 1 << m.kind; pend.pm = 1 << m.p; pend.tm = 1 << m.p2; pend.dm = 1;
             const double sg = (m.flags & MOPF_NEG_S) ? -1.0 : 1.0;
-            sm.c = m.kind <= MOP_RX ? sg * coef[m.coef] : coef[m.coef];   // rotations: (-t, s) flip together
-            sm.s = sg * coef[m.coef + 1];
-            smops[(si & 1) * kMaxMopsPerSub + t] = sm;
+            pend.c = m.kind <= MOP_RX ? sg * coef[m.coef] : coef[m.coef];   // rotations: (-t, s) flip together
+            pend.s = sg * coef[m.coef + 1];
+            pend_valid = true;
         }
     };
-    stage_mops(0);
+    auto commit_mop = [&](int si) {
+        if (pend_valid) smops[(si & 1) * kMaxMopsPerSub + threadIdx.x] = pend;
+    };
+    fetch_mop(0);
+    commit_mop(0);
     __syncthreads();
     const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tc.base;
     const cplx* src = a.in0 + lane_off;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
     for (int si = 0; si < st->nsubs; ++si) {
         const DevSub sub = a.subs[st->sub_begin + si];
         __syncthreads();
-        stage_mops(si + 1);
+        fetch_mop(si + 1);
         cplx v[1 << R];
         if (active) {
             const unsigned b = chunk_base<R>(threadIdx.x, sub);
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
 #pragma unroll
             for (int j = 0; j < (1 << R); ++j) tile[swz(b | amp_offset<R>(j, sub))] = v[j];
         }
+        commit_mop(si + 1);
     }
     __syncthreads();
     cplx* dst = a.out0 + lane_off;
@@ -324,35 +334,42 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
     const Tile2 tc = tile_setup2(st, tables);
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
     auto enabled = [&](int jblock) { return jblock < 0 ? (a.front != 0) : (jblock >= a.from && jblock < a.to); };
-    auto stage_mops = [&](int si) {  // decode sub-stage si into smops[si & 1]
+    SMop pend;                 // decode of the next sub-stage: fetched early, committed to LDS late (see apply kernel)
+    bool pend_valid = false;
+    auto fetch_mop = [&](int si) {
+        pend_valid = false;
         if (si >= st->nsubs) return;
         const DevSub sub = a.subs[st->sub_begin + si];
-        for (int t = threadIdx.x; t < sub.nmops; t += blockDim.x) {
+        const int t = threadIdx.x;
+        if (t < sub.nmops) {
             const DevMop m = a.mops[sub.mop_begin + t];
             const bool on = enabled(m.jblock);
-            SMop sm;
-            sm.km = 1 << m.kind;
-            if ((a.debug & 1) && m.kind != MOP_REDUCE) sm.km = 1 << 20;
-            if ((a.debug & 2) && m.kind == MOP_REDUCE) sm.km = 1 << 20;
+            pend.km = 1 << m.kind;
+            if ((a.debug & 1) && m.kind != MOP_REDUCE) pend.km = 1 << 20;
+            if ((a.debug & 2) && m.kind == MOP_REDUCE) pend.km = 1 << 20;
             if (m.kind == MOP_REDUCE) {
-                sm.pm = m.flags;
-                sm.slots[0] = on ? m.slot : -1; sm.slots[1] = on ? m.p : -1;
-                sm.slots[2] = on ? m.p2 : -1;   sm.slots[3] = on ? m.coef : -1;
-                sm.dm = on ? 2 : 1;
+                pend.pm = m.flags;
+                pend.slots[0] = on ? m.slot : -1; pend.slots[1] = on ? m.p : -1;
+                pend.slots[2] = on ? m.p2 : -1;   pend.slots[3] = on ? m.coef : -1;
+                pend.dm = on ? 2 : 1;
                 int r = 0;  // index among the reductions of this sub-stage
                 for (int u = 0; u < t; ++u) r += a.mops[sub.mop_begin + u].kind == MOP_REDUCE;
-                sm.tm = r;
+                pend.tm = r;
             } else {
-                sm.pm = 1 << m.p; sm.tm = 1 << m.p2;
-                sm.dm = (on && m.slot >= 0) ? 2 : 1;
+                pend.pm = 1 << m.p; pend.tm = 1 << m.p2;
+                pend.dm = (on && m.slot >= 0) ? 2 : 1;
                 const double sg = (m.flags & MOPF_NEG_S) ? -1.0 : 1.0;
-                sm.c = m.kind <= MOP_RX ? sg * coef[m.coef] : coef[m.coef];
-                sm.s = sg * coef[m.coef + 1];
+                pend.c = m.kind <= MOP_RX ? sg * coef[m.coef] : coef[m.coef];
+                pend.s = sg * coef[m.coef + 1];
             }
-            smops[(si & 1) * kMaxMopsPerSub + t] = sm;
+            pend_valid = true;
         }
     };
-    stage_mops(0);
+    auto commit_mop = [&](int si) {
+        if (pend_valid) smops[(si & 1) * kMaxMopsPerSub + threadIdx.x] = pend;
+    };
+    fetch_mop(0);
+    commit_mop(0);
     __syncthreads();
     const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tc.base;
     {
@@ -398,8 +415,7 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
         const int par = si & 1;
         __syncthreads();
         flush(par ^ 1);
-        __syncthreads();          // smops[par ^ 1] / scratch[par ^ 1] are consumed before they are rewritten
-        stage_mops(si + 1);
+        fetch_mop(si + 1);        // registers only; written to smops[par ^ 1] after the micro-op loop
         cplx w[NA], z[NA];
         const unsigned b = chunk_base<R>(threadIdx.x, sub);
         if (active) {
@@ -442,6 +458,7 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
 #pragma unroll
             for (int j = 0; j < NA; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); tw[p] = w[j]; tz[p] = z[j]; }
         }
+        commit_mop(si + 1);       // flush(par ^ 1) of this iteration is long done: every wave passed the loop's barrier
         prev_n = sub.nmops;
     }
     __syncthreads();

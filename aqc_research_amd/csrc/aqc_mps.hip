@@ -1,6 +1,6 @@
 // MPS helpers on the GPU: Gamma*lambda folding, <mps1|mps2> by transfer matrices and
 // MPS -> dense state.  Reference: mps_operations.py:126-213.  Both contractions are chains of
-// small complex GEMMs; one LDS-tiled fp64 zgemm kernel serves them.
+// small complex GEMMs; one LDS-tiled fp64 MFMA zgemm kernel serves them.
 #include <hip/hip_runtime.h>
 
 #include "aqc_launch.h"
@@ -20,19 +20,25 @@ __global__ void mps_scale_kernel(cplx* g, const double* lam, int rows, int cols)
 }
 
 // C[M x N] (+)= op(A) * B, row-major.  CONJ_T: op(A)[m][k] = conj(A[k][m]) with A stored (K x M).
-constexpr int TM = 64, TN = 64, TK = 8;
+//
+// fp64 matrix cores: one v_mfma_f64_16x16x4_f64 multiplies a 16x4 by a 4x16 real tile.  Operand layout
+// (probed on gfx950, tools/ubench/mfma_f64_probe.hip): lane l supplies A[l%16][l/16] and B[l/16][l%16] and
+// receives D[4r + l/16][l%16] in accumulator register r.  A complex product is four real ones; the planes
+// are split (re / im) while the tiles are staged into LDS so that every operand read is one b64.
+// Workgroup = 4 waves, 64 x 64 outputs; wave w owns rows [16w, 16w+16) and all four 16-column tiles.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int TM = 64, TN = 64, TK = 16;
 template <bool CONJ_T, bool ACCUM>
 __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const cplx* __restrict__ A, int lda,
                                                     const cplx* __restrict__ B, int ldb, cplx* __restrict__ C, int ldc) {
-    __shared__ cplx sa[TK][TM + 1];
-    __shared__ cplx sb[TK][TN + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+    __shared__ double sar[TK][TM + 4], sai[TK][TM + 4];
+    __shared__ double sbr[TK][TN + 4], sbi[TK][TN + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    cplx acc[4][4];
+    double4_t cre[4], cim[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = make_double2(0.0, 0.0);
+    for (int t = 0; t < 4; ++t) { cre[t] = double4_t{0, 0, 0, 0}; cim[t] = double4_t{0, 0, 0, 0}; }
     for (int k0 = 0; k0 < K; k0 += TK) {
         for (int e = threadIdx.x; e < TK * TM; e += 256) {
             int kk, mm;
@@ -42,39 +48,41 @@ __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const c
             if (gm < M && gk < K) {
                 if (CONJ_T) { v = A[(size_t)gk * lda + gm]; v.y = -v.y; } else { v = A[(size_t)gm * lda + gk]; }
             }
-            sa[kk][mm] = v;
+            sar[kk][mm] = v.x;
+            sai[kk][mm] = v.y;
         }
         for (int e = threadIdx.x; e < TK * TN; e += 256) {
             const int kk = e / TN, nn = e % TN;
             const int gk = k0 + kk, gn = n0 + nn;
-            sb[kk][nn] = (gk < K && gn < N) ? B[(size_t)gk * ldb + gn] : make_double2(0.0, 0.0);
+            const cplx v = (gk < K && gn < N) ? B[(size_t)gk * ldb + gn] : make_double2(0.0, 0.0);
+            sbr[kk][nn] = v.x;
+            sbi[kk][nn] = v.y;
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < TK; ++kk) {
-            cplx a[4], b[4];
+        for (int ks = 0; ks < TK; ks += 4) {
+            const double ar = sar[ks + lk][16 * wave + li];
+            const double ai = sai[ks + lk][16 * wave + li];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sa[kk][ty + 16 * i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sb[kk][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j].x += a[i].x * b[j].x - a[i].y * b[j].y;
-                    acc[i][j].y += a[i].x * b[j].y + a[i].y * b[j].x;
-                }
+            for (int t = 0; t < 4; ++t) {
+                const double br = sbr[ks + lk][16 * t + li];
+                const double bi = sbi[ks + lk][16 * t + li];
+                cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[t], 0, 0, 0);
+                cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[t], 0, 0, 0);
+                cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[t], 0, 0, 0);
+                cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[t], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + 16 * wave + 4 * r + lk, gn = n0 + 16 * t + li;
             if (gm < M && gn < N) {
                 cplx* c = C + (size_t)gm * ldc + gn;
-                if (ACCUM) { c->x += acc[i][j].x; c->y += acc[i][j].y; } else { *c = acc[i][j]; }
+                if (ACCUM) { c->x += cre[t][r]; c->y += cim[t][r]; } else { *c = make_double2(cre[t][r], cim[t][r]); }
             }
         }
 }

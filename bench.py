@@ -52,10 +52,26 @@ def build_circuit(w):
     return TrotterAnsatz(w["n"], make_trotter_like_circuit(w["n"], w["layers"]), second_order=True)
 
 
-def cpu_baseline(circ, ncols=1, seconds=12.0):
-    """Reference algorithm restated in NumPy (oracle/aqc_oracle.py), timed on the host cores
-    of this box on a bounded sample of the same workload (1 thread)."""
+def host_cores():
+    """Cores this process may really use: the cgroup CPU quota when there is one, else the affinity
+    mask capped at the GPU box's per-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
+def cpu_baseline(circ, ncols=1, seconds=8.0):
+    """The reference algorithm (one pass per gate, one per inner product) timed on the host cores of
+    this box on a bounded sample of the same workload: `value` is the compiled C restatement
+    (oracle/aqc_ref.c) with one evaluation per core at a time -- the way the reference uses cores
+    (job_executor.py:141) -- and the single-thread C and NumPy (oracle/aqc_oracle.py) rates ride along."""
     from oracle import aqc_oracle as orc
+    from oracle import aqc_ref as cref
 
     try:
         from threadpoolctl import threadpool_limits
@@ -65,36 +81,62 @@ def cpu_baseline(circ, ncols=1, seconds=12.0):
         limiter = None
     rng = np.random.default_rng(7)
     a = orc.as_ansatz(circ)
+    cores = host_cores()
+
+    def timed(fn, budget, cap=10000):
+        fn()  # warm-up
+        t0, count = time.perf_counter(), 0
+        while count < 1 or (time.perf_counter() - t0 < budget and count < cap):
+            count += fn()
+        return count, time.perf_counter() - t0
+
     if ncols == 1:
         target = orc.rand_state(a.n, rng)
         x = np.zeros(a.dim, complex)
         x[0] = 1
 
-        def one():
+        def numpy_one():
             th = orc.rand_thetas(a.num_thetas, rng)
-            vh = orc.v_dagger_mul_vec(a, th, target)
-            orc.grad_of_dot_product(a, th, x, vh)
+            orc.grad_of_dot_product(a, th, x, orc.v_dagger_mul_vec(a, th, target))
+            return 1
+
+        def c_batch(threads):
+            def run():
+                th = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(threads)])
+                cref.eval_batch(a, th, target, 0, threads)
+                return threads
+            return run
+
+        n_all, t_all = timed(c_batch(cores), seconds)
+        n_one, t_one = timed(c_batch(1), seconds / 4)
     else:
         u = np.linalg.qr(rng.standard_normal((a.dim, ncols)) + 1j * rng.standard_normal((a.dim, ncols)))[0]
         eye = np.eye(a.dim, ncols, dtype=complex)
 
-        def one():
+        def numpy_one():
             orc.sketching_objective_and_gradient(a, orc.rand_thetas(a.num_thetas, rng), eye, u)
+            return 1
 
-    one()  # warm-up
-    t0, count = time.perf_counter(), 0
-    while count < 2 or (time.perf_counter() - t0 < seconds and count < 200):
-        one()
-        count += 1
-    dt = time.perf_counter() - t0
+        def c_one():
+            th = orc.rand_thetas(a.num_thetas, rng)
+            cref.grad_of_matrix_dot_product(a, th, eye, cref.v_dagger_mul_mat(a, th, u))
+            return 1
+
+        cores = 1
+        n_all, t_all = timed(c_one, seconds)
+        n_one, t_one = n_all, t_all
+    n_np, t_np = timed(numpy_one, seconds / 2, cap=200)
     if limiter is not None:
         limiter.restore_original_limits()
     return {
-        "value": count / dt,
+        "value": n_all / t_all,
         "unit": "evals/s",
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": f"{count} objective+gradient evaluations of the same ansatz (NumPy restatement of the reference, 1 thread, {dt:.1f} s)",
+        "sample": f"{n_all} objective+gradient evaluations of the same ansatz in {t_all:.1f} s: C restatement of the "
+                  f"reference algorithm, {cores} thread(s), one evaluation per thread",
+        "c_1thread_evals_per_s": n_one / t_one,
+        "numpy_1thread_evals_per_s": n_np / t_np,
     }
 
 

@@ -261,3 +261,51 @@ def test_20_qubit_properties():
     ws.apply(False, BUF_Z, BUF_X)
     assert maxdiff(ws.download(BUF_X)[0], y) < 1e-12      # V V^H y = y
     ws.close()
+
+
+def test_full_size_direct_parity_headline_batch():
+    """BASELINE headline at its full size -- 16 qubits, 40 blocks, 64 lanes with 64 different thetas,
+    exactly the bench's unit of work -- compared lane by lane with the compiled CPU restatement."""
+    from oracle import aqc_ref as cref
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n, L, B = 16, 40, 64
+    rng = np.random.default_rng(1640)
+    a = orc.Ansatz(n, "cx", orc.spin_blocks(n, L))
+    thetas = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(B)])
+    y = orc.rand_state(n, rng)
+    ws = Workspace(HipContext.of(make_circ(a)), batch=B)
+    ws.broadcast(BUF_Y, y)
+    ws.set_basis(BUF_X, 0)
+    ws.gather_setup([0])
+    hs, grads = ws.eval(thetas, gather=True)
+    hs_ref, g_ref = cref.eval_batch(a, thetas, y, 0, threads=8)
+    assert maxdiff(hs[:, 0], hs_ref) < TOL
+    assert maxdiff(grads, g_ref) < TOL
+    ws.close()
+
+
+@pytest.mark.parametrize("order2", [True, False])
+def test_full_size_direct_parity_20_qubits(order2):
+    """BASELINE configs[3] size (2^20 amplitudes, Trotter ansatz, Neel basis state): direct comparison."""
+    from oracle import aqc_ref as cref
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n = 20
+    rng = np.random.default_rng(2020)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 2), second_order=order2)
+    a = orc.as_ansatz(circ)
+    thetas = orc.rand_thetas(circ.num_thetas, rng)[None, :]
+    y = orc.rand_state(n, rng)
+    neel = int("01" * (n // 2), 2)
+    ws = Workspace(HipContext.of(circ), batch=1)
+    ws.broadcast(BUF_Y, y)
+    ws.set_basis(BUF_X, neel)
+    ws.gather_setup([neel])
+    hs, grads = ws.eval(thetas, gather=True)
+    hs_ref, g_ref = cref.eval_batch(a, thetas, y, neel, threads=1)
+    assert maxdiff(hs[:, 0], hs_ref) < TOL
+    assert maxdiff(grads, g_ref) < TOL
+    ws.close()

@@ -318,6 +318,10 @@ __global__ __launch_bounds__(512) void apply_stage_kernel2(StageArgs a) {
 }
 
 // ---- forward w/z sweep with in-flight inner products, r = 4 -----------------------------------------
+// w and z live in registers for the whole stage (2 x 2^R amplitudes per thread); LDS only carries them from one
+// sub-stage's register layout to the next, and the two vectors take turns in ONE tile buffer.  That halves the
+// LDS footprint (64 KB at k = 12), so two workgroups share a CU and each SIMD has a second wave to issue from
+// while the first waits on LDS, a barrier or a DPP reduction.
 template <int ENT, int R>
 __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageArgs a) {
     constexpr int NA = 1 << R;  // amplitudes per thread and vector
@@ -325,12 +329,11 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevStage* st = a.stage;
     const unsigned tsize = 1u << st->k;
-    cplx* tw = reinterpret_cast<cplx*>(smem);
-    cplx* tz = tw + tsize;
-    unsigned* tables = reinterpret_cast<unsigned*>(tz + tsize);
+    cplx* tt = reinterpret_cast<cplx*>(smem);
+    unsigned* tables = reinterpret_cast<unsigned*>(tt + tsize);
     const int nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* scratch = reinterpret_cast<double*>(tables + 320);  // [2][kMaxReducePerSub][nwaves * 4 rows][8]
-    SMop* smops = reinterpret_cast<SMop*>(scratch + (size_t)2 * kMaxReducePerSub * nwaves * 32);  // [2][kMaxMopsPerSub]
+    double* scratch = reinterpret_cast<double*>(tables + 320);  // [kMaxReducePerSub][nwaves * 4 rows][8]
+    SMop* smops = reinterpret_cast<SMop*>(scratch + (size_t)kMaxReducePerSub * nwaves * 32);  // [kMaxMopsPerSub]
     const Tile2 tc = tile_setup2(st, tables);
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
     auto enabled = [&](int jblock) { return jblock < 0 ? (a.front != 0) : (jblock >= a.from && jblock < a.to); };
@@ -365,35 +368,58 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
             pend_valid = true;
         }
     };
-    auto commit_mop = [&](int si) {
-        if (pend_valid) smops[(si & 1) * kMaxMopsPerSub + threadIdx.x] = pend;
+    auto commit_mop = [&]() {
+        if (pend_valid) smops[threadIdx.x] = pend;
     };
-    fetch_mop(0);
-    commit_mop(0);
-    __syncthreads();
     const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tc.base;
-    {
-        const cplx* sw = a.in0 + lane_off;
-        const cplx* sz = a.in1 + lane_off;
-#if AQC_OPT_UNROLL
-#pragma unroll 8
-#endif
-        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {   // 16 HBM loads in flight per thread
-            const unsigned off = tc.dlo[l & 63u] + tc.dhi[l >> 6], p = swz(l);
-            tw[p] = sw[off];
-            tz[p] = sz[off];
+    const cplx* sw = a.in0 + lane_off;
+    const cplx* sz = a.in1 + lane_off;
+    cplx* dw = a.out0 + lane_off;
+    cplx* dz = a.out1 + lane_off;
+    const int nsubs_run = (a.debug & 4) ? 0 : st->nsubs;   // timing experiment: memory phases only
+    if (nsubs_run == 0) {   // nothing to do in this stage: plain copy
+        __syncthreads();
+        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {
+            const unsigned off = tc.dlo[l & 63u] + tc.dhi[l >> 6];
+            dw[off] = sw[off];
+            dz[off] = sz[off];
         }
+        return;
     }
     cplx* partial = a.partial + (size_t)blockIdx.y * a.nslots * a.ntiles_max;
     const unsigned nchunks = tsize >> R;
     const bool active = threadIdx.x < nchunks;
-
-    int prev_n = 0;
-    auto flush = [&](int par) {  // fixed-order cross-wave sums of the previous sub-stage's reductions
-        for (int t = threadIdx.x; t < prev_n; t += blockDim.x) {
-            const SMop m = smops[par * kMaxMopsPerSub + t];
+    auto load_tile = [&](const cplx* src) {   // HBM -> LDS, coalesced runs of the stage's low bits
+#if AQC_OPT_UNROLL
+#pragma unroll 8
+#endif
+        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) tt[swz(l)] = src[tc.dlo[l & 63u] + tc.dhi[l >> 6]];
+    };
+    auto store_tile = [&](cplx* dst) {
+        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) dst[tc.dlo[l & 63u] + tc.dhi[l >> 6]] = tt[swz(l)];
+    };
+    auto regs_from_tile = [&](cplx (&v)[NA], const DevSub& sub) {
+        if (active) {
+            const unsigned b = chunk_base<R>(threadIdx.x, sub);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) v[j] = tt[swz(b | amp_offset<R>(j, sub))];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) v[j] = make_double2(0.0, 0.0);
+        }
+    };
+    auto regs_to_tile = [&](const cplx (&v)[NA], const DevSub& sub) {
+        if (active) {
+            const unsigned b = chunk_base<R>(threadIdx.x, sub);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) tt[swz(b | amp_offset<R>(j, sub))] = v[j];
+        }
+    };
+    auto flush = [&](int count) {  // fixed-order cross-wave sums of the finished sub-stage's reductions
+        for (int t = threadIdx.x; t < count; t += blockDim.x) {
+            const SMop m = smops[t];
             if (!(m.km & (1 << MOP_REDUCE)) || !(m.dm & 2)) continue;
-            const double* sc = scratch + ((size_t)par * kMaxReducePerSub + m.tm) * nwaves * 32;
+            const double* sc = scratch + (size_t)m.tm * nwaves * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (m.slots[q] < 0) continue;
@@ -409,31 +435,29 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
         }
     };
 
-    const int nsubs_run = (a.debug & 4) ? 0 : st->nsubs;   // timing experiment: memory phases only
+    cplx w[NA], z[NA];
+    DevSub sub = a.subs[st->sub_begin];
+    fetch_mop(0);
+    commit_mop();
+    load_tile(sw);
+    __syncthreads();
+    regs_from_tile(w, sub);
+    __syncthreads();
+    load_tile(sz);
+    __syncthreads();
+    regs_from_tile(z, sub);
+
     for (int si = 0; si < nsubs_run; ++si) {
-        const DevSub sub = a.subs[st->sub_begin + si];
-        const int par = si & 1;
-        __syncthreads();
-        flush(par ^ 1);
-        fetch_mop(si + 1);        // registers only; written to smops[par ^ 1] after the micro-op loop
-        cplx w[NA], z[NA];
-        const unsigned b = chunk_base<R>(threadIdx.x, sub);
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < NA; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); w[j] = tw[p]; z[j] = tz[p]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NA; ++j) { w[j] = make_double2(0.0, 0.0); z[j] = make_double2(0.0, 0.0); }
-        }
-        const SMop* smp = smops + par * kMaxMopsPerSub;
+        const bool last = si + 1 == nsubs_run;
+        fetch_mop(si + 1);        // registers only; written to smops once this sub-stage's flush has read them
         cplx d0 = make_double2(0.0, 0.0), d1 = d0, d2 = d0, d3 = d0;  // newest ... oldest pending inner products
-        SMop mnext = smp[0];
+        SMop mnext = smops[0];
         for (int i = 0; i < sub.nmops; ++i) {
             const SMop m = mnext;
 #if AQC_OPT_PREFETCH
-            mnext = smp[i + 1 < sub.nmops ? i + 1 : i];   // fetch the next descriptor under this micro-op's arithmetic
+            mnext = smops[i + 1 < sub.nmops ? i + 1 : i];   // fetch the next descriptor under this micro-op's arithmetic
 #else
-            if (i + 1 < sub.nmops) mnext = smp[i + 1];
+            if (i + 1 < sub.nmops) mnext = smops[i + 1];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             const int km = __builtin_amdgcn_readfirstlane(m.km);  // wave-uniform by construction
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
                     const double v[8] = {d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
                     const double tot = reduce8_row(v, lane);
                     if ((lane & 15) < 8)
-                        scratch[(((size_t)par * kMaxReducePerSub + mp2) * nwaves * 4 + wave * 4 + (lane >> 4)) * 8 + (lane & 7)] = tot;
+                        scratch[(((size_t)mp2) * nwaves * 4 + wave * 4 + (lane >> 4)) * 8 + (lane & 7)] = tot;
                 }
                 d0 = d1 = d2 = d3 = make_double2(0.0, 0.0);
             }
@@ -454,23 +478,19 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
                 if (dm & 2) { d3 = d2; d2 = d1; d1 = d0; d0 = d; }
             }
         }
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < NA; ++j) { const unsigned p = swz(b | amp_offset<R>(j, sub)); tw[p] = w[j]; tz[p] = z[j]; }
-        }
-        commit_mop(si + 1);       // flush(par ^ 1) of this iteration is long done: every wave passed the loop's barrier
-        prev_n = sub.nmops;
-    }
-    __syncthreads();
-    if (nsubs_run) flush((st->nsubs - 1) & 1);
-    {
-        cplx* dw = a.out0 + lane_off;
-        cplx* dz = a.out1 + lane_off;
-        for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {
-            const unsigned off = tc.dlo[l & 63u] + tc.dhi[l >> 6], p = swz(l);
-            dw[off] = tw[p];
-            dz[off] = tz[p];
-        }
+        // hand over to the next sub-stage's register layout (or to HBM): w first, then z, through the one tile
+        const DevSub next = a.subs[st->sub_begin + (last ? si : si + 1)];
+        __syncthreads();          // every wave finished the loop (scratch complete) and its earlier reads of the tile
+        regs_to_tile(w, sub);
+        flush(sub.nmops);
+        __syncthreads();
+        commit_mop();             // flush has read this sub-stage's descriptors; visible after the next barrier
+        if (last) store_tile(dw); else regs_from_tile(w, next);
+        __syncthreads();
+        regs_to_tile(z, sub);
+        __syncthreads();
+        if (last) store_tile(dz); else regs_from_tile(z, next);
+        sub = next;
     }
 }
 
@@ -478,8 +498,8 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
 size_t apply2_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned) + (size_t)2 * kMaxMopsPerSub * sizeof(SMop); }
 size_t sweep2_lds_bytes(int k, int threads, int reg_bits) {
     const int maxr = reg_bits == 4 ? kMaxReducePerSub : kMaxReducePerSub / 2;
-    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * maxr * (threads / 64) * 32 * sizeof(double) +
-           (size_t)2 * kMaxMopsPerSub * sizeof(SMop);
+    return ((size_t)16 << k) + 320 * sizeof(unsigned) + (size_t)maxr * (threads / 64) * 32 * sizeof(double) +
+           (size_t)kMaxMopsPerSub * sizeof(SMop);
 }
 int apply2_threads(int k) { return std::max(64, 1 << (k - 4)); }
 int sweep2_threads(int k, int r) { return std::max(64, 1 << (k - r)); }

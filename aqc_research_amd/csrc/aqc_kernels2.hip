@@ -439,6 +439,7 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
     DevSub sub = a.subs[st->sub_begin];
     fetch_mop(0);
     commit_mop();
+    __syncthreads();          // offset tables (tile_setup2) and the first descriptors are in LDS
     load_tile(sw);
     __syncthreads();
     regs_from_tile(w, sub);

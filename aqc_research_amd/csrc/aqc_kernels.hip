@@ -72,6 +72,28 @@ __device__ __forceinline__ TileCtx tile_setup(const DevStage* st, unsigned* tabl
     return t;
 }
 
+// Gate-group descriptors and their coefficients are staged in LDS in chunks: fetching them per group costs two
+// dependent global loads (descriptor -> coefficient address), ~1.5 us that a single-wave workgroup cannot hide.
+constexpr int kOpChunk = 32;
+__device__ __forceinline__ void stage_ops(const StageArgs& a, const DevStage* st, const double* coef, int first,
+                                          DevOp* s_ops, double* s_cf) {
+    const int cnt = min(kOpChunk, st->nops - first);
+    const DevOp* ops = a.ops + st->op_begin + first;
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) s_ops[t] = ops[t];
+    for (int t = threadIdx.x; t < cnt * 10; t += blockDim.x) {
+        const int o = t / 10;
+        s_cf[t] = coef[(size_t)ops[o].coef * kCoefStride + (t - 10 * o)];
+    }
+}
+__device__ __forceinline__ DevOp uniform_op(const DevOp& v) {   // same value in every lane -> scalar registers
+    DevOp o;
+    o.type = __builtin_amdgcn_readfirstlane(v.type); o.p0 = __builtin_amdgcn_readfirstlane(v.p0);
+    o.p1 = __builtin_amdgcn_readfirstlane(v.p1);     o.flags = __builtin_amdgcn_readfirstlane(v.flags);
+    o.coef = __builtin_amdgcn_readfirstlane(v.coef); o.slot = __builtin_amdgcn_readfirstlane(v.slot);
+    o.jblock = __builtin_amdgcn_readfirstlane(v.jblock); o.pad = 0;
+    return o;
+}
+
 // ------------------------------------------------------------------------------------------
 // V / V^H on one vector per lane
 // ------------------------------------------------------------------------------------------
@@ -93,22 +115,19 @@ __global__ __launch_bounds__(512) void apply_stage_kernel(StageArgs a) {
 
     const double* coef = a.coef + (size_t)blockIdx.y * a.ncoef * kCoefStride;
     const int nops = st->nops;
-    DevOp op_next = a.ops[nops > 0 ? st->op_begin : 0];
-    if (nops == 0) op_next.coef = 0;   // empty stage (pure copy): keep the prefetch in bounds
-    double cf_next[10];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
+    DevOp* s_ops = reinterpret_cast<DevOp*>(tables + 320);
+    double* s_cf = reinterpret_cast<double*>(s_ops + kOpChunk);
     for (int i = 0; i < nops; ++i) {
-        const DevOp op = op_next;
-        double cf[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) cf[j] = cf_next[j];
-        if (i + 1 < nops) {
-            op_next = a.ops[st->op_begin + i + 1];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
+        const int ci = i & (kOpChunk - 1);
+        if (ci == 0) {
+            if (i) __syncthreads();   // every wave is done with the previous chunk
+            stage_ops(a, st, coef, i, s_ops, s_cf);
         }
         __syncthreads();
+        const DevOp op = uniform_op(s_ops[ci]);
+        double cf[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) cf[j] = s_cf[ci * 10 + j];
         if (op.type == 1) {
             const int plo = min(op.p0, op.p1), phi = max(op.p0, op.p1);
             const unsigned ic = 1u << op.p0, it = 1u << op.p1;
@@ -181,22 +200,19 @@ __global__ __launch_bounds__(512) void sweep_stage_kernel(StageArgs a) {
     };
 
     const int nops = st->nops;
-    DevOp op_next = a.ops[nops > 0 ? st->op_begin : 0];
-    if (nops == 0) op_next.coef = 0;   // empty stage (pure copy): keep the prefetch in bounds
-    double cf_next[10];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
+    DevOp* s_ops = reinterpret_cast<DevOp*>(scratch + (size_t)2 * nwaves * 40);
+    double* s_cf = reinterpret_cast<double*>(s_ops + kOpChunk);
     for (int i = 0; i < nops; ++i) {
-        const DevOp op = op_next;   // descriptor and coefficients were fetched under the previous group's arithmetic
-        double cf[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) cf[j] = cf_next[j];
-        if (i + 1 < nops) {
-            op_next = a.ops[st->op_begin + i + 1];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) cf_next[j] = coef[(size_t)op_next.coef * kCoefStride + j];
+        const int ci = i & (kOpChunk - 1);
+        if (ci == 0) {
+            if (i) __syncthreads();   // every wave is done with the previous chunk
+            stage_ops(a, st, coef, i, s_ops, s_cf);
         }
         __syncthreads();
+        const DevOp op = uniform_op(s_ops[ci]);
+        double cf[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) cf[j] = s_cf[ci * 10 + j];
         flush();
         cplx d[kSlotsPerGroup];
 #pragma unroll
@@ -425,9 +441,10 @@ __global__ void vdot_final_kernel(const cplx* part, int nparts, cplx* out) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-size_t apply_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned); }
+constexpr size_t kOpStageBytes = kOpChunk * (sizeof(DevOp) + 10 * sizeof(double));
+size_t apply_lds_bytes(int k) { return ((size_t)16 << k) + 320 * sizeof(unsigned) + kOpStageBytes; }
 size_t sweep_lds_bytes(int k, int threads) {
-    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * (threads / 64) * 4 * 10 * sizeof(double);
+    return ((size_t)32 << k) + 320 * sizeof(unsigned) + (size_t)2 * (threads / 64) * 4 * 10 * sizeof(double) + kOpStageBytes;
 }
 
 template <typename K>

@@ -91,3 +91,9 @@ if __name__ == "__main__":
                 continue
             cfgs.append({"env": {"AQC_KERNEL_V2": v2, "AQC_THREADS": thr, "AQC_LOW_BITS": 2}, "ks": ks, "ka": ks})
         run(B=int(sys.argv[2]) if len(sys.argv) > 2 else 1, configs=cfgs, steps=50)
+    elif which == "b1v2":   # latency regime: per-group kernels vs register-blocked kernels on small tiles
+        cfgs = [{"env": {"AQC_KERNEL_V2": 0, "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": 4}, "ks": 0, "ka": 0}]
+        for r, ks, ka in ((3, 9, 10), (3, 10, 10), (3, 10, 11), (4, 10, 10), (4, 11, 11), (3, 9, 9), (3, 8, 8)):
+            cfgs.append({"env": {"AQC_KERNEL_V2": 1, "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": r}, "ks": ks, "ka": ka})
+        print("n=16 L=40 B=1"); run(B=1, configs=cfgs, steps=50)
+        print("n=12 trotter2 B=1"); run(n=12, B=1, configs=cfgs, steps=50, trotter_layers=2)

@@ -185,8 +185,13 @@ class SpLHSObjectiveBase:
         self._hs2 = np.zeros(self._num_states)
         self._fobj = 1.0
         self._weight = 1.0
-        # device side: a private one-lane workspace; Y = target, Z = V^H target, X / X2 = lhs states
-        self._ws: Workspace = Workspace(HipContext.of(circuit), batch=1, ncols=1, device=int(user_parameters.get("device", 0)))
+        # device side: a private one-lane workspace; Y = target, Z = V^H target, X / X2 = lhs states.
+        # user_parameters["workspace"] substitutes a lane of a lockstep batch (lockstep.LaneView).
+        self._ws = user_parameters.get("workspace", None)
+        if self._ws is None:
+            self._ws = Workspace(HipContext.of(circuit), batch=1, ncols=1, device=int(user_parameters.get("device", 0)))
+        elif self._ws.T != circuit.num_thetas or self._ws.dim != circuit.dimension:
+            raise ValueError("user_parameters['workspace'] belongs to a different ansatz")
 
     def _store_latest_thetas(self, thetas: np.ndarray):
         self._last_thetas = np.array(thetas, dtype=np.float64)

@@ -31,6 +31,8 @@ class UserOptions:
         self.time_limit = -1
         self.seed = 1234
         self.device = 0
+        self.num_seeds = 1                 # random restarts per horizon (lockstep lanes of one workspace)
+        self.theta_jitter = 0.1            # restart s > 0 starts from Trotter angles + jitter * pi * U(-1, 1)
         self.__dict__.update(kw)
 
 
@@ -62,9 +64,48 @@ def _horizon_job(job_index: int, cfg: Dict) -> Dict:
     }
 
 
+def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
+    """All restarts of one horizon: they share the ansatz, so they run as lanes of one batched workspace
+    (lockstep.py); the record of the best restart is returned with the fidelities of all of them."""
+    from ..lockstep import run_jobs_lockstep
+
+    opts: UserOptions = cfg["opts"]
+    h = cfg["horizon"]
+    n = opts.num_qubits
+    evol_time = opts.evol_time_step * h
+    target = trotter_state(n, evol_time=evol_time, num_steps=opts.trotter_steps_per_horizon * h, delta=opts.delta,
+                           second_order=opts.second_order_trotter)
+    circ = trotter_ansatz(n, opts.num_layers_inc * h, opts.second_order_trotter)
+    trotter_thetas = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=evol_time, delta=opts.delta)
+    neel = neel_state_index(n)
+
+    def restart(s: int, c: Dict, workspace) -> Dict:
+        thetas0 = trotter_thetas.copy()
+        if s > 0:   # restart 0 is the plain Trotter initial point
+            thetas0 += opts.theta_jitter * np.pi * (2.0 * c["rng"].random(thetas0.size) - 1.0)
+        user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: neel, enable_optim_stats=False, verbose=0,
+                    maxiter=opts.maxiter, workspace=workspace)
+        objv = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+        objv.set_target(target)
+        res = AqcOptimizer(optimizer_name="lbfgs", maxiter=opts.maxiter).optimize(
+            objv, circ, thetas0, stopper=EarlyStopper(fidelity_thr=opts.fidelity_thr),
+            timeout=TimeoutChecker(time_limit=opts.time_limit))
+        return {"restart": s, "fidelity": float(res["fidelity"]), "cost": float(res["cost"]),
+                "num_iters": int(res["num_iters"]), "num_fun_ev": int(res["num_fun_ev"]), "thetas": res["thetas"]}
+
+    recs = run_jobs_lockstep(circ, [{} for _ in range(opts.num_seeds)], opts.seed + 1000 * h, restart,
+                             nlanes=min(64, opts.num_seeds), device=opts.device)
+    ok = [r for r in recs if r["status"] == "ok"]
+    best = max(ok, key=lambda r: r["fidelity"])
+    return {"horizon": h, "evol_time": evol_time, "num_layers": circ.num_layers, "num_thetas": circ.num_thetas,
+            "fidelity": best["fidelity"], "cost": best["cost"], "thetas": best["thetas"], "best_restart": best["restart"],
+            "fidelities": [r["fidelity"] for r in ok], "num_fun_ev": int(sum(r["num_fun_ev"] for r in ok))}
+
+
 def run_simulation(opts: Optional[UserOptions] = None) -> List[Dict]:
     """One optimisation per time horizon; returns the list of result records (run_simulation,
     time_evol_best_init.py:337-395)."""
     opts = opts or UserOptions()
     configs = [{"opts": opts, "horizon": h} for h in range(1, opts.num_horizons + 1)]
-    return run_jobs(configs, opts.seed, _horizon_job, tolerate_failure=False)
+    job = _seeded_horizon_job if opts.num_seeds > 1 else _horizon_job
+    return run_jobs(configs, opts.seed, job, tolerate_failure=False)

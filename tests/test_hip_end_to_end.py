@@ -81,3 +81,19 @@ def test_asp_time_evolution_driver():
     for r in res:
         assert r["fidelity"] >= r["fidelity_trotter_init"] - 1e-9 and r["fidelity"] > 0.9
         assert r["thetas"].shape == (r["num_thetas"],)
+
+
+def test_asp_driver_with_lockstep_restarts():
+    """Random restarts of a horizon run as lockstep lanes; restart 0 is the plain Trotter start, so the best of
+    the restarts can only match or beat the single-start driver."""
+    from aqc_research_amd.model_sp_lhs.time_evol import UserOptions, run_simulation
+
+    n = 8
+    base = dict(num_qubits=n, num_horizons=2, num_layers_inc=1, trotter_steps_per_horizon=6, maxiter=20)
+    single = run_simulation(UserOptions(**base))
+    multi = run_simulation(UserOptions(num_seeds=5, theta_jitter=0.02, **base))
+    assert [r["status"] for r in multi] == ["ok", "ok"]
+    for s, m in zip(single, multi):
+        assert len(m["fidelities"]) == 5 and m["thetas"].shape == (m["num_thetas"],)
+        assert abs(m["fidelities"][0] - s["fidelity"]) < 1e-7       # restart 0 == the single-start run
+        assert m["fidelity"] >= s["fidelity"] - 1e-9

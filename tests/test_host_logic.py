@@ -7,6 +7,8 @@ import textwrap
 import numpy as np
 import pytest
 
+from oracle import aqc_oracle as orc
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -157,3 +159,88 @@ def test_trotter_initialisation_matches_exact_evolution():
     th = init_ansatz_to_trotter(circ, np.full(circ.num_thetas, 7.0), evol_time=1.0, delta=1.0, layer_range=(1, 2))
     v2 = circ.subset2q(th).reshape(3, 3, 12)
     assert np.all(v2[0] == 7.0) and np.all(v2[2] == 7.0) and np.all(th[: 12] == 7.0) and np.count_nonzero(v2[1]) == 9
+
+
+def test_lockstep_round_logic_with_stub_workspace(monkeypatch):
+    """The lockstep coordinator (threads, rounds, call merging, early retirement) checked on the CPU: the
+    batched workspace is replaced by a stub whose eval() is the oracle."""
+    import threading
+
+    from aqc_research_amd import ParametricCircuit, lockstep
+    from aqc_research_amd.engine import BUF_X, BUF_Y
+
+    n = 4
+    a = orc.Ansatz(n, "cx", orc.spin_blocks(n, 5))
+    circ = ParametricCircuit(n, "cx", a.blocks)
+    calls = []
+
+    class StubCtx:
+        @staticmethod
+        def of(c):
+            return StubCtx()
+
+    class StubWorkspace:
+        def __init__(self, ctx, batch=1, ncols=1, device=0):
+            self.batch, self.T, self.dim, self.ctx, self.device = batch, a.num_thetas, 1 << n, ctx, device
+            self.y = np.zeros((batch, 1 << n), complex)
+            self.basis = np.zeros(batch, dtype=np.int64)
+            self.idx = None
+
+        def upload(self, buf, data, lane=None):
+            assert buf == BUF_Y
+            self.y[lane] = data
+
+        def set_basis(self, buf, index):
+            self.basis = np.array(index)
+
+        def gather_setup(self, idx):
+            self.idx = np.array(idx)
+
+        def eval(self, thetas, vdag=True, gather=False, grad=True, x_buf=BUF_X, block_range=None, front_layer=True):
+            calls.append(threading.current_thread().name)
+            hs = np.zeros((self.batch, len(self.idx)), complex)
+            g = np.zeros((self.batch, self.T), complex)
+            for b in range(self.batch):
+                vh = orc.v_dagger_mul_vec(a, thetas[b], self.y[b])
+                hs[b] = vh[self.idx]
+                x = np.zeros(1 << n, complex)
+                x[self.basis[b]] = 1
+                g[b] = orc.grad_of_dot_product(a, thetas[b], x, vh, block_range, front_layer)
+            return hs, g
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(lockstep, "Workspace", StubWorkspace)
+    monkeypatch.setattr(lockstep, "HipContext", StubCtx)
+    rng = np.random.default_rng(8)
+    ys = [orc.rand_state(n, rng) for _ in range(3)]
+    ths = [[orc.rand_thetas(a.num_thetas, rng) for _ in range(4)] for _ in range(3)]
+    batch = lockstep.LockstepBatch(circ, 3)
+
+    def job(view, lane):
+        view.upload(BUF_Y, ys[lane])
+        view.set_basis(BUF_X, lane)
+        view.gather_setup([0, 1, 2])
+        out = []
+        for r in range(2 + lane):     # lanes retire after 2, 3 and 4 rounds
+            hs, g = view.eval(ths[lane][r], vdag=True, gather=True, grad=True)
+            out.append((hs[0].copy(), g[0].copy()))
+        return out
+
+    res = batch.run([(lambda v, lane=lane: job(v, lane)) for lane in range(3)])
+    assert batch.rounds == 4 and len(calls) == 4          # one merged native call per round
+    for lane in range(3):
+        assert not isinstance(res[lane], BaseException), res[lane]
+        for r, (hs, g) in enumerate(res[lane]):
+            vh = orc.v_dagger_mul_vec(a, ths[lane][r], ys[lane])
+            x = np.zeros(1 << n, complex)
+            x[lane] = 1
+            assert np.allclose(hs, vh[:3], atol=1e-14) and np.allclose(g, orc.grad_of_dot_product(a, ths[lane][r], x, vh), atol=1e-14)
+    with pytest.raises(ValueError):   # lanes must agree on the gathered amplitudes
+        batch.lane(0).gather_setup([0, 1])
+    # a failing job hands its exception back and does not dead-lock the others
+    def bad(view):
+        raise KeyError("boom")
+    res = batch.run([bad, lambda v: job(v, 1)[0][0][0]])
+    assert isinstance(res[0], KeyError) and isinstance(res[1], complex)

@@ -2,8 +2,8 @@
 //
 // A context (aqc_ctx) is the immutable gate program of one ansatz.  A workspace (aqc_ws) binds
 // it to one HIP device + one stream and keeps `batch` independent evaluations resident in HBM:
-//   thetas[B][T] -> coef[B][n+L][12]           (coef_kernel, once per theta upload)
-//   Y, Z, X, W, ZW : [B][2^n][pitch] complex128 (pitch = columns padded to a power of two)
+//   thetas[B][T] -> coef[B][n+L+1][24]         (coef_kernel + sign_kernel, once per theta upload)
+//   Y, Z, X, W, ZW, X2 : [B][2^n][pitch] complex128 (pitch = columns padded to a power of two)
 //   partial[B][5*G][ntiles], grads[B][T]        (inner-product partials and their fixed-order sum)
 // Nothing below ever falls back to host arithmetic: if HIP is unusable every call fails loudly.
 #include <hip/hip_runtime_api.h>

@@ -164,8 +164,20 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # AQC_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than ranks (ranks then share
+        # a device and the tiny timing / record tensors travel over gloo on the CPU); the real path is nccl.
+        backend = os.environ.get("AQC_BENCH_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        if backend == "nccl":
+            if local_rank >= ndev:
+                raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= ndev
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend)
+    tdev = f"cuda:{local_rank}" if dist is not None and dist.get_backend() == "nccl" else "cpu"
     n_gpus = max(args.gpus, world) if world > 1 else args.gpus
     if world == 1 and args.gpus > 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU); running 1 GPU", file=sys.stderr)
@@ -231,7 +243,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([wall], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
@@ -242,7 +254,7 @@ def main():
     if dist is not None:
         import torch
 
-        rec = torch.from_numpy(record).to(f"cuda:{local_rank}")
+        rec = torch.from_numpy(record).to(tdev)
         allrec = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
 

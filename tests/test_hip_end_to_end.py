@@ -97,3 +97,48 @@ def test_asp_driver_with_lockstep_restarts():
         assert len(m["fidelities"]) == 5 and m["thetas"].shape == (m["num_thetas"],)
         assert abs(m["fidelities"][0] - s["fidelity"]) < 1e-7       # restart 0 == the single-start run
         assert m["fidelity"] >= s["fidelity"] - 1e-9
+
+
+def test_column_sharded_aqc_objective_two_ranks(tmp_path):
+    """Full-unitary AQC objective with the sketching columns split over two ranks (gloo all-reduce of the
+    (trace, gradient) record; both ranks share this box's one GPU): every rank must return the value and
+    gradient of the unsharded evaluation, which itself is checked against the oracle."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "shard.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {root!r})
+        import numpy as np, torch.distributed as dist
+        from oracle import aqc_oracle as orc
+        from aqc_research_amd import ParametricCircuit
+        from aqc_research_amd.circuit_structures import create_ansatz_structure
+        from aqc_research_amd.model_sketching.sk_core import FullRangeSketchingVectors, SketchingObjectiveEx
+        dist.init_process_group(backend="gloo")
+        n = 5
+        circ = ParametricCircuit(n, "cz", create_ansatz_structure(n, "spin", "full", 11))
+        rng = np.random.default_rng(42)
+        target = np.linalg.qr(rng.standard_normal((32, 32)) + 1j * rng.standard_normal((32, 32)))[0]
+        th = orc.rand_thetas(circ.num_thetas, rng)
+        f1, g1 = SketchingObjectiveEx(circ, FullRangeSketchingVectors(target)).objective_and_gradient(th)
+        sharded = SketchingObjectiveEx(circ, FullRangeSketchingVectors(target), column_shard=True)
+        f2, g2 = sharded.objective_and_gradient(th)
+        f3, g3 = sharded.objective_and_gradient(th + 0.01)          # second call re-uses the resident slab
+        f0, g0 = orc.sketching_objective_and_gradient(circ, th, np.eye(32, dtype=complex), target)
+        f4, g4 = orc.sketching_objective_and_gradient(circ, th + 0.01, np.eye(32, dtype=complex), target)
+        err = max(abs(f1 - f0), abs(f2 - f0), abs(f3 - f4), np.abs(g1 - g0).max(), np.abs(g2 - g0).max(), np.abs(g3 - g4).max())
+        print("RANK", dist.get_rank(), "ERR", err, flush=True)
+        assert err < 1e-10 and sharded._shard is not None
+        dist.barrier()
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                         capture_output=True, text=True, env=env, timeout=280)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ERR") == 2

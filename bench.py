@@ -347,6 +347,17 @@ def main():
                 "note": "algorithmic bytes = 64 B x 2^n x columns x gate groups x lanes per launch (SURVEY 8d); a launch "
                         "fuses many gate groups in LDS, so achieved may exceed what HBM itself could stream",
             },
+            # The fused launches are bound by the fp64 vector ALU, not by HBM: SURVEY 8(d)'s unfused flop count
+            # (V^H 28 / block + 14 / front qubit, sweep 48 + 36, inner products 32 + 24 per element) against
+            # the 78.6 TFLOP/s fp64 peak of MI355X_MICROARCH.md, over the whole evaluation (wall clock).
+            "roofline_fp64": {
+                "bound": "valu_fp64",
+                "achieved": N * (108.0 * (G - n) + 74.0 * n) * value / n_gpus / 1e12,
+                "peak": 78.6,
+                "unit": "TFLOP/s",
+                "frac": N * (108.0 * (G - n) + 74.0 * n) * value / n_gpus / 1e12 / 78.6,
+                "flops_per_eval": N * (108.0 * (G - n) + 74.0 * n),
+            },
             "kernel_ms_per_step": {k: v[1] / prof_steps for k, v in prof.items()},
             "device_ms_per_step_events": ev_ms / K,
             "latency_batch1_ms": latency,

@@ -54,6 +54,9 @@ SIGNATURES = {
     "aqc_ws_grad_from": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "aqc_ws_cd_sweep": (c_int, [_P, _D, _D]),
     "aqc_zgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, _D, c_int, _D, c_int, _D, c_int]),
+    "aqc_gate_1q": (c_int, [c_int, c_int, c_int64, c_int, _D, _D, _D]),
+    "aqc_gate_2q": (c_int, [c_int, c_int, c_int64, c_int, c_int, _D, _D, _D]),
+    "aqc_gate_dot": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int, _D, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),
     "aqc_ws_mps_dot": (c_int, [_P, c_int, c_int, _D]),

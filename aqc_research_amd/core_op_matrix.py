@@ -8,8 +8,89 @@ from typing import Optional
 
 import numpy as np
 
+from . import gates
 from .engine import BUF_X, BUF_Y, BUF_Z, HipContext
 from .parametric_circuit import TrotterAnsatz
+
+
+# ---- gate-level building blocks (core_op_matrix.py:32-477): qubit numbers are plain bit indices of the row,
+# matrices are (2^n, k) with k <= 2^n, modified in place; workspace arguments are accepted and left untouched.
+
+def _mat_ok(*mats) -> int:
+    n = -1
+    for m in mats:
+        if not (isinstance(m, np.ndarray) and m.ndim == 2 and m.dtype == np.complex128 and m.flags.c_contiguous and m.shape[1] <= m.shape[0]):
+            raise ValueError("expects C-contiguous complex128 matrices of shape (2^n, k), k <= 2^n")
+        n = gates.shape_of(m)[0]
+    if any(m.shape != mats[0].shape for m in mats):
+        raise ValueError("matrices differ in shape")
+    return n
+
+
+def gate2x2_mul_mat(qubit_no: int, gate2x2: np.ndarray, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """mat <- (I x g x I) mat (core_op_matrix.py:392-427)."""
+    _mat_ok(mat)
+    return gates.apply_1q(gate2x2, int(qubit_no), mat, mat)
+
+
+def rx_mul_mat(angle: float, qubit_no: int, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """core_op_matrix.py:32-63."""
+    _mat_ok(mat)
+    return gates.apply_1q(gates.rx_matrix(float(angle)), int(qubit_no), mat, mat)
+
+
+def ry_mul_mat(angle: float, qubit_no: int, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """core_op_matrix.py:66-97."""
+    _mat_ok(mat)
+    return gates.apply_1q(gates.ry_matrix(float(angle)), int(qubit_no), mat, mat)
+
+
+def rz_mul_mat(angle: float, qubit_no: int, mat: np.ndarray, ___: Optional[np.ndarray] = None) -> np.ndarray:
+    """core_op_matrix.py:100-127."""
+    _mat_ok(mat)
+    return gates.apply_1q(gates.rz_matrix(float(angle)), int(qubit_no), mat, mat)
+
+
+def cx_mul_mat(ctrl: int, targ: int, ___: float, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """core_op_matrix.py:130-178."""
+    _mat_ok(mat)
+    return gates.apply_2q(gates.controlled([[0, 1], [1, 0]]), int(ctrl), int(targ), mat, mat)
+
+
+def cz_mul_mat(ctrl: int, targ: int, ___: float, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """core_op_matrix.py:181-229."""
+    _mat_ok(mat)
+    return gates.apply_2q(gates.controlled([[1, 0], [0, -1]]), int(ctrl), int(targ), mat, mat)
+
+
+def cp_mul_mat(ctrl: int, targ: int, angle: float, mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.ndarray:
+    """core_op_matrix.py:232-281."""
+    _mat_ok(mat)
+    return gates.apply_2q(gates.controlled([[1, 0], [0, np.exp(1j * float(angle))]]), int(ctrl), int(targ), mat, mat)
+
+
+def x_dot_mat(qubit_no: int, w_mat: np.ndarray, z_mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.complex128:
+    """0.5j <X w|z>_F (core_op_matrix.py:284-317)."""
+    _mat_ok(w_mat, z_mat)
+    return gates.dot(0, int(qubit_no), -1, w_mat, z_mat)
+
+
+def y_dot_mat(qubit_no: int, w_mat: np.ndarray, z_mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.complex128:
+    """0.5j <Y w|z>_F (core_op_matrix.py:320-353)."""
+    _mat_ok(w_mat, z_mat)
+    return gates.dot(1, int(qubit_no), -1, w_mat, z_mat)
+
+
+def z_dot_mat(qubit_no: int, w_mat: np.ndarray, z_mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.complex128:
+    """0.5j <Z w|z>_F (core_op_matrix.py:356-389)."""
+    _mat_ok(w_mat, z_mat)
+    return gates.dot(2, int(qubit_no), -1, w_mat, z_mat)
+
+
+def derv_cphase(ctrl: int, targ: int, w_mat: np.ndarray, z_mat: np.ndarray, workspace: Optional[np.ndarray] = None) -> np.complex128:
+    """Derivative of <w|z> by the CPhase angle, taken before the gate: -1j <P11 w|z>_F (core_op_matrix.py:430-477)."""
+    _mat_ok(w_mat, z_mat)
+    return gates.dot(3, int(ctrl), int(targ), w_mat, z_mat)
 
 
 def _check(circ, thetas, mat: np.ndarray, name: str) -> np.ndarray:

@@ -881,6 +881,76 @@ int aqc_zgemm(int device, int conj_trans_a, int M, int N, int K, const double* A
     return rc;
 }
 
+// ---- gate-level building blocks (one-shot, host pointers) ---------------------------------------
+
+namespace {
+
+struct DevBuf {   // RAII for the one-shot calls
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+int gate_args_ok(int device, int n, int64_t ncols) {
+    if (n < 1 || n > 30 || ncols < 1 || ((size_t)ncols << n) > ((size_t)1 << kMaxBits)) return fail("invalid array shape");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: the aqc_hip path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("device out of range");
+    return 0;
+}
+
+}  // namespace
+
+int aqc_gate_1q(int device, int n, int64_t ncols, int qubit, const double* gate, const double* src, double* dst) {
+    if (!gate || !src || !dst) return fail("null argument");
+    if (gate_args_ok(device, n, ncols)) return 1;
+    if (qubit < 0 || qubit >= n) return fail("qubit out of range");
+    HIP_OK(hipSetDevice(device));
+    const size_t bytes = sizeof(double2) * ((size_t)ncols << n);
+    DevBuf d;
+    HIP_OK(d.alloc(bytes));
+    HIP_OK(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
+    HIP_OK(launch_gate1q(d.p, d.p, n, (size_t)ncols, qubit, gate, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(dst, d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aqc_gate_2q(int device, int n, int64_t ncols, int ctrl, int targ, const double* gate, const double* src, double* dst) {
+    if (!gate || !src || !dst) return fail("null argument");
+    if (gate_args_ok(device, n, ncols)) return 1;
+    if (n < 2 || ctrl < 0 || ctrl >= n || targ < 0 || targ >= n || ctrl == targ) return fail("invalid qubit pair");
+    HIP_OK(hipSetDevice(device));
+    const size_t bytes = sizeof(double2) * ((size_t)ncols << n);
+    DevBuf d;
+    HIP_OK(d.alloc(bytes));
+    HIP_OK(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
+    HIP_OK(launch_gate2q(d.p, d.p, n, (size_t)ncols, ctrl, targ, gate, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(dst, d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aqc_gate_dot(int device, int n, int64_t ncols, int kind, int q0, int q1, const double* w, const double* z, double* out) {
+    if (!w || !z || !out) return fail("null argument");
+    if (gate_args_ok(device, n, ncols)) return 1;
+    if (kind < 0 || kind > 3 || q0 < 0 || q0 >= n) return fail("invalid inner-product kind or qubit");
+    if (kind == 3 && (n < 2 || q1 < 0 || q1 >= n || q1 == q0)) return fail("invalid qubit pair");
+    HIP_OK(hipSetDevice(device));
+    const size_t bytes = sizeof(double2) * ((size_t)ncols << n);
+    DevBuf dw, dz, dp;
+    HIP_OK(dw.alloc(bytes));
+    HIP_OK(dz.alloc(bytes));
+    HIP_OK(dp.alloc(sizeof(double2) * (size_t)(gate_dot_parts(n, (size_t)ncols, kind) + 1)));
+    HIP_OK(hipMemcpy(dw.p, w, bytes, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dz.p, z, bytes, hipMemcpyHostToDevice));
+    double2* parts = static_cast<double2*>(dp.p);
+    HIP_OK(launch_gate_dot(dw.p, dz.p, n, (size_t)ncols, kind, q0, q1, parts + 1, parts, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out, parts, sizeof(double2), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---- coordinate descent ------------------------------------------------------------------------
 
 int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io, double* fobj) {

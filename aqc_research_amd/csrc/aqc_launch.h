@@ -61,4 +61,12 @@ hipError_t launch_cd_update(void* w, void* z, size_t npairs, int hbit, int kind,
                             const double* theta_in, double* theta_out, int tindex, double dim, hipStream_t s);
 hipError_t launch_cd_entangle(void* w, void* z, size_t ngroups, int cbit, int tbit, int ent, hipStream_t s);
 
+
+// aqc_gate.hip (gate-level building blocks, one pass per call)
+hipError_t launch_gate1q(const void* src, void* dst, int n, size_t ncols, int q, const double* g, hipStream_t s);
+hipError_t launch_gate2q(const void* src, void* dst, int n, size_t ncols, int qc, int qt, const double* g, hipStream_t s);
+int gate_dot_parts(int n, size_t ncols, int kind);
+hipError_t launch_gate_dot(const void* w, const void* z, int n, size_t ncols, int kind, int q0, int q1, void* partial, void* out,
+                           hipStream_t s);
+
 }  // namespace aqc

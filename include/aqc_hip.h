@@ -144,6 +144,22 @@ int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out /* 1 c128 */)
 int aqc_zgemm(int device, int conj_trans_a, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
               double* C, int ldc);
 
+/* ---- gate-level building blocks, one pass per call over a (2^n x ncols) row-major c128 array in HOST memory
+ * (ncols = 1: state vector).  Qubit numbers are bit indices of the row (Qiskit order); the Python shim converts
+ * the big-endian `pos` of the state-vector functions (core_operations.py:34-43).  dst may equal src.
+ * aqc_gate_1q: dst = (I x g x I) src, g = row-major 2x2 (4 c128)
+ *   replaces gate2x2_mul_vec :46, proj00/11_mul_vec :122,:143, rx/ry/rz_mul_vec :164,:200,:236 of core_operations.py
+ *   and rx/ry/rz_mul_mat :32,:66,:100, gate2x2_mul_mat :392 of core_op_matrix.py.
+ * aqc_gate_2q: dst = (4x4 on the pair, index 2*bit_ctrl + bit_targ; 16 c128 row-major) src
+ *   replaces cx/cz/cp_mul_vec :422,:468,:514, derv_cphase_mul_vec :561, block_mul_vec :354 (core_operations.py)
+ *   and cx/cz/cp_mul_mat :130,:181,:232 (core_op_matrix.py).
+ * aqc_gate_dot: kind 0 / 1 / 2 = 0.5j<Xw|z>, 0.5j<Yw|z>, 0.5j<Zw|z> on qubit q0 (dot_x/y/z :267,:296,:325;
+ *   x/y/z_dot_mat :284,:320,:356); kind 3 = -1j<P11(q0,q1) w|z> (derv_cphase, core_op_matrix.py:430). */
+int aqc_gate_1q(int device, int n, int64_t ncols, int qubit, const double* gate, const double* src, double* dst);
+int aqc_gate_2q(int device, int n, int64_t ncols, int ctrl, int targ, const double* gate, const double* src, double* dst);
+int aqc_gate_dot(int device, int n, int64_t ncols, int kind, int q0, int q1, const double* w, const double* z,
+                 double* out /* 1 c128 */);
+
 /* ---- coordinate descent (core_op_matrix.py:765  coord_descent_single_sweep(circ, thetas, target,
  * workspace)).  Square workspace (ncols == 2^n) with the target unitary in AQC_BUF_Y.  One
  * Gauss-Seidel sweep over all parameters of 1 - |<V,U>|^2/d^2; thetas are updated in place and

@@ -290,12 +290,62 @@ def gen_mps():
     np.savez_compressed(os.path.join(HERE, "mps.npz"), **data)
 
 
+def gen_primitives():
+    """Gate-level building blocks on random data.  ``pos`` arguments of the
+    state-vector functions are the reference's own (big-endian) positions, stored as given."""
+    rng = np.random.default_rng(4242)
+    data = {}
+    n = 5
+    N = 2**n
+    vec, w, z = rand_vec(N, rng), rand_vec(N, rng), rand_vec(N, rng)
+    data["n"], data["vec"], data["w"], data["z"] = np.int64(n), vec, w, z
+    angles = np.array([0.37, -1.9, 2.6])
+    data["angles"] = angles
+    pairs = np.array([[0, 1], [3, 1], [4, 0], [2, 4]])
+    data["pairs"] = pairs
+    tmp = np.zeros(N, np.complex128)
+    for name, fn in (("rx", cop.rx_mul_vec), ("ry", cop.ry_mul_vec), ("rz", cop.rz_mul_vec)):
+        data[f"sv/{name}"] = np.stack([[fn(n, pos, float(a), vec.copy(), tmp.copy()) for pos in range(n)] for a in angles])
+    for name, fn in (("dot_x", cop.dot_x), ("dot_y", cop.dot_y), ("dot_z", cop.dot_z)):
+        data[f"sv/{name}"] = np.array([fn(n, pos, w.copy(), z.copy(), tmp.copy()) for pos in range(n)])
+    for name, fn in (("cx", cop.cx_mul_vec), ("cz", cop.cz_mul_vec), ("cp", cop.cp_mul_vec)):
+        data[f"sv/{name}"] = np.stack([fn(n, int(c), int(t), 0.83, vec.copy(), tmp.copy()) for c, t in pairs])
+    data["sv/derv_cp"] = np.stack([cop.derv_cphase_mul_vec(n, int(c), int(t), 0.83, vec.copy(), tmp.copy()).copy() for c, t in pairs])
+    data["sv/proj00"] = np.stack([cop.proj00_mul_vec(n, pos, vec.copy()) for pos in range(n)])
+    data["sv/proj11"] = np.stack([cop.proj11_mul_vec(n, pos, vec.copy()) for pos in range(n)])
+    mats = rng.standard_normal((3, 2, 2)) + 1j * rng.standard_normal((3, 2, 2))   # c_mat, t_mat, g_mat
+    data["block_mats"] = mats
+    ws2 = np.zeros((2, N), np.complex128)
+    data["sv/block"] = np.stack([cop.block_mul_vec(n, int(c), int(t), mats[0], mats[1], mats[2], vec.copy(), ws2.copy(), False) for c, t in pairs])
+    data["sv/block_dagger"] = np.stack([cop.block_mul_vec(n, int(c), int(t), mats[0], mats[1], mats[2], vec.copy(), ws2.copy(), True) for c, t in pairs])
+    # matrices: (2^n x k), k = 3 and k = 2^n; qubit numbers are plain bit indices there
+    for k in (3, N):
+        m = rng.standard_normal((N, k)) + 1j * rng.standard_normal((N, k))
+        wm = rng.standard_normal((N, k)) + 1j * rng.standard_normal((N, k))
+        zm = rng.standard_normal((N, k)) + 1j * rng.standard_normal((N, k))
+        data[f"mat{k}/m"], data[f"mat{k}/w"], data[f"mat{k}/z"] = m, wm, zm
+        wsm = np.zeros((N, k), np.complex128)
+        for name, fn in (("rx", com.rx_mul_mat), ("ry", com.ry_mul_mat), ("rz", com.rz_mul_mat)):
+            data[f"mat{k}/{name}"] = np.stack([fn(0.37, q, m.copy(), wsm.copy()) for q in range(n)])
+        data[f"mat{k}/gate2x2"] = np.stack([com.gate2x2_mul_mat(q, mats[0], m.copy(), wsm.copy()) for q in range(n)])
+        for name, fn in (("cx", com.cx_mul_mat), ("cz", com.cz_mul_mat), ("cp", com.cp_mul_mat)):
+            data[f"mat{k}/{name}"] = np.stack([fn(int(c), int(t), 0.83, m.copy(), wsm.copy()) for c, t in pairs])
+        for name, fn in (("x_dot", com.x_dot_mat), ("y_dot", com.y_dot_mat), ("z_dot", com.z_dot_mat)):
+            data[f"mat{k}/{name}"] = np.array([fn(q, wm.copy(), zm.copy(), wsm.copy()) for q in range(n)])
+        data[f"mat{k}/derv_cphase"] = np.array([com.derv_cphase(int(c), int(t), wm.copy(), zm.copy(), wsm.copy()) for c, t in pairs])
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), **data)
+
+
 if __name__ == "__main__":
+    if "--primitives-only" in sys.argv:   # added later: leaves the earlier fixture files byte-identical
+        gen_primitives()
+        sys.exit(0)
     gen_state_vector()
     gen_gate2x2()
     gen_matrix()
     gen_objectives()
     gen_mps()
+    gen_primitives()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -106,3 +106,43 @@ def test_layout_generators_and_properties():
     tb = orc.trotter_blocks(5, 2)
     assert tb.shape == (2, 24) and np.all(tb[0, 0::3] == tb[1, 0::3] + 1)
     assert np.array_equal(orc.cyclic_spin_blocks(4, 4), np.array([[0, 2, 1, 3], [1, 3, 2, 0]]))
+
+
+PRIM = load("primitives.npz")
+
+
+def test_primitives_golden():
+    """The oracle's elementary gates and inner products against the reference's own single-gate functions
+    (tests/golden/make_golden.py::gen_primitives).  State-vector positions are big-endian: qubit = n-1-pos."""
+    n = int(PRIM["n"])
+    vec, w, z, angles, pairs = PRIM["vec"], PRIM["w"], PRIM["z"], PRIM["angles"], PRIM["pairs"]
+    for name, fn in (("rx", orc.rx), ("ry", orc.ry), ("rz", orc.rz)):
+        for i, a in enumerate(angles):
+            for pos in range(n):
+                v = vec.copy()
+                fn(v, 1 << (n - 1 - pos), float(a))
+                assert maxdiff(v, PRIM[f"sv/{name}"][i, pos]) < TOL
+    for name, fn in (("dot_x", orc.dot_x), ("dot_y", orc.dot_y), ("dot_z", orc.dot_z)):
+        for pos in range(n):
+            assert abs(fn(w, z, 1 << (n - 1 - pos)) - PRIM[f"sv/{name}"][pos]) < TOL
+    for name in ("cx", "cz", "cp"):
+        for i, (c, t) in enumerate(pairs):
+            v = vec.copy()
+            orc._entangle(v, 1 << (n - 1 - c), 1 << (n - 1 - t), name, 0.83)
+            assert maxdiff(v, PRIM[f"sv/{name}"][i]) < TOL
+    for k in (3, 1 << n):
+        m, wm, zm = PRIM[f"mat{k}/m"], PRIM[f"mat{k}/w"], PRIM[f"mat{k}/z"]
+        for name, fn in (("rx", orc.rx), ("ry", orc.ry), ("rz", orc.rz)):
+            for q in range(n):
+                v = m.copy().ravel()
+                fn(v, k << q, 0.37)
+                assert maxdiff(v.reshape(m.shape), PRIM[f"mat{k}/{name}"][q]) < TOL
+        for name, fn in (("x_dot", orc.dot_x), ("y_dot", orc.dot_y), ("z_dot", orc.dot_z)):
+            for q in range(n):
+                assert abs(fn(wm.ravel(), zm.ravel(), k << q) - PRIM[f"mat{k}/{name}"][q]) < 10 * TOL
+        for i, (c, t) in enumerate(pairs):
+            assert abs(orc.dot_cp11(wm.ravel(), zm.ravel(), k << c, k << t) - PRIM[f"mat{k}/derv_cphase"][i]) < 10 * TOL
+            for name in ("cx", "cz", "cp"):
+                v = m.copy().ravel()
+                orc._entangle(v, k << c, k << t, name, 0.83)
+                assert maxdiff(v.reshape(m.shape), PRIM[f"mat{k}/{name}"][i]) < TOL

@@ -41,3 +41,87 @@ def fast_dot_gradient(
     ws.mps_to_vec(1, BUF_Z, 0)
     ws.grad(block_range, bool(front_layer))
     return ws.get_grads()[0]
+
+
+# ---- single gates on an MPS (mps_dot_objective.py:245-516) ------------------------------------------------
+# 1-qubit gates are exact at the MPS level (bond dimensions do not change): the (2, chi_l * chi_r) tensor of
+# the site is a one-qubit "state" with chi_l * chi_r columns for aqc_gate_1q.  2-qubit gates are applied to
+# the densified state on the device and returned as an exact MPS (dense, no-truncation semantics: n <~ 26).
+
+from . import gates as _gates  # noqa: E402
+from .mps_operations import mps_dot as _mps_dot, mps_to_vector as _mps_to_vector, vector_to_exact_mps as _to_mps  # noqa: E402
+
+_X = np.array([[0, 1], [1, 0]], dtype=np.complex128)
+_Y = np.array([[0, -1j], [1j, 0]], dtype=np.complex128)
+_Z = np.array([[1, 0], [0, -1]], dtype=np.complex128)
+
+
+def _gate1q_mul_mps(gate: np.ndarray, qubit: int, mps_vec):
+    if not check_mps(mps_vec):
+        raise ValueError("not a valid MPS in Qiskit format")
+    gam, lam = mps_vec
+    if not (isinstance(qubit, (int, np.integer)) and 0 <= qubit < len(gam)):
+        raise ValueError("qubit out of range")
+    g0, g1 = gam[qubit]
+    site = np.ascontiguousarray(np.stack([g0, g1]).reshape(2, -1), dtype=np.complex128)
+    _gates.apply_1q(gate, 0, site, site)
+    new = list(gam)
+    new[qubit] = (site[0].reshape(g0.shape).copy(), site[1].reshape(g1.shape).copy())
+    return new, [np.array(v, dtype=np.float64) for v in lam]
+
+
+def x_mul_mps(qubit: int, mps_vec):
+    return _gate1q_mul_mps(_X, qubit, mps_vec)
+
+
+def y_mul_mps(qubit: int, mps_vec):
+    return _gate1q_mul_mps(_Y, qubit, mps_vec)
+
+
+def z_mul_mps(qubit: int, mps_vec):
+    return _gate1q_mul_mps(_Z, qubit, mps_vec)
+
+
+def rx_mul_mps(angle: float, qubit: int, mps_vec):
+    return _gate1q_mul_mps(_gates.rx_matrix(float(angle)), qubit, mps_vec)
+
+
+def ry_mul_mps(angle: float, qubit: int, mps_vec):
+    return _gate1q_mul_mps(_gates.ry_matrix(float(angle)), qubit, mps_vec)
+
+
+def rz_mul_mps(angle: float, qubit: int, mps_vec):
+    return _gate1q_mul_mps(_gates.rz_matrix(float(angle)), qubit, mps_vec)
+
+
+def _gate2q_mul_mps(g2x2, ctrl: int, targ: int, mps_vec):
+    vec = _mps_to_vector(mps_vec)
+    _gates.apply_2q(_gates.controlled(g2x2), int(ctrl), int(targ), vec, vec)
+    return _to_mps(vec)
+
+
+def cx_mul_mps(_: float, ctrl: int, targ: int, mps_vec, *, trunc_thr: float = no_truncation_threshold()):
+    return _gate2q_mul_mps(_X, ctrl, targ, mps_vec)
+
+
+def cz_mul_mps(_: float, ctrl: int, targ: int, mps_vec, *, trunc_thr: float = no_truncation_threshold()):
+    return _gate2q_mul_mps(_Z, ctrl, targ, mps_vec)
+
+
+def cp_mul_mps(angle: float, ctrl: int, targ: int, mps_vec, *, trunc_thr: float = no_truncation_threshold()):
+    return _gate2q_mul_mps(np.diag([1.0, np.exp(1j * float(angle))]), ctrl, targ, mps_vec)
+
+
+def dot_x(qubit: int, w_vec, z_vec) -> np.complex128:
+    """0.5j <X w|z> (mps_dot_objective.py:471-484)."""
+    return np.complex128(0.5j * _mps_dot(x_mul_mps(qubit, w_vec), z_vec))
+
+
+def dot_y(qubit: int, w_vec, z_vec) -> np.complex128:
+    """0.5j <Y w|z> (mps_dot_objective.py:487-500)."""
+    return np.complex128(0.5j * _mps_dot(y_mul_mps(qubit, w_vec), z_vec))
+
+
+def dot_z(qubit: int, w_vec, z_vec) -> np.complex128:
+    """0.5j <Z w|z> (mps_dot_objective.py:503-516)."""
+    return np.complex128(0.5j * _mps_dot(z_mul_mps(qubit, w_vec), z_vec))

@@ -85,3 +85,30 @@ def test_mps_objective_matches_sv_oracle():
         assert abs(obj.objective(th) - o.objective(th)) < TOL
         assert maxdiff(obj.gradient(th), o.gradient(th)) < TOL
         th = th + 0.1 * rng.standard_normal(th.size)
+
+
+def test_single_gates_on_mps_dense_semantics():
+    """mps_dot_objective.py:245-516 (P2): gate on MPS == gate on the dense state (what test_mps.py:57-199 pins);
+    1-qubit gates keep the bond dimensions."""
+    from aqc_research_amd import mps_dot_objective as mdo
+    from aqc_research_amd.mps_operations import mps_to_vector
+
+    n, chi = 6, 5
+    rng = np.random.default_rng(66)
+    a, b = orc.random_mps(n, chi, rng), orc.random_mps(n, chi, rng)
+    va, vb = orc.mps_to_vector(a), orc.mps_to_vector(b)
+    for q in range(n):
+        for name, rot in (("rx", orc.rx), ("ry", orc.ry), ("rz", orc.rz)):
+            out = getattr(mdo, f"{name}_mul_mps")(0.71, q, a)
+            ref = va.copy()
+            rot(ref, 1 << q, 0.71)
+            assert maxdiff(mps_to_vector(out), ref) < TOL
+            assert [g[0].shape for g in out[0]] == [g[0].shape for g in a[0]]
+        for name, dot in (("dot_x", orc.dot_x), ("dot_y", orc.dot_y), ("dot_z", orc.dot_z)):
+            assert abs(getattr(mdo, name)(q, a, b) - dot(va, vb, 1 << q)) < TOL
+    for c, t in ((0, 1), (4, 2), (5, 0)):
+        for name, ent in (("cx", "cx"), ("cz", "cz"), ("cp", "cp")):
+            out = getattr(mdo, f"{name}_mul_mps")(0.4, c, t, a)
+            ref = va.copy()
+            orc._entangle(ref, 1 << c, 1 << t, ent, 0.4)
+            assert maxdiff(mps_to_vector(out), ref) < TOL

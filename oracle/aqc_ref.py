@@ -22,15 +22,42 @@ _ENT = {"cx": 0, "cz": 1, "cp": 2}
 _lib = None
 
 
+def _cpu_tag() -> str:
+    """Identifies the host CPU's instruction set: the library is built with -march=native, and a copy built in
+    one container may be carried to a box with a different CPU."""
+    import hashlib
+
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((line for line in f if line.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(flags.encode()).hexdigest()[:16]
+
+
+def ensure_built() -> str:
+    """Builds ``libaqc_ref.so`` (gcc is part of the image) unless an up-to-date copy made on this CPU exists."""
+    path = os.path.join(_HERE, "libaqc_ref.so")
+    src = os.path.join(_HERE, "aqc_ref.c")
+    stamp = os.path.join(_HERE, "libaqc_ref.stamp")
+    tag = _cpu_tag()
+    try:
+        with open(stamp) as f:
+            same_cpu = f.read().strip() == tag
+    except OSError:
+        same_cpu = False
+    if not (same_cpu and os.path.exists(path) and os.path.getmtime(path) >= os.path.getmtime(src)):
+        subprocess.run(["make", "-B", "-C", _HERE], check=True, capture_output=True)
+        with open(stamp, "w") as f:
+            f.write(tag + "\n")
+    return path
+
+
 def lib() -> ctypes.CDLL:
-    """Loads (building it first if needed: gcc is part of the image) ``libaqc_ref.so``."""
+    """Loads ``libaqc_ref.so``, building it first if needed."""
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libaqc_ref.so")
-        src = os.path.join(_HERE, "aqc_ref.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
-        _lib = ctypes.CDLL(path)
+        _lib = ctypes.CDLL(ensure_built())
         i32, i64, ptr = ctypes.c_int, ctypes.c_long, ctypes.c_void_p
         _lib.aqc_ref_apply.argtypes = [i32, i32, ptr, i32, i32, i32, ptr, i64, i32, ptr]
         _lib.aqc_ref_grad.argtypes = [i32, i32, ptr, i32, i32, i32, ptr, i64, ptr, ptr, i32, i32, i32, ptr]

@@ -52,6 +52,17 @@ def build_circuit(w):
     return TrotterAnsatz(w["n"], make_trotter_like_circuit(w["n"], w["layers"]), second_order=True)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def host_cores():
     """Cores this process may really use: the cgroup CPU quota when there is one, else the affinity
     mask capped at the GPU box's per-GPU CPU share (16)."""
@@ -137,6 +148,7 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
                   f"reference algorithm, {cores} thread(s), one evaluation per thread",
         "c_1thread_evals_per_s": n_one / t_one,
         "numpy_1thread_evals_per_s": n_np / t_np,
+        "host": {"cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "blas_threads": 1},
     }
 
 

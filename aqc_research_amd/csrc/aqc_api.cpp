@@ -239,6 +239,9 @@ struct aqc_ws {
     double2* d_vdot_part = nullptr;
     double2* d_vdot_out = nullptr;
     long long* d_index = nullptr;
+    long long* d_tmp_index = nullptr;   // one-shot gather / vdot: never disturb the persistent gather set-up
+    double2* d_tmp_small = nullptr;
+    size_t tmp_index_cap = 0, tmp_small_cap = 0;
     long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
     size_t small_cap = 0, index_cap = 0;
     int* d_theta_slots = nullptr;
@@ -306,6 +309,22 @@ int ensure_small(aqc_ws* ws, size_t n_cplx) {
     ws->d_small = nullptr;
     HIP_OK(hipMalloc((void**)&ws->d_small, n_cplx * sizeof(double2)));
     ws->small_cap = n_cplx;
+    return 0;
+}
+
+int ensure_tmp(aqc_ws* ws, size_t n_index, size_t n_cplx) {
+    if (n_index > ws->tmp_index_cap) {
+        if (ws->d_tmp_index) HIP_OK(hipFree(ws->d_tmp_index));
+        ws->d_tmp_index = nullptr;
+        HIP_OK(hipMalloc((void**)&ws->d_tmp_index, n_index * sizeof(long long)));
+        ws->tmp_index_cap = n_index;
+    }
+    if (n_cplx > ws->tmp_small_cap) {
+        if (ws->d_tmp_small) HIP_OK(hipFree(ws->d_tmp_small));
+        ws->d_tmp_small = nullptr;
+        HIP_OK(hipMalloc((void**)&ws->d_tmp_small, n_cplx * sizeof(double2)));
+        ws->tmp_small_cap = n_cplx;
+    }
     return 0;
 }
 
@@ -550,7 +569,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_subs) (void)hipFree(p->d_subs);
         if (p->d_mops) (void)hipFree(p->d_mops);
     }
-    void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index,
+    void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index, ws->d_tmp_index, ws->d_tmp_small,
                     ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
@@ -757,15 +776,15 @@ int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* 
         if (index[i] < 0 || index[i] >= dim) return fail("gather index out of range");
         elem[i] = (long long)index[i] << ws->col_bits;
     }
-    if (ensure_index(ws, count) || ensure_small(ws, (size_t)ws->batch * count)) return 1;
-    ws->gather_count = 0;
-    HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));   // the temporaries may be re-allocated
+    if (ensure_tmp(ws, count, (size_t)ws->batch * count)) return 1;
+    HIP_OK(hipMemcpyAsync(ws->d_tmp_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     {
         ProfScope ps(ws, AQC_K_MISC);
-        HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, count, ws->batch, ws->d_small, ws->stream));
+        HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_tmp_index, count, ws->batch, ws->d_tmp_small, ws->stream));
     }
-    HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch * count, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipMemcpyAsync(out, ws->d_tmp_small, sizeof(double2) * (size_t)ws->batch * count, hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     return 0;
 }
@@ -774,14 +793,14 @@ int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out) {
     if (check_buf(ws, buf_a) || check_buf(ws, buf_b)) return 1;
     if (!out) return fail("null output");
     HIP_OK(hipSetDevice(ws->device));
-    if (ensure_small(ws, ws->batch)) return 1;
-    ws->gather_count = 0;
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (ensure_tmp(ws, 0, ws->batch)) return 1;
     {
         ProfScope ps(ws, AQC_K_MISC);
         HIP_OK(launch_vdot(ws->bufs[buf_a], ws->bufs[buf_b], ws->lane_elems, ws->lane_elems, ws->batch, ws->d_vdot_part,
-                           ws->vdot_parts, ws->d_small, ws->stream));
+                           ws->vdot_parts, ws->d_tmp_small, ws->stream));
     }
-    HIP_OK(hipMemcpyAsync(out, ws->d_small, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipMemcpyAsync(out, ws->d_tmp_small, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     return 0;
 }

@@ -309,3 +309,39 @@ def test_full_size_direct_parity_20_qubits(order2):
     assert maxdiff(hs[:, 0], hs_ref) < TOL
     assert maxdiff(grads, g_ref) < TOL
     ws.close()
+
+
+def test_large_state_24_qubits_properties():
+    """2^24 amplitudes (256 MiB per buffer, 8 stages per pass): beyond any size the CPU restatements are practical
+    for in a test, so size-independent properties only -- norm preservation, V V^H = 1 on a sample of amplitudes,
+    the objective's gradient against central differences of the same path, repeatability."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n = 24
+    rng = np.random.default_rng(24)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", 30))
+    ws = Workspace(HipContext.of(circ), batch=1)
+    th = orc.rand_thetas(circ.num_thetas, rng)
+    y = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    y /= np.linalg.norm(y)
+    ws.upload(BUF_Y, y)
+    ws.set_basis(BUF_X, 5)
+    ws.gather_setup([5])
+    hs, g = ws.eval(th[None, :], gather=True)
+    hs2, g2 = ws.eval(th[None, :], gather=True)
+    assert np.array_equal(g, g2) and np.array_equal(hs, hs2)            # bit-reproducible
+    z = ws.download(BUF_Z, lane=0)
+    assert abs(np.linalg.norm(z) - 1) < 1e-12
+    sample = rng.integers(0, 1 << n, 64)
+    ws.apply(False, BUF_Z, BUF_X)                                      # V V^H y
+    assert maxdiff(ws.gather(BUF_X, sample)[0], y[sample]) < 1e-12
+    ws.set_basis(BUF_X, 5)
+    for t in (0, 3 * n + 17, circ.num_thetas - 1):                     # d/dtheta <V e5|y> = d/dtheta (V^H y)[5]
+        f = []
+        for sgn in (+1, -1):
+            e = np.zeros_like(th); e[t] = sgn * 1e-5
+            f.append(ws.eval((th + e)[None, :], gather=True, grad=False)[0][0, 0])
+        assert abs((f[0] - f[1]) / 2e-5 - g[0, t]) < 1e-8
+    ws.close()

@@ -56,6 +56,17 @@ SIGNATURES = {
     "aqc_zgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, _D, c_int, _D, c_int, _D, c_int]),
     "aqc_gate_1q": (c_int, [c_int, c_int, c_int64, c_int, _D, _D, _D]),
     "aqc_gate_2q": (c_int, [c_int, c_int, c_int64, c_int, c_int, _D, _D, _D]),
+    "aqc_mps_create": (c_int, [c_int, c_int, POINTER(c_int32), _D, _D, POINTER(_P)]),
+    "aqc_mps_destroy": (c_int, [_P]),
+    "aqc_mps_clone": (c_int, [_P, POINTER(_P)]),
+    "aqc_mps_num_qubits": (c_int, [_P]),
+    "aqc_mps_dims": (c_int, [_P, POINTER(c_int32)]),
+    "aqc_mps_discarded_weight": (c_double, [_P]),
+    "aqc_mps_export": (c_int, [_P, _D, _D]),
+    "aqc_mps_gate1": (c_int, [_P, c_int, _D]),
+    "aqc_mps_gate2": (c_int, [_P, c_int, c_int, _D, c_double, c_int]),
+    "aqc_mps_dot": (c_int, [_P, _P, _D]),
+    "aqc_svd": (c_int, [c_int, c_int, c_int, _D, _D, _D, _D, POINTER(c_int)]),
     "aqc_gate_dot": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int, _D, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),

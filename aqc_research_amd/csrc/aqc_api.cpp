@@ -213,6 +213,8 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
 
 }  // namespace
 
+namespace aqc { int set_error(const std::string& msg) { g_error = msg; return 1; } }  // for the other translation units
+
 struct aqc_ctx {
     Program prog;
     std::mutex mu;

@@ -1,5 +1,6 @@
 // Host-visible launch interface of aqc_kernels.hip.
 #pragma once
+#include <string>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -68,5 +69,18 @@ hipError_t launch_gate2q(const void* src, void* dst, int n, size_t ncols, int qc
 int gate_dot_parts(int n, size_t ncols, int kind);
 hipError_t launch_gate_dot(const void* w, const void* z, int n, size_t ncols, int kind, int q0, int q1, void* partial, void* out,
                            hipStream_t s);
+
+
+// aqc_api.cpp: thread-local message behind aqc_last_error(); returns 1
+int set_error(const std::string& msg);
+
+// aqc_svd.hip (one-sided Jacobi SVD + the pieces of a truncated 2-qubit MPS gate)
+hipError_t launch_svd_identity(void* V, int cols, hipStream_t s);
+hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, int* rotations, hipStream_t s);
+hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
+hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
+hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,
+                            int k, int mode, double rescale, void* tq, void* tq1, hipStream_t s);
+hipError_t launch_mps_colscale(void* t, const double* lam, size_t rows, int cols, int mul, hipStream_t s);
 
 }  // namespace aqc

@@ -1,0 +1,447 @@
+// Device-resident matrix-product states with truncated 2-qubit gates (C ABI: aqc_mps_*, aqc_svd).
+//
+// This is the arithmetic the reference delegates to qiskit-aer's matrix_product_state simulator
+// (mps_operations.py:252-257, reached from mps_dot_objective.py:245-468): 1-qubit gates act on the physical index
+// of one site tensor; a 2-qubit gate contracts two neighbouring sites, applies the 4x4 matrix, and splits the
+// result with an SVD whose smallest singular values are discarded while the sum of their squares stays below
+// `trunc_thr`; non-neighbouring qubits are brought together by swaps.  Aer itself is third party and absent from
+// this image, so its truncation arithmetic is PARITY UNPINNED; with trunc_thr -> 0 every operation is exact and
+// is tested against the dense state-vector oracle (the level the reference's own tests pin).
+//
+// Representation: site q holds T_q = Gamma_q . diag(lambda_q) as a [2][chi_l][chi_r] row-major complex128 tensor
+// (the form _preprocess_mps builds, mps_operations.py:126-156) plus the Schmidt vector lambda_q of the bond to
+// its right; |psi> = prod_q T_q.  A gate on (q, q+1) forms theta = diag(lambda_{q-1}) T_q T_{q+1}, so only one
+// division by lambda (on the left bond) is needed when the new T_q is extracted.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/aqc_hip.h"
+#include "aqc_launch.h"
+
+using namespace aqc;
+
+namespace {
+
+int failf(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return set_error(buf);
+}
+
+#define HIP_OK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return failf("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Scratch {   // grow-only device buffer
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) HIP_OK(hipFree(p));
+        p = nullptr; cap = 0;
+        HIP_OK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// Round-robin tournament: rounds x (n2/2) pairs over n2 = even(cols) players; index >= cols is a bye (-1).
+void tournament(int cols, std::vector<int>& pairs, int& rounds, int& per_round) {
+    const int n2 = cols + (cols & 1);
+    rounds = n2 - 1;
+    per_round = n2 / 2;
+    pairs.assign((size_t)std::max(rounds, 0) * per_round * 2, -1);
+    std::vector<int> ring(n2);
+    std::iota(ring.begin(), ring.end(), 0);
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = 0; i < per_round; ++i) {
+            int a = ring[i], b = ring[n2 - 1 - i];
+            if (a > b) std::swap(a, b);
+            if (b >= cols) { a = -1; b = -1; }
+            pairs[((size_t)r * per_round + i) * 2] = a;
+            pairs[((size_t)r * per_round + i) * 2 + 1] = b;
+        }
+        std::rotate(ring.begin() + 1, ring.end() - 1, ring.end());   // player 0 stays, the others move one seat
+    }
+}
+
+struct SvdWork {
+    Scratch pairs, flag, sigma;
+    std::vector<int> h_pairs;
+    int cached_cols = -1, rounds = 0, per_round = 0;
+    void release() { pairs.release(); flag.release(); sigma.release(); }
+};
+
+// Orthogonalises the columns of the column-major W (rows x cols) in place, accumulating V (cols x cols);
+// returns the column norms in h_sigma.  `sweeps_out` reports the number of sweeps used.
+int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st, std::vector<double>& h_sigma, int* sweeps_out) {
+    if (sw.cached_cols != cols) {
+        tournament(cols, sw.h_pairs, sw.rounds, sw.per_round);
+        if (sw.pairs.reserve(std::max<size_t>(sw.h_pairs.size(), 2) * sizeof(int))) return 1;
+        if (!sw.h_pairs.empty()) HIP_OK(hipMemcpyAsync(sw.pairs.p, sw.h_pairs.data(), sw.h_pairs.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+        sw.cached_cols = cols;
+    }
+    if (sw.flag.reserve(sizeof(int)) || sw.sigma.reserve(sizeof(double) * std::max(cols, 1))) return 1;
+    HIP_OK(launch_svd_identity(V, cols, st));
+    const double tol = 1e-15;
+    int sweeps = 0;
+    for (; sweeps < 60 && cols > 1; ++sweeps) {
+        HIP_OK(hipMemsetAsync(sw.flag.p, 0, sizeof(int), st));
+        for (int r = 0; r < sw.rounds; ++r)
+            HIP_OK(launch_jacobi_round(W, rows, V, cols, static_cast<int*>(sw.pairs.p) + (size_t)r * sw.per_round * 2, sw.per_round, tol,
+                                       static_cast<int*>(sw.flag.p), st));
+        int rotations = 0;
+        HIP_OK(hipMemcpyAsync(&rotations, sw.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (rotations == 0) { ++sweeps; break; }
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    h_sigma.resize(cols);
+    HIP_OK(launch_svd_norms(W, rows, cols, static_cast<double*>(sw.sigma.p), st));
+    HIP_OK(hipMemcpyAsync(h_sigma.data(), sw.sigma.p, sizeof(double) * cols, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace
+
+struct aqc_mps {
+    int device = 0, n = 0;
+    hipStream_t stream = nullptr;
+    std::vector<int> dims;                    // n + 1 bond dimensions, dims[0] = dims[n] = 1
+    std::vector<double2*> t;                  // per site: [2][dims[q]][dims[q+1]]
+    std::vector<std::vector<double>> lam;     // n - 1 Schmidt vectors (host copy)
+    std::vector<double*> d_lam;               // the same on the device
+    Scratch theta, work, vmat, ord, tmp;
+    SvdWork svd;
+    double discarded = 0.0;                   // accumulated discarded weight (sum of squared singular values)
+    int last_sweeps = 0;
+};
+
+namespace {
+
+size_t site_elems(const aqc_mps* m, int q) { return (size_t)2 * m->dims[q] * m->dims[q + 1]; }
+
+int set_lambda(aqc_mps* m, int bond, const std::vector<double>& v) {
+    m->lam[bond] = v;
+    if (m->d_lam[bond]) HIP_OK(hipFree(m->d_lam[bond]));
+    m->d_lam[bond] = nullptr;
+    HIP_OK(hipMalloc((void**)&m->d_lam[bond], sizeof(double) * v.size()));
+    HIP_OK(hipMemcpyAsync(m->d_lam[bond], v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, m->stream));
+    HIP_OK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+void destroy(aqc_mps* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (double2* p : m->t) if (p) (void)hipFree(p);
+    for (double* p : m->d_lam) if (p) (void)hipFree(p);
+    m->theta.release(); m->work.release(); m->vmat.release(); m->ord.release(); m->tmp.release(); m->svd.release();
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int new_mps(int device, int n, aqc_mps** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return failf("no HIP device available: the aqc_hip path has no CPU fallback");
+    if (device < 0 || device >= ndev) return failf("device out of range");
+    if (n < 1 || n > 4096) return failf("number of qubits out of range");
+    HIP_OK(hipSetDevice(device));
+    aqc_mps* m = new aqc_mps();
+    m->device = device; m->n = n;
+    m->dims.assign(n + 1, 1);
+    m->t.assign(n, nullptr);
+    m->lam.assign(std::max(n - 1, 0), {});
+    m->d_lam.assign(std::max(n - 1, 0), nullptr);
+    if (hipStreamCreate(&m->stream) != hipSuccess) { delete m; return failf("hipStreamCreate failed"); }
+    *out = m;
+    return 0;
+}
+
+// One 4x4 gate on the neighbouring sites (q, q+1); matrix index = 2 * bit_q + bit_{q+1}.
+int gate_adjacent(aqc_mps* m, int q, const double* g16, double trunc_thr, int max_bond) {
+    const int chil = m->dims[q], chim = m->dims[q + 1], chir = m->dims[q + 2];
+    const int rows = 2 * chil, cols = 2 * chir;
+    hipStream_t st = m->stream;
+    if (m->theta.reserve(sizeof(double2) * (size_t)rows * cols)) return 1;
+    // theta0[(a,l), (b,r)] = sum_m T_q[(a,l), m] T_{q+1}[b][m][r]
+    for (int b = 0; b < 2; ++b)
+        HIP_OK(launch_zgemm(false, false, rows, chir, chim, m->t[q], chim, m->t[q + 1] + (size_t)b * chim * chir, chir,
+                            static_cast<double2*>(m->theta.p) + (size_t)b * chir, cols, st));
+    // Jacobi runs on the side with fewer columns
+    const int mode = cols <= rows ? 0 : 1;
+    const int wrows = mode == 0 ? rows : cols, wcols = mode == 0 ? cols : rows;
+    if (m->work.reserve(sizeof(double2) * (size_t)wrows * wcols) || m->vmat.reserve(sizeof(double2) * (size_t)wcols * wcols)) return 1;
+    const double* lam_left = q > 0 ? m->d_lam[q - 1] : nullptr;
+    HIP_OK(launch_mps_theta(m->theta.p, lam_left, chil, chir, g16, mode, m->work.p, st));
+    std::vector<double> sigma;
+    if (jacobi_svd(m->svd, m->work.p, wrows, m->vmat.p, wcols, st, sigma, &m->last_sweeps)) return 1;
+    // order, rank and truncation (host: wcols numbers)
+    std::vector<int> ord(wcols);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return sigma[a] > sigma[b]; });
+    const double smax = sigma[ord[0]];
+    if (!(smax > 0.0) || !std::isfinite(smax)) return failf("2-qubit gate produced a zero or non-finite state");
+    int k = 0;
+    double total = 0.0;
+    for (int j = 0; j < wcols; ++j) {
+        total += sigma[ord[j]] * sigma[ord[j]];
+        if (sigma[ord[j]] > 1e-14 * smax) k = j + 1;          // drop numerically zero values (rank deficiency)
+    }
+    if (max_bond > 0) k = std::min(k, max_bond);
+    double dropped = 0.0;
+    if (trunc_thr > 0.0) {                                     // discard the tail while its weight stays below the threshold
+        while (k > 1 && dropped + sigma[ord[k - 1]] * sigma[ord[k - 1]] < trunc_thr) { dropped += sigma[ord[k - 1]] * sigma[ord[k - 1]]; --k; }
+    }
+    double kept = 0.0;
+    for (int j = 0; j < k; ++j) kept += sigma[ord[j]] * sigma[ord[j]];
+    const double rescale = kept > 0.0 ? std::sqrt(total / kept) : 1.0;   // keep the norm of the state
+    m->discarded += total - kept;
+    // new tensors
+    double2 *tq = nullptr, *tq1 = nullptr;
+    HIP_OK(hipMalloc((void**)&tq, sizeof(double2) * (size_t)rows * k));
+    HIP_OK(hipMalloc((void**)&tq1, sizeof(double2) * (size_t)k * cols));
+    if (m->ord.reserve(sizeof(int) * wcols)) return 1;
+    HIP_OK(hipMemcpyAsync(m->ord.p, ord.data(), sizeof(int) * wcols, hipMemcpyHostToDevice, st));
+    HIP_OK(launch_mps_split(m->work.p, m->vmat.p, static_cast<int*>(m->ord.p), static_cast<double*>(m->svd.sigma.p), lam_left, chil, chir, k,
+                            mode, rescale, tq, tq1, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipFree(m->t[q]));
+    HIP_OK(hipFree(m->t[q + 1]));
+    m->t[q] = tq;
+    m->t[q + 1] = tq1;
+    m->dims[q + 1] = k;
+    std::vector<double> lam(k);
+    for (int j = 0; j < k; ++j) lam[j] = sigma[ord[j]] * rescale;
+    return set_lambda(m, q, lam);
+}
+
+void permute_gate(const double* g, bool flip, double* out) {   // flip: swap the roles of the two qubits (index 2a+b -> 2b+a)
+    static const int p[4] = {0, 2, 1, 3};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const int si = flip ? p[i] : i, sj = flip ? p[j] : j;
+            out[2 * (4 * i + j)] = g[2 * (4 * si + sj)];
+            out[2 * (4 * i + j) + 1] = g[2 * (4 * si + sj) + 1];
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int aqc_mps_create(int device, int n, const int32_t* dims, const double* gammas, const double* lambdas, aqc_mps** out) {
+    if (!dims || !gammas || !out || (n > 1 && !lambdas)) return failf("null MPS argument");
+    if (n < 1) return failf("number of qubits out of range");
+    if (dims[0] != 1 || dims[n] != 1) return failf("MPS boundary bond dimensions must be 1");
+    for (int q = 0; q <= n; ++q) if (dims[q] < 1) return failf("MPS bond dimensions must be positive");
+    aqc_mps* m = nullptr;
+    if (new_mps(device, n, &m)) return 1;
+    m->dims.assign(dims, dims + n + 1);
+    size_t off = 0, loff = 0;
+    for (int q = 0; q < n; ++q) {
+        const size_t ne = site_elems(m, q);
+        if (hipMalloc((void**)&m->t[q], sizeof(double2) * ne) != hipSuccess ||
+            hipMemcpyAsync(m->t[q], gammas + 2 * off, sizeof(double2) * ne, hipMemcpyHostToDevice, m->stream) != hipSuccess) {
+            destroy(m);
+            return failf("MPS upload failed");
+        }
+        off += ne;
+        if (q < n - 1) {
+            std::vector<double> lam(lambdas + loff, lambdas + loff + dims[q + 1]);
+            loff += dims[q + 1];
+            for (double v : lam) if (!(v > 0.0)) { destroy(m); return failf("MPS Schmidt coefficients must be positive"); }
+            if (set_lambda(m, q, lam)) { destroy(m); return 1; }
+            if (launch_mps_colscale(m->t[q], m->d_lam[q], (size_t)2 * dims[q], dims[q + 1], 1, m->stream) != hipSuccess) { destroy(m); return failf("MPS scale failed"); }
+        }
+    }
+    if (hipStreamSynchronize(m->stream) != hipSuccess) { destroy(m); return failf("MPS upload failed"); }
+    *out = m;
+    return 0;
+}
+
+int aqc_mps_destroy(aqc_mps* m) {
+    destroy(m);
+    return 0;
+}
+
+int aqc_mps_clone(const aqc_mps* src, aqc_mps** out) {
+    if (!src || !out) return failf("null argument");
+    aqc_mps* m = nullptr;
+    if (new_mps(src->device, src->n, &m)) return 1;
+    m->dims = src->dims;
+    m->discarded = src->discarded;
+    for (int q = 0; q < src->n; ++q) {
+        const size_t bytes = sizeof(double2) * site_elems(src, q);
+        if (hipMalloc((void**)&m->t[q], bytes) != hipSuccess || hipMemcpy(m->t[q], src->t[q], bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+            destroy(m);
+            return failf("MPS clone failed");
+        }
+        if (q < src->n - 1 && set_lambda(m, q, src->lam[q])) { destroy(m); return 1; }
+    }
+    *out = m;
+    return 0;
+}
+
+int aqc_mps_num_qubits(const aqc_mps* m) { return m ? m->n : -1; }
+
+int aqc_mps_dims(const aqc_mps* m, int32_t* dims) {
+    if (!m || !dims) return failf("null argument");
+    for (int q = 0; q <= m->n; ++q) dims[q] = m->dims[q];
+    return 0;
+}
+
+double aqc_mps_discarded_weight(const aqc_mps* m) { return m ? m->discarded : -1.0; }
+
+/* Gamma_q = T_q / lambda_q and the lambdas, packed like the inputs of aqc_mps_create */
+int aqc_mps_export(aqc_mps* m, double* gammas, double* lambdas) {
+    if (!m || !gammas || (m->n > 1 && !lambdas)) return failf("null argument");
+    HIP_OK(hipSetDevice(m->device));
+    size_t off = 0, loff = 0;
+    for (int q = 0; q < m->n; ++q) {
+        const size_t ne = site_elems(m, q);
+        if (m->tmp.reserve(sizeof(double2) * ne)) return 1;
+        HIP_OK(hipMemcpyAsync(m->tmp.p, m->t[q], sizeof(double2) * ne, hipMemcpyDeviceToDevice, m->stream));
+        if (q < m->n - 1) {
+            HIP_OK(launch_mps_colscale(m->tmp.p, m->d_lam[q], (size_t)2 * m->dims[q], m->dims[q + 1], 0, m->stream));
+            std::memcpy(lambdas + loff, m->lam[q].data(), sizeof(double) * m->lam[q].size());
+            loff += m->lam[q].size();
+        }
+        HIP_OK(hipMemcpyAsync(gammas + 2 * off, m->tmp.p, sizeof(double2) * ne, hipMemcpyDeviceToHost, m->stream));
+        HIP_OK(hipStreamSynchronize(m->stream));
+        off += ne;
+    }
+    return 0;
+}
+
+int aqc_mps_gate1(aqc_mps* m, int qubit, const double* gate) {
+    if (!m || !gate) return failf("null argument");
+    if (qubit < 0 || qubit >= m->n) return failf("qubit out of range");
+    HIP_OK(hipSetDevice(m->device));
+    HIP_OK(launch_gate1q(m->t[qubit], m->t[qubit], 1, (size_t)m->dims[qubit] * m->dims[qubit + 1], 0, gate, m->stream));
+    return 0;
+}
+
+/* 4x4 gate (index 2 * bit_ctrl + bit_targ) on any pair of qubits */
+int aqc_mps_gate2(aqc_mps* m, int ctrl, int targ, const double* gate, double trunc_thr, int max_bond) {
+    if (!m || !gate) return failf("null argument");
+    if (ctrl < 0 || ctrl >= m->n || targ < 0 || targ >= m->n || ctrl == targ) return failf("invalid qubit pair");
+    if (!(trunc_thr >= 0.0)) return failf("trunc_thr must be non-negative");
+    HIP_OK(hipSetDevice(m->device));
+    static const double swap_gate[32] = {1, 0, 0, 0, 0, 0, 0, 0,  0, 0, 0, 0, 1, 0, 0, 0,  0, 0, 1, 0, 0, 0, 0, 0,  0, 0, 0, 0, 0, 0, 1, 0};
+    const int lo = std::min(ctrl, targ), hi = std::max(ctrl, targ);
+    // bring qubit `hi` down to position lo + 1 by swaps, apply, swap back (the route Aer takes as well)
+    for (int p = hi - 1; p > lo; --p)
+        if (gate_adjacent(m, p, swap_gate, trunc_thr, max_bond)) return 1;
+    double g[32];
+    permute_gate(gate, ctrl > targ, g);      // site lo carries the lower qubit: flip when ctrl is the upper one
+    if (gate_adjacent(m, lo, g, trunc_thr, max_bond)) return 1;
+    for (int p = lo + 1; p < hi; ++p)
+        if (gate_adjacent(m, p, swap_gate, trunc_thr, max_bond)) return 1;
+    return 0;
+}
+
+/* <a|b> by transfer matrices (mps_dot, mps_operations.py:192-213) */
+int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out) {
+    if (!a || !b || !out) return failf("null argument");
+    if (a->n != b->n || a->device != b->device) return failf("MPS operands differ in size or device");
+    HIP_OK(hipSetDevice(a->device));
+    HIP_OK(hipStreamSynchronize(b->stream));
+    hipStream_t st = a->stream;
+    const int n = a->n;
+    size_t need = 1;
+    for (int q = 0; q <= n; ++q) need = std::max(need, (size_t)a->dims[q] * b->dims[q]);
+    for (int q = 0; q < n; ++q) need = std::max(need, (size_t)a->dims[q] * b->dims[q + 1]);
+    if (a->tmp.reserve(sizeof(double2) * 3 * need)) return 1;
+    double2* e = static_cast<double2*>(a->tmp.p);
+    double2* en = e + need;
+    double2* t = en + need;
+    // E[x][y] = sum_bit conj(A_0[bit][0][x]) B_0[bit][0][y]
+    HIP_OK(launch_zgemm(true, false, a->dims[1], b->dims[1], 2, a->t[0], a->dims[1], b->t[0], b->dims[1], e, b->dims[1], st));
+    for (int q = 1; q < n; ++q) {
+        const int xa = a->dims[q], ua = a->dims[q + 1], yb = b->dims[q], vb = b->dims[q + 1];
+        for (int bit = 0; bit < 2; ++bit) {
+            HIP_OK(launch_zgemm(false, false, xa, vb, yb, e, yb, b->t[q] + (size_t)bit * yb * vb, vb, t, vb, st));
+            HIP_OK(launch_zgemm(true, bit == 1, ua, vb, xa, a->t[q] + (size_t)bit * xa * ua, ua, t, vb, en, vb, st));
+        }
+        std::swap(e, en);
+    }
+    HIP_OK(hipMemcpyAsync(out, e, sizeof(double2), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+/* A (m x n, row-major, host) = U diag(S) Vh with k = min(m, n), S descending; U (m x k), Vh (k x n) row-major.
+ * The SVD kernel of the MPS engine, exposed for testing and for callers that need a device SVD. */
+int aqc_svd(int device, int m, int n, const double* a_in, double* u_out, double* s_out, double* vh_out, int* sweeps) {
+    if (!a_in || !u_out || !s_out || !vh_out || m < 1 || n < 1) return failf("invalid SVD arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return failf("no HIP device available: the aqc_hip path has no CPU fallback");
+    if (device < 0 || device >= ndev) return failf("device out of range");
+    HIP_OK(hipSetDevice(device));
+    const int mode = n <= m ? 0 : 1, k = std::min(m, n);
+    const int wrows = mode == 0 ? m : n, wcols = k;
+    // work matrix: column-major A (mode 0) or column-major A^H (mode 1); pure re-layout of the input
+    std::vector<double> w((size_t)2 * wrows * wcols);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            const double re = a_in[2 * ((size_t)i * n + j)], im = a_in[2 * ((size_t)i * n + j) + 1];
+            const size_t e = mode == 0 ? (size_t)j * m + i : (size_t)i * n + j;
+            w[2 * e] = re;
+            w[2 * e + 1] = mode == 0 ? im : -im;
+        }
+    Scratch dw, dv;
+    SvdWork sw;
+    std::vector<double> sigma;
+    int rc = 1;
+    do {
+        if (dw.reserve(sizeof(double) * w.size()) || dv.reserve(sizeof(double2) * (size_t)wcols * wcols)) break;
+        if (hipMemcpy(dw.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice) != hipSuccess) { failf("SVD upload failed"); break; }
+        if (jacobi_svd(sw, dw.p, wrows, dv.p, wcols, nullptr, sigma, sweeps)) break;
+        std::vector<double> hw(w.size()), hv((size_t)2 * wcols * wcols);
+        if (hipMemcpy(hw.data(), dw.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hv.data(), dv.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost) != hipSuccess) { failf("SVD download failed"); break; }
+        std::vector<int> ord(wcols);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sigma[x] > sigma[y]; });
+        // pure re-layout + the 1/sigma normalisation of the orthogonal columns
+        for (int j = 0; j < k; ++j) {
+            const int c = ord[j];
+            const double s = sigma[c], inv = s > 0.0 ? 1.0 / s : 0.0;
+            s_out[j] = s;
+            for (int i = 0; i < m; ++i) {   // U[i][j]
+                const double* src = mode == 0 ? &hw[2 * ((size_t)c * m + i)] : &hv[2 * ((size_t)c * m + i)];
+                const double f = mode == 0 ? inv : 1.0;
+                u_out[2 * ((size_t)i * k + j)] = src[0] * f;
+                u_out[2 * ((size_t)i * k + j) + 1] = src[1] * f;
+            }
+            for (int i = 0; i < n; ++i) {   // Vh[j][i] = conj(V[i][j])
+                const double* src = mode == 0 ? &hv[2 * ((size_t)c * n + i)] : &hw[2 * ((size_t)c * n + i)];
+                const double f = mode == 0 ? 1.0 : inv;
+                vh_out[2 * ((size_t)j * n + i)] = src[0] * f;
+                vh_out[2 * ((size_t)j * n + i) + 1] = -src[1] * f;
+            }
+        }
+        rc = 0;
+    } while (false);
+    dw.release(); dv.release(); sw.release();
+    return rc;
+}
+
+}  // extern "C"

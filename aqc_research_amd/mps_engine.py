@@ -1,0 +1,267 @@
+"""
+Device-resident matrix-product states with truncated 2-qubit gates (C ABI ``aqc_mps_*``): the part of the
+reference that runs inside qiskit-aer's ``matrix_product_state`` simulator (``mps_operations.py:216-298``,
+``mps_dot_objective.py:41-468``), for registers too large for a dense state.
+
+``DeviceMPS`` wraps one state; ``fast_dot_gradient_mps`` is the gate-by-gate gradient sweep of
+``mps_dot_objective.fast_dot_gradient`` (:41-242) on two such states, ``v_mul_mps`` / ``v_dagger_mul_mps`` the
+circuit applications of ``mps_operations.py:326-371``.  With ``trunc_thr -> 0`` everything is exact (tested
+against the dense oracle); Aer's truncation arithmetic itself is third party and parity unpinned.
+"""
+import ctypes
+from ctypes import POINTER, byref, c_double, c_int, c_int32, c_void_p
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib, gates
+from ._lib import check, dptr
+
+_X = np.array([[0, 1], [1, 0]], dtype=np.complex128)
+_Y = np.array([[0, -1j], [1j, 0]], dtype=np.complex128)
+_Z = np.array([[1, 0], [0, -1]], dtype=np.complex128)
+_P11 = np.diag([0, 0, 0, 1]).astype(np.complex128)
+
+
+def _pack(qiskit_mps):
+    gam, lam = qiskit_mps
+    n = len(gam)
+    dims = np.ones(n + 1, dtype=np.int32)
+    for q in range(n):
+        g0 = np.asarray(gam[q][0])
+        if g0.ndim != 2 or np.asarray(gam[q][1]).shape != g0.shape or g0.shape[0] != dims[q]:
+            raise ValueError("inconsistent MPS tensor shapes")
+        dims[q + 1] = g0.shape[1]
+    if dims[n] != 1 or len(lam) != n - 1:
+        raise ValueError("not a valid MPS in Qiskit format")
+    g = np.concatenate([np.stack([np.asarray(a, dtype=np.complex128), np.asarray(b, dtype=np.complex128)]).ravel() for a, b in gam])
+    lm = np.concatenate([np.asarray(v, dtype=np.float64).ravel() for v in lam]) if n > 1 else np.zeros(1)
+    for q in range(n - 1):
+        if np.asarray(lam[q]).size != dims[q + 1]:
+            raise ValueError("Schmidt vector size differs from the bond dimension")
+    return n, dims, np.ascontiguousarray(g), np.ascontiguousarray(lm)
+
+
+class DeviceMPS:
+    """One MPS resident on the GPU."""
+
+    def __init__(self, handle: c_void_p):
+        self.handle = handle
+        self._L = _lib.lib()
+
+    @classmethod
+    def from_qiskit(cls, qiskit_mps, device: int = 0) -> "DeviceMPS":
+        n, dims, g, lm = _pack(qiskit_mps)
+        h = c_void_p()
+        check(_lib.lib().aqc_mps_create(device, n, dims.ctypes.data_as(POINTER(c_int32)), dptr(g), dptr(lm), byref(h)))
+        return cls(h)
+
+    @classmethod
+    def basis_state(cls, num_qubits: int, index: int = 0, device: int = 0) -> "DeviceMPS":
+        """Product state |index> (bit q of ``index`` = qubit q)."""
+        gam = [((np.array([[1.0 - ((index >> q) & 1)]], dtype=np.complex128)), np.array([[float((index >> q) & 1)]], dtype=np.complex128))
+               for q in range(num_qubits)]
+        return cls.from_qiskit((gam, [np.ones(1) for _ in range(num_qubits - 1)]), device)
+
+    def clone(self) -> "DeviceMPS":
+        h = c_void_p()
+        check(self._L.aqc_mps_clone(self.handle, byref(h)))
+        return DeviceMPS(h)
+
+    @property
+    def num_qubits(self) -> int:
+        return int(self._L.aqc_mps_num_qubits(self.handle))
+
+    @property
+    def bond_dims(self) -> np.ndarray:
+        d = np.zeros(self.num_qubits + 1, dtype=np.int32)
+        check(self._L.aqc_mps_dims(self.handle, d.ctypes.data_as(POINTER(c_int32))))
+        return d
+
+    @property
+    def discarded_weight(self) -> float:
+        """Sum of the squared singular values dropped by all truncations so far."""
+        return float(self._L.aqc_mps_discarded_weight(self.handle))
+
+    def to_qiskit(self):
+        d = self.bond_dims
+        n = self.num_qubits
+        sizes = [2 * int(d[q]) * int(d[q + 1]) for q in range(n)]
+        g = np.empty(sum(sizes), dtype=np.complex128)
+        lm = np.empty(max(int(d[1:n].sum()), 1), dtype=np.float64)
+        check(self._L.aqc_mps_export(self.handle, dptr(g), dptr(lm)))
+        gam, lam, off, loff = [], [], 0, 0
+        for q in range(n):
+            t = g[off:off + sizes[q]].reshape(2, int(d[q]), int(d[q + 1]))
+            gam.append((t[0].copy(), t[1].copy()))
+            off += sizes[q]
+            if q < n - 1:
+                lam.append(lm[loff:loff + int(d[q + 1])].copy())
+                loff += int(d[q + 1])
+        return gam, lam
+
+    def gate1(self, gate, qubit: int) -> "DeviceMPS":
+        g = np.ascontiguousarray(gate, dtype=np.complex128)
+        if g.shape != (2, 2):
+            raise ValueError("expects a 2x2 gate")
+        check(self._L.aqc_mps_gate1(self.handle, int(qubit), dptr(g)))
+        return self
+
+    def gate2(self, gate4, ctrl: int, targ: int, trunc_thr: float = 0.0, max_bond: int = 0) -> "DeviceMPS":
+        g = np.ascontiguousarray(gate4, dtype=np.complex128)
+        if g.shape != (4, 4):
+            raise ValueError("expects a 4x4 gate")
+        check(self._L.aqc_mps_gate2(self.handle, int(ctrl), int(targ), dptr(g), float(trunc_thr), int(max_bond)))
+        return self
+
+    def dot(self, other: "DeviceMPS") -> np.complex128:
+        """<self|other>."""
+        out = np.empty(1, dtype=np.complex128)
+        check(self._L.aqc_mps_dot(self.handle, other.handle, dptr(out)))
+        return np.complex128(out[0])
+
+    def close(self) -> None:
+        if self.handle:
+            self._L.aqc_mps_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def svd(a: np.ndarray, device: int = 0):
+    """(U, S, Vh, sweeps) of a complex matrix by the engine's one-sided Jacobi kernel."""
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    if a.ndim != 2:
+        raise ValueError("expects a matrix")
+    m, n = a.shape
+    k = min(m, n)
+    u, s, vh = np.empty((m, k), dtype=np.complex128), np.empty(k), np.empty((k, n), dtype=np.complex128)
+    sweeps = c_int(0)
+    check(_lib.lib().aqc_svd(device, m, n, dptr(a), dptr(u), dptr(s), dptr(vh), byref(sweeps)))
+    return u, s, vh, sweeps.value
+
+
+# ---- circuits on MPS ------------------------------------------------------------------------------------
+
+def _ent_matrix(entangler: str, angle: float) -> np.ndarray:
+    if entangler == "cx":
+        return gates.controlled(_X)
+    if entangler == "cz":
+        return gates.controlled(_Z)
+    return gates.controlled(np.diag([1.0, np.exp(1j * angle)]))
+
+
+def _blocks_of(circ):
+    """(running index i, parameter block j, ctrl, targ) incl. the virtual trailing half-layer of a 2nd-order
+    Trotter ansatz (parametric_circuit.py:328-333)."""
+    L = circ.num_blocks
+    trotter = hasattr(circ, "is_second_order")
+    tail = 3 * (circ.num_qubits // 2) if (trotter and circ.is_second_order) else 0
+    return trotter, [(i, i % L, int(circ.blocks[0, i % L]), int(circ.blocks[1, i % L])) for i in range(L + tail)]
+
+
+def _apply_circuit(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: float, max_bond: int) -> DeviceMPS:
+    n = circ.num_qubits
+    th = np.asarray(thetas, dtype=np.float64)
+    t1 = th[: 3 * n].reshape(n, 3)
+    tpb = 5 if circ.entangler == "cp" else 4
+    t2 = th[3 * n:].reshape(-1, tpb)
+    rs = gates.rx_matrix if circ.entangler == "cx" else gates.rz_matrix
+    trotter, blocks = _blocks_of(circ)
+    if not inverse:   # core_operations.py:671-708
+        for q in range(n):
+            mps.gate1(gates.rz_matrix(t1[q, 0]) @ gates.ry_matrix(t1[q, 1]) @ gates.rz_matrix(t1[q, 2]), q)
+        for i, j, c, t in blocks:
+            b = t2[j]
+            if trotter and i % 3 == 0:
+                mps.gate1(gates.rz_matrix(-np.pi / 2), c)
+            mps.gate2(_ent_matrix(circ.entangler, b[4] if tpb == 5 else 0.0), c, t, trunc_thr, max_bond)
+            mps.gate1(gates.rz_matrix(b[1]) @ gates.ry_matrix(b[0]), c)
+            mps.gate1(rs(b[3]) @ gates.ry_matrix(b[2]), t)
+            if trotter and i % 3 == 2:
+                mps.gate1(gates.rz_matrix(np.pi / 2), t)
+    else:             # core_operations.py:787-818
+        for i, j, c, t in reversed(blocks):
+            b = t2[j]
+            if trotter and i % 3 == 2:
+                mps.gate1(gates.rz_matrix(-np.pi / 2), t)
+            mps.gate1(gates.ry_matrix(-b[2]) @ rs(-b[3]), t)
+            mps.gate1(gates.ry_matrix(-b[0]) @ gates.rz_matrix(-b[1]), c)
+            mps.gate2(_ent_matrix(circ.entangler, -b[4] if tpb == 5 else 0.0), c, t, trunc_thr, max_bond)
+            if trotter and i % 3 == 0:
+                mps.gate1(gates.rz_matrix(np.pi / 2), c)
+        for q in range(n):
+            mps.gate1(gates.rz_matrix(-t1[q, 2]) @ gates.ry_matrix(-t1[q, 1]) @ gates.rz_matrix(-t1[q, 0]), q)
+    return mps
+
+
+def v_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_bond: int = 0) -> DeviceMPS:
+    """V(thetas)|mps> on a copy (mps_operations.py:326-346)."""
+    return _apply_circuit(circ, thetas, mps.clone(), False, trunc_thr, max_bond)
+
+
+def v_dagger_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_bond: int = 0) -> DeviceMPS:
+    """V(thetas)^H|mps> on a copy (mps_operations.py:349-371)."""
+    return _apply_circuit(circ, thetas, mps.clone(), True, trunc_thr, max_bond)
+
+
+def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, trunc_thr: float = 0.0, max_bond: int = 0,
+                          block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> np.ndarray:
+    """Complex gradient of <V lvec|phi> given vh_phi = V^H|phi>, gate by gate on two MPS
+    (mps_dot_objective.py:41-242): w <- lvec, z <- vh_phi; every gate is applied to both and each parametrised
+    rotation records 0.5j <P w|z>; the CPhase derivative is -1j <P11 w|z> taken before the gate."""
+    n = circ.num_qubits
+    th = np.asarray(thetas, dtype=np.float64)
+    tpb = 5 if circ.entangler == "cp" else 4
+    L = circ.num_blocks
+    lo, hi = (0, L) if block_range is None else (int(block_range[0]), int(block_range[1]))
+    grad = np.zeros(circ.num_thetas, dtype=np.complex128)
+    g1 = grad[: 3 * n].reshape(n, 3)
+    g2 = grad[3 * n:].reshape(-1, tpb)
+    t1 = th[: 3 * n].reshape(n, 3)
+    t2 = th[3 * n:].reshape(-1, tpb)
+    w, z = lvec.clone(), vh_phi.clone()
+    pauli = {"x": _X, "y": _Y, "z": _Z}
+
+    def both(gate, q):
+        w.gate1(gate, q)
+        z.gate1(gate, q)
+
+    def dot(p: str, q: int) -> np.complex128:   # 0.5j <P w|z>: P acts on a scratch copy of w's site only
+        pw = w.clone().gate1(pauli[p], q)
+        val = 0.5j * pw.dot(z)
+        pw.close()
+        return val
+
+    for q in range(n):   # front layer: Rz(t2), Ry(t1), Rz(t0), rightmost first (core_operations.py:921-935)
+        for slot, mat, p in ((2, gates.rz_matrix, "z"), (1, gates.ry_matrix, "y"), (0, gates.rz_matrix, "z")):
+            both(mat(t1[q, slot]), q)
+            if front_layer:
+                g1[q, slot] = dot(p, q)
+    rs, ps = (gates.rx_matrix, "x") if circ.entangler == "cx" else (gates.rz_matrix, "z")
+    trotter, blocks = _blocks_of(circ)
+    for i, j, c, t in blocks:
+        b = t2[j]
+        live = lo <= j < hi
+        if trotter and i % 3 == 0:
+            both(gates.rz_matrix(-np.pi / 2), c)
+        if live and tpb == 5:    # -1j <P11 w|z> before the gate (core_op_matrix.py:430-477)
+            pw = w.clone().gate2(_P11, c, t, 0.0, 0)
+            g2[j, 4] += -1j * pw.dot(z)
+            pw.close()
+        ent = _ent_matrix(circ.entangler, b[4] if tpb == 5 else 0.0)
+        z.gate2(ent, c, t, trunc_thr, max_bond)
+        w.gate2(ent, c, t, trunc_thr, max_bond)
+        for slot, mat, p, q in ((0, gates.ry_matrix, "y", c), (1, gates.rz_matrix, "z", c), (2, gates.ry_matrix, "y", t), (3, rs, ps, t)):
+            both(mat(b[slot]), q)
+            if live:
+                g2[j, slot] += dot(p, q)
+        if trotter and i % 3 == 2:
+            both(gates.rz_matrix(np.pi / 2), t)
+    w.close()
+    z.close()
+    return grad

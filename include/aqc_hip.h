@@ -160,6 +160,31 @@ int aqc_gate_2q(int device, int n, int64_t ncols, int ctrl, int targ, const doub
 int aqc_gate_dot(int device, int n, int64_t ncols, int kind, int q0, int q1, const double* w, const double* z,
                  double* out /* 1 c128 */);
 
+/* ---- device-resident MPS with truncated 2-qubit gates: the arithmetic the reference hands to qiskit-aer's
+ * matrix_product_state simulator (mps_operations.py:216-298 mps_from_circuit / qcircuit_mul_mps; gate level:
+ * mps_dot_objective.py:245-468).  Qiskit MPS format in and out (mps_operations.py:33): `dims` = n+1 bond
+ * dimensions (dims[0] = dims[n] = 1), `gammas` = per site [2][dims[q]][dims[q+1]] c128 packed back to back,
+ * `lambdas` = the n-1 Schmidt vectors packed back to back.  trunc_thr: the smallest singular values are dropped
+ * while the sum of their squares stays below it (Aer's matrix_product_state_truncation_threshold); max_bond <= 0
+ * means unlimited.  Aer's own arithmetic is third party: truncated results are parity unpinned. */
+typedef struct aqc_mps aqc_mps;
+int aqc_mps_create(int device, int n, const int32_t* dims, const double* gammas, const double* lambdas, aqc_mps** out);
+int aqc_mps_destroy(aqc_mps* mps);
+int aqc_mps_clone(const aqc_mps* src, aqc_mps** out);
+int aqc_mps_num_qubits(const aqc_mps* mps);
+int aqc_mps_dims(const aqc_mps* mps, int32_t* dims /* n+1 */);
+double aqc_mps_discarded_weight(const aqc_mps* mps);
+int aqc_mps_export(aqc_mps* mps, double* gammas, double* lambdas);
+/* {x,y,z,rx,ry,rz}_mul_mps (mps_dot_objective.py:245-377): 2x2 gate, row-major 4 c128 */
+int aqc_mps_gate1(aqc_mps* mps, int qubit, const double* gate);
+/* {cx,cp,cz}_mul_mps (:380-468) and any other 4x4 (index 2*bit_ctrl + bit_targ, 16 c128) on any qubit pair */
+int aqc_mps_gate2(aqc_mps* mps, int ctrl, int targ, const double* gate, double trunc_thr, int max_bond);
+/* <a|b>  (mps_dot, mps_operations.py:192-213) */
+int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out /* 1 c128 */);
+/* one-sided Jacobi SVD on the device (the kernel behind aqc_mps_gate2): A (m x n row-major) = U diag(S) Vh,
+ * k = min(m, n), S descending, U (m x k), Vh (k x n); *sweeps (optional) = Jacobi sweeps used */
+int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, double* vh, int* sweeps);
+
 /* ---- coordinate descent (core_op_matrix.py:765  coord_descent_single_sweep(circ, thetas, target,
  * workspace)).  Square workspace (ncols == 2^n) with the target unitary in AQC_BUF_Y.  One
  * Gauss-Seidel sweep over all parameters of 1 - |<V,U>|^2/d^2; thetas are updated in place and

@@ -1,0 +1,132 @@
+"""GPU: device-resident MPS engine (truncated 2-qubit gates by one-sided Jacobi SVD).  Exactness with
+trunc_thr -> 0 against the dense oracle -- the level the reference's own MPS tests pin (test_mps.py:57-199,
+test_mps_fast_dot_gradient.py:126-153) -- plus the truncation contract and a register beyond dense reach."""
+import numpy as np
+import pytest
+
+from oracle import aqc_oracle as orc
+from tests.helpers import TOL, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 3), (3, 7), (16, 16), (40, 64), (64, 40), (128, 128)])
+def test_jacobi_svd(shape):
+    from aqc_research_amd.mps_engine import svd
+
+    rng = np.random.default_rng(sum(shape))
+    a = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    if shape == (16, 16):
+        a[:, 5] = a[:, 2] * (0.3 - 2j)        # rank deficient
+        a[:, 9] = 0
+    u, s, vh, sweeps = svd(a)
+    k = min(shape)
+    assert sweeps < 40 and np.all(np.diff(s) <= 1e-13)
+    assert maxdiff(s, np.linalg.svd(a, compute_uv=False)) < 1e-11 * max(1.0, s[0])
+    assert maxdiff((u * s) @ vh, a) < 1e-11 * max(1.0, s[0])
+    good = s > 1e-12 * s[0]
+    assert maxdiff(u[:, good].conj().T @ u[:, good], np.eye(int(good.sum()))) < 1e-11
+    assert maxdiff(vh[good] @ vh[good].conj().T, np.eye(int(good.sum()))) < 1e-11
+
+
+def _dense(mps):
+    return orc.mps_to_vector(mps.to_qiskit())
+
+
+def test_gates_exact_against_dense():
+    from aqc_research_amd import gates
+    from aqc_research_amd.mps_engine import DeviceMPS
+
+    n, chi = 7, 4
+    rng = np.random.default_rng(70)
+    q_mps = orc.random_mps(n, chi, rng)
+    ref = orc.mps_to_vector(q_mps)
+    m = DeviceMPS.from_qiskit(q_mps)
+    assert maxdiff(_dense(m), ref) < TOL                      # import / export round trip
+    other = DeviceMPS.from_qiskit(orc.random_mps(n, 3, rng))
+    assert abs(m.dot(other) - np.vdot(ref, _dense(other))) < TOL
+    m.gate1(gates.ry_matrix(0.7), 3)
+    orc.ry(ref, 1 << 3, 0.7)
+    for c, t, ent in ((0, 1, "cx"), (2, 1, "cz"), (1, 5, "cp"), (6, 0, "cx"), (3, 4, "cp"), (5, 2, "cx")):
+        g = gates.controlled({"cx": [[0, 1], [1, 0]], "cz": [[1, 0], [0, -1]], "cp": np.diag([1, np.exp(0.9j)])}[ent])
+        m.gate2(g, c, t)
+        orc._entangle(ref, 1 << c, 1 << t, ent, 0.9)
+        assert maxdiff(_dense(m), ref) < TOL
+    g4 = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))[0]   # generic 2-qubit unitary
+    m.gate2(g4, 4, 1)
+    v = ref.reshape([2] * n)                                   # axis n-1-q <-> qubit q
+    v = np.moveaxis(v, (n - 1 - 4, n - 1 - 1), (0, 1)).reshape(4, -1)
+    v = (g4 @ v).reshape([2, 2] + [2] * (n - 2))
+    ref = np.moveaxis(v, (0, 1), (n - 1 - 4, n - 1 - 1)).reshape(-1)
+    assert maxdiff(_dense(m), ref) < TOL
+    assert m.discarded_weight < 1e-20
+    c = m.clone()
+    c.gate1(gates.rx_matrix(1.0), 0)
+    assert maxdiff(_dense(m), ref) < TOL                      # clone is independent
+    assert m.bond_dims.max() <= 2 ** (n // 2)
+
+
+@pytest.mark.parametrize("kind", ["cx", "cz", "cp", "trotter2"])
+def test_native_gradient_and_circuit_against_oracle(kind):
+    from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+    from aqc_research_amd.mps_engine import DeviceMPS, fast_dot_gradient_mps, v_dagger_mul_mps, v_mul_mps
+
+    n = 6
+    rng = np.random.default_rng(len(kind) * 13)
+    if kind == "trotter2":
+        a = orc.Ansatz(n, "cx", orc.trotter_blocks(n, 1), True, True)
+        circ = TrotterAnsatz(n, a.blocks, second_order=True)
+    else:
+        blocks = np.stack([rng.permutation(n)[:2] for _ in range(9)], axis=1).astype(np.int64)
+        a = orc.Ansatz(n, kind, blocks)
+        circ = ParametricCircuit(n, kind, blocks)
+    th = orc.rand_thetas(a.num_thetas, rng)
+    x_q, y_q = orc.random_mps(n, 2, rng), orc.random_mps(n, 3, rng)
+    x, y = orc.mps_to_vector(x_q), orc.mps_to_vector(y_q)
+    xm, ym = DeviceMPS.from_qiskit(x_q), DeviceMPS.from_qiskit(y_q)
+    assert maxdiff(_dense(v_mul_mps(circ, th, xm)), orc.v_mul_vec(a, th, x)) < 10 * TOL
+    vhy = v_dagger_mul_mps(circ, th, ym)
+    vhy_ref = orc.v_dagger_mul_vec(a, th, y)
+    assert maxdiff(_dense(vhy), vhy_ref) < 10 * TOL
+    g = fast_dot_gradient_mps(circ, th, xm, vhy)
+    assert maxdiff(g, orc.grad_of_dot_product(a, th, x, vhy_ref)) < 100 * TOL
+    br = (2, min(7, a.num_blocks))
+    gp = fast_dot_gradient_mps(circ, th, xm, vhy, block_range=br, front_layer=False)
+    assert maxdiff(gp, orc.grad_of_dot_product(a, th, x, vhy_ref, br, False)) < 100 * TOL
+
+
+def test_truncation_contract_and_large_register():
+    """trunc_thr > 0: bonds shrink, the norm is kept, the error is of the order of the discarded weight;
+    and a 40-qubit register (2^40 amplitudes dense) runs with small bonds."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.mps_engine import DeviceMPS, fast_dot_gradient_mps, v_dagger_mul_mps, v_mul_mps
+
+    n = 10
+    rng = np.random.default_rng(3)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", 54))
+    th = orc.rand_thetas(circ.num_thetas, rng)
+    zero = DeviceMPS.basis_state(n)
+    exact = v_mul_mps(circ, th, zero)
+    cut = v_mul_mps(circ, th, zero, trunc_thr=1e-4)
+    assert exact.bond_dims.max() == 32 and cut.bond_dims.max() < 32
+    disc = cut.discarded_weight
+    assert 0 < disc < 1e-2 and abs(cut.dot(cut) - 1) < 10 * disc
+    assert 1 - abs(exact.dot(cut)) ** 2 < 10 * disc
+    capped = v_mul_mps(circ, th, zero, max_bond=8)
+    assert capped.bond_dims.max() == 8
+    a = orc.as_ansatz(circ)
+    assert maxdiff(_dense(exact), orc.v_mul_vec(a, th, np.eye(1 << n, 1, dtype=complex).ravel())) < 10 * TOL
+
+    n = 40
+    circ = ParametricCircuit(n, "cz", create_ansatz_structure(n, "spin", "full", n - 1))   # one brickwork layer
+    th = 0.5 * orc.rand_thetas(circ.num_thetas, rng)
+    zero = DeviceMPS.basis_state(n)
+    target = v_mul_mps(circ, th + 0.05, zero, trunc_thr=1e-14)
+    vh = v_dagger_mul_mps(circ, th, target, trunc_thr=1e-14)
+    assert abs(vh.dot(vh) - 1) < 1e-9 and vh.bond_dims.max() <= 16
+    g = fast_dot_gradient_mps(circ, th, zero, vh, trunc_thr=1e-14)
+    for t in (1, 3 * n + 6, circ.num_thetas - 2):           # <V 0|target> against central differences
+        e = np.zeros_like(th); e[t] = 1e-5
+        f = [v_mul_mps(circ, th + s * e, zero, trunc_thr=1e-14).dot(target) for s in (+1, -1)]
+        assert abs((f[0] - f[1]) / 2e-5 - g[t]) < 1e-7

@@ -160,7 +160,8 @@ class SpLHSObjectiveBase:
     def __init__(self, user_parameters: dict, circuit: ParametricCircuit, use_mps: bool = False, verbose: bool = False):
         if not isinstance(user_parameters, dict):
             raise TypeError("user_parameters must be a dict")
-        self._params, self._circuit, self._verbose, self._use_mps = user_parameters, circuit, verbose, bool(use_mps)
+        self._params, self._circuit, self._verbose = user_parameters, circuit, verbose
+        self._use_mps = bool(use_mps) or bool(user_parameters.get("_use_mps", False))
         self._target = None
         self._last_thetas = np.empty(0)
         n = int(user_parameters["num_qubits"])
@@ -188,7 +189,16 @@ class SpLHSObjectiveBase:
         # device side: a private one-lane workspace; Y = target, Z = V^H target, X / X2 = lhs states.
         # user_parameters["workspace"] substitutes a lane of a lockstep batch (lockstep.LaneView).
         self._ws = user_parameters.get("workspace", None)
-        if self._ws is None:
+        self._native_mps = False
+        if self._use_mps and self._ws is None:
+            from ..mps_dot_objective import use_dense
+
+            # registers beyond dense reach (or a real truncation threshold): no 2^n buffers at all, the objective
+            # runs on the device MPS engine (objective_lhs_sur_fast_mps_trotter.py)
+            self._native_mps = not use_dense(n, float(user_parameters.get("trunc_thr", 1e-16)))
+        if self._native_mps:
+            pass
+        elif self._ws is None:
             self._ws = Workspace(HipContext.of(circuit), batch=1, ncols=1, device=int(user_parameters.get("device", 0)))
         elif self._ws.T != circuit.num_thetas or self._ws.dim != circuit.dimension:
             raise ValueError("user_parameters['workspace'] belongs to a different ansatz")

@@ -28,6 +28,8 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
             raise TypeError("expects a TrotterAnsatz (objective_lhs_sur_fast_mps_trotter.py:82)")
         if int(user_parameters["max_flips"]) != 1:
             raise ValueError("expects max_flips=1 in case of using MPS")
+        user_parameters = dict(user_parameters)
+        user_parameters["_use_mps"] = True
         super().__init__(
             user_parameters=user_parameters,
             circ=circ,
@@ -44,5 +46,41 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
         if not check_mps(target) or len(target[0]) != self._circuit.num_qubits:
             raise ValueError("target must be an MPS in Qiskit format matching the circuit")
         self._target = target
-        self._ws.mps_upload(0, target)
-        self._ws.mps_to_vec(0, BUF_Y, 0)
+        if not self._native_mps:
+            self._ws.mps_upload(0, target)
+            self._ws.mps_to_vec(0, BUF_Y, 0)
+            return
+        from ..mps_engine import DeviceMPS
+
+        self._target_dev = DeviceMPS.from_qiskit(target, device=int(self._params.get("device", 0)))
+        self._vh = None
+        self._basis_dev = {}
+
+    # ---- native MPS mode: no dense state anywhere (objective_lhs_sur_fast_mps_trotter.py:114-227) ----------
+    def _basis(self, state_no: int):
+        from ..mps_engine import DeviceMPS
+
+        if state_no not in self._basis_dev:
+            self._basis_dev[state_no] = DeviceMPS.basis_state(self._circuit.num_qubits, int(self._state_handler.state_indices[state_no]),
+                                                              device=int(self._params.get("device", 0)))
+        return self._basis_dev[state_no]
+
+    def _evaluate(self, thetas) -> None:
+        if not self._native_mps:
+            return super()._evaluate(thetas)
+        from ..mps_engine import v_dagger_mul_mps
+
+        if self._vh is not None:
+            self._vh.close()
+        self._vh = v_dagger_mul_mps(self._circuit, thetas, self._target_dev, trunc_thr=self._trunc_thr)   # V^H|target>
+        for i in range(self._num_states):
+            self._hs[i] = self._basis(i).dot(self._vh)                                                   # <state_i|V^H|target>
+        self._grad0 = None
+
+    def _sweep(self, state_no: int, front: bool):
+        if not self._native_mps:
+            return super()._sweep(state_no, front)
+        from ..mps_engine import fast_dot_gradient_mps
+
+        return fast_dot_gradient_mps(self._circuit, self._last_thetas, self._basis(state_no), self._vh, trunc_thr=self._trunc_thr,
+                                     block_range=self._block_range, front_layer=front)

@@ -46,7 +46,7 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         self._speculative = bool(user_parameters.get("speculative_gradient", True)) and not self._dense
         self._grad0 = None       # cached complex gradient of the |state_0> term at self._last_thetas
         self._x2_state = -1      # state currently held in BUF_X2
-        if not self._dense:
+        if not self._dense and self._ws is not None:
             self._ws.set_basis(BUF_X, int(self._state_handler.state_indices[0]))
             self._ws.gather_setup(self._state_handler.state_indices)
 
@@ -67,15 +67,13 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         else:
             self._ws.set_basis(BUF_X, int(self._state_handler.state_indices[state_no]))
 
-    def objective(self, thetas: np.ndarray) -> float:
-        if self._target is None:
-            raise RuntimeError("set_target() has not been called")
-        self._store_latest_thetas(thetas)
+    def _evaluate(self, thetas: np.ndarray) -> None:
+        """Z = V^H|target> and hs[i] = <state_i|Z> on the device (objective_lhs_sur_max.py:96-108)."""
         ws = self._ws
         front = bool(self._front_layer or self._block_range == (0, self._circuit.num_blocks))
         if self._dense:
             ws.set_thetas(thetas)
-            ws.apply(True, BUF_Y, BUF_Z)  # V^H |target>   (objective_lhs_sur_max.py:96-102)
+            ws.apply(True, BUF_Y, BUF_Z)
             self._hs[:] = self._projections()
             self._grad0 = None
         else:
@@ -83,6 +81,12 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
                             block_range=self._block_range, front_layer=front)
             self._hs[:] = hs[0]
             self._grad0 = g[0] if self._speculative else None
+
+    def objective(self, thetas: np.ndarray) -> float:
+        if self._target is None:
+            raise RuntimeError("set_target() has not been called")
+        self._store_latest_thetas(thetas)
+        self._evaluate(thetas)
         np.copyto(self._hs2, np.absolute(self._hs) ** 2)
         # hysteresis: the leading state changes only for a 10 % better candidate (:113-117)
         max_proj = self._hs2[self._max_no]

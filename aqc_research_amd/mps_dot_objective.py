@@ -12,6 +12,20 @@ from .engine import BUF_X, BUF_Z, HipContext
 from .mps_operations import check_mps, no_truncation_threshold
 
 
+_DENSE_MAX_QUBITS = 24
+
+
+def use_dense(num_qubits: int, trunc_thr: float) -> bool:
+    """Dense (exact) evaluation on the fused state-vector kernels when the register fits and no real truncation
+    is asked for; the native MPS engine otherwise.  AQC_MPS_METHOD = dense | mps overrides."""
+    import os
+
+    forced = os.environ.get("AQC_MPS_METHOD", "auto")
+    if forced in ("dense", "mps"):
+        return forced == "dense"
+    return num_qubits <= _DENSE_MAX_QUBITS and trunc_thr <= 1e-12
+
+
 def fast_dot_gradient(
     circ,
     thetas: np.ndarray,
@@ -33,23 +47,32 @@ def fast_dot_gradient(
     if block_range is not None and not (isinstance(block_range, tuple) and len(block_range) == 2
                                         and 0 <= block_range[0] < block_range[1] <= circ.num_blocks):
         raise ValueError("block_range must be a tuple (from, to) with 0 <= from < to <= num_blocks")
-    ws = HipContext.of(circ).workspace(1, 1)
-    ws.set_thetas(th)
-    ws.mps_upload(0, lvec)
-    ws.mps_upload(1, vh_phi)
-    ws.mps_to_vec(0, BUF_X, 0)
-    ws.mps_to_vec(1, BUF_Z, 0)
-    ws.grad(block_range, bool(front_layer))
-    return ws.get_grads()[0]
+    if use_dense(circ.num_qubits, trunc_thr):
+        ws = HipContext.of(circ).workspace(1, 1)
+        ws.set_thetas(th)
+        ws.mps_upload(0, lvec)
+        ws.mps_upload(1, vh_phi)
+        ws.mps_to_vec(0, BUF_X, 0)
+        ws.mps_to_vec(1, BUF_Z, 0)
+        ws.grad(block_range, bool(front_layer))
+        return ws.get_grads()[0]
+    from .mps_engine import DeviceMPS, fast_dot_gradient_mps   # registers beyond dense reach, or real truncation
+
+    w, z = DeviceMPS.from_qiskit(lvec), DeviceMPS.from_qiskit(vh_phi)
+    try:
+        return fast_dot_gradient_mps(circ, th, w, z, trunc_thr=float(trunc_thr), block_range=block_range, front_layer=bool(front_layer))
+    finally:
+        w.close()
+        z.close()
 
 
 # ---- single gates on an MPS (mps_dot_objective.py:245-516) ------------------------------------------------
 # 1-qubit gates are exact at the MPS level (bond dimensions do not change): the (2, chi_l * chi_r) tensor of
-# the site is a one-qubit "state" with chi_l * chi_r columns for aqc_gate_1q.  2-qubit gates are applied to
-# the densified state on the device and returned as an exact MPS (dense, no-truncation semantics: n <~ 26).
+# the site is a one-qubit "state" with chi_l * chi_r columns for aqc_gate_1q.  2-qubit gates run on the native MPS
+# engine (contraction + truncated Jacobi SVD on the device, any register size).
 
 from . import gates as _gates  # noqa: E402
-from .mps_operations import mps_dot as _mps_dot, mps_to_vector as _mps_to_vector, vector_to_exact_mps as _to_mps  # noqa: E402
+from .mps_operations import mps_dot as _mps_dot  # noqa: E402
 
 _X = np.array([[0, 1], [1, 0]], dtype=np.complex128)
 _Y = np.array([[0, -1j], [1j, 0]], dtype=np.complex128)
@@ -94,22 +117,32 @@ def rz_mul_mps(angle: float, qubit: int, mps_vec):
     return _gate1q_mul_mps(_gates.rz_matrix(float(angle)), qubit, mps_vec)
 
 
-def _gate2q_mul_mps(g2x2, ctrl: int, targ: int, mps_vec):
-    vec = _mps_to_vector(mps_vec)
-    _gates.apply_2q(_gates.controlled(g2x2), int(ctrl), int(targ), vec, vec)
-    return _to_mps(vec)
+def _gate2q_mul_mps(g2x2, ctrl: int, targ: int, mps_vec, trunc_thr: float):
+    """Controlled gate on the MPS itself: contraction of the two sites, truncated SVD on the device
+    (mps_engine.DeviceMPS.gate2); the singular values whose squares sum to less than trunc_thr are dropped."""
+    from .mps_engine import DeviceMPS
+
+    if not check_mps(mps_vec):
+        raise ValueError("not a valid MPS in Qiskit format")
+    if not (isinstance(trunc_thr, float) and trunc_thr >= 0):
+        raise ValueError("trunc_thr must be a non-negative float")
+    m = DeviceMPS.from_qiskit(mps_vec)
+    try:
+        return m.gate2(_gates.controlled(g2x2), int(ctrl), int(targ), float(trunc_thr)).to_qiskit()
+    finally:
+        m.close()
 
 
 def cx_mul_mps(_: float, ctrl: int, targ: int, mps_vec, *, trunc_thr: float = no_truncation_threshold()):
-    return _gate2q_mul_mps(_X, ctrl, targ, mps_vec)
+    return _gate2q_mul_mps(_X, ctrl, targ, mps_vec, trunc_thr)
 
 
 def cz_mul_mps(_: float, ctrl: int, targ: int, mps_vec, *, trunc_thr: float = no_truncation_threshold()):
-    return _gate2q_mul_mps(_Z, ctrl, targ, mps_vec)
+    return _gate2q_mul_mps(_Z, ctrl, targ, mps_vec, trunc_thr)
 
 
 def cp_mul_mps(angle: float, ctrl: int, targ: int, mps_vec, *, trunc_thr: float = no_truncation_threshold()):
-    return _gate2q_mul_mps(np.diag([1.0, np.exp(1j * float(angle))]), ctrl, targ, mps_vec)
+    return _gate2q_mul_mps(np.diag([1.0, np.exp(1j * float(angle))]), ctrl, targ, mps_vec, trunc_thr)
 
 
 def dot_x(qubit: int, w_vec, z_vec) -> np.complex128:

@@ -109,22 +109,33 @@ def vector_to_exact_mps(vec: np.ndarray) -> QiskitMPS:
     return gam, lam
 
 
-def _apply_to_mps(circ, thetas, mps_vec, inverse: bool) -> QiskitMPS:
+def _apply_to_mps(circ, thetas, mps_vec, inverse: bool, trunc_thr) -> QiskitMPS:
     if not check_mps(mps_vec) or len(mps_vec[0]) != circ.num_qubits:
         raise ValueError("MPS does not match the circuit")
-    ws = HipContext.of(circ).workspace(1, 1)
-    ws.set_thetas(thetas)
-    ws.mps_upload(0, mps_vec)
-    ws.mps_to_vec(0, BUF_Y, 0)
-    ws.apply(inverse, BUF_Y, BUF_Z)
-    return vector_to_exact_mps(ws.download(BUF_Z, lane=0))
+    thr = _NO_TRUNCATION_THR if trunc_thr is None else float(trunc_thr)
+    from .mps_dot_objective import use_dense
+
+    if use_dense(circ.num_qubits, thr):   # exact: fused state-vector kernels on the densified state
+        ws = HipContext.of(circ).workspace(1, 1)
+        ws.set_thetas(thetas)
+        ws.mps_upload(0, mps_vec)
+        ws.mps_to_vec(0, BUF_Y, 0)
+        ws.apply(inverse, BUF_Y, BUF_Z)
+        return vector_to_exact_mps(ws.download(BUF_Z, lane=0))
+    from . import mps_engine                # large registers / real truncation: gate by gate on the MPS
+
+    m = mps_engine.DeviceMPS.from_qiskit(mps_vec)
+    try:
+        return mps_engine._apply_circuit(circ, thetas, m, inverse, thr, 0).to_qiskit()
+    finally:
+        m.close()
 
 
 def v_mul_mps(circ, thetas: np.ndarray, mps_vec, *, trunc_thr: Optional[float] = _NO_TRUNCATION_THR) -> QiskitMPS:
-    """V |mps> as an exact MPS (mps_operations.py:326-346; no truncation is applied)."""
-    return _apply_to_mps(circ, thetas, mps_vec, False)
+    """V |mps> (mps_operations.py:326-346): exact below 25 qubits, truncated-SVD MPS arithmetic beyond."""
+    return _apply_to_mps(circ, thetas, mps_vec, False, trunc_thr)
 
 
 def v_dagger_mul_mps(circ, thetas: np.ndarray, mps_vec, *, trunc_thr: Optional[float] = _NO_TRUNCATION_THR) -> QiskitMPS:
-    """V^H |mps> as an exact MPS (mps_operations.py:349-371; no truncation is applied)."""
-    return _apply_to_mps(circ, thetas, mps_vec, True)
+    """V^H |mps> (mps_operations.py:349-371): exact below 25 qubits, truncated-SVD MPS arithmetic beyond."""
+    return _apply_to_mps(circ, thetas, mps_vec, True, trunc_thr)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "aqc_mps_gate1": (c_int, [_P, c_int, _D]),
     "aqc_mps_gate2": (c_int, [_P, c_int, c_int, _D, c_double, c_int]),
     "aqc_mps_dot": (c_int, [_P, _P, _D]),
+    "aqc_mps_dot_ops": (c_int, [_P, _P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_svd": (c_int, [c_int, c_int, c_int, _D, _D, _D, _D, POINTER(c_int)]),
     "aqc_gate_dot": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int, _D, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),

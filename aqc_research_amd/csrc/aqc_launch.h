@@ -77,6 +77,9 @@ int set_error(const std::string& msg);
 // aqc_svd.hip (one-sided Jacobi SVD + the pieces of a truncated 2-qubit MPS gate)
 hipError_t launch_svd_identity(void* V, int cols, hipStream_t s);
 hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, int* rotations, hipStream_t s);
+bool svd_fits_small(int rows, int cols);
+hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
+                               int* sweeps_out, hipStream_t s);
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
 hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,

@@ -97,10 +97,15 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         sw.cached_cols = cols;
     }
     if (sw.flag.reserve(sizeof(int)) || sw.sigma.reserve(sizeof(double) * std::max(cols, 1))) return 1;
-    HIP_OK(launch_svd_identity(V, cols, st));
     const double tol = 1e-15;
     int sweeps = 0;
-    for (; sweeps < 60 && cols > 1; ++sweeps) {
+    if (svd_fits_small(rows, cols)) {   // one launch: matrix and V live in the LDS of one workgroup
+        HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, static_cast<int*>(sw.flag.p), st));
+        HIP_OK(hipMemcpyAsync(&sweeps, sw.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_OK(launch_svd_identity(V, cols, st));
+    }
+    for (; !svd_fits_small(rows, cols) && sweeps < 60 && cols > 1; ++sweeps) {
         HIP_OK(hipMemsetAsync(sw.flag.p, 0, sizeof(int), st));
         for (int r = 0; r < sw.rounds; ++r)
             HIP_OK(launch_jacobi_round(W, rows, V, cols, static_cast<int*>(sw.pairs.p) + (size_t)r * sw.per_round * 2, sw.per_round, tol,
@@ -110,11 +115,11 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         HIP_OK(hipStreamSynchronize(st));
         if (rotations == 0) { ++sweeps; break; }
     }
-    if (sweeps_out) *sweeps_out = sweeps;
     h_sigma.resize(cols);
     HIP_OK(launch_svd_norms(W, rows, cols, static_cast<double*>(sw.sigma.p), st));
     HIP_OK(hipMemcpyAsync(h_sigma.data(), sw.sigma.p, sizeof(double) * cols, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    if (sweeps_out) *sweeps_out = sweeps;   // the single-launch path delivers its count with this synchronisation
     return 0;
 }
 
@@ -125,6 +130,7 @@ struct aqc_mps {
     hipStream_t stream = nullptr;
     std::vector<int> dims;                    // n + 1 bond dimensions, dims[0] = dims[n] = 1
     std::vector<double2*> t;                  // per site: [2][dims[q]][dims[q+1]]
+    std::vector<size_t> t_cap, lam_cap;       // allocated elements (buffers only grow)
     std::vector<std::vector<double>> lam;     // n - 1 Schmidt vectors (host copy)
     std::vector<double*> d_lam;               // the same on the device
     Scratch theta, work, vmat, ord, tmp;
@@ -139,11 +145,25 @@ size_t site_elems(const aqc_mps* m, int q) { return (size_t)2 * m->dims[q] * m->
 
 int set_lambda(aqc_mps* m, int bond, const std::vector<double>& v) {
     m->lam[bond] = v;
-    if (m->d_lam[bond]) HIP_OK(hipFree(m->d_lam[bond]));
-    m->d_lam[bond] = nullptr;
-    HIP_OK(hipMalloc((void**)&m->d_lam[bond], sizeof(double) * v.size()));
-    HIP_OK(hipMemcpyAsync(m->d_lam[bond], v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, m->stream));
+    if (v.size() > m->lam_cap[bond]) {
+        HIP_OK(hipStreamSynchronize(m->stream));
+        if (m->d_lam[bond]) HIP_OK(hipFree(m->d_lam[bond]));
+        m->d_lam[bond] = nullptr;
+        HIP_OK(hipMalloc((void**)&m->d_lam[bond], sizeof(double) * v.size()));
+        m->lam_cap[bond] = v.size();
+    }
+    HIP_OK(hipMemcpyAsync(m->d_lam[bond], m->lam[bond].data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, m->stream));
+    HIP_OK(hipStreamSynchronize(m->stream));   // the host vector may be replaced by the next gate
+    return 0;
+}
+
+int reserve_site(aqc_mps* m, int q, size_t elems) {   // contents are NOT preserved
+    if (elems <= m->t_cap[q]) return 0;
     HIP_OK(hipStreamSynchronize(m->stream));
+    if (m->t[q]) HIP_OK(hipFree(m->t[q]));
+    m->t[q] = nullptr;
+    HIP_OK(hipMalloc((void**)&m->t[q], sizeof(double2) * elems));
+    m->t_cap[q] = elems;
     return 0;
 }
 
@@ -167,6 +187,8 @@ int new_mps(int device, int n, aqc_mps** out) {
     m->device = device; m->n = n;
     m->dims.assign(n + 1, 1);
     m->t.assign(n, nullptr);
+    m->t_cap.assign(n, 0);
+    m->lam_cap.assign(std::max(n - 1, 0), 0);
     m->lam.assign(std::max(n - 1, 0), {});
     m->d_lam.assign(std::max(n - 1, 0), nullptr);
     if (hipStreamCreate(&m->stream) != hipSuccess) { delete m; return failf("hipStreamCreate failed"); }
@@ -214,18 +236,13 @@ int gate_adjacent(aqc_mps* m, int q, const double* g16, double trunc_thr, int ma
     const double rescale = kept > 0.0 ? std::sqrt(total / kept) : 1.0;   // keep the norm of the state
     m->discarded += total - kept;
     // new tensors
-    double2 *tq = nullptr, *tq1 = nullptr;
-    HIP_OK(hipMalloc((void**)&tq, sizeof(double2) * (size_t)rows * k));
-    HIP_OK(hipMalloc((void**)&tq1, sizeof(double2) * (size_t)k * cols));
+    // theta has consumed the old site tensors: the new ones go into the same (grow-only) buffers
+    if (reserve_site(m, q, (size_t)rows * k) || reserve_site(m, q + 1, (size_t)k * cols)) return 1;
     if (m->ord.reserve(sizeof(int) * wcols)) return 1;
     HIP_OK(hipMemcpyAsync(m->ord.p, ord.data(), sizeof(int) * wcols, hipMemcpyHostToDevice, st));
     HIP_OK(launch_mps_split(m->work.p, m->vmat.p, static_cast<int*>(m->ord.p), static_cast<double*>(m->svd.sigma.p), lam_left, chil, chir, k,
-                            mode, rescale, tq, tq1, st));
-    HIP_OK(hipStreamSynchronize(st));
-    HIP_OK(hipFree(m->t[q]));
-    HIP_OK(hipFree(m->t[q + 1]));
-    m->t[q] = tq;
-    m->t[q + 1] = tq1;
+                            mode, rescale, m->t[q], m->t[q + 1], st));
+    HIP_OK(hipStreamSynchronize(st));           // `ord` (host vector) goes out of scope
     m->dims[q + 1] = k;
     std::vector<double> lam(k);
     for (int j = 0; j < k; ++j) lam[j] = sigma[ord[j]] * rescale;
@@ -257,7 +274,7 @@ int aqc_mps_create(int device, int n, const int32_t* dims, const double* gammas,
     size_t off = 0, loff = 0;
     for (int q = 0; q < n; ++q) {
         const size_t ne = site_elems(m, q);
-        if (hipMalloc((void**)&m->t[q], sizeof(double2) * ne) != hipSuccess ||
+        if (reserve_site(m, q, ne) ||
             hipMemcpyAsync(m->t[q], gammas + 2 * off, sizeof(double2) * ne, hipMemcpyHostToDevice, m->stream) != hipSuccess) {
             destroy(m);
             return failf("MPS upload failed");
@@ -289,7 +306,7 @@ int aqc_mps_clone(const aqc_mps* src, aqc_mps** out) {
     m->discarded = src->discarded;
     for (int q = 0; q < src->n; ++q) {
         const size_t bytes = sizeof(double2) * site_elems(src, q);
-        if (hipMalloc((void**)&m->t[q], bytes) != hipSuccess || hipMemcpy(m->t[q], src->t[q], bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+        if (reserve_site(m, q, site_elems(src, q)) || hipMemcpy(m->t[q], src->t[q], bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
             destroy(m);
             return failf("MPS clone failed");
         }
@@ -357,27 +374,50 @@ int aqc_mps_gate2(aqc_mps* m, int ctrl, int targ, const double* gate, double tru
     return 0;
 }
 
-/* <a|b> by transfer matrices (mps_dot, mps_operations.py:192-213) */
-int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out) {
-    if (!a || !b || !out) return failf("null argument");
+/* <(prod_i G_i on qubit_i) a | b> by transfer matrices (mps_dot, mps_operations.py:192-213; with one Pauli this is
+ * the 0.5j<P w|z> of mps_dot_objective.py:471-516 without building P.w).  G_i acts on a's side, so site qubit_i of b
+ * is read through G_i^H: <G a|b> = <a|G^H b>.  nops = 0: plain <a|b>. */
+int aqc_mps_dot_ops(aqc_mps* a, aqc_mps* b, int nops, const int32_t* qubits, const double* gates, double* out) {
+    if (!a || !b || !out || nops < 0 || (nops > 0 && (!qubits || !gates))) return failf("invalid argument");
     if (a->n != b->n || a->device != b->device) return failf("MPS operands differ in size or device");
     HIP_OK(hipSetDevice(a->device));
     HIP_OK(hipStreamSynchronize(b->stream));
     hipStream_t st = a->stream;
     const int n = a->n;
-    size_t need = 1;
+    std::vector<int> op_of(n, -1);
+    for (int i = 0; i < nops; ++i) {
+        if (qubits[i] < 0 || qubits[i] >= n || op_of[qubits[i]] >= 0) return failf("operator qubits must be distinct and in range");
+        op_of[qubits[i]] = i;
+    }
+    size_t need = 1, site_max = 1;
     for (int q = 0; q <= n; ++q) need = std::max(need, (size_t)a->dims[q] * b->dims[q]);
-    for (int q = 0; q < n; ++q) need = std::max(need, (size_t)a->dims[q] * b->dims[q + 1]);
-    if (a->tmp.reserve(sizeof(double2) * 3 * need)) return 1;
+    for (int q = 0; q < n; ++q) {
+        need = std::max(need, (size_t)a->dims[q] * b->dims[q + 1]);
+        if (op_of[q] >= 0) site_max = std::max(site_max, site_elems(b, q));
+    }
+    if (a->tmp.reserve(sizeof(double2) * (3 * need + site_max))) return 1;
     double2* e = static_cast<double2*>(a->tmp.p);
     double2* en = e + need;
     double2* t = en + need;
+    double2* bsite = t + need;
+    auto b_site = [&](int q, const double2** ptr) -> int {   // site q of b, seen through G^H when an operator sits there
+        *ptr = b->t[q];
+        if (op_of[q] < 0) return 0;
+        const double* g = gates + 8 * (size_t)op_of[q];
+        const double gh[8] = {g[0], -g[1], g[4], -g[5], g[2], -g[3], g[6], -g[7]};   // conjugate transpose of the 2x2
+        HIP_OK(launch_gate1q(b->t[q], bsite, 1, (size_t)b->dims[q] * b->dims[q + 1], 0, gh, st));
+        *ptr = bsite;
+        return 0;
+    };
+    const double2* bq = nullptr;
+    if (b_site(0, &bq)) return 1;
     // E[x][y] = sum_bit conj(A_0[bit][0][x]) B_0[bit][0][y]
-    HIP_OK(launch_zgemm(true, false, a->dims[1], b->dims[1], 2, a->t[0], a->dims[1], b->t[0], b->dims[1], e, b->dims[1], st));
+    HIP_OK(launch_zgemm(true, false, a->dims[1], b->dims[1], 2, a->t[0], a->dims[1], bq, b->dims[1], e, b->dims[1], st));
     for (int q = 1; q < n; ++q) {
         const int xa = a->dims[q], ua = a->dims[q + 1], yb = b->dims[q], vb = b->dims[q + 1];
+        if (b_site(q, &bq)) return 1;
         for (int bit = 0; bit < 2; ++bit) {
-            HIP_OK(launch_zgemm(false, false, xa, vb, yb, e, yb, b->t[q] + (size_t)bit * yb * vb, vb, t, vb, st));
+            HIP_OK(launch_zgemm(false, false, xa, vb, yb, e, yb, bq + (size_t)bit * yb * vb, vb, t, vb, st));
             HIP_OK(launch_zgemm(true, bit == 1, ua, vb, xa, a->t[q] + (size_t)bit * xa * ua, ua, t, vb, en, vb, st));
         }
         std::swap(e, en);
@@ -386,6 +426,8 @@ int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out) {
     HIP_OK(hipStreamSynchronize(st));
     return 0;
 }
+
+int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out) { return aqc_mps_dot_ops(a, b, 0, nullptr, nullptr, out); }
 
 /* A (m x n, row-major, host) = U diag(S) Vh with k = min(m, n), S descending; U (m x k), Vh (k x n) row-major.
  * The SVD kernel of the MPS engine, exposed for testing and for callers that need a device SVD. */

@@ -77,6 +77,90 @@ __global__ __launch_bounds__(kSvdThreads) void svd_norms_kernel(const cplx* __re
     if (threadIdx.x == 0) sigma[blockIdx.x] = sqrt(a);
 }
 
+// Whole SVD in ONE launch when the work matrix and V fit into the LDS of one workgroup (rows, cols <= 64: bond
+// dimensions up to 32): 32 half-waves, one column pair each per round, __syncthreads between rounds, the sweep
+// loop and the convergence test inside the kernel.  Replaces ~500 launches of jacobi_round_kernel.
+constexpr int kSmallMax = 64;
+__global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
+                                                            const int2* __restrict__ pairs, int rounds, int per_round, double tol,
+                                                            int max_sweeps, int* __restrict__ sweeps_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* sw = reinterpret_cast<cplx*>(smem);            // [cols][rows]
+    cplx* sv = sw + (size_t)cols * rows;                  // [cols][cols]
+    __shared__ int rotated;
+    const int tid = threadIdx.x, grp = tid >> 5, lane = tid & 31;
+    for (int i = tid; i < rows * cols; i += blockDim.x) sw[i] = W[i];
+    for (int i = tid; i < cols * cols; i += blockDim.x) sv[i] = make_double2((i / cols) == (i % cols) ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const int2 pq = grp < per_round ? pairs[r * per_round + grp] : make_int2(-1, -1);
+            if (pq.x >= 0 && pq.y >= 0 && pq.x < cols && pq.y < cols) {
+                cplx* wp = sw + (size_t)pq.x * rows;
+                cplx* wq = sw + (size_t)pq.y * rows;
+                double a = 0.0, b = 0.0, gr = 0.0, gi = 0.0;
+                for (int i = lane; i < rows; i += 32) {
+                    const cplx x = wp[i], y = wq[i];
+                    a += x.x * x.x + x.y * x.y;
+                    b += y.x * y.x + y.y * y.y;
+                    gr += x.x * y.x + x.y * y.y;
+                    gi += x.x * y.y - x.y * y.x;
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {   // butterfly inside the half-wave: every lane gets the totals
+                    a += __shfl_xor(a, off, 32); b += __shfl_xor(b, off, 32);
+                    gr += __shfl_xor(gr, off, 32); gi += __shfl_xor(gi, off, 32);
+                }
+                const double g2 = gr * gr + gi * gi;
+                if (g2 > tol * tol * a * b && g2 != 0.0) {
+                    if (lane == 0) atomicAdd(&rotated, 1);
+                    const double g = sqrt(g2);
+                    const double zeta = (b - a) / (2.0 * g);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                    const double er = gr / g, ei = -gi / g;
+                    cplx* vp = sv + (size_t)pq.x * cols;
+                    cplx* vq = sv + (size_t)pq.y * cols;
+                    for (int i = lane; i < rows + cols; i += 32) {
+                        cplx* xp = i < rows ? wp + i : vp + (i - rows);
+                        cplx* yp = i < rows ? wq + i : vq + (i - rows);
+                        const cplx x = *xp, y0 = *yp;
+                        const cplx y = make_double2(y0.x * er - y0.y * ei, y0.x * ei + y0.y * er);
+                        *xp = make_double2(c * x.x - s * y.x, c * x.y - s * y.y);
+                        *yp = make_double2(s * x.x + c * y.x, s * x.y + c * y.y);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int any = rotated;
+        __syncthreads();
+        if (any == 0) { ++sweep; break; }
+    }
+    for (int i = tid; i < rows * cols; i += blockDim.x) W[i] = sw[i];
+    for (int i = tid; i < cols * cols; i += blockDim.x) V[i] = sv[i];
+    if (tid == 0) *sweeps_out = sweep;
+}
+
+bool svd_fits_small(int rows, int cols) { return rows <= kSmallMax && cols <= kSmallMax && cols >= 2; }
+hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
+                               int* sweeps_out, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * kSmallMax * kSmallMax * (int)sizeof(cplx));   // + the static flag < 160 KiB
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t lds = sizeof(cplx) * ((size_t)cols * rows + (size_t)cols * cols);
+    jacobi_small_kernel<<<1, 1024, lds, s>>>(static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols, static_cast<const int2*>(pairs), rounds,
+                                             per_round, tol, max_sweeps, sweeps_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_svd_identity(void* V, int cols, hipStream_t s) {
     const size_t total = (size_t)cols * cols;
     svd_identity_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<cplx*>(V), cols);

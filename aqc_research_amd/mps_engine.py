@@ -20,7 +20,7 @@ from ._lib import check, dptr
 _X = np.array([[0, 1], [1, 0]], dtype=np.complex128)
 _Y = np.array([[0, -1j], [1j, 0]], dtype=np.complex128)
 _Z = np.array([[1, 0], [0, -1]], dtype=np.complex128)
-_P11 = np.diag([0, 0, 0, 1]).astype(np.complex128)
+_P1 = np.diag([0, 1]).astype(np.complex128)
 
 
 def _pack(qiskit_mps):
@@ -118,6 +118,15 @@ class DeviceMPS:
         """<self|other>."""
         out = np.empty(1, dtype=np.complex128)
         check(self._L.aqc_mps_dot(self.handle, other.handle, dptr(out)))
+        return np.complex128(out[0])
+
+    def dot_ops(self, other: "DeviceMPS", ops) -> np.complex128:
+        """<(prod G_i on qubit_i) self|other> for ``ops = [(qubit, 2x2 gate), ...]`` on distinct qubits, without
+        building the transformed state."""
+        qs = np.ascontiguousarray([q for q, _ in ops], dtype=np.int32)
+        gs = np.ascontiguousarray(np.stack([np.asarray(g, dtype=np.complex128) for _, g in ops]))
+        out = np.empty(1, dtype=np.complex128)
+        check(self._L.aqc_mps_dot_ops(self.handle, other.handle, len(ops), qs.ctypes.data_as(POINTER(c_int32)), dptr(gs), dptr(out)))
         return np.complex128(out[0])
 
     def close(self) -> None:
@@ -231,11 +240,8 @@ def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, t
         w.gate1(gate, q)
         z.gate1(gate, q)
 
-    def dot(p: str, q: int) -> np.complex128:   # 0.5j <P w|z>: P acts on a scratch copy of w's site only
-        pw = w.clone().gate1(pauli[p], q)
-        val = 0.5j * pw.dot(z)
-        pw.close()
-        return val
+    def dot(p: str, q: int) -> np.complex128:   # 0.5j <P w|z>, P folded into the transfer-matrix chain
+        return 0.5j * w.dot_ops(z, [(q, pauli[p])])
 
     for q in range(n):   # front layer: Rz(t2), Ry(t1), Rz(t0), rightmost first (core_operations.py:921-935)
         for slot, mat, p in ((2, gates.rz_matrix, "z"), (1, gates.ry_matrix, "y"), (0, gates.rz_matrix, "z")):
@@ -250,9 +256,7 @@ def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, t
         if trotter and i % 3 == 0:
             both(gates.rz_matrix(-np.pi / 2), c)
         if live and tpb == 5:    # -1j <P11 w|z> before the gate (core_op_matrix.py:430-477)
-            pw = w.clone().gate2(_P11, c, t, 0.0, 0)
-            g2[j, 4] += -1j * pw.dot(z)
-            pw.close()
+            g2[j, 4] += -1j * w.dot_ops(z, [(c, _P1), (t, _P1)])
         ent = _ent_matrix(circ.entangler, b[4] if tpb == 5 else 0.0)
         z.gate2(ent, c, t, trunc_thr, max_bond)
         w.gate2(ent, c, t, trunc_thr, max_bond)

@@ -181,6 +181,9 @@ int aqc_mps_gate1(aqc_mps* mps, int qubit, const double* gate);
 int aqc_mps_gate2(aqc_mps* mps, int ctrl, int targ, const double* gate, double trunc_thr, int max_bond);
 /* <a|b>  (mps_dot, mps_operations.py:192-213) */
 int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out /* 1 c128 */);
+/* <(prod_i G_i on qubits[i]) a|b> without forming G.a: dot_{x,y,z} (mps_dot_objective.py:471-516) up to the factor
+ * 0.5j with one Pauli; two projectors |1><1| give the CPhase derivative term.  gates: nops 2x2 matrices (4 c128 each) */
+int aqc_mps_dot_ops(aqc_mps* a, aqc_mps* b, int nops, const int32_t* qubits, const double* gates, double* out);
 /* one-sided Jacobi SVD on the device (the kernel behind aqc_mps_gate2): A (m x n row-major) = U diag(S) Vh,
  * k = min(m, n), S descending, U (m x k), Vh (k x n); *sweeps (optional) = Jacobi sweeps used */
 int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, double* vh, int* sweeps);

@@ -200,3 +200,27 @@ def test_mps_objective_native_mode_matches_dense_mode(monkeypatch):
     o2 = SpSurrogateObjectiveFastMpsTrotter(user_parameters=user, circ=circ); o2.set_target(tgt)
     fd = (o2.objective(th + e) - o2.objective(th - e)) / 2e-5
     assert abs(fd - g[7]) < 1e-5
+
+
+def test_lbfgs_on_the_native_mps_objective_32_qubits():
+    """A short L-BFGS run on a 32-qubit register (no dense state anywhere): the surrogate objective must go down
+    from its perturbed start towards the planted optimum."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_fast_mps_trotter import SpSurrogateObjectiveFastMpsTrotter
+    from aqc_research_amd.mps_engine import DeviceMPS, v_mul_mps
+    from aqc_research_amd.optimizer import AqcOptimizer
+
+    n = 32
+    rng = np.random.default_rng(32)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 1), second_order=False)
+    th_true = 0.3 * orc.rand_thetas(circ.num_thetas, rng)
+    target = v_mul_mps(circ, th_true, DeviceMPS.basis_state(n), trunc_thr=1e-12).to_qiskit()
+    user = dict(num_qubits=n, max_flips=1, enable_optim_stats=False, verbose=0, maxiter=6, trunc_thr=1e-12)
+    objv = SpSurrogateObjectiveFastMpsTrotter(user_parameters=user, circ=circ)
+    objv.set_target(target)
+    th0 = th_true + 0.03 * rng.standard_normal(th_true.size)
+    f0 = objv.objective(th0)
+    res = AqcOptimizer(optimizer_name="lbfgs", maxiter=6).optimize(objv, circ, th0)
+    assert objv._native_mps and f0 > 1e-3
+    assert res["cost"] < 0.2 * f0 and res["fidelity"] > 1 - 0.2 * f0

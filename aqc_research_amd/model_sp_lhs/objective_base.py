@@ -34,7 +34,12 @@ class ThinStateHandler:
                 for q in sub:
                     v ^= 1 << q  # Qiskit bit order (core_operations.py:34-43)
                 idx.append(v)
-        self._state_idx = np.asarray(idx, dtype=np.int64) ^ np.int64(base_index)
+        # int64 indices up to 62 qubits (what the dense kernels gather with); Python integers beyond, where only
+        # the MPS engine can run and consumes them bit by bit
+        if self._n <= 62:
+            self._state_idx = np.asarray(idx, dtype=np.int64) ^ np.int64(base_index)
+        else:
+            self._state_idx = np.array([v ^ int(base_index) for v in idx], dtype=object)
 
     @property
     def num_states(self) -> int:

@@ -59,6 +59,7 @@ class DeviceMPS:
     @classmethod
     def basis_state(cls, num_qubits: int, index: int = 0, device: int = 0) -> "DeviceMPS":
         """Product state |index> (bit q of ``index`` = qubit q)."""
+        index = int(index)   # Python integer: registers beyond 63 qubits
         gam = [((np.array([[1.0 - ((index >> q) & 1)]], dtype=np.complex128)), np.array([[float((index >> q) & 1)]], dtype=np.complex128))
                for q in range(num_qubits)]
         return cls.from_qiskit((gam, [np.ones(1) for _ in range(num_qubits - 1)]), device)

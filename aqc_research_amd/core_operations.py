@@ -7,7 +7,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from . import _lib, gates
+from . import gates
 from .engine import BUF_X, BUF_Y, BUF_Z, HipContext
 
 

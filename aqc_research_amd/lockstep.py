@@ -18,7 +18,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .engine import BUF_X, BUF_X2, BUF_Y, BUF_Z, HipContext, Workspace
+from .engine import BUF_X, BUF_X2, HipContext, Workspace
 
 __all__ = ["LockstepBatch", "LaneView", "run_jobs_lockstep"]
 

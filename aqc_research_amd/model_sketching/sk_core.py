@@ -3,7 +3,7 @@ Full / sketched unitary-AQC objective ``1 - Re<X|V^H|Y>/k`` on the GPU: drop-in 
 SketchingObjectiveEx + FullRangeSketchingVectors (sk_core.py:34-326).
 """
 from time import perf_counter
-from typing import Optional, Tuple, Union
+from typing import Tuple
 
 import numpy as np
 

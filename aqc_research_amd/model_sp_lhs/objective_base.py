@@ -5,11 +5,11 @@ model_sp_lhs/objective_base.py:42-255,437-834; all vector arithmetic is delegate
 HIP workspace, only scalars live here.
 """
 import itertools
-from typing import Callable, List, Optional, Tuple, Union
+from typing import List, Optional, Tuple
 
 import numpy as np
 
-from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+from ..engine import BUF_Y, HipContext, Workspace
 from ..parametric_circuit import ParametricCircuit
 
 

@@ -8,8 +8,7 @@ reference that runs inside qiskit-aer's ``matrix_product_state`` simulator (``mp
 circuit applications of ``mps_operations.py:326-371``.  With ``trunc_thr -> 0`` everything is exact (tested
 against the dense oracle); Aer's truncation arithmetic itself is third party and parity unpinned.
 """
-import ctypes
-from ctypes import POINTER, byref, c_double, c_int, c_int32, c_void_p
+from ctypes import POINTER, byref, c_int, c_int32, c_void_p
 from typing import Optional, Tuple
 
 import numpy as np

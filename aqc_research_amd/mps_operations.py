@@ -12,7 +12,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from .engine import BUF_X, BUF_Y, BUF_Z, HipContext
+from .engine import BUF_Y, BUF_Z, HipContext
 
 _NO_TRUNCATION_THR = 1e-16
 QiskitMPS = Tuple[List[Tuple[np.ndarray, np.ndarray]], List[np.ndarray]]

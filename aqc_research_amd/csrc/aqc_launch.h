@@ -77,6 +77,9 @@ int set_error(const std::string& msg);
 // aqc_svd.hip (one-sided Jacobi SVD + the pieces of a truncated 2-qubit MPS gate)
 hipError_t launch_svd_identity(void* V, int cols, hipStream_t s);
 hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, int* rotations, hipStream_t s);
+hipError_t launch_svd_load(const void* a, int m, int n, int mode, void* work, hipStream_t s);
+hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, const double* sigma, int m, int n, int k, int mode, void* u, void* vh,
+                               double* s_sorted, hipStream_t s);
 bool svd_fits_small(int rows, int cols);
 hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
                                int* sweeps_out, hipStream_t s);

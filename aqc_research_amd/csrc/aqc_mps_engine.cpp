@@ -439,50 +439,30 @@ int aqc_svd(int device, int m, int n, const double* a_in, double* u_out, double*
     HIP_OK(hipSetDevice(device));
     const int mode = n <= m ? 0 : 1, k = std::min(m, n);
     const int wrows = mode == 0 ? m : n, wcols = k;
-    // work matrix: column-major A (mode 0) or column-major A^H (mode 1); pure re-layout of the input
-    std::vector<double> w((size_t)2 * wrows * wcols);
-    for (int i = 0; i < m; ++i)
-        for (int j = 0; j < n; ++j) {
-            const double re = a_in[2 * ((size_t)i * n + j)], im = a_in[2 * ((size_t)i * n + j) + 1];
-            const size_t e = mode == 0 ? (size_t)j * m + i : (size_t)i * n + j;
-            w[2 * e] = re;
-            w[2 * e + 1] = mode == 0 ? im : -im;
-        }
-    Scratch dw, dv;
+    const size_t na = (size_t)m * n;
+    Scratch da, dw, dv, du, dvh, dord, dss;
     SvdWork sw;
     std::vector<double> sigma;
     int rc = 1;
     do {
-        if (dw.reserve(sizeof(double) * w.size()) || dv.reserve(sizeof(double2) * (size_t)wcols * wcols)) break;
-        if (hipMemcpy(dw.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice) != hipSuccess) { failf("SVD upload failed"); break; }
+        if (da.reserve(sizeof(double2) * na) || dw.reserve(sizeof(double2) * na) || dv.reserve(sizeof(double2) * (size_t)wcols * wcols) ||
+            du.reserve(sizeof(double2) * (size_t)m * k) || dvh.reserve(sizeof(double2) * (size_t)k * n) || dord.reserve(sizeof(int) * k) ||
+            dss.reserve(sizeof(double) * k)) break;
+        if (hipMemcpy(da.p, a_in, sizeof(double2) * na, hipMemcpyHostToDevice) != hipSuccess) { failf("SVD upload failed"); break; }
+        if (launch_svd_load(da.p, m, n, mode, dw.p, nullptr) != hipSuccess) { failf("SVD load kernel failed"); break; }
         if (jacobi_svd(sw, dw.p, wrows, dv.p, wcols, nullptr, sigma, sweeps)) break;
-        std::vector<double> hw(w.size()), hv((size_t)2 * wcols * wcols);
-        if (hipMemcpy(hw.data(), dw.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(hv.data(), dv.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost) != hipSuccess) { failf("SVD download failed"); break; }
         std::vector<int> ord(wcols);
         std::iota(ord.begin(), ord.end(), 0);
         std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sigma[x] > sigma[y]; });
-        // pure re-layout + the 1/sigma normalisation of the orthogonal columns
-        for (int j = 0; j < k; ++j) {
-            const int c = ord[j];
-            const double s = sigma[c], inv = s > 0.0 ? 1.0 / s : 0.0;
-            s_out[j] = s;
-            for (int i = 0; i < m; ++i) {   // U[i][j]
-                const double* src = mode == 0 ? &hw[2 * ((size_t)c * m + i)] : &hv[2 * ((size_t)c * m + i)];
-                const double f = mode == 0 ? inv : 1.0;
-                u_out[2 * ((size_t)i * k + j)] = src[0] * f;
-                u_out[2 * ((size_t)i * k + j) + 1] = src[1] * f;
-            }
-            for (int i = 0; i < n; ++i) {   // Vh[j][i] = conj(V[i][j])
-                const double* src = mode == 0 ? &hv[2 * ((size_t)c * n + i)] : &hw[2 * ((size_t)c * n + i)];
-                const double f = mode == 0 ? 1.0 : inv;
-                vh_out[2 * ((size_t)j * n + i)] = src[0] * f;
-                vh_out[2 * ((size_t)j * n + i) + 1] = -src[1] * f;
-            }
-        }
+        if (hipMemcpy(dord.p, ord.data(), sizeof(int) * k, hipMemcpyHostToDevice) != hipSuccess) { failf("SVD upload failed"); break; }
+        if (launch_svd_assemble(dw.p, dv.p, static_cast<int*>(dord.p), static_cast<double*>(sw.sigma.p), m, n, k, mode, du.p, dvh.p,
+                                static_cast<double*>(dss.p), nullptr) != hipSuccess) { failf("SVD assemble kernel failed"); break; }
+        if (hipMemcpy(u_out, du.p, sizeof(double2) * (size_t)m * k, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(vh_out, dvh.p, sizeof(double2) * (size_t)k * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(s_out, dss.p, sizeof(double) * k, hipMemcpyDeviceToHost) != hipSuccess) { failf("SVD download failed"); break; }
         rc = 0;
     } while (false);
-    dw.release(); dv.release(); sw.release();
+    da.release(); dw.release(); dv.release(); du.release(); dvh.release(); dord.release(); dss.release(); sw.release();
     return rc;
 }
 

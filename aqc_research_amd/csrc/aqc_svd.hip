@@ -145,6 +145,52 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
     if (tid == 0) *sweeps_out = sweep;
 }
 
+// Generic entry (aqc_svd): A row-major (m x n) -> Jacobi work matrix, and (W, V, order, sigma) -> U (m x k), Vh (k x n).
+// mode 0 (n <= m): work = column-major A;  mode 1: work = column-major A^H (the conjugate of row-major A).
+__global__ void svd_load_kernel(const cplx* __restrict__ a, int m, int n, int mode, cplx* __restrict__ work) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)m * n) return;
+    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+    const cplx v = a[idx];
+    if (mode == 0) work[(size_t)j * m + i] = v;
+    else work[idx] = make_double2(v.x, -v.y);
+}
+__global__ void svd_assemble_kernel(const cplx* __restrict__ W, const cplx* __restrict__ V, const int* __restrict__ ord,
+                                    const double* __restrict__ sigma, int m, int n, int k, int mode, cplx* __restrict__ u,
+                                    cplx* __restrict__ vh, double* __restrict__ s_sorted) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nu = (size_t)m * k, nv = (size_t)k * n;
+    if (idx < nu) {
+        const int i = (int)(idx / k), j = (int)(idx - (size_t)i * k), c = ord[j];
+        const double inv = sigma[c] > 0.0 ? 1.0 / sigma[c] : 0.0;
+        cplx v = mode == 0 ? W[(size_t)c * m + i] : V[(size_t)c * m + i];
+        if (mode == 0) { v.x *= inv; v.y *= inv; }
+        u[idx] = v;
+    } else if (idx < nu + nv) {
+        const size_t e = idx - nu;
+        const int j = (int)(e / n), i = (int)(e - (size_t)j * n), c = ord[j];
+        const double inv = sigma[c] > 0.0 ? 1.0 / sigma[c] : 0.0;
+        cplx v = mode == 0 ? V[(size_t)c * n + i] : W[(size_t)c * n + i];
+        if (mode == 1) { v.x *= inv; v.y *= inv; }
+        vh[e] = make_double2(v.x, -v.y);
+    } else if (idx < nu + nv + (size_t)k) {
+        const int j = (int)(idx - nu - nv);
+        s_sorted[j] = sigma[ord[j]];
+    }
+}
+hipError_t launch_svd_load(const void* a, int m, int n, int mode, void* work, hipStream_t s) {
+    const size_t total = (size_t)m * n;
+    svd_load_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<const cplx*>(a), m, n, mode, static_cast<cplx*>(work));
+    return hipGetLastError();
+}
+hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, const double* sigma, int m, int n, int k, int mode, void* u, void* vh,
+                               double* s_sorted, hipStream_t s) {
+    const size_t total = (size_t)m * k + (size_t)k * n + k;
+    svd_assemble_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<const cplx*>(W), static_cast<const cplx*>(V), ord, sigma, m, n, k, mode,
+                                                                        static_cast<cplx*>(u), static_cast<cplx*>(vh), s_sorted);
+    return hipGetLastError();
+}
+
 bool svd_fits_small(int rows, int cols) { return rows <= kSmallMax && cols <= kSmallMax && cols >= 2; }
 hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
                                int* sweeps_out, hipStream_t s) {

@@ -444,25 +444,28 @@ int aqc_svd(int device, int m, int n, const double* a_in, double* u_out, double*
     SvdWork sw;
     std::vector<double> sigma;
     int rc = 1;
+    hipStream_t st = nullptr;
+    HIP_OK(hipStreamCreate(&st));   // the rounds are many short dependent launches: keep them off the legacy default stream
     do {
         if (da.reserve(sizeof(double2) * na) || dw.reserve(sizeof(double2) * na) || dv.reserve(sizeof(double2) * (size_t)wcols * wcols) ||
             du.reserve(sizeof(double2) * (size_t)m * k) || dvh.reserve(sizeof(double2) * (size_t)k * n) || dord.reserve(sizeof(int) * k) ||
             dss.reserve(sizeof(double) * k)) break;
         if (hipMemcpy(da.p, a_in, sizeof(double2) * na, hipMemcpyHostToDevice) != hipSuccess) { failf("SVD upload failed"); break; }
-        if (launch_svd_load(da.p, m, n, mode, dw.p, nullptr) != hipSuccess) { failf("SVD load kernel failed"); break; }
-        if (jacobi_svd(sw, dw.p, wrows, dv.p, wcols, nullptr, sigma, sweeps)) break;
+        if (launch_svd_load(da.p, m, n, mode, dw.p, st) != hipSuccess) { failf("SVD load kernel failed"); break; }
+        if (jacobi_svd(sw, dw.p, wrows, dv.p, wcols, st, sigma, sweeps)) break;
         std::vector<int> ord(wcols);
         std::iota(ord.begin(), ord.end(), 0);
         std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sigma[x] > sigma[y]; });
         if (hipMemcpy(dord.p, ord.data(), sizeof(int) * k, hipMemcpyHostToDevice) != hipSuccess) { failf("SVD upload failed"); break; }
         if (launch_svd_assemble(dw.p, dv.p, static_cast<int*>(dord.p), static_cast<double*>(sw.sigma.p), m, n, k, mode, du.p, dvh.p,
-                                static_cast<double*>(dss.p), nullptr) != hipSuccess) { failf("SVD assemble kernel failed"); break; }
+                                static_cast<double*>(dss.p), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { failf("SVD assemble kernel failed"); break; }
         if (hipMemcpy(u_out, du.p, sizeof(double2) * (size_t)m * k, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(vh_out, dvh.p, sizeof(double2) * (size_t)k * n, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(s_out, dss.p, sizeof(double) * k, hipMemcpyDeviceToHost) != hipSuccess) { failf("SVD download failed"); break; }
         rc = 0;
     } while (false);
     da.release(); dw.release(); dv.release(); du.release(); dvh.release(); dord.release(); dss.release(); sw.release();
+    (void)hipStreamDestroy(st);
     return rc;
 }
 

@@ -26,41 +26,48 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return r;
 }
 
+// One wave per column pair (4 pairs per workgroup): no barriers, the four sums go through one shuffle butterfly.
 __global__ __launch_bounds__(kSvdThreads) void jacobi_round_kernel(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
-                                                                   const int2* __restrict__ pairs, double tol, int* __restrict__ rotations) {
-    __shared__ double red[kSvdThreads];
-    const int2 pq = pairs[blockIdx.x];
+                                                                   const int2* __restrict__ pairs, int npairs, double tol,
+                                                                   int* __restrict__ rotations) {
+    const int lane = threadIdx.x & 63, pair = blockIdx.x * (kSvdThreads / 64) + (threadIdx.x >> 6);
+    if (pair >= npairs) return;
+    const int2 pq = pairs[pair];
     if (pq.x < 0 || pq.y < 0 || pq.x >= cols || pq.y >= cols) return;   // bye of an odd tournament
     cplx* wp = W + (size_t)pq.x * rows;
     cplx* wq = W + (size_t)pq.y * rows;
     double a = 0.0, b = 0.0, gr = 0.0, gi = 0.0;
-    for (int i = threadIdx.x; i < rows; i += kSvdThreads) {
+    for (int i = lane; i < rows; i += 64) {
         const cplx x = wp[i], y = wq[i];
         a += x.x * x.x + x.y * x.y;
         b += y.x * y.x + y.y * y.y;
         gr += x.x * y.x + x.y * y.y;      // conj(x) * y
         gi += x.x * y.y - x.y * y.x;
     }
-    a = block_sum(a, red); b = block_sum(b, red); gr = block_sum(gr, red); gi = block_sum(gi, red);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {   // xor butterfly: every lane ends with the same totals, fixed order
+        a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64);
+        gr += __shfl_xor(gr, off, 64); gi += __shfl_xor(gi, off, 64);
+    }
     const double g2 = gr * gr + gi * gi;
     if (g2 <= tol * tol * a * b || g2 == 0.0) return;                    // already orthogonal (or a zero column)
-    if (threadIdx.x == 0) atomicAdd(rotations, 1);
+    if (lane == 0) atomicAdd(rotations, 1);
     const double g = sqrt(g2);
     const double zeta = (b - a) / (2.0 * g);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
     const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
     const double er = gr / g, ei = -gi / g;                              // e^{-i phi}, phi = arg(gamma)
     // (x, y) <- (c x - s e^{-i phi} y,  s x + c e^{-i phi} y): makes the pair's Gram matrix diagonal
-    auto rotate = [&](cplx* xp, cplx* yp, int len) {
-        for (int i = threadIdx.x; i < len; i += kSvdThreads) {
-            const cplx x = xp[i], y0 = yp[i];
-            const cplx y = make_double2(y0.x * er - y0.y * ei, y0.x * ei + y0.y * er);
-            xp[i] = make_double2(c * x.x - s * y.x, c * x.y - s * y.y);
-            yp[i] = make_double2(s * x.x + c * y.x, s * x.y + c * y.y);
-        }
-    };
-    rotate(wp, wq, rows);
-    rotate(V + (size_t)pq.x * cols, V + (size_t)pq.y * cols, cols);
+    cplx* vp = V + (size_t)pq.x * cols;
+    cplx* vq = V + (size_t)pq.y * cols;
+    for (int i = lane; i < rows + cols; i += 64) {
+        cplx* xp = i < rows ? wp + i : vp + (i - rows);
+        cplx* yp = i < rows ? wq + i : vq + (i - rows);
+        const cplx x = *xp, y0 = *yp;
+        const cplx y = make_double2(y0.x * er - y0.y * ei, y0.x * ei + y0.y * er);
+        *xp = make_double2(c * x.x - s * y.x, c * x.y - s * y.y);
+        *yp = make_double2(s * x.x + c * y.x, s * x.y + c * y.y);
+    }
 }
 
 __global__ void svd_identity_kernel(cplx* V, int cols) {
@@ -213,8 +220,8 @@ hipError_t launch_svd_identity(void* V, int cols, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, int* rotations, hipStream_t s) {
-    jacobi_round_kernel<<<npairs, kSvdThreads, 0, s>>>(static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols,
-                                                       static_cast<const int2*>(pairs), tol, rotations);
+    jacobi_round_kernel<<<(npairs + kSvdThreads / 64 - 1) / (kSvdThreads / 64), kSvdThreads, 0, s>>>(
+        static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols, static_cast<const int2*>(pairs), npairs, tol, rotations);
     return hipGetLastError();
 }
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s) {

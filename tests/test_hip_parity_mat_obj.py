@@ -204,3 +204,36 @@ def test_zgemm_entry_point():
     assert maxdiff(zgemm(a, b), a @ b) < 1e-12
     c = rng.standard_normal((70, 5)) + 1j * rng.standard_normal((70, 5))
     assert maxdiff(zgemm(a, c, conj_trans_a=True), a.conj().T @ c) < 1e-12
+
+
+@pytest.mark.parametrize("ent", ["cx", "cz", "cp"])
+def test_matrix_gradient_equals_parameter_shift(ent):
+    """The reference's own check of grad_of_matrix_dot_product (test_core_op_matrix.py:114-140,305-336): every
+    rotation angle obeys df/dt = (f(t + pi/2) - f(t - pi/2)) / 2 ... in the reference's form: shift pi, scale 1/4
+    for half-angle rotations; the CPhase angle: shift pi/2, scale 1/2 -- evaluated with the HIP path itself."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd import core_op_matrix as com
+
+    n, k = 4, 5
+    rng = np.random.default_rng(31)
+    blocks = np.stack([rng.permutation(n)[:2] for _ in range(6)], axis=1).astype(np.int64)
+    circ = ParametricCircuit(n, ent, blocks)
+    th = orc.rand_thetas(circ.num_thetas, rng)
+    x = rng.standard_normal((1 << n, k)) + 1j * rng.standard_normal((1 << n, k))
+    y = rng.standard_normal((1 << n, k)) + 1j * rng.standard_normal((1 << n, k))
+
+    def f(t):   # <V(t) X | Y>_F
+        return np.vdot(com.v_mul_mat(circ, t, x.copy()), y)
+
+    g = com.grad_of_matrix_dot_product(circ, th, x.copy(), com.v_dagger_mul_mat(circ, th, y.copy()))
+    tpb = 5 if ent == "cp" else 4
+    for t in range(circ.num_thetas):
+        is_cp_angle = ent == "cp" and t >= 3 * n and (t - 3 * n) % tpb == 4
+        e = np.zeros_like(th)
+        if is_cp_angle:     # f is a*e^{i t} + b in the CPhase angle: derivative = (f(t + pi/2) - f(t - pi/2)) / 2
+            e[t] = np.pi / 2
+            shift = (f(th + e) - f(th - e)) / 2
+        else:               # half-angle rotation: f = a cos(t/2) + b sin(t/2): derivative = (f(t + pi) - f(t - pi)) / 4
+            e[t] = np.pi
+            shift = (f(th + e) - f(th - e)) / 4
+        assert abs(shift - g[t]) < 1e-9 * max(1.0, abs(g[t]))

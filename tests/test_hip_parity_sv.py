@@ -345,3 +345,41 @@ def test_large_state_24_qubits_properties():
             f.append(ws.eval((th + e)[None, :], gather=True, grad=False)[0][0, 0])
         assert abs((f[0] - f[1]) / 2e-5 - g[0, t]) < 1e-8
     ws.close()
+
+
+@pytest.mark.parametrize("kind", ["cx", "cp", "trotter2"])
+def test_gradient_vs_numeric_taylor_order(kind):
+    """The reference's gradient harness (utils_dot_gradient_test.py:166-305): analytic gradient of the real
+    objective against central differences with steps tau = 0.25 * 2^-k -- the relative errors fall, the last ones
+    are <= 1e-5, and the Taylor residual |f(t + tau d) - f(t) - tau <g, d>| shrinks with order ~2."""
+    from aqc_research_amd import core_operations as cop
+
+    n = 5
+    rng = np.random.default_rng(55)
+    if kind == "trotter2":
+        a = orc.Ansatz(n, "cx", orc.trotter_blocks(n, 1), True, True)
+    else:
+        a = orc.Ansatz(n, kind, np.stack([rng.permutation(n)[:2] for _ in range(8)], axis=1).astype(np.int64))
+    circ = make_circ(a)
+    th = orc.rand_thetas(a.num_thetas, rng)
+    x, y = orc.rand_state(n, rng), orc.rand_state(n, rng)
+    ws = np.zeros((4, 1 << n), complex)
+
+    def fobj(t):   # 1 - |<V x|y>|^2
+        return 1.0 - abs(np.vdot(cop.v_mul_vec(circ, t, x, np.zeros_like(x), ws), y)) ** 2
+
+    vhy = cop.v_dagger_mul_vec(circ, th, y, np.zeros_like(y), ws)
+    h = np.vdot(x, vhy)                                       # <V x|y> = <x|V^H y>
+    grad = (-2 * np.conj(h) * cop.grad_of_dot_product(circ, th, x, vhy, ws)).real   # objective_lhs_sur_max.py:160-170 form
+    d = rng.standard_normal(th.size)
+    d /= np.linalg.norm(d)
+    f0 = fobj(th)
+    taus = [0.25 * 2.0 ** -k for k in range(4, 12)]
+    rel, resid = [], []
+    for tau in taus:
+        fd = (fobj(th + tau * d) - fobj(th - tau * d)) / (2 * tau)
+        rel.append(abs(fd - grad @ d) / max(abs(grad @ d), 1e-12))
+        resid.append(abs(fobj(th + tau * d) - f0 - tau * (grad @ d)))
+    assert max(rel[-4:]) <= 1e-5
+    orders = [np.log2(resid[i] / resid[i + 1]) for i in range(3)]   # largest steps: far from round-off
+    assert all(1.8 <= o <= 2.2 for o in orders), orders

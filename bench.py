@@ -155,8 +155,8 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=0, help="independent evaluations resident per GPU (default: 64 state vectors / 8 matrices)")
     ap.add_argument("--workload", default="sv16_l40", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,12 +221,12 @@ def main():
                             for _ in range(B)])
         ws.upload(BUF_Y, targets)
         ws.set_identity(BUF_X)
-    nsets = K + W
+    nsets = min(K + W, 64)       # thetas change every step (nothing is served from a cache); the bank is cycled
     bank = np.pi * (2 * rng.random((nsets, B, T)) - 1)
     ws.theta_bank(bank)
 
     def step(i):
-        ws.use_theta_set(i)
+        ws.use_theta_set(i % nsets)
         ws.apply(True, BUF_Y, BUF_Z)
         if ncols == 1:
             ws.gather_launch(BUF_Z)       # hs = <state_i|V^H|target>

@@ -478,12 +478,15 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     int ka = tile_bits_apply > 0 ? tile_bits_apply : env_int("AQC_TILE_BITS_APPLY", 0);
     int ks = tile_bits_sweep > 0 ? tile_bits_sweep : env_int("AQC_TILE_BITS_SWEEP", 0);
     const int force_v2 = env_int("AQC_KERNEL_V2", -1);
+    // Measured on MI355X (tools/tune.py mid / b1k): the register-blocked kernels pay off once 2^12-amplitude tiles x
+    // lanes give every CU two workgroups (>= 512); below that the per-group kernels win, best with ~512 workgroups but
+    // never with tiles under 2^10 (every extra stage is an extra launch and an extra HBM round trip).
     const size_t big_tiles = (size_t)batch << std::max(0, ws->nbits - 12);
-    const bool want_v2 = force_v2 >= 0 ? force_v2 != 0 : big_tiles >= 256;
+    const bool want_v2 = force_v2 >= 0 ? force_v2 != 0 : big_tiles >= 512;
     auto pick = [&](int kmax) {
-        int k = std::min(kmax, ws->nbits);
-        if (!want_v2)
-            while (k > 8 && ((size_t)batch << (ws->nbits - k)) < 256) --k;
+        if (want_v2) return std::min(kmax, ws->nbits);
+        int k = std::min(11, ws->nbits);
+        while (k > 10 && ((size_t)batch << (ws->nbits - k)) < 512) --k;
         return k;
     };
     if (ka <= 0) ka = pick(13);

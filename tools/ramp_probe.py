@@ -13,7 +13,7 @@ tg = rng.random((B, 1 << n)) + 1j * rng.random((B, 1 << n))
 ws.upload(BUF_Y, tg / np.linalg.norm(tg, axis=1, keepdims=True)); ws.set_basis(BUF_X, 0); ws.gather_setup(np.arange(n + 1))
 ws.theta_bank(np.pi * (2 * rng.random((4, B, circ.num_thetas)) - 1))
 t_start = time.perf_counter()
-for chunk in range(40):
+for chunk in range(int(os.environ.get("CHUNKS", 40))):
     ws.sync(); t0 = time.perf_counter()
     for i in range(25):
         ws.use_theta_set(i % 4); ws.apply(True, BUF_Y, BUF_Z); ws.gather_launch(BUF_Z); ws.grad(None, True)

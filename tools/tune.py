@@ -97,3 +97,17 @@ if __name__ == "__main__":
             cfgs.append({"env": {"AQC_KERNEL_V2": 1, "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": r}, "ks": ks, "ka": ka})
         print("n=16 L=40 B=1"); run(B=1, configs=cfgs, steps=50)
         print("n=12 trotter2 B=1"); run(n=12, B=1, configs=cfgs, steps=50, trotter_layers=2)
+    elif which == "mid":    # family / tile choice for middling batch sizes
+        for B in (2, 4, 8, 16, 32):
+            cfgs = [{"env": {"AQC_KERNEL_V2": "", "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": 4}, "ks": 0, "ka": 0}]   # automatic choice
+            for v2, ks, ka in ((0, 8, 8), (0, 9, 9), (0, 10, 10), (0, 11, 11), (1, 10, 11), (1, 11, 12), (1, 12, 13)):
+                cfgs.append({"env": {"AQC_KERNEL_V2": v2, "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": 4}, "ks": ks, "ka": ka})
+            print(f"n=16 L=40 B={B}"); run(B=B, configs=cfgs, steps=30)
+    elif which == "b1k":
+        cfgs = [{"env": {"AQC_KERNEL_V2": "", "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": 4}, "ks": 0, "ka": 0}]
+        for ks, ka in ((8, 8), (9, 9), (10, 10), (9, 10), (10, 9), (8, 9), (11, 11)):
+            cfgs.append({"env": {"AQC_KERNEL_V2": 0, "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": 4}, "ks": ks, "ka": ka})
+        print("n=16 L=40 B=1"); run(B=1, configs=cfgs, steps=50)
+        print("n=12 trotter2 B=1"); run(n=12, B=1, configs=cfgs, steps=50, trotter_layers=2)
+        print("n=20 L=40 B=1"); run(n=20, B=1, configs=cfgs[:1] + [{"env": {"AQC_KERNEL_V2": v2, "AQC_THREADS": 0, "AQC_SWEEP_REG_BITS": 4}, "ks": ks, "ka": ka}
+                                                                   for v2, ks, ka in ((0, 10, 10), (0, 11, 11), (0, 12, 12), (1, 12, 13))], steps=20)

@@ -447,7 +447,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     if (!out) return fail("out pointer is null");
     *out = nullptr;
     if (!ctx) return fail("null context");
-    if (batch < 1) return fail("batch must be >= 1");
+    if (batch < 1 || batch > 65535) return fail("batch must be in [1, 65535] (lanes are the y dimension of the launch grid)");
     if (ncols < 1) return fail("ncols must be >= 1");
     const Program& prog = ctx->prog;
     int ndev = 0;

@@ -1,0 +1,203 @@
+"""
+Multi-start optimisation at kernel speed: B independent state-preparation problems that share one ansatz
+(the seeds / restarts / targets of one time horizon -- config 4 of BASELINE.json) are evaluated as the B lanes of
+one workspace AND optimised by one vectorised L-BFGS, so the host does O(1) NumPy work per iteration instead of
+B Python optimizer loops (``lockstep.py`` keeps the per-job scipy optimizers and is host-bound at ~6 k evals/s).
+
+``BatchedSurrogateObjective`` is the lane-vectorised form of ``SpSurrogateObjectiveMax`` (objective_lhs_sur_max.py:
+82-191: surrogate ``1 - (1-w)|h_0|^2 - w|h_max|^2`` over the flip states, 10 % hysteresis of the leading state,
+exponentially smoothed weight); ``batched_lbfgs`` is a standard L-BFGS (two-loop recursion, memory m, Armijo
+backtracking) written over arrays of shape (B, T).  The optimizer trajectory is not the reference's (that one is
+scipy's L-BFGS-B behind a Qiskit wrapper and is not pinned by anything); what is checked is that every
+lane reaches the fidelity scipy reaches on the same problem.
+"""
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+from .engine import BUF_X, BUF_X2, BUF_Y, HipContext, Workspace
+from .model_sp_lhs.objective_base import ThinStateHandler
+
+__all__ = ["BatchedSurrogateObjective", "batched_lbfgs"]
+
+
+class BatchedSurrogateObjective:
+    """B lanes of the surrogate state-preparation objective on one workspace.  ``targets``: (B, 2^n) complex128;
+    ``base_index``: computational-basis preparation (e.g. the Neel pattern) shared by all lanes."""
+
+    _gamma = 0.1  # objective_lhs_sur_max.py:40
+
+    def __init__(self, circ, targets: np.ndarray, *, max_flips: int = 1, base_index: int = 0,
+                 block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, device: int = 0):
+        targets = np.ascontiguousarray(targets, dtype=np.complex128)
+        if targets.ndim != 2 or targets.shape[1] != circ.dimension:
+            raise ValueError("targets must have shape (lanes, 2^n)")
+        self.circ, self.batch, self.T = circ, targets.shape[0], circ.num_thetas
+        self._states = ThinStateHandler(circ.num_qubits, max_flips, base_index=base_index)
+        self._idx = np.asarray(self._states.state_indices, dtype=np.int64)
+        self._block_range = None if block_range is None else (int(block_range[0]), int(block_range[1]))
+        self._front = bool(front_layer or block_range is None or tuple(block_range) == (0, circ.num_blocks))
+        self.ws = Workspace(HipContext.of(circ), batch=self.batch, ncols=1, device=device)
+        self.ws.upload(BUF_Y, targets)
+        self.ws.set_basis(BUF_X, int(self._idx[0]))
+        self.ws.gather_setup(self._idx)
+        self.weight = np.ones(self.batch)
+        self.max_no = np.zeros(self.batch, dtype=np.int64)
+        self.fidelity = np.full(self.batch, -1.0)
+        self.num_evals = 0
+
+    def value_and_grad(self, thetas: np.ndarray, update_state: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """f[B], g[B][T] at thetas[B][T].  ``update_state=False`` evaluates with the current weights / leading states
+        without touching them (line-search trials); ``True`` first applies the hysteresis and the weight smoothing --
+        once per accepted step, as an objective()/gradient() pair does -- and evaluates under the new state."""
+        th = np.ascontiguousarray(thetas, dtype=np.float64).reshape(self.batch, self.T)
+        hs, g0 = self.ws.eval(th, vdag=True, gather=True, grad=True, x_buf=BUF_X, block_range=self._block_range,
+                              front_layer=self._front)
+        self.num_evals += self.batch
+        return self._assemble(hs, g0, None, update_state)
+
+    def _assemble(self, hs, g0, gm_in, update_state: bool):
+        """Value and gradient from the device results (hs, g0[, gm]) under the current / the updated state; keeps the
+        raw results so that ``commit`` can re-assemble accepted trial points without another device evaluation."""
+        hs2 = np.abs(hs) ** 2
+        lanes = np.arange(self.batch)
+        max_no = self.max_no
+        if update_state:   # 10 % hysteresis (objective_lhs_sur_max.py:113-117), lane-wise
+            max_no = self.max_no.copy()
+            best = hs2[lanes, max_no]
+            for i in range(hs2.shape[1]):
+                better = 1.1 * best < hs2[:, i]
+                best = np.where(better, hs2[:, i], best)
+                max_no = np.where(better, i, max_no)
+        w = self.weight
+        if update_state:   # smoothed weight from the value under the old one (objective_lhs_sur_max.py:186); the value and
+            f_old = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[lanes, max_no]          # gradient returned below use the NEW
+            w = w + self._gamma * (np.sqrt(np.abs(f_old)) - w)                   # state, so that all trial points of the
+            self.max_no, self.weight, self.fidelity = max_no, w, hs2[:, 0].copy()  # next line search see one function
+        f = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[lanes, max_no]
+        h0 = hs[:, 0]
+        lead = max_no != 0
+        grad = np.where(lead[:, None], (g0 * (-2.0 * (1.0 - w) * np.conj(h0))[:, None]).real,
+                        (g0 * (-2.0 * np.conj(h0))[:, None]).real)
+        gm = gm_in
+        if lead.any():     # second sweep from the leading flip state, only where it is not |state_0>
+            if gm is None:
+                self.ws.set_basis(BUF_X2, self._idx[max_no])
+                _, gm = self.ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=self._block_range,
+                                     front_layer=self._front)
+                self._gm_states = max_no.copy()
+            hm = hs[lanes, max_no]
+            grad = grad + np.where(lead[:, None], (gm * (-2.0 * w * np.conj(hm))[:, None]).real, 0.0)
+        self.last_raw = (hs, g0, gm, max_no.copy())
+        return f, grad
+
+    def commit(self, rows_hs: np.ndarray, rows_g0: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """State update (hysteresis + weight smoothing) at points whose device results are already known -- the trial
+        points a line search accepted, lane by lane -- and the value / gradient under the new state, assembled on the
+        host.  Returns None when some lane would lead with a flip state other than |state_0>: its second sweep depends
+        on the state chosen now, so the caller evaluates on the device instead."""
+        hs2 = np.abs(rows_hs) ** 2
+        lanes = np.arange(self.batch)
+        probe = self.max_no.copy()
+        best = hs2[lanes, probe]
+        for i in range(hs2.shape[1]):
+            better = 1.1 * best < hs2[:, i]
+            best = np.where(better, hs2[:, i], best)
+            probe = np.where(better, i, probe)
+        if (probe != 0).any():
+            return None            # caller re-evaluates on the device
+        return self._assemble(rows_hs, rows_g0, None, True)
+
+    def close(self) -> None:
+        self.ws.close()
+
+
+def batched_lbfgs(fun: Callable[[np.ndarray, bool], Tuple[np.ndarray, np.ndarray]], x0: np.ndarray, *, maxiter: int = 100,
+                  memory: int = 10, gtol: float = 1e-7, ftol: float = 1e-12, c1: float = 1e-4, max_backtracks: int = 12,
+                  stop: Optional[Callable[[np.ndarray, np.ndarray], np.ndarray]] = None) -> Dict:
+    """Minimises B functions at once: ``fun(x[B][T], update_state) -> (f[B], g[B][T])``.  Lanes that converged keep
+    being evaluated at their final point (the batch is evaluated as a whole anyway) but no longer move.
+    ``stop(f, x) -> bool[B]`` is an optional extra per-lane stopping rule (e.g. a fidelity threshold)."""
+    x = np.array(x0, dtype=np.float64)
+    B, T = x.shape
+    f, g = fun(x, True)
+    S = np.zeros((memory, B, T))
+    Y = np.zeros((memory, B, T))
+    rho = np.zeros((memory, B))
+    count = 0
+    active = np.ones(B, dtype=bool)
+    nit = np.zeros(B, dtype=np.int64)
+    nfev = 1
+    lanes = np.arange(B)
+    for _ in range(maxiter):
+        active &= np.max(np.abs(g), axis=1) > gtol
+        if stop is not None:
+            active &= ~stop(f, x)
+        if not active.any():
+            break
+        # two-loop recursion, all lanes at once
+        q = g.copy()
+        k = min(count, memory)
+        alpha = np.zeros((k, B))
+        for j in range(k - 1, -1, -1):
+            slot = (count - k + j) % memory
+            alpha[j] = rho[slot] * np.einsum("bt,bt->b", S[slot], q)
+            q -= alpha[j][:, None] * Y[slot]
+        if k:
+            last = (count - 1) % memory
+            yy = np.einsum("bt,bt->b", Y[last], Y[last])
+            gamma = np.where((yy > 0) & (rho[last] > 0), 1.0 / np.where(rho[last] * yy > 0, rho[last] * yy, 1.0), 1.0)
+            q *= gamma[:, None]
+        else:
+            q /= np.maximum(np.linalg.norm(g, axis=1), 1.0)[:, None]      # first step: at most unit length
+        for j in range(k):
+            slot = (count - k + j) % memory
+            beta = rho[slot] * np.einsum("bt,bt->b", Y[slot], q)
+            q += (alpha[j] - beta)[:, None] * S[slot]
+        d = -q
+        slope = np.einsum("bt,bt->b", g, d)
+        bad = slope >= 0                                                  # not a descent direction: steepest descent
+        d[bad] = -g[bad]
+        slope[bad] = -np.einsum("bt,bt->b", g[bad], g[bad])
+        # Armijo backtracking, lane-wise step lengths; trial evaluations do not touch the objective's state
+        step = np.where(active, 1.0, 0.0)
+        done = ~active
+        f_new, g_new, x_new = f.copy(), g.copy(), x.copy()
+        owner = getattr(fun, "__self__", None)          # objectives that expose their raw device results can commit
+        raw_hs = raw_g0 = None                          # accepted trial points on the host (no second evaluation)
+        can_commit = owner is not None and hasattr(owner, "commit") and getattr(owner, "last_raw", None) is not None
+        if can_commit:
+            raw_hs, raw_g0 = owner.last_raw[0].copy(), owner.last_raw[1].copy()   # rows of lanes that do not move
+        for _bt in range(max_backtracks):
+            trial = x + step[:, None] * d
+            ft, gt = fun(trial, False)
+            nfev += 1
+            ok = (~done) & (ft <= f + c1 * step * slope)
+            f_new[ok], g_new[ok], x_new[ok] = ft[ok], gt[ok], trial[ok]
+            if can_commit:
+                raw_hs[ok], raw_g0[ok] = owner.last_raw[0][ok], owner.last_raw[1][ok]
+            done |= ok
+            if done.all():
+                break
+            step = np.where(done, step, 0.5 * step)
+        moved = done & active & (x_new != x).any(axis=1)
+        # accepted points: the state update (hysteresis / weight smoothing) happens here, once per step
+        acc = owner.commit(raw_hs, raw_g0) if can_commit else None
+        if acc is None:
+            acc = fun(x_new, True)
+            nfev += 1
+        f_acc, g_acc = acc
+        s = x_new - x
+        y = g_acc - g
+        sy = np.einsum("bt,bt->b", s, y)
+        good = moved & (sy > 1e-12 * np.einsum("bt,bt->b", y, y))
+        slot = count % memory
+        S[slot] = np.where(good[:, None], s, 0.0)
+        Y[slot] = np.where(good[:, None], y, 0.0)
+        rho[slot] = np.where(good, 1.0 / np.where(good, sy, 1.0), 0.0)
+        count += 1
+        small = np.abs(f - f_acc) <= ftol * np.maximum(1.0, np.abs(f))
+        nit += active
+        active &= moved & ~small
+        x, f, g = x_new, f_acc, g_acc
+    return {"x": x, "fun": f, "jac": g, "nit": nit, "nfev": nfev, "lanes_converged": ~active, "lanes": lanes}

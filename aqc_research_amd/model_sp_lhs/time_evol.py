@@ -33,6 +33,7 @@ class UserOptions:
         self.device = 0
         self.num_seeds = 1                 # random restarts per horizon (lockstep lanes of one workspace)
         self.theta_jitter = 0.1            # restart s > 0 starts from Trotter angles + jitter * pi * U(-1, 1)
+        self.vectorised_lbfgs = False      # restarts driven by ONE vectorised L-BFGS (batched_optimizer.py) instead of scipy per lane
         self.__dict__.update(kw)
 
 
@@ -93,6 +94,22 @@ def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
         return {"restart": s, "fidelity": float(res["fidelity"]), "cost": float(res["cost"]),
                 "num_iters": int(res["num_iters"]), "num_fun_ev": int(res["num_fun_ev"]), "thetas": res["thetas"]}
 
+    if opts.vectorised_lbfgs:   # all restarts as lanes of one batched objective, one optimizer for all of them
+        from ..batched_optimizer import BatchedSurrogateObjective, batched_lbfgs
+
+        starts = np.tile(trotter_thetas, (opts.num_seeds, 1))
+        for s in range(1, opts.num_seeds):
+            rng = np.random.default_rng(opts.seed + 1000 * h + 7 * (s + 1))
+            starts[s] += opts.theta_jitter * np.pi * (2.0 * rng.random(trotter_thetas.size) - 1.0)
+        bo = BatchedSurrogateObjective(circ, np.tile(target, (opts.num_seeds, 1)), base_index=neel, device=opts.device)
+        res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= opts.fidelity_thr)
+        fids = bo.fidelity.copy()
+        evals = bo.num_evals
+        bo.close()
+        best = int(np.argmax(fids))
+        return {"horizon": h, "evol_time": evol_time, "num_layers": circ.num_layers, "num_thetas": circ.num_thetas,
+                "fidelity": float(fids[best]), "cost": float(res["fun"][best]), "thetas": res["x"][best].copy(), "best_restart": best,
+                "fidelities": [float(v) for v in fids], "num_fun_ev": int(evals)}
     recs = run_jobs_lockstep(circ, [{} for _ in range(opts.num_seeds)], opts.seed + 1000 * h, restart,
                              nlanes=min(64, opts.num_seeds), device=opts.device)
     ok = [r for r in recs if r["status"] == "ok"]

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""S independent state-preparation optimisations that share an ansatz: scipy L-BFGS one after the other, the same in
+lockstep (lockstep.py), and the vectorised multi-start L-BFGS on the batched objective (batched_optimizer.py)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective, batched_lbfgs  # noqa: E402
+from aqc_research_amd.lockstep import LockstepBatch  # noqa: E402
+from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax  # noqa: E402
+from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index, trotter_ansatz, trotter_state  # noqa: E402
+from aqc_research_amd.optimizer import AqcOptimizer  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+maxiter = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+circ = trotter_ansatz(n, 2, True)
+neel = neel_state_index(n)
+rng = np.random.default_rng(3)
+base = trotter_state(n, evol_time=1.2, num_steps=6, delta=1.0, second_order=True)
+th_t = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=1.2, delta=1.0)
+targets, starts = [], []
+for j in range(S):
+    pert = base + 0.05 * (rng.standard_normal(base.size) + 1j * rng.standard_normal(base.size)) / np.sqrt(base.size)
+    targets.append(pert / np.linalg.norm(pert))
+    starts.append(th_t + 0.05 * rng.standard_normal(th_t.size))
+targets, starts = np.stack(targets), np.stack(starts)
+
+
+def optimise(target, th0, workspace=None):
+    user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: neel, enable_optim_stats=False, verbose=0, maxiter=maxiter)
+    if workspace is not None:
+        user["workspace"] = workspace
+    objv = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+    objv.set_target(target)
+    res = AqcOptimizer(optimizer_name="lbfgs", maxiter=maxiter).optimize(objv, circ, th0)
+    return res["fidelity"], res["num_fun_ev"]
+
+
+optimise(targets[0], starts[0])
+t0 = time.perf_counter()
+seq = [optimise(targets[j], starts[j]) for j in range(S)]
+t_seq = time.perf_counter() - t0
+batch = LockstepBatch(circ, nlanes=S)
+t0 = time.perf_counter()
+lock = batch.run([(lambda view, j=j: optimise(targets[j], starts[j], workspace=view)) for j in range(S)])
+t_lock = time.perf_counter() - t0
+batch.close()
+bo = BatchedSurrogateObjective(circ, targets, base_index=neel)
+bo.value_and_grad(starts, update_state=False)
+t0 = time.perf_counter()
+res = batched_lbfgs(bo.value_and_grad, starts, maxiter=maxiter)
+t_bat = time.perf_counter() - t0
+fid = bo.fidelity
+print(f"n={n} T={circ.num_thetas} jobs={S} maxiter={maxiter}")
+print(f"  scipy, one after the other: {t_seq:.3f} s, mean fidelity {np.mean([r[0] for r in seq]):.6f} ({sum(r[1] for r in seq)} evaluations)")
+print(f"  scipy in lockstep lanes   : {t_lock:.3f} s, mean fidelity {np.mean([r[0] for r in lock]):.6f}")
+print(f"  vectorised L-BFGS         : {t_bat:.3f} s, mean fidelity {fid.mean():.6f}, min {fid.min():.6f} ({bo.num_evals} lane evaluations, "
+      f"{bo.num_evals / t_bat:,.0f} evals/s, {int(res['nit'].max())} iterations)")
+print(f"  speed-up vs sequential {t_seq / t_bat:.1f}x, vs lockstep {t_lock / t_bat:.1f}x")
+bo.close()

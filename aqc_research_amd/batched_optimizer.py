@@ -18,7 +18,7 @@ import numpy as np
 from .engine import BUF_X, BUF_X2, BUF_Y, HipContext, Workspace
 from .model_sp_lhs.objective_base import ThinStateHandler
 
-__all__ = ["BatchedSurrogateObjective", "batched_lbfgs"]
+__all__ = ["BatchedSurrogateObjective", "BatchedSketchingObjective", "batched_lbfgs"]
 
 
 class BatchedSurrogateObjective:
@@ -201,3 +201,38 @@ def batched_lbfgs(fun: Callable[[np.ndarray, bool], Tuple[np.ndarray, np.ndarray
         active &= moved & ~small
         x, f, g = x_new, f_acc, g_acc
     return {"x": x, "fun": f, "jac": g, "nit": nit, "nfev": nfev, "lanes_converged": ~active, "lanes": lanes}
+
+
+class BatchedSketchingObjective:
+    """B lanes of the full-range AQC objective ``1 - Re<V, U_b>/d`` (``SketchingObjectiveEx`` +
+    ``FullRangeSketchingVectors``, sk_core.py:167-326): random restarts and / or different target unitaries on one
+    workspace.  ``targets``: (B, d, d) complex128, or (d, d) shared by all ``lanes``."""
+
+    def __init__(self, circ, targets: np.ndarray, lanes: Optional[int] = None, device: int = 0):
+        t = np.ascontiguousarray(targets, dtype=np.complex128)
+        d = circ.dimension
+        if t.shape == (d, d):
+            if not lanes:
+                raise ValueError("give the number of lanes for a shared target")
+            t = np.ascontiguousarray(np.broadcast_to(t, (int(lanes), d, d)))
+        if t.ndim != 3 or t.shape[1:] != (d, d):
+            raise ValueError("targets must have shape (lanes, 2^n, 2^n)")
+        self.circ, self.batch, self.T, self._d = circ, t.shape[0], circ.num_thetas, d
+        self.ws = Workspace(HipContext.of(circ), batch=self.batch, ncols=d, device=device)
+        self.ws.upload(BUF_Y, t)
+        self.ws.set_identity(BUF_X)
+        self.num_evals = 0
+
+    def value_and_grad(self, thetas: np.ndarray, update_state: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        from .engine import BUF_Z
+
+        th = np.ascontiguousarray(thetas, dtype=np.float64).reshape(self.batch, self.T)
+        self.ws.set_thetas(th)
+        self.ws.apply(True, BUF_Y, BUF_Z)                       # V^H U            (sk_core.py:191)
+        trace = self.ws.vdot(BUF_X, BUF_Z)                      # <I|V^H U>        (:192)
+        self.ws.grad(None, True)                                # sweep            (:193)
+        self.num_evals += self.batch
+        return 1.0 - trace.real / self._d, -self.ws.get_grads().real / self._d
+
+    def close(self) -> None:
+        self.ws.close()

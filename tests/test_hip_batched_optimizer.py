@@ -92,3 +92,31 @@ def test_asp_driver_with_vectorised_restarts():
     for s, m in zip(single, multi):
         assert len(m["fidelities"]) == 6 and m["thetas"].shape == (m["num_thetas"],)
         assert m["fidelity"] > s["fidelity"] - 5e-3 and m["fidelity"] > 0.9
+
+
+def test_batched_aqc_restarts_recover_planted_unitaries():
+    """Full-range AQC objective over lanes: first evaluation == the oracle's objective and gradient per lane; the
+    vectorised L-BFGS then compiles every planted unitary from a perturbed start."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.batched_optimizer import BatchedSketchingObjective, batched_lbfgs
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+
+    n, lanes = 3, 5
+    rng = np.random.default_rng(9)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", 14))
+    a = orc.as_ansatz(circ)
+    eye = np.eye(1 << n, dtype=complex)
+    truth = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(lanes)])
+    targets = np.stack([orc.v_mul_mat(a, t, eye) for t in truth])
+    starts = truth + 0.1 * rng.standard_normal(truth.shape)
+    bo = BatchedSketchingObjective(circ, targets)
+    f, g = bo.value_and_grad(starts)
+    for b in range(lanes):
+        fr, gr = orc.sketching_objective_and_gradient(a, starts[b], eye, targets[b])
+        assert abs(f[b] - fr) < TOL and maxdiff(g[b], gr) < TOL
+    res = batched_lbfgs(bo.value_and_grad, starts, maxiter=300, gtol=1e-9)
+    bo.close()
+    assert np.all(res["fun"] < 1e-6)
+    for b in range(lanes):
+        v = orc.v_mul_mat(a, res["x"][b], eye)
+        assert abs(np.vdot(v, targets[b])) / (1 << n) > 1 - 1e-6

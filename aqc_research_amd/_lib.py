@@ -24,6 +24,7 @@ _D = POINTER(c_double)
 SIGNATURES = {
     "aqc_version": (c_char_p, []),
     "aqc_last_error": (c_char_p, []),
+    "aqc_device_count": (c_int, []),
     "aqc_create": (c_int, [c_int, c_int, POINTER(c_int32), c_int, c_int, c_int, POINTER(_P)]),
     "aqc_destroy": (c_int, [_P]),
     "aqc_num_thetas": (c_int, [_P]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "aqc_ws_profile_get": (c_int, [_P, c_int, POINTER(c_int64), POINTER(c_double)]),
     "aqc_ws_profile_reset": (c_int, [_P]),
     "aqc_ws_plan_info": (c_int, [_P, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "aqc_ws_kernel_family": (c_int, [_P, c_int]),
     "aqc_plan_query": (
         c_int,
         [_P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],

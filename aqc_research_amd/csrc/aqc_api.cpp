@@ -397,6 +397,11 @@ extern "C" {
 const char* aqc_version(void) { return "aqc_hip 0.1.0 (gfx950)"; }
 const char* aqc_last_error(void) { return g_error.c_str(); }
 
+int aqc_device_count(void) {
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+}
+
 int aqc_create(int num_qubits, int entangler, const int32_t* blocks, int num_blocks, int trotter, int second_order,
                aqc_ctx** out) {
     if (!out) return fail("out pointer is null");
@@ -477,7 +482,11 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     const int low_bits = env_int("AQC_LOW_BITS", 3);
     int ka = tile_bits_apply > 0 ? tile_bits_apply : env_int("AQC_TILE_BITS_APPLY", 0);
     int ks = tile_bits_sweep > 0 ? tile_bits_sweep : env_int("AQC_TILE_BITS_SWEEP", 0);
-    const int force_v2 = env_int("AQC_KERNEL_V2", -1);
+    // AQC_KERNEL_FAMILY = 1 (per-group) | 2 (register-blocked VALU) forces a family (tests run every family);
+    // AQC_KERNEL_V2 = 0 / 1 is the older spelling of the same switch.
+    const int family = env_int("AQC_KERNEL_FAMILY", 0);
+    if (family < 0 || family > 2) { delete ws; return fail("AQC_KERNEL_FAMILY must be 1 (per-group) or 2 (register-blocked)"); }
+    const int force_v2 = family ? family - 1 : env_int("AQC_KERNEL_V2", -1);
     // Measured on MI355X (tools/tune.py mid / b1k): the register-blocked kernels pay off once 2^12-amplitude tiles x
     // lanes give every CU two workgroups (>= 512); below that the per-group kernels win, best with ~512 workgroups but
     // never with tiles under 2^10 (every extra stage is an extra launch and an extra HBM round trip).
@@ -712,7 +721,9 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
         a.partial = ws->d_partial;
         a.nslots = ws->nslots;
         a.ntiles_max = p.ntiles;
+#ifdef AQC_TUNING   // timing experiments only (tools/tune.py); never part of the shipped library
         a.debug = env_int("AQC_DEBUG_SKIP", 0);
+#endif
         a.from = block_from;
         a.to = block_to;
         a.front = front_layer ? 1 : 0;
@@ -742,6 +753,8 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
         ProfScope ps(ws, AQC_K_COEF);
         HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
         ws->coef_valid = true;
+    } else if ((do_vdag || grads) && ensure_coef(ws)) {
+        return 1;
     }
     if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
     size_t nsm = 0;
@@ -849,6 +862,14 @@ int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count) {
     }
     HIP_OK(hipStreamSynchronize(ws->stream));
     if (ensure_index(ws, count) || ensure_small(ws, (size_t)ws->batch * count)) return 1;
+    if (2 * (size_t)ws->batch * count > ws->pin_small) {   // aqc_ws_eval stages the gathered amplitudes in pinned memory
+        double* pin = nullptr;
+        const size_t want = 2 * (size_t)ws->batch * count;
+        HIP_OK(hipHostMalloc((void**)&pin, sizeof(double) * (ws->pin_thetas + ws->pin_grads + want), hipHostMallocDefault));
+        if (ws->h_pin) HIP_OK(hipHostFree(ws->h_pin));
+        ws->h_pin = pin;
+        ws->pin_small = want;
+    }
     HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     ws->gather_count = count;
@@ -1220,6 +1241,12 @@ int aqc_ws_plan_info(aqc_ws* ws, int which, int* num_stages, int* tile_bits, int
     if (tile_bits) *tile_bits = p.k;
     if (num_tiles) *num_tiles = p.ntiles;
     return 0;
+}
+
+int aqc_ws_kernel_family(aqc_ws* ws, int which) {
+    if (!ws) return -1;
+    const DevPlan& p = which == 0 ? ws->inv : (which == 1 ? ws->sweep : ws->fwd);
+    return p.v2 ? 2 : 1;
 }
 
 // ---- one-shot host-pointer entry points -------------------------------------------------------

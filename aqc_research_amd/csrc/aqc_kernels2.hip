@@ -348,8 +348,10 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
             const DevMop m = a.mops[sub.mop_begin + t];
             const bool on = enabled(m.jblock);
             pend.km = 1 << m.kind;
+#ifdef AQC_TUNING
             if ((a.debug & 1) && m.kind != MOP_REDUCE) pend.km = 1 << 20;
             if ((a.debug & 2) && m.kind == MOP_REDUCE) pend.km = 1 << 20;
+#endif
             if (m.kind == MOP_REDUCE) {
                 pend.pm = m.flags;
                 pend.slots[0] = on ? m.slot : -1; pend.slots[1] = on ? m.p : -1;
@@ -376,7 +378,11 @@ __global__ __launch_bounds__(R == 4 ? 256 : 512) void sweep_stage_kernel2(StageA
     const cplx* sz = a.in1 + lane_off;
     cplx* dw = a.out0 + lane_off;
     cplx* dz = a.out1 + lane_off;
+#ifdef AQC_TUNING
     const int nsubs_run = (a.debug & 4) ? 0 : st->nsubs;   // timing experiment: memory phases only
+#else
+    const int nsubs_run = st->nsubs;
+#endif
     if (nsubs_run == 0) {   // nothing to do in this stage: plain copy
         __syncthreads();
         for (unsigned l = threadIdx.x; l < tsize; l += blockDim.x) {

@@ -13,6 +13,19 @@ from . import _lib
 from ._lib import BUF_W, BUF_X, BUF_X2, BUF_Y, BUF_Z, BUF_ZW, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, check, dptr  # noqa: F401
 
 
+def default_device() -> int:
+    """Device of the function-level drop-ins: ``AQC_DEVICE`` if set, else this process's ``LOCAL_RANK`` (one process
+    per GPU under torch.distributed.run / job_executor), else 0."""
+    import os
+
+    for name in ("AQC_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(name, "")
+        if v.strip().isdigit():
+            # ranks outnumbering the visible GPUs (CPU rehearsals with gloo) share devices round-robin
+            return int(v) % max(1, _lib.lib().aqc_device_count()) if name == "LOCAL_RANK" else int(v)
+    return 0
+
+
 def _structure_key(circ) -> tuple:
     trotter = hasattr(circ, "is_second_order")
     blocks = np.ascontiguousarray(circ.blocks, dtype=np.int32)
@@ -56,8 +69,10 @@ class HipContext:
             ctx = cls._cache[key] = cls(circ)
         return ctx
 
-    def workspace(self, batch: int = 1, ncols: int = 1, device: int = 0, **kw) -> "Workspace":
+    def workspace(self, batch: int = 1, ncols: int = 1, device: Optional[int] = None, **kw) -> "Workspace":
         """Cached workspace for the given shape (function-level drop-ins reuse it)."""
+        if device is None:
+            device = default_device()
         key = (batch, ncols, device, tuple(sorted(kw.items())))
         ws = self._ws.get(key)
         if ws is None:
@@ -130,6 +145,11 @@ class Workspace:
         check(self._L.aqc_ws_broadcast(self.handle, buf, dptr(a)))
 
     def download(self, buf: int, lane: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if out is not None:   # the pointer goes straight to a D2H copy: refuse anything that is not the exact layout
+            want = self._shape() if lane is None else self._shape()[1:]
+            if not (isinstance(out, np.ndarray) and out.dtype == np.complex128 and out.flags.c_contiguous
+                    and out.flags.writeable and out.size == int(np.prod(want))):
+                raise ValueError(f"out must be a writable C-contiguous complex128 array of {int(np.prod(want))} elements")
         if lane is None:
             res = np.empty(self._shape(), dtype=np.complex128) if out is None else out
             check(self._L.aqc_ws_download(self.handle, buf, dptr(res)))
@@ -245,6 +265,18 @@ class Workspace:
         a, b, c = c_int(), c_int(), c_int()
         check(self._L.aqc_ws_plan_info(self.handle, which, byref(a), byref(b), byref(c)))
         return a.value, b.value, c.value
+
+    _FAMILIES = {1: ("valu_fp64", "sweep_stage_kernel"), 2: ("valu_fp64", "sweep_stage_kernel2"), 3: ("mfma", "sweep_mfma_kernel")}
+
+    def kernel_family(self, which: int = 1) -> int:
+        """1 per-gate-group, 2 register-blocked (both fp64 VALU), 3 fp64 matrix cores."""
+        return int(self._L.aqc_ws_kernel_family(self.handle, which))
+
+    def family_name(self) -> str:
+        return self._FAMILIES[self.kernel_family(1)][0]
+
+    def sweep_kernel_name(self) -> str:
+        return self._FAMILIES[self.kernel_family(1)][1]
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -7,7 +7,7 @@ from typing import Tuple
 
 import numpy as np
 
-from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext, zgemm
+from ..engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace, zgemm
 from ..parametric_circuit import ParametricCircuit
 
 
@@ -161,7 +161,11 @@ class SketchingObjectiveEx:
         """Workspace for the circuit's current structure (blocks may be edited between calls)."""
         ctx = HipContext.of(self._circ)
         if self._ws is None or self._structure != ctx.key:
-            self._ws = ctx.workspace(1, self._skvecs.num_skvecs, self._device)
+            # A PRIVATE workspace: X = I and the target stay resident in it between evaluations, so it must not be
+            # the cached one the function-level drop-ins (core_op_matrix) share and overwrite.
+            if self._ws is not None:
+                self._ws.close()
+            self._ws = Workspace(ctx, batch=1, ncols=self._skvecs.num_skvecs, device=self._device)
             self._structure = ctx.key
             if getattr(self._skvecs, "device_resident", False):
                 self._ws.set_identity(BUF_X)
@@ -216,7 +220,9 @@ class SketchingObjectiveEx:
         resident = getattr(self._skvecs, "device_resident", False)
         fresh = self._ws is None or self._structure != ctx.key
         if fresh:
-            self._ws = ctx.workspace(1, c1 - c0, self._device)
+            if self._ws is not None:
+                self._ws.close()
+            self._ws = Workspace(ctx, batch=1, ncols=c1 - c0, device=self._device)   # private, see _workspace
             self._structure = ctx.key
         ws = self._ws
         if fresh or not resident:

@@ -138,7 +138,7 @@ class _Result:
         self.x, self.fun, self.nit, self.nfev, self.njev = x, fun, nit, nfev, njev
 
 
-def _adam(fun, jac, x0, maxiter, lr, beta1=0.9, beta2=0.99, eps=1e-10, tol=1e-6):
+def _adam(fun, jac, x0, maxiter, lr, beta1=0.9, beta2=0.99, eps=1e-8, tol=1e-6):  # Qiskit ADAM: noise_factor 1e-8
     x, m, v = np.array(x0, dtype=float), np.zeros_like(x0, dtype=float), np.zeros_like(x0, dtype=float)
     t = 0
     for t in range(1, maxiter + 1):
@@ -149,7 +149,7 @@ def _adam(fun, jac, x0, maxiter, lr, beta1=0.9, beta2=0.99, eps=1e-10, tol=1e-6)
         x = x - step
         if np.linalg.norm(step) < tol:
             break
-    return _Result(x, float(fun(x)), t, 1, t)
+    return _Result(x, float(fun(x)), t, t, t)   # Qiskit reports nfev = t
 
 
 class AqcOptimizer:
@@ -157,7 +157,7 @@ class AqcOptimizer:
     (optimizer.py:479-628: cost, num_iters, num_fun_ev, num_grad_ev, ini_thetas, thetas, blocks,
     entangler, stats, is_timeout, fidelity)."""
 
-    _optimizers = ["adam", "lbfgs"]
+    _optimizers = ["adam", "lbfgs", "cobyla"]   # bobyqa (scikit-quant, absent here) is not offered
 
     def __init__(self, *, optimizer_name: str = "lbfgs", maxiter: int = 1000, learn_rate: float = 0.1,
                  lbfgs_maxcor: Optional[int] = None, verbose: bool = False):
@@ -181,6 +181,10 @@ class AqcOptimizer:
             objv.set_status_trackers(timeout=timeout, stopper=stopper)
             if self._name == "adam":
                 res = _adam(objv.objective, objv.gradient, thetas_0, self._maxiter, self._lr)
+            elif self._name == "cobyla":   # gradient-free choice of optimizer.py:593 (Qiskit COBYLA wraps scipy's)
+                r = minimize(objv.objective, np.array(thetas_0, dtype=float), method="COBYLA", tol=1e-3,
+                             options={"maxiter": self._maxiter})
+                res = _Result(r.x, float(r.fun), getattr(r, "nit", None) or r.nfev, r.nfev, 0)
             else:
                 opts = {"maxfun": 5 * self._maxiter, "maxiter": self._maxiter}
                 if self._maxcor:

@@ -28,7 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # fp64 vector peak = fp64 matrix (MFMA) peak on gfx950
+PARITY_TOL = 1e-10       # north-star tolerance (complex fp64, absolute)
 
 WORKLOADS = {
     # name: (n, layout, L, kind)
@@ -38,6 +40,11 @@ WORKLOADS = {
     "sv20_trotter2": dict(n=20, layers=2, kind="trotter2", desc="20-qubit ASP, 2nd-order Trotter ansatz (2 layers), state-vector objective+gradient"),
     "mat10_l40": dict(n=10, blocks=40, kind="generic", ncols=1024, desc="10-qubit full-unitary AQC (1024x1024 target), cx spin ansatz L=40, matrix objective+gradient"),
     "mat5_cyc180": dict(n=5, blocks=180, kind="cyclic", ncols=32, desc="5-qubit full AQC (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks), matrix objective+gradient"),
+    # config 3 through the MPS front door: every step re-uploads each lane's target as a QiskitMPS (host tensors),
+    # contracts it to the dense state on the device (mps_to_vector chain) and runs V^H + gather + sweep on it
+    "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=16 uploaded + densified every evaluation"),
+    "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=64 uploaded + densified every evaluation"),
+    "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=256 uploaded + densified every evaluation"),
 }
 
 
@@ -162,6 +169,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("AQC_DEBUG_SKIP"):   # a work-skipping switch of tuning builds: never time with it
+        raise SystemExit("bench.py: AQC_DEBUG_SKIP is set; refusing to time a run that may skip work")
 
     # stdout carries exactly one JSON line: anything libraries print there (RCCL prints a version banner when a
     # communicator is created) is diverted to stderr until the result is written
@@ -205,13 +214,21 @@ def main():
     G = ctx.num_gate_groups
     ncols = w.get("ncols", 1)
     N = (1 << n) * ncols          # complex128 elements per lane
-    B = args.batch if args.batch > 0 else (64 if ncols == 1 else (8 if ncols >= 256 else 64))
+    chi = w.get("chi", 0)
+    B = args.batch if args.batch > 0 else (8 if chi else (64 if ncols == 1 else (8 if ncols >= 256 else 64)))
     K, W = args.steps, args.warmup
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule
     ws = Workspace(ctx, batch=B, ncols=ncols, device=local_rank)
     flip_idx = orc.flip_state_indices(n, 1)
-    if ncols == 1:
+    mps_targets = None
+    if chi:   # lanes cycle through a few distinct random Vidal-form targets (their normalisation is host SVD work)
+        distinct = [orc.random_mps(n, chi, rng) for _ in range(min(B, 2))]
+        mps_targets = [distinct[b % len(distinct)] for b in range(B)]
+        zero_mps = ([(np.ones((1, 1), complex), np.zeros((1, 1), complex)) for _ in range(n)], [np.ones(1) for _ in range(n - 1)])
+        targets = np.stack([orc.mps_to_vector(m) for m in distinct])[[b % len(distinct) for b in range(B)]]
+        ws.gather_setup(flip_idx)
+    elif ncols == 1:
         targets = np.stack([orc.rand_state(n, rng) for _ in range(B)])
         ws.upload(BUF_Y, targets)
         ws.set_basis(BUF_X, 0)  # x = |0>
@@ -227,6 +244,12 @@ def main():
 
     def step(i):
         ws.use_theta_set(i % nsets)
+        if mps_targets is not None:   # QiskitMPS operands arrive from the host on every evaluation (mps_dot_objective.py:41)
+            for b in range(B):
+                ws.mps_upload(0, zero_mps)
+                ws.mps_to_vec(0, BUF_X, b)
+                ws.mps_upload(1, mps_targets[b])
+                ws.mps_to_vec(1, BUF_Y, b)
         ws.apply(True, BUF_Y, BUF_Z)
         if ncols == 1:
             ws.gather_launch(BUF_Z)       # hs = <state_i|V^H|target>
@@ -277,6 +300,27 @@ def main():
         allrec = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
 
+    # ---- the timed work is checked, not assumed: the last step's (hs, gradient) of a few lanes against the C
+    # restatement of the reference algorithm (oracle/aqc_ref.c) on the same (theta, target) --------------------
+    last_th = bank[(W + K - 1) % nsets]
+    check_lanes = sorted(set([0, B // 3, (2 * B) // 3, B - 1]))[: (4 if N <= (1 << 17) else 2)]
+    parity = 0.0
+    from oracle import aqc_ref as cref
+
+    if ncols == 1:
+        for b in check_lanes:
+            h_ref, g_ref = cref.eval_batch(circ, last_th[b][None, :], targets[b], 0, 1)
+            parity = max(parity, abs(hs[b, 0] - h_ref[0]), float(np.abs(grads[b] - g_ref[0]).max()))
+    else:
+        eye = np.eye(1 << n, ncols, dtype=complex)
+        for b in check_lanes[:1]:
+            vhy = cref.v_dagger_mul_mat(circ, last_th[b], targets[b])
+            g_ref = cref.grad_of_matrix_dot_product(circ, last_th[b], eye, vhy)
+            parity = max(parity, abs(hs[b, 0] - np.vdot(eye, vhy)) / ncols, float(np.abs(grads[b] - g_ref).max()) / ncols)
+    if not parity < PARITY_TOL:
+        print(f"bench.py: rank {rank}: timed result deviates from the oracle by {parity:g} (> {PARITY_TOL:g})", file=sys.stderr)
+        os._exit(3)
+
     out = None
     if rank == 0:
         # ---- per-kernel durations on this stream (HIP events around every launch) ----------
@@ -296,13 +340,18 @@ def main():
         sweep_avg_ms = sweep_ms / max(sweep_launches, 1)
         sweep_bytes_per_launch = sweep_bytes_per_step * prof_steps / max(sweep_launches, 1)
         achieved = sweep_bytes_per_launch / (sweep_avg_ms * 1e-3) / 1e9 if sweep_avg_ms > 0 else 0.0
+        # useful fp64 work of the sweep (SURVEY 8d's unfused count per element: two operands 48 / block + 36 / front
+        # qubit, inner products 32 + 24), spread over the sweep's launches of one step
+        sweep_flops_per_step = float(N) * (80.0 * (G - n) + 60.0 * n) * B
+        sweep_flops_per_launch = sweep_flops_per_step * prof_steps / max(sweep_launches, 1)
+        sweep_tflops = sweep_flops_per_launch / (sweep_avg_ms * 1e-3) / 1e12 if sweep_avg_ms > 0 else 0.0
         stages_inv, k_inv, tiles_inv = ws.plan_info(0)
         stages_sw, k_sw, tiles_sw = ws.plan_info(1)
 
         # ---- single-evaluation latency (batch 1, host-visible result each call) ---------------
         latency = None
         latency_rounds = None
-        if not args.no_latency and ncols == 1:
+        if not args.no_latency and ncols == 1 and not chi:
             ws1 = Workspace(ctx, batch=1, device=local_rank)
             ws1.upload(BUF_Y, targets[0])
             ws1.set_basis(BUF_X, 0)
@@ -354,33 +403,46 @@ def main():
                 "num_thetas": T,
                 "gate_groups": G,
                 "batch_per_gpu": B,
-                "path": "state-vector (core_operations)" if ncols == 1 else "matrix (core_op_matrix)",
+                "path": ("MPS front door (mps_dot_objective), dense route" if chi else "state-vector (core_operations)") if ncols == 1 else "matrix (core_op_matrix)",
+                "mps_bond_dimension": chi or None,
                 "columns": ncols,
                 "tile_bits": {"vdag": k_inv, "sweep": k_sw},
                 "launches_per_eval_step": {"vdag": stages_inv, "sweep": stages_sw},
             },
+            # The sweep launches fuse many gate groups per HBM round trip, so what bounds them is fp64 arithmetic, not
+            # HBM: achieved = SURVEY 8(d)'s useful flops of one sweep launch / its average duration (HIP events on the
+            # workspace stream), against the 78.6 TFLOP/s fp64 peak (vector = matrix on gfx950).
             "roofline": {
-                "bound": "hbm",
-                "kernel": "sweep_stage_kernel2" if stages_sw and ws.plan_info(1)[1] >= 4 and B * (N >> 12) >= 256 else "sweep_stage_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "bound": ws.family_name(),
+                "kernel": ws.sweep_kernel_name(),
+                "achieved": sweep_tflops,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": sweep_tflops / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "avg_launch_ms": sweep_avg_ms,
-                "algorithmic_bytes_per_launch": sweep_bytes_per_launch,
-                "note": "algorithmic bytes = 64 B x 2^n x columns x gate groups x lanes per launch (SURVEY 8d); a launch "
-                        "fuses many gate groups in LDS, so achieved may exceed what HBM itself could stream",
+                "flops_per_launch": sweep_flops_per_launch,
             },
+            # byte view of the same launches (information only: SURVEY 8d's per-gate-group byte model is not a lower
+            # bound for a fused launch; `traffic_bytes_per_launch` is the rocprofv3 PMC measurement)
+            "hbm": {
+                "traffic_bytes_per_launch": traffic,
+                "achieved_GBps": (traffic / (sweep_avg_ms * 1e-3) / 1e9) if traffic and sweep_avg_ms > 0 else None,
+                "frac_of_8TBps": (traffic / (sweep_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and sweep_avg_ms > 0 else None,
+                "algorithmic_bytes_per_launch": sweep_bytes_per_launch,
+                "algorithmic_GBps": achieved,
+            },
+            "parity_maxerr": parity,
+            "parity_lanes_checked": len(check_lanes) if ncols == 1 else 1,
+            "debug_skip": os.environ.get("AQC_DEBUG_SKIP", ""),
             # The fused launches are bound by the fp64 vector ALU, not by HBM: SURVEY 8(d)'s unfused flop count
             # (V^H 28 / block + 14 / front qubit, sweep 48 + 36, inner products 32 + 24 per element) against
             # the 78.6 TFLOP/s fp64 peak of MI355X_MICROARCH.md, over the whole evaluation (wall clock).
-            "roofline_fp64": {
-                "bound": "valu_fp64",
+            "fp64_whole_eval": {
                 "achieved": N * (108.0 * (G - n) + 74.0 * n) * value / n_gpus / 1e12,
-                "peak": 78.6,
+                "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": N * (108.0 * (G - n) + 74.0 * n) * value / n_gpus / 1e12 / 78.6,
+                "frac": N * (108.0 * (G - n) + 74.0 * n) * value / n_gpus / 1e12 / FP64_PEAK_TFLOPS,
                 "flops_per_eval": N * (108.0 * (G - n) + 74.0 * n),
             },
             "kernel_ms_per_step": {k: v[1] / prof_steps for k, v in prof.items()},

@@ -42,6 +42,9 @@ enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC
 
 const char* aqc_version(void);
 const char* aqc_last_error(void);
+/* number of visible HIP devices (0 when HIP is unusable); the reference's counterpart is
+ * joblib's worker count, job_executor.py:136-143 */
+int aqc_device_count(void);
 
 /* ---- ansatz description: ParametricCircuit / TrotterAnsatz
  *      (parametric_circuit.py:24-70,267-320; validity rules :234-254,391-423) */
@@ -204,6 +207,8 @@ int aqc_ws_profile_reset(aqc_ws* ws);
 /* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
 int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,
                      int* num_stages, int* tile_bits, int* num_tiles);
+/* kernel family that runs plan `which`: 1 per-gate-group (VALU), 2 register-blocked (VALU), 3 matrix-core (MFMA) */
+int aqc_ws_kernel_family(aqc_ws* ws, int which);
 /* host-only planner introspection (no GPU needed): stage s of plan `which` for the given tiling;
  * ops_out receives gate-group indices (forward program order), bits_out the local address bits */
 int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage,

@@ -32,3 +32,12 @@ def mps_from(d, key, tag):
 
 def maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0
+
+
+def free_port() -> int:
+    """A TCP port that is free right now (rendezvous of the 2-rank tests; avoids collisions between parallel runs)."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]

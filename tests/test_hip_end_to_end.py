@@ -108,6 +108,8 @@ def test_column_sharded_aqc_objective_two_ranks(tmp_path):
     import sys
     import textwrap
 
+    from tests.helpers import free_port
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "shard.py"
     script.write_text(textwrap.dedent(f"""
@@ -138,7 +140,7 @@ def test_column_sharded_aqc_objective_two_ranks(tmp_path):
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
                          capture_output=True, text=True, env=env, timeout=280)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ERR") == 2

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import aqc_oracle as orc
+from tests.helpers import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -53,7 +54,7 @@ def test_run_jobs_gloo_world2(tmp_path):
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", str(script)]
+           "--master-port", str(free_port()), str(script)]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     import json

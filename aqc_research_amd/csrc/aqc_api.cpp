@@ -68,7 +68,17 @@ struct DevPlan {
     DevMop* d_mops = nullptr;
     int k = 0, ntiles = 0, reg_bits = 0;
     bool v2 = false;              // run the register-blocked kernels
+    // matrix-core kernels (family 3)
+    bool v3 = false;
+    std::vector<DevSub3> h_subs3;
+    DevSub3* d_subs3 = nullptr;
+    double* d_umat = nullptr;     // [batch][nsubs][12][64]
+    double2* d_rpart = nullptr;   // sweep plan only: [batch][nsubs][ntiles][256]
+    bool u_valid = false;         // d_umat matches the coefficients in use
+    int family() const { return v3 ? 3 : (v2 ? 2 : 1); }
 };
+
+unsigned swz3_host(unsigned l) { return l ^ ((l >> 4) & 15u) ^ ((l >> 8) & 15u); }
 
 // Micro-ops of one gate group on register bits (pc, pt); forward or conjugate-transposed order.
 // with_dots: the sweep; every group ends with a MOP_REDUCE that folds its inner products.
@@ -81,12 +91,12 @@ void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, bool w
     auto rot = [&](int kind, int p, int pair, int flags, int slot) {
         const int coef = pair < 0 ? konst : rec + kLiftOffset + 2 * pair;
         const bool has = with_dots && slot >= 0;
-        out.push_back({kind, p, 0, flags, coef, has ? slot : -1, g.jblock, 0});
+        out.push_back({kind, p, 0, flags, coef, has ? slot : -1, g.jblock, pair < 0 ? -1 : g.theta0 + pair});
         if (has) dots.push_back({slot, kind});
     };
     auto reduce = [&]() {
         if (dots.empty()) return;
-        DevMop m = {MOP_REDUCE, -1, -1, 0, -1, -1, g.jblock, 0};
+        DevMop m = {MOP_REDUCE, -1, -1, 0, -1, -1, g.jblock, -2};
         int kinds = 0;
         for (size_t j = 0; j < dots.size(); ++j) {  // newest first
             const auto& d = dots[dots.size() - 1 - j];
@@ -116,7 +126,7 @@ void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, bool w
     if (!inverse) {  // core_operations.py:956-1017
         if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, -1, MOPF_NEG_S, -1);   // Rz(-pi/2) on control
         const bool cpdot = with_dots && prog.entangler == 2;
-        out.push_back({ekind, pc, pt, 0, rec + 8, cpdot ? slot0 + 4 : -1, g.jblock, 0});
+        out.push_back({ekind, pc, pt, 0, rec + 8, cpdot ? slot0 + 4 : -1, g.jblock, prog.entangler == 2 ? g.theta0 + 4 : -2});
         if (cpdot) { dots.push_back({slot0 + 4, MOP_CP}); reduce(); }
         rot(MOP_RY, pc, 0, 0, slot0 + 0);
         rot(MOP_RZ, pc, 1, 0, slot0 + 1);
@@ -130,20 +140,24 @@ void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, bool w
         rot(MOP_RY, pt, 2, neg, -1);
         rot(MOP_RZ, pc, 1, neg, -1);
         rot(MOP_RY, pc, 0, neg, -1);
-        out.push_back({ekind, pc, pt, neg, rec + 8, -1, g.jblock, 0});
+        out.push_back({ekind, pc, pt, neg, rec + 8, -1, g.jblock, prog.entangler == 2 ? g.theta0 + 4 : -2});
         if (g.flags & FLAG_PRE_RZ) rot(MOP_RZ, pc, -1, 0, -1);
     }
 }
 
-void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots) {
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma = false) {
     out.plan = plan;
     out.h_stages.clear();
     out.h_ops.clear();
     out.h_subs.clear();
     out.h_mops.clear();
+    out.h_subs3.clear();
     out.reg_bits = reg_bits;
-    out.v2 = reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
-    if (out.v2) {
+    out.v3 = mfma && reg_bits == 4 && (int)plan.stages.front().bits.size() >= 8;
+    out.v2 = !out.v3 && reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
+    if (out.v3) {
+        split_substages(prog, out.plan, 4, 1 << 30);   // a sub-stage is one 16 x 16 unitary: any number of groups
+    } else if (out.v2) {
         int max_ops = reg_bits == 4 ? kMaxOpsPerSub : kMaxOpsPerSub / 2;
         if (prog.entangler == 2) max_ops /= 2;   // CP: two reductions per block
         split_substages(prog, out.plan, reg_bits, max_ops);
@@ -188,7 +202,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
         }
         ds.sub_begin = (int)out.h_subs.size();
         ds.nsubs = 0;
-        if (out.v2) {
+        if (out.v2 || out.v3) {
             for (const SubStage& sub : st.subs) {
                 DevSub dsub;
                 memset(&dsub, 0, sizeof dsub);
@@ -205,6 +219,30 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
                 dsub.nmops = (int)out.h_mops.size() - dsub.mop_begin;
                 out.h_subs.push_back(dsub);
                 ++ds.nsubs;
+                if (out.v3) {   // slot tables: amplitude bits = register bits, chunk bits = the other local bits, ascending
+                    DevSub3 d3;
+                    memset(&d3, 0, sizeof d3);
+                    d3.mop_begin = dsub.mop_begin;
+                    d3.nmops = dsub.nmops;
+                    std::vector<int> cbits;
+                    for (int j = 0; j < ds.k; ++j)
+                        if (reg_of[j] < 0) cbits.push_back(j);
+                    for (int j = 0; j < 4; ++j) d3.bits[j] = dsub.bits[j];
+                    auto deposit = [](unsigned v, const int* bits, int nb) {
+                        unsigned o = 0;
+                        for (int j = 0; j < nb; ++j)
+                            if (v >> j & 1) o |= 1u << bits[j];
+                        return o;
+                    };
+                    const int nc = (int)cbits.size();
+                    for (unsigned v = 0; v < 16; ++v) {
+                        d3.dep_a[v] = (uint16_t)swz3_host(deposit(v, dsub.bits, 4));
+                        d3.dep_clo[v] = (uint16_t)swz3_host(deposit(v, cbits.data(), std::min(nc, 4)));
+                    }
+                    for (unsigned g = 0; g < 64; ++g)
+                        d3.dep_chi[g] = nc > 4 && g < (1u << (nc - 4)) ? (uint16_t)swz3_host(deposit(g, cbits.data() + 4, nc - 4)) : 0;
+                    out.h_subs3.push_back(d3);
+                }
             }
         }
         out.h_stages.push_back(ds);
@@ -250,6 +288,8 @@ struct aqc_ws {
     int* d_slot_ntiles = nullptr;
     int nslots = 0, vdot_parts = 0;
     bool coef_valid = false;
+    bool need_coef = false;           // something besides the stage kernels reads d_coef (coordinate descent)
+    UJob* d_ujobs = nullptr;          // family 3: [V^H subs | sweep subs | V subs]
     struct MpsSlot {
         std::vector<int> dims;          // n + 1 bond dimensions
         std::vector<size_t> offset;     // element offset of site q inside d_t
@@ -279,6 +319,10 @@ int upload_plan(DevPlan& p) {
         HIP_OK(hipMemcpy(p.d_subs, p.h_subs.data(), p.h_subs.size() * sizeof(DevSub), hipMemcpyHostToDevice));
     if (!p.h_mops.empty())
         HIP_OK(hipMemcpy(p.d_mops, p.h_mops.data(), p.h_mops.size() * sizeof(DevMop), hipMemcpyHostToDevice));
+    if (p.v3 && !p.h_subs3.empty()) {
+        HIP_OK(hipMalloc((void**)&p.d_subs3, p.h_subs3.size() * sizeof(DevSub3)));
+        HIP_OK(hipMemcpy(p.d_subs3, p.h_subs3.data(), p.h_subs3.size() * sizeof(DevSub3), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -367,9 +411,55 @@ int copy_out(aqc_ws* ws, double* dst, const double2* src, size_t rows) {
     return 0;
 }
 
+// family 3: the 16 x 16 unitaries of the plan's sub-stages for the coefficients in use
+// Jobs are laid out [V^H | sweep | V]: the objective+gradient path (V^H then the sweep) is built by one launch.
+int ensure_umat(aqc_ws* ws, DevPlan& p) {
+    if (!p.v3 || p.u_valid) return 0;
+    const int T = ws->ctx->prog.num_thetas();
+    const int ninv = ws->inv.v3 ? (int)ws->inv.h_subs3.size() : 0, nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
+    const int nfwd = ws->fwd.v3 ? (int)ws->fwd.h_subs3.size() : 0;
+    ProfScope ps(ws, AQC_K_COEF);
+    if (&p == &ws->fwd) {
+        HIP_OK(launch_ubuild(ws->d_ujobs + ninv + nsw, nfwd, ws->d_thetas, T, ws->batch, ws->stream));
+        p.u_valid = true;
+    } else {
+        HIP_OK(launch_ubuild(ws->d_ujobs, ninv + nsw, ws->d_thetas, T, ws->batch, ws->stream));
+        ws->inv.u_valid = ws->sweep.u_valid = true;
+    }
+    return 0;
+}
+
+int run_coef(aqc_ws* ws) {
+    const Program& prog = ws->ctx->prog;
+    ws->fwd.u_valid = ws->inv.u_valid = ws->sweep.u_valid = false;
+    ws->coef_valid = true;
+    if (ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef) return 0;   // the matrix-core path reads the thetas directly
+    ProfScope ps(ws, AQC_K_COEF);
+    HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
+    return 0;
+}
+
 int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
     DevPlan& p = inverse ? ws->inv : ws->fwd;
     const Program& prog = ws->ctx->prog;
+    if (p.v3) {
+        if (ensure_umat(ws, p)) return 1;
+        for (size_t s = 0; s < p.h_stages.size(); ++s) {
+            Stage3Args a;
+            memset(&a, 0, sizeof a);
+            a.stage = p.h_stages[s];
+            a.subs = p.d_subs3;
+            a.umat = p.d_umat;
+            a.nsubs_total = (int)p.h_subs3.size();
+            a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
+            a.out0 = ws->bufs[dst_buf];
+            a.lane_stride = ws->lane_elems;
+            a.ntiles = p.ntiles;
+            ProfScope ps(ws, AQC_K_APPLY);
+            HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+        }
+        return 0;
+    }
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
         StageArgs a;
         memset(&a, 0, sizeof a);
@@ -464,6 +554,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     HIP_OK(hipSetDevice(device));
     HIP_OK(init_kernels());
     HIP_OK(init_kernels2());
+    HIP_OK(init_kernels3());
 
     aqc_ws* ws = new aqc_ws();
     ws->ctx = ctx;
@@ -482,17 +573,22 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     const int low_bits = env_int("AQC_LOW_BITS", 3);
     int ka = tile_bits_apply > 0 ? tile_bits_apply : env_int("AQC_TILE_BITS_APPLY", 0);
     int ks = tile_bits_sweep > 0 ? tile_bits_sweep : env_int("AQC_TILE_BITS_SWEEP", 0);
-    // AQC_KERNEL_FAMILY = 1 (per-group) | 2 (register-blocked VALU) forces a family (tests run every family);
-    // AQC_KERNEL_V2 = 0 / 1 is the older spelling of the same switch.
-    const int family = env_int("AQC_KERNEL_FAMILY", 0);
-    if (family < 0 || family > 2) { delete ws; return fail("AQC_KERNEL_FAMILY must be 1 (per-group) or 2 (register-blocked)"); }
-    const int force_v2 = family ? family - 1 : env_int("AQC_KERNEL_V2", -1);
+    // Kernel family.  Default: the matrix-core kernels (family 3) whenever the lane has at least 2^8 elements (16 chunks
+    // x 16 register-bit values per MFMA group); they won every measured workload, throughput and single-evaluation
+    // latency alike (profiles/r02_family_comparison.txt).  Smaller registers run the per-group kernels.
+    // AQC_KERNEL_FAMILY = 1 (per-group) | 2 (register-blocked VALU) | 3 forces a family (tests run every family);
+    // AQC_KERNEL_V2 = 0 / 1 is the older spelling of 1 / 2.
+    const int family = env_int("AQC_KERNEL_FAMILY", env_int("AQC_KERNEL_V2", -1) >= 0 ? env_int("AQC_KERNEL_V2", -1) + 1 : 0);
+    if (family < 0 || family > 3) { delete ws; return fail("AQC_KERNEL_FAMILY must be 1 (per-group), 2 (register-blocked) or 3 (matrix cores)"); }
+    const bool want_v3 = (family == 3 || family == 0) && ws->nbits >= 8;
+    const int force_v2 = family == 3 ? 0 : (family ? family - 1 : -1);
     // Measured on MI355X (tools/tune.py mid / b1k): the register-blocked kernels pay off once 2^12-amplitude tiles x
     // lanes give every CU two workgroups (>= 512); below that the per-group kernels win, best with ~512 workgroups but
     // never with tiles under 2^10 (every extra stage is an extra launch and an extra HBM round trip).
     const size_t big_tiles = (size_t)batch << std::max(0, ws->nbits - 12);
     const bool want_v2 = force_v2 >= 0 ? force_v2 != 0 : big_tiles >= 512;
     auto pick = [&](int kmax) {
+        if (want_v3) return std::min(12, ws->nbits);
         if (want_v2) return std::min(kmax, ws->nbits);
         int k = std::min(11, ws->nbits);
         while (k > 10 && ((size_t)batch << (ws->nbits - k)) < 512) --k;
@@ -515,9 +611,10 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         }
         return best;
     };
-    lower_plan(prog, best_plan(ka, false), ws->fwd, want_v2 ? 4 : 0, false);
-    lower_plan(prog, best_plan(ka, true), ws->inv, want_v2 ? 4 : 0, false);
-    lower_plan(prog, best_plan(ks, false), ws->sweep, want_v2 ? (env_int("AQC_SWEEP_REG_BITS", 4) == 3 ? 3 : 4) : 0, true);
+    if (want_v3) { ka = std::min(std::max(ka, 8), 12); ks = std::max(ks, 8); }   // MFMA tiles: 2^8 .. 2^12 amplitudes
+    lower_plan(prog, best_plan(ka, false), ws->fwd, (want_v2 || want_v3) ? 4 : 0, false, want_v3);
+    lower_plan(prog, best_plan(ka, true), ws->inv, (want_v2 || want_v3) ? 4 : 0, false, want_v3);
+    lower_plan(prog, best_plan(ks, false), ws->sweep, want_v3 ? 4 : (want_v2 ? (env_int("AQC_SWEEP_REG_BITS", 4) == 3 ? 3 : 4) : 0), true, want_v3);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -526,7 +623,8 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     const int T = prog.num_thetas();
     const int G = (int)prog.groups.size();
     ws->nslots = G * kSlotsPerGroup;
-    std::vector<int> theta_slots(2 * (size_t)std::max(T, 1), -1), slot_ntiles((size_t)std::max(ws->nslots, 1), ws->sweep.ntiles);
+    const int partial_tiles = ws->sweep.v3 ? 1 : ws->sweep.ntiles;   // family 3: rgrad_kernel writes one value per slot
+    std::vector<int> theta_slots(2 * (size_t)std::max(T, 1), -1), slot_ntiles((size_t)std::max(ws->nslots, 1), partial_tiles);
     auto feed = [&](int theta, int slot) {
         if (theta_slots[2 * theta] < 0) theta_slots[2 * theta] = slot; else theta_slots[2 * theta + 1] = slot;
     };
@@ -541,6 +639,10 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         }
     }
 
+    if (env_int("AQC_VERBOSE", 0) && want_v3)
+        fprintf(stderr, "aqc_hip: matrix-core kernels, tiles 2^%d (V / V^H, %d workgroups per CU) / 2^%d (sweep, %d per CU), sub-stages %zu / %zu / %zu\n",
+                ws->inv.k, mfma_occupancy(ws->inv.k, false), ws->sweep.k, mfma_occupancy(ws->sweep.k, true), ws->fwd.h_subs3.size(),
+                ws->inv.h_subs3.size(), ws->sweep.h_subs3.size());
 #define WS_TRY(x) do { if ((x) != 0) { aqc_ws_destroy(ws); return 1; } } while (0)
 #define WS_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail("%s failed: %s", #x, hipGetErrorString(e_)); aqc_ws_destroy(ws); return 1; } } while (0)
     WS_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
@@ -554,7 +656,21 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         WS_HIP(hipMalloc((void**)&ws->bufs[b], sizeof(double2) * (size_t)batch * ws->lane_elems));
         WS_HIP(hipMemsetAsync(ws->bufs[b], 0, sizeof(double2) * (size_t)batch * ws->lane_elems, ws->stream));
     }
-    WS_HIP(hipMalloc((void**)&ws->d_partial, sizeof(double2) * (size_t)batch * std::max(ws->nslots, 1) * ws->sweep.ntiles));
+    WS_HIP(hipMalloc((void**)&ws->d_partial, sizeof(double2) * (size_t)batch * std::max(ws->nslots, 1) * partial_tiles));
+    for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep})
+        if (p->v3) WS_HIP(hipMalloc((void**)&p->d_umat, sizeof(double) * (size_t)batch * std::max<size_t>(p->h_subs3.size(), 1) * 12 * 64));
+    {
+        std::vector<UJob> jobs;
+        for (DevPlan* p : {&ws->inv, &ws->sweep, &ws->fwd})
+            if (p->v3)
+                for (size_t i = 0; i < p->h_subs3.size(); ++i) jobs.push_back({p->d_subs3 + i, p->d_mops, p->d_umat, (int)i, (int)p->h_subs3.size()});
+        if (!jobs.empty()) {
+            WS_HIP(hipMalloc((void**)&ws->d_ujobs, sizeof(UJob) * jobs.size()));
+            WS_HIP(hipMemcpy(ws->d_ujobs, jobs.data(), sizeof(UJob) * jobs.size(), hipMemcpyHostToDevice));
+        }
+    }
+    if (ws->sweep.v3)
+        WS_HIP(hipMalloc((void**)&ws->sweep.d_rpart, sizeof(double2) * (size_t)batch * std::max<size_t>(ws->sweep.h_subs3.size(), 1) * ws->sweep.ntiles * 256));
     WS_HIP(hipMalloc((void**)&ws->d_grads, sizeof(double2) * (size_t)batch * std::max(T, 1)));
     WS_HIP(hipMalloc((void**)&ws->d_theta_slots, sizeof(int) * theta_slots.size()));
     WS_HIP(hipMalloc((void**)&ws->d_slot_ntiles, sizeof(int) * slot_ntiles.size()));
@@ -582,9 +698,12 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_ops) (void)hipFree(p->d_ops);
         if (p->d_subs) (void)hipFree(p->d_subs);
         if (p->d_mops) (void)hipFree(p->d_mops);
+        if (p->d_subs3) (void)hipFree(p->d_subs3);
+        if (p->d_umat) (void)hipFree(p->d_umat);
+        if (p->d_rpart) (void)hipFree(p->d_rpart);
     }
     void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index, ws->d_tmp_index, ws->d_tmp_small,
-                    ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out};
+                    ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out, ws->d_ujobs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
@@ -604,12 +723,7 @@ int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas) {
     ws->d_thetas = ws->d_thetas_own;
     HIP_OK(hipMemcpyAsync(ws->d_thetas, thetas, sizeof(double) * (size_t)ws->batch * T, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));  // the host buffer may be reused right away
-    {
-        ProfScope ps(ws, AQC_K_COEF);
-        HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
-    }
-    ws->coef_valid = true;
-    return 0;
+    return run_coef(ws);
 }
 
 int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
@@ -704,6 +818,71 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
         return fail("invalid block_range [%d, %d)", block_from, block_to);
     HIP_OK(hipSetDevice(ws->device));
     DevPlan& p = ws->sweep;
+    if (p.v3) {
+        if (ensure_umat(ws, p)) return 1;
+        const int nsubs = (int)p.h_subs3.size();
+        for (size_t s = 0; s < p.h_stages.size(); ++s) {
+            Stage3Args a;
+            memset(&a, 0, sizeof a);
+            a.stage = p.h_stages[s];
+            a.subs = p.d_subs3;
+            a.umat = p.d_umat;
+            a.nsubs_total = nsubs;
+            a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
+            a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
+            a.out0 = ws->bufs[AQC_BUF_W];
+            a.out1 = ws->bufs[AQC_BUF_ZW];
+            a.lane_stride = ws->lane_elems;
+            a.rpart = p.d_rpart;
+            a.ntiles = p.ntiles;
+            a.store_out = s + 1 < p.h_stages.size() ? 1 : 0;
+#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the sweep workgroups of this launch, on stderr
+            static unsigned long long* d_stamps = nullptr;
+            const size_t nwg = (size_t)p.ntiles * ws->batch;
+            const bool stamps = env_int("AQC_STAMPS", 0) != 0;
+            a.debug = env_int("AQC_DEBUG_SKIP", 0);
+            if (stamps) {
+                if (!d_stamps) HIP_OK(hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 65536 * kStampSlots));
+                if (nwg <= 65536) { HIP_OK(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream)); a.stamps = d_stamps; }
+            }
+#endif
+            {
+                ProfScope ps(ws, AQC_K_SWEEP);
+                HIP_OK(launch_sweep3(p.ntiles, ws->batch, p.k, ws->stream, a));
+            }
+#ifdef AQC_TUNING
+            if (a.stamps) {
+                std::vector<unsigned long long> h(nwg * kStampSlots);
+                HIP_OK(hipStreamSynchronize(ws->stream));
+                HIP_OK(hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                const int ns = p.h_stages[s].nsubs;
+                double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0;
+                for (size_t w = 0; w < nwg; ++w) {
+                    const unsigned long long* t = h.data() + w * kStampSlots;
+                    load += (double)(t[1] - t[0]);
+                    store += (double)(t[kStampSlots - 1] - t[kStampSlots - 2]);
+                    total += (double)(t[kStampSlots - 1] - t[0]);
+                    for (int i = 0; i < ns && 5 + 4 * i < kStampSlots - 2; ++i) {
+                        top += (double)(t[2 + 4 * i] - (i ? t[5 + 4 * (i - 1)] : t[1]));
+                        mf += (double)(t[3 + 4 * i] - t[2 + 4 * i]);
+                        bar += (double)(t[4 + 4 * i] - t[3 + 4 * i]);
+                        red += (double)(t[5 + 4 * i] - t[4 + 4 * i]);
+                    }
+                }
+                const double n = (double)nwg;
+                fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups): total %.0f cycles = load %.0f + per sub-stage "
+                        "[top barrier %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f\n", s, ns, nwg, total / n, load / n,
+                        top / n / ns, mf / n / ns, bar / n / ns, red / n / ns, store / n);
+            }
+#endif
+        }
+        ProfScope ps(ws, AQC_K_FINALIZE);
+        HIP_OK(launch_rgrad(p.d_subs3, p.d_mops, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
+                            ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
+        HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
+                               1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
+        return 0;
+    }
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
         StageArgs a;
         memset(&a, 0, sizeof a);
@@ -750,9 +929,7 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
         memcpy(pin_th, thetas, sizeof(double) * nth);
         ws->d_thetas = ws->d_thetas_own;
         HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
-        ProfScope ps(ws, AQC_K_COEF);
-        HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
-        ws->coef_valid = true;
+        if (run_coef(ws)) return 1;
     } else if ((do_vdag || grads) && ensure_coef(ws)) {
         return 1;
     }
@@ -845,10 +1022,7 @@ int aqc_ws_use_theta_set(aqc_ws* ws, int set_index) {
     HIP_OK(hipSetDevice(ws->device));
     const Program& prog = ws->ctx->prog;
     ws->d_thetas = ws->d_theta_bank + (size_t)set_index * ws->batch * prog.num_thetas();
-    ProfScope ps(ws, AQC_K_COEF);
-    HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
-    ws->coef_valid = true;
-    return 0;
+    return run_coef(ws);
 }
 
 int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count) {
@@ -1246,7 +1420,7 @@ int aqc_ws_plan_info(aqc_ws* ws, int which, int* num_stages, int* tile_bits, int
 int aqc_ws_kernel_family(aqc_ws* ws, int which) {
     if (!ws) return -1;
     const DevPlan& p = which == 0 ? ws->inv : (which == 1 ? ws->sweep : ws->fwd);
-    return p.v2 ? 2 : 1;
+    return p.family();
 }
 
 // ---- one-shot host-pointer entry points -------------------------------------------------------

@@ -57,7 +57,8 @@ struct DevMop {
     int32_t coef;    // offset (in doubles) of the (c, s) pair inside the lane's coefficient array
     int32_t slot;    // inner-product slot fed by this micro-op, -1 if none
     int32_t jblock;  // block index mod L for the block_range test, -1 = front layer
-    int32_t pad;
+    int32_t pad;     // index of the theta behind this micro-op (matrix-core path: sincos straight from the thetas);
+                     // -1 = the constant Trotter Rz(+-pi/2), -2 = no angle (CX, CZ, MOP_REDUCE)
     // MOP_REDUCE: reduces the (up to 4) most recent inner products of the thread; `slot` is the slot of
     // the newest one, p / p2 / coef those of the 2nd / 3rd / 4th newest (-1 = none); `flags` packs the
     // MopKind of each producer (4 bits each, newest first) for the 0.5 / 0.5j / -1j factor.
@@ -68,6 +69,18 @@ struct DevSub {
     int32_t nbits;
     int32_t nmops;
     int32_t mop_begin;
+};
+
+// Matrix-core kernels (aqc_kernels3.hip): LDS slot tables of one sub-stage.  The local index of (amplitude a, chunk c)
+// is deposit(a -> register bits) | deposit(c -> the other local bits); the tables hold swz3() of the three parts
+// (the swizzle is GF(2)-linear, so slot = dep_a[a] ^ dep_clo[c & 15] ^ dep_chi[c >> 4]).
+struct DevSub3 {
+    int32_t mop_begin, nmops;
+    int32_t bits[4];        // register bits (local bit positions, ascending)
+    int32_t pad[2];
+    uint16_t dep_a[16];
+    uint16_t dep_clo[16];
+    uint16_t dep_chi[64];   // up to 2^14-amplitude tiles
 };
 
 constexpr int kMaxMopsPerSub = 64;   // 8 gate groups x (7 micro-ops + 1 reduction)

@@ -1,0 +1,671 @@
+// Matrix-core stage kernels (gfx950): the sweep on v_mfma_f64_16x16x4_f64.
+//
+// Same tiling as the other two families (one workgroup = one LDS tile of 2^k amplitudes of one lane,
+// every gate group of the stage applied before the tile goes back to HBM) and the same sub-stages
+// (aqc_plan.cpp: split_substages, 4 "register bits" per sub-stage).  What changes is how a sub-stage is
+// executed.  All its gates act on the 4 register bits, so the whole sub-stage is ONE 16 x 16 complex
+// unitary U per lane (ubuild_kernel multiplies the micro-ops into it, a few microseconds for all
+// sub-stages of all lanes).  The tile is a 16 x C matrix W (row = value of the register bits, column =
+// "chunk" = the other k - 4 local bits) and the sub-stage is W <- U W: a complex GEMM on the matrix cores.
+// Every inner product of the sub-stage is a function of R = Z W^H (16 x 16, another GEMM with the chunks
+// as the summed dimension): <P_g w_g | z_g> = Tr(P_g R_g) with R_g = U_g R U_g^H, so the per-gate
+// work on the 2^n-vectors disappears; rgrad_kernel walks the micro-ops over the 16 x 16 matrix instead.
+//
+// MFMA operand layout (tools/ubench/mfma_f64_probe.hip): lane l feeds A[l%16][l/16] and B[l/16][l%16]
+// and owns D[4r + l/16][l%16], r = 0..3.  Per group of 16 chunks:
+//   product 1  W'^T = W^T U^T : A = W^T (M = chunk, K = input amplitude), B = U^T, D = W'^T
+//              input  ("L1") lane l, K-step s : amplitude 4s + l/16 of chunk l%16
+//              output ("L2") lane l, register r: amplitude l%16 of chunk 4r + l/16
+//   product 2  R += Z' W'^H   : A = Z' (M = amplitude of z, K = chunk), B = W'^H -- exactly the L2 registers,
+//              so the outputs of product 1 feed product 2 without any data movement.
+// Complex products use the 3-multiplication form (T1 = ar br, T2 = ai bi, T3 = (ar + ai)(br + bi)):
+// 9 real 16x16x16 products per group of 16 chunks for the sweep, 3 for V / V^H; the handful of fp64 adds
+// rides on the otherwise idle vector ALU.  Sums are accumulated in a fixed order (MFMA K-chains, then a
+// fixed-order sum over waves and tiles): run-to-run identical, no float atomics.
+#include <hip/hip_runtime.h>
+
+#include "aqc_device.h"
+#include "aqc_launch.h"
+#include "aqc_math.h"
+
+namespace aqc {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// LDS slot of local index l: XOR-folds index bits 4..11 into the low nibble so that both access patterns
+// of a sub-stage (16 lanes along the chunk bits, 16 lanes along the register bits) spread over the 16-byte
+// bank groups.  GF(2)-linear: swz3(x ^ y) == swz3(x) ^ swz3(y), which the host tables rely on.
+__host__ __device__ __forceinline__ unsigned swz3(unsigned l) { return l ^ ((l >> 4) & 15u) ^ ((l >> 8) & 15u); }
+
+__device__ __forceinline__ double4_t mfma(double a, double b, double4_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// o = U v for one group of 16 chunks, in two halves so that the callers can software-pipeline: the 12 MFMAs
+// (u_mfma: v[s] = L1 operand of K-step s) and the fp64 adds that turn the three real products into the complex
+// result (u_combine: o[r] = L2 result register r).  Three-multiplication form with the U-side sums precomputed by
+// ubuild_kernel (planes u0 = Re U, u1 = Im U - Re U, u2 = Re U + Im U):
+//   K1 = (vx + vy) u0, K2 = vx u1, K3 = vy u2;  Re = K1 - K3, Im = K1 + K2      -- 3 fp64 adds per amplitude.
+// fp64 MFMA and the vector ALU do NOT overlap on gfx950 (tools/ubench/mfma_f64_shadow.hip: every v_add_f64 issued
+// between MFMAs costs its full 4 cycles), so every vector instruction saved here is matrix time gained.
+struct Acc3 { double4_t k1, k2, k3; };
+__device__ __forceinline__ void u_mfma(const cplx (&v)[4], const double (&u0)[4], const double (&u1)[4], const double (&u2)[4], Acc3& t) {
+    t.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; t.k2 = t.k1; t.k3 = t.k1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        t.k1 = mfma(v[s].x + v[s].y, u0[s], t.k1);
+        t.k2 = mfma(v[s].x, u1[s], t.k2);
+        t.k3 = mfma(v[s].y, u2[s], t.k3);
+    }
+}
+__device__ __forceinline__ void u_combine(const Acc3& t, cplx (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o[r].x = t.k1[r] - t.k3[r];
+        o[r].y = t.k1[r] + t.k2[r];
+    }
+}
+
+#ifdef AQC_TUNING   // in-kernel stamps (diagnostic builds only): where a workgroup's time goes
+#define AQC_STAMP(slot) do { if (a.stamps && threadIdx.x == 0 && (slot) < kStampSlots) \
+    a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AQC_DBG_AND(x) && (x)
+#define AQC_DBG_TEST(x) (x)
+#else
+#define AQC_STAMP(slot) do { } while (0)
+#define AQC_DBG_AND(x)
+#define AQC_DBG_TEST(x) false
+#endif
+
+template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
+    // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
+    // work itself runs at 64 cycles per MFMA either way, and the per-wave cost of a sub-stage (operand prefetch, address
+    // set-up, R hand-over, barriers) doubles: 14.2k vs 13.0k cycles per sub-stage.  kSweepWaves12 = 8 re-enables them.)
+    static constexpr int kSweepWaves12 = 4;
+    static constexpr int kWaves = (SWEEP && K == 12) ? kSweepWaves12 : (K >= 10 ? 4 : (1 << (K - 8)));
+    static constexpr int kGroups = 1 << (K - 8);                       // groups of 16 chunks x 16 amplitudes
+    static constexpr int kGpw = kGroups / kWaves;                      // groups per wave: 1, 2 or 4
+    static constexpr int kLoads = (1 << (K - 6)) / kWaves;             // 16-byte HBM accesses per thread and vector
+};
+
+struct SubRegs {   // everything a lane needs for one sub-stage, fetched one sub-stage ahead (no load on the critical path)
+    double u0[4], u1[4], u2[4];
+    unsigned l1a, l1b, l2a, l2b;  // L1 slot of this lane = l1a ^ l1b, L2 slot = l2a ^ l2b (combined only at the point of use
+                                  // so that the prefetch is not waited for early)
+    unsigned sa[4], sc[4];        // step terms: amplitude 4s (L1), chunk 4r (L2)   (wave-uniform)
+    unsigned gt[4];               // group terms of this wave's groups                (wave-uniform)
+};
+
+template <int GPW>
+__device__ __forceinline__ void fetch_sub(SubRegs& x, const DevSub3* subs, const double* umat, int sub_index, int lane, int wave,
+                                          int nwaves) {
+    const DevSub3* sub = subs + sub_index;
+    const double* up = umat + (size_t)sub_index * 12 * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        x.u0[s] = up[(0 * 4 + s) * 64 + lane];
+        x.u1[s] = up[(1 * 4 + s) * 64 + lane];
+        x.u2[s] = up[(2 * 4 + s) * 64 + lane];
+    }
+    x.l1a = sub->dep_clo[lane & 15]; x.l1b = sub->dep_a[lane >> 4];
+    x.l2a = sub->dep_a[lane & 15];   x.l2b = sub->dep_clo[lane >> 4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { x.sa[s] = sub->dep_a[4 * s]; x.sc[s] = sub->dep_clo[4 * s]; }
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) x.gt[j] = sub->dep_chi[wave + j * nwaves];
+}
+
+// LDS byte addresses of one sub-stage: one per-lane base for each layout and wave-uniform XOR terms kept in SGPRs
+// (16 << slot arithmetic done once; every access is then a single v_xor_b32 with a scalar operand).
+template <int GPW>
+struct SubAddr {
+    unsigned a1, a2;                 // per lane: L1 / L2 byte address inside a tile
+    unsigned k1[GPW][4], k2[GPW][4];  // uniform: ((step term ^ group term) << 4) for L1 (K-step s) and L2 (register r)
+};
+template <int GPW>
+__device__ __forceinline__ void sub_addr(SubAddr<GPW>& x, const SubRegs& c, unsigned lds_base) {
+    x.a1 = ((c.l1a ^ c.l1b) << 4) + lds_base;
+    x.a2 = ((c.l2a ^ c.l2b) << 4) + lds_base;
+    unsigned sa[4], sc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { sa[s] = __builtin_amdgcn_readfirstlane(c.sa[s]); sc[s] = __builtin_amdgcn_readfirstlane(c.sc[s]); }
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+        const unsigned g = __builtin_amdgcn_readfirstlane(c.gt[j]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { x.k1[j][s] = (sa[s] ^ g) << 4; x.k2[j][s] = (sc[s] ^ g) << 4; }
+    }
+}
+// LDS accesses by absolute 32-bit LDS address (the tile region starts at LDS address `lds_base`, checked once per
+// kernel to be a multiple of the XOR span, so base + (a ^ k) == (base + a) ^ k and no add is left on the access path).
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) dbl2_t* lds_cplx_ptr;
+__device__ __forceinline__ cplx lds_get(unsigned addr) {
+    const dbl2_t v = *reinterpret_cast<lds_cplx_ptr>(addr);
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_put(unsigned addr, cplx v) { *reinterpret_cast<lds_cplx_ptr>(addr) = dbl2_t{v.x, v.y}; }
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)p);
+}
+
+// HBM <-> LDS: 16 B per lane, runs of the stage's low local bits are contiguous in HBM.  l & 63 == lane for
+// every element a thread touches and l >> 6 is wave-uniform; all loads of a thread are in flight together.
+template <int K, int NV>
+__device__ __forceinline__ void load_tiles3(cplx* t0, cplx* t1, const cplx* s0, const cplx* s1, const DevStage& st, unsigned lo, int wave) {
+    constexpr int NL = TileShape<K, NV == 2>::kLoads, NW = TileShape<K, NV == 2>::kWaves;
+    cplx v0[NL], v1[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const unsigned off = lo + st.dhi[wave + i * NW];
+        v0[i] = s0[off];
+        if (NV == 2) v1[i] = s1[off];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const unsigned slot = swz3((unsigned)((wave + i * NW) << 6) | (threadIdx.x & 63u));
+        t0[slot] = v0[i];
+        if (NV == 2) t1[slot] = v1[i];
+    }
+}
+template <int K, bool SWEEP>
+__device__ __forceinline__ void store_tile3(const cplx* tile, cplx* dst, const DevStage& st, unsigned lo, int wave) {
+    constexpr int NL = TileShape<K, SWEEP>::kLoads, NW = TileShape<K, SWEEP>::kWaves;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const unsigned slot = swz3((unsigned)((wave + i * NW) << 6) | (threadIdx.x & 63u));
+        dst[lo + st.dhi[wave + i * NW]] = tile[slot];
+    }
+}
+__device__ __forceinline__ size_t tile_base3(const DevStage& st) {
+    size_t base = 0;
+    const unsigned tile = blockIdx.x;
+    for (int i = 0; i < st.nub; ++i) base |= (size_t)((tile >> i) & 1u) << st.ubits[i];
+    return base;
+}
+
+// ---- V / V^H -------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kernel(const Stage3Args a) {
+    using TS = TileShape<K>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevStage& st = a.stage;
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    const unsigned lds_base = lds_address(smem);
+    if (lds_base & ((16u << K) - 1)) __builtin_trap();   // XOR addressing needs the tile aligned to its own size
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tile_base3(st);
+    const double* umat = a.umat + (size_t)blockIdx.y * a.nsubs_total * 12 * 64;
+    const unsigned lo = st.dlo[lane];
+    SubRegs cur, nxt;
+    if (st.nsubs > 0) fetch_sub<TS::kGpw>(cur, a.subs, umat, st.sub_begin, lane, wave, TS::kWaves);
+    load_tiles3<K, 1>(tw, nullptr, a.in0 + lane_off, nullptr, st, lo, wave);
+    // Every load so far has landed before the loop: otherwise the compiler's wait-count analysis, merging the loop
+    // entry with the back edge, makes the first use of `cur` inside the loop wait for the prefetch of `nxt` as well.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    for (int si = 0; si < st.nsubs; ++si) {
+        __syncthreads();
+        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, TS::kWaves);
+        SubAddr<TS::kGpw> ad;   // clustered software pipeline, see sweep_mfma_kernel
+        sub_addr(ad, cur, lds_base);
+        cplx v[2][4];
+        Acc3 acc;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]);
+#pragma unroll
+        for (int j = 0; j <= TS::kGpw; ++j) {
+            if (j + 1 < TS::kGpw) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[(j + 1) & 1][s] = lds_get(ad.a1 ^ ad.k1[j + 1][s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double sv[4];
+            cplx o[4];
+            if (j < TS::kGpw) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sv[s] = v[j & 1][s].x + v[j & 1][s].y;
+            }
+            if (j > 0) u_combine(acc, o);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < TS::kGpw) {
+                acc.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; acc.k2 = acc.k1; acc.k3 = acc.k1;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc.k1 = mfma(sv[s], cur.u0[s], acc.k1);
+                    acc.k2 = mfma(v[j & 1][s].x, cur.u1[s], acc.k2);
+                    acc.k3 = mfma(v[j & 1][s].y, cur.u2[s], acc.k3);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds_put(ad.a2 ^ ad.k2[j - 1][r], o[r]);
+            }
+        }
+        if (si + 1 < st.nsubs) cur = nxt;
+    }
+    __syncthreads();
+    store_tile3<K, false>(tw, a.out0 + lane_off, st, lo, wave);
+}
+
+// ---- forward w / z sweep with R = Z W^H per sub-stage ------------------------------------------------------
+// One barrier per sub-stage: the per-wave R of sub-stage s goes to an LDS scratch before it, the fixed-order sum over
+// the waves (64 entries per wave) right after it.  The scratch is written again only at the end of the NEXT
+// sub-stage's matrix work; `done` (an LDS counter every wave bumps after its scratch reads) makes that formally
+// safe without a second barrier -- the wait never spins in practice and is bounded.  2^11 tiles are the exception:
+// two workgroups share a CU only if each stays within exactly 80 KiB (tiles + scratch), so there the 4 bytes of the
+// counter are not affordable and a second barrier takes its place.
+template <int K> struct SweepShape : TileShape<K, true> {};   // (no comma inside the __launch_bounds__ macro arguments)
+template <int K>
+__global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void sweep_mfma_kernel(const Stage3Args a) {
+    using TS = TileShape<K, true>;
+    constexpr int kSlots = TS::kWaves > 4 ? 4 : TS::kWaves;   // scratch slots; 8 waves reduce in pairs first
+    constexpr unsigned tsize = 1u << K;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevStage& st = a.stage;
+    cplx* tw = reinterpret_cast<cplx*>(smem);
+    cplx* tz = tw + tsize;
+    cplx* scratch = tz + tsize;   // [kWaves][4][64]: per-wave R of the current sub-stage
+    constexpr bool kFlag = K != 11;
+    const unsigned lds_base = lds_address(smem);
+    if (lds_base & ((32u << K) - 1)) __builtin_trap();   // XOR addressing needs the two tiles aligned to their joint size
+    unsigned* done = reinterpret_cast<unsigned*>(scratch + kSlots * 256);   // kFlag only (sweep3_lds_bytes)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tile_base3(st);
+    const double* umat = a.umat + (size_t)blockIdx.y * a.nsubs_total * 12 * 64;
+    cplx* rpart = a.rpart + (((size_t)blockIdx.y * a.nsubs_total + st.sub_begin) * a.ntiles + blockIdx.x) * 256;
+    const unsigned lo = st.dlo[lane];
+    SubRegs cur, nxt;
+    AQC_STAMP(0);
+    if (kFlag && threadIdx.x == 0) *done = 0;
+    if (st.nsubs > 0) fetch_sub<TS::kGpw>(cur, a.subs, umat, st.sub_begin, lane, wave, TS::kWaves);
+    load_tiles3<K, 2>(tw, tz, a.in0 + lane_off, a.in1 + lane_off, st, lo, wave);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see apply_mfma_kernel
+    __syncthreads();
+    AQC_STAMP(1);
+    for (int si = 0; si < st.nsubs; ++si) {
+        AQC_STAMP(2 + 4 * si);
+        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, TS::kWaves);
+        double4_t t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
+        // Software pipeline over the wave's groups, written as CLUSTERS that the compiler may not interleave
+        // (sched_barrier): on gfx950 an fp64 MFMA and vector-ALU instructions of the same SIMD do not overlap, and every
+        // switch between the two costs a few cycles, so the fastest stream is long runs of back-to-back MFMAs with all
+        // the fp64 adds bunched between them.  Per iteration j:  LDS reads of group j + 1 (issue only) | adds: operand
+        // sums of group j, complex results of group j - 1 | 36 MFMAs: U w and U z of group j, then Z' W'^H of group
+        // j - 1 | LDS writes of group j - 1.
+        SubAddr<TS::kGpw> ad;
+        sub_addr(ad, cur, lds_base);
+        constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
+        const unsigned a1z = ad.a1 | ZOFF, a2z = ad.a2 | ZOFF;
+        cplx vw[2][4], vz[2][4];   // operands of group j (slot j & 1) and j + 1
+        Acc3 aw, az;               // products of group j - 1 until they are combined, then of group j
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get(a1z ^ ad.k1[0][s]); }
+#pragma unroll
+        for (int j = 0; j <= TS::kGpw; ++j) {
+            if (j + 1 < TS::kGpw AQC_DBG_AND(!(a.debug & 2))) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    vw[(j + 1) & 1][s] = lds_get(ad.a1 ^ ad.k1[j + 1][s]);
+                    vz[(j + 1) & 1][s] = lds_get(a1z ^ ad.k1[j + 1][s]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double sw[4], sz[4], zs[4], wd[4];
+            cplx ow[4], oz[4];
+            if (j < TS::kGpw) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { sw[s] = vw[j & 1][s].x + vw[j & 1][s].y; sz[s] = vz[j & 1][s].x + vz[j & 1][s].y; }
+            }
+            if (j > 0) {
+                u_combine(aw, ow);
+                u_combine(az, oz);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { zs[r] = oz[r].x + oz[r].y; wd[r] = ow[r].x - ow[r].y; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < TS::kGpw) {
+                aw.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; aw.k2 = aw.k1; aw.k3 = aw.k1; az.k1 = aw.k1; az.k2 = aw.k1; az.k3 = aw.k1;
+#pragma unroll
+                for (int s = 0; s < (AQC_DBG_TEST(a.debug & 8) ? 0 : 4); ++s) {
+                    aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
+                    aw.k2 = mfma(vw[j & 1][s].x, cur.u1[s], aw.k2);
+                    aw.k3 = mfma(vw[j & 1][s].y, cur.u2[s], aw.k3);
+                    az.k1 = mfma(sz[s], cur.u0[s], az.k1);
+                    az.k2 = mfma(vz[j & 1][s].x, cur.u1[s], az.k2);
+                    az.k3 = mfma(vz[j & 1][s].y, cur.u2[s], az.k3);
+                }
+            }
+            if (j > 0 AQC_DBG_AND(!(a.debug & 4))) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // R += Z' W'^H over the 4 chunks of K-step r
+                    t1 = mfma(oz[r].x, ow[r].x, t1);
+                    t2 = mfma(oz[r].y, ow[r].y, t2);
+                    t3 = mfma(zs[r], wd[r], t3);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j > 0 AQC_DBG_AND(!(a.debug & 1))) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lds_put(ad.a2 ^ ad.k2[j - 1][r], ow[r]); lds_put(a2z ^ ad.k2[j - 1][r], oz[r]); }
+            }
+        }
+        AQC_STAMP(3 + 4 * si);
+        if (kFlag && si > 0) {   // the previous sub-stage's scratch has been read by everyone (bounded wait, see above)
+            const unsigned want = (unsigned)(si * kSlots);
+            for (int spin = 0; spin < 4096 && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        cplx rr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[r] = make_double2(t1[r] + t2[r], t3[r] - t1[r] + t2[r]);   // Re R = T1 + T2, Im R = T3 - T1 + T2
+        if (TS::kWaves > 4) {   // 8 waves: wave w + 4 hands its R to wave w through the scratch, wave w publishes the pair's sum
+            if (wave >= 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[((wave - 4) * 4 + r) * 64 + lane] = rr[r];
+            }
+            __syncthreads();   // the sub-stage's tile updates are visible as well
+            if (wave < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cplx p = scratch[(wave * 4 + r) * 64 + lane];
+                    scratch[(wave * 4 + r) * 64 + lane] = make_double2(rr[r].x + p.x, rr[r].y + p.y);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[(wave * 4 + r) * 64 + lane] = rr[r];
+        }
+        __syncthreads();   // the sub-stage's tile updates and every slot of the scratch are visible
+        AQC_STAMP(4 + 4 * si);
+        for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {   // fixed-order sum over the slots
+            double re = 0.0, im = 0.0;
+#pragma unroll
+            for (int w = 0; w < kSlots; ++w) { const cplx p = scratch[w * 256 + e]; re += p.x; im += p.y; }
+            rpart[(size_t)si * a.ntiles * 256 + e] = make_double2(re, im);
+        }
+        if (kFlag) { if (lane == 0 && wave < kSlots) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        else __syncthreads();
+        AQC_STAMP(5 + 4 * si);
+        if (si + 1 < st.nsubs) cur = nxt;
+    }
+    AQC_STAMP(kStampSlots - 2);
+    if (a.store_out) {   // the last stage's w and z are never read again (only the gradient entries are results)
+        store_tile3<K, true>(tw, a.out0 + lane_off, st, lo, wave);
+        store_tile3<K, true>(tz, a.out1 + lane_off, st, lo, wave);
+    }
+    AQC_STAMP(kStampSlots - 1);
+}
+
+// ---- small kernels: U of every sub-stage, gradient entries from R -----------------------------------------
+// Both walk the micro-ops of ONE sub-stage over a 16 x 16 complex matrix in LDS with one wave.  The micro-ops are decoded
+// 64 at a time (one per lane, straight from the lane's thetas: sincos of the half angle; no coefficient kernel on this
+// path), so the serial loop only reads LDS.
+struct Gate2 {   // one micro-op: a 2 x 2 rotation on register bit p, or an entangler on bits (p, p2)
+    int kind, p, p2, slot;
+    double c, s;
+    int jblock, pad;
+};
+__device__ __forceinline__ void stage_gates(Gate2* gates, const DevMop* mops, int begin, int count, const double* thetas, int lane) {
+    if (lane < count) {
+        const DevMop m = mops[begin + lane];
+        Gate2 g;
+        g.kind = m.kind; g.p = m.p; g.p2 = m.p2; g.jblock = m.jblock; g.pad = 0;
+        g.slot = m.kind == MOP_REDUCE ? -1 : m.slot;
+        g.c = 1.0; g.s = 0.0;
+        if (m.kind <= MOP_RX) {          // rotation by theta: (cos, sin) of theta / 2; pad < 0: the Trotter Rz(+-pi/2)
+            const double half = m.pad >= 0 ? 0.5 * thetas[m.pad] : 0.78539816339744831;
+            sincos(half, &g.s, &g.c);
+        } else if (m.kind == MOP_CP) {   // diag(1, 1, 1, e^{i theta})
+            sincos(thetas[m.pad], &g.s, &g.c);
+        }
+        if (m.flags & MOPF_NEG_S) g.s = -g.s;
+        gates[lane] = g;
+    }
+}
+// x <- G x on the pair (x0: bit clear, x1: bit set) of a rotation (elementary_operations.py:159-251)
+__device__ __forceinline__ void rot_pair(int kind, double c, double s, cplx& x0, cplx& x1) {
+    if (kind == MOP_RY) ry2(x0, x1, c, s);
+    else if (kind == MOP_RZ) rz2(x0, x1, c, s);
+    else rx2(x0, x1, c, s);
+}
+__device__ __forceinline__ int ins0(int v, int p) { return ((v >> p) << (p + 1)) | (v & ((1 << p) - 1)); }
+
+// One unitary per (job, lane): U = product of the sub-stage's micro-ops, written as MFMA B operands
+// umat[lane][sub][plane (re, im - re, re + im)][K-step s][l] = U[l % 16][4 s + l / 16].  Jobs cover the sub-stages of
+// several plans (V^H and the sweep are built by one launch).
+__global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const double* thetas, int T) {
+    __shared__ cplx u[256];   // [row = output amplitude][col = input amplitude]
+    __shared__ Gate2 gates[64];
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const UJob job = jobs[blockIdx.x];
+    const DevSub3 sub = *job.sub;
+    const double* th = thetas + (size_t)b * T;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int e = lane + 64 * m;
+        u[e] = make_double2((e >> 4) == (e & 15) ? 1.0 : 0.0, 0.0);
+    }
+    for (int base = 0; base < sub.nmops; base += 64) {
+        const int count = min(64, sub.nmops - base);
+        __syncthreads();
+        stage_gates(gates, job.mops, sub.mop_begin + base, count, th, lane);
+        __syncthreads();
+        for (int i = 0; i < count; ++i) {
+            const Gate2 g = gates[i];
+            if (g.kind == MOP_REDUCE) continue;
+            if (g.kind <= MOP_RX) {   // U <- G U: 8 row pairs x 16 columns, two pairs per lane, in place
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int t = lane + 64 * q, col = t & 15, r0 = ins0(t >> 4, g.p), r1 = r0 | (1 << g.p);
+                    cplx x0 = u[r0 * 16 + col], x1 = u[r1 * 16 + col];
+                    rot_pair(g.kind, g.c, g.s, x0, x1);
+                    u[r0 * 16 + col] = x0; u[r1 * 16 + col] = x1;
+                }
+            } else {                  // entanglers: a row permutation (CX) or a phase on the rows with both bits set
+                cplx v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = lane + 64 * q, row = e >> 4, col = e & 15;
+                    const bool cset = row >> g.p & 1, tset = row >> g.p2 & 1;
+                    v[q] = u[((g.kind == MOP_CX && cset) ? row ^ (1 << g.p2) : row) * 16 + col];
+                    if (g.kind != MOP_CX && cset && tset) v[q] = g.kind == MOP_CZ ? make_double2(-v[q].x, -v[q].y) : cmul(v[q], g.c, g.s);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[lane + 64 * q] = v[q];   // all reads of the wave precede its writes
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    double* out = job.umat + ((size_t)b * job.nsubs + job.index) * 12 * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const cplx v = u[(lane & 15) * 16 + 4 * s + (lane >> 4)];
+        out[(0 * 4 + s) * 64 + lane] = v.x;         // u0 = Re U
+        out[(1 * 4 + s) * 64 + lane] = v.y - v.x;   // u1 = Im U - Re U
+        out[(2 * 4 + s) * 64 + lane] = v.x + v.y;   // u2 = Re U + Im U
+    }
+}
+
+// Gradient entries of one sub-stage from its R = Z W^H (summed over tiles in a fixed order).  R belongs to the
+// END of the sub-stage; walking the micro-ops backwards, each inner product is a trace against the current R
+// (the value right after its rotation, core_operations.py:921-935) and the gate is then peeled off both
+// sides, R <- G^H R G.  A rotation on bit p only mixes the four entries (j0|j1, i0|i1) of a 2 x 2 block, so every
+// lane owns one of the 64 blocks: one LDS round trip per micro-op.  One wave per (sub-stage, lane).
+__global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const DevMop* mops, const double* thetas, int T,
+                                                  const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
+                                                  int from, int to, int front) {
+    __shared__ cplx R[256];       // R[j * 16 + i] = sum_c z_c[j] conj(w_c[i])
+    __shared__ Gate2 gates[64];
+    __shared__ cplx dterm[64][8];  // per micro-op of the staged batch: the 8 diagonal-block terms of its inner product
+    const int lane = threadIdx.x, si = blockIdx.x, b = blockIdx.y;
+    const DevSub3 sub = subs[si];
+    const double* th = thetas + (size_t)b * T;
+    const cplx* rp = rpart + ((size_t)b * nsubs_total + si) * ntiles * 256;
+    {   // fixed-order sum over the tiles, 8 tiles (32 loads per lane) in flight at a time
+        cplx acc[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+        for (int t0 = 0; t0 < ntiles; t0 += 8) {
+            cplx v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[u][r] = t0 + u < ntiles ? rp[(size_t)(t0 + u) * 256 + 64 * r + lane] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[r].x += v[u][r].x; acc[r].y += v[u][r].y; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)   // MFMA D layout: entry 64 r + l is R[4 r + l / 16][l % 16]
+            R[(4 * r + (lane >> 4)) * 16 + (lane & 15)] = acc[r];
+    }
+    cplx* out = partial + (size_t)b * nslots;
+    const int jp = lane >> 3, ip = lane & 7;
+    for (int top = sub.nmops; top > 0; top -= 64) {
+        const int base = max(0, top - 64), count = top - base;
+        __syncthreads();
+        stage_gates(gates, mops, sub.mop_begin + base, count, th, lane);
+        __syncthreads();
+        for (int i = count - 1; i >= 0; --i) {
+            const Gate2 g = gates[i];
+            if (g.kind == MOP_REDUCE) continue;
+            if (g.kind <= MOP_RX) {
+                const int j0 = ins0(jp, g.p), j1 = j0 | (1 << g.p), i0 = ins0(ip, g.p), i1 = i0 | (1 << g.p);
+                cplx b00 = R[j0 * 16 + i0], b01 = R[j0 * 16 + i1], b10 = R[j1 * 16 + i0], b11 = R[j1 * 16 + i1];
+                if (jp == ip) {   // diagonal blocks carry the inner product of this rotation (value right after it)
+                    cplx d;
+                    if (g.kind == MOP_RY) d = make_double2(b10.x - b01.x, b10.y - b01.y);        // <Y w|z> / i
+                    else if (g.kind == MOP_RZ) d = make_double2(b00.x - b11.x, b00.y - b11.y);   // <Z w|z>
+                    else d = make_double2(b01.x + b10.x, b01.y + b10.y);                          // <X w|z>
+                    dterm[i][jp] = d;
+                }
+                rot_pair(g.kind, g.c, -g.s, b00, b10);   // rows: G^H on the z side
+                rot_pair(g.kind, g.c, -g.s, b01, b11);
+                const double sc = g.kind == MOP_RY ? -g.s : g.s;   // columns: conj(G^H) = G for Rz / Rx, G^H for Ry
+                rot_pair(g.kind, g.c, sc, b00, b01);
+                rot_pair(g.kind, g.c, sc, b10, b11);
+                R[j0 * 16 + i0] = b00; R[j0 * 16 + i1] = b01; R[j1 * 16 + i0] = b10; R[j1 * 16 + i1] = b11;
+            } else {
+                if (lane < 8) {   // CP: <P11 w|z> = sum of the 4 diagonal entries with both bits set (commutes with the gate)
+                    cplx d = make_double2(0.0, 0.0);
+                    if (lane < 4 && g.kind == MOP_CP) {
+                        const int lo = g.p < g.p2 ? g.p : g.p2, hi = g.p < g.p2 ? g.p2 : g.p;
+                        const int i3 = ins0(ins0(lane, lo), hi) | (1 << g.p) | (1 << g.p2);
+                        d = R[i3 * 16 + i3];
+                    }
+                    dterm[i][lane] = d;
+                }
+                cplx v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {   // R'[j][i] = conj(phi_j) phi_i R[pi(j)][pi(i)]
+                    const int e = lane + 64 * q, j = e >> 4, c = e & 15;
+                    const bool jb = (j >> g.p & 1) && (j >> g.p2 & 1), ib = (c >> g.p & 1) && (c >> g.p2 & 1);
+                    const int js = (g.kind == MOP_CX && (j >> g.p & 1)) ? j ^ (1 << g.p2) : j;
+                    const int is = (g.kind == MOP_CX && (c >> g.p & 1)) ? c ^ (1 << g.p2) : c;
+                    v[q] = R[js * 16 + is];
+                    if (g.kind == MOP_CZ && (jb != ib)) v[q] = make_double2(-v[q].x, -v[q].y);
+                    if (g.kind == MOP_CP) {
+                        if (jb) v[q] = cmul(v[q], g.c, -g.s);
+                        if (ib) v[q] = cmul(v[q], g.c, g.s);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) R[lane + 64 * q] = v[q];   // all reads of the wave precede its writes
+            }
+            __syncthreads();
+        }
+        if (lane < count) {   // one micro-op per lane: sum its 8 terms, apply the factor, store the slot
+            const Gate2 g = gates[lane];
+            const bool on = g.jblock < 0 ? (front != 0) : (g.jblock >= from && g.jblock < to);
+            if (g.kind != MOP_REDUCE && g.slot >= 0 && on) {
+                double re = 0.0, im = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { re += dterm[lane][q].x; im += dterm[lane][q].y; }
+                cplx v;   // factors: Ry 0.5, Rz / Rx 0.5j, CP -1j (core_operations.py:267-351,972-975)
+                if (g.kind == MOP_RY) v = make_double2(0.5 * re, 0.5 * im);
+                else if (g.kind == MOP_CP) v = make_double2(im, -re);
+                else v = make_double2(-0.5 * im, 0.5 * re);
+                out[g.slot] = v;
+            }
+        }
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+int mfma_threads(int k, bool sweep) { return (sweep && k == 12) ? 64 * SweepShape<12>::kWaves : 64 * std::min(4, 1 << std::max(0, k - 8)); }
+size_t apply3_lds_bytes(int k) { return (size_t)16 << k; }
+size_t sweep3_lds_bytes(int k) {   // two tiles + R scratch of up to 4 slots (+ the `done` counter, except for 2^11 tiles)
+    return ((size_t)32 << k) + (size_t)std::min(4, mfma_threads(k, true) / 64) * 256 * sizeof(cplx) + (k != 11 ? 16 : 0);
+}
+
+template <typename F>
+static hipError_t big_lds(F kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t init_kernels3() {
+    hipError_t e;
+#define AQC_TRY(x) if ((e = (x)) != hipSuccess) return e
+    AQC_TRY(big_lds(apply_mfma_kernel<8>)); AQC_TRY(big_lds(apply_mfma_kernel<9>)); AQC_TRY(big_lds(apply_mfma_kernel<10>));
+    AQC_TRY(big_lds(apply_mfma_kernel<11>)); AQC_TRY(big_lds(apply_mfma_kernel<12>));
+    AQC_TRY(big_lds(sweep_mfma_kernel<8>)); AQC_TRY(big_lds(sweep_mfma_kernel<9>)); AQC_TRY(big_lds(sweep_mfma_kernel<10>));
+    AQC_TRY(big_lds(sweep_mfma_kernel<11>)); AQC_TRY(big_lds(sweep_mfma_kernel<12>));
+#undef AQC_TRY
+    return hipSuccess;
+}
+int mfma_occupancy(int k, bool sweep) {   // resident workgroups per CU for the tile size (diagnostics)
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    const int t = mfma_threads(k, sweep);
+    const size_t l = sweep ? sweep3_lds_bytes(k) : apply3_lds_bytes(k);
+#define AQC_OCC(KK) case KK: e = sweep ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sweep_mfma_kernel<KK>, t, l) \
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, apply_mfma_kernel<KK>, t, l); break
+    switch (k) { AQC_OCC(8); AQC_OCC(9); AQC_OCC(10); AQC_OCC(11); AQC_OCC(12); default: break; }
+#undef AQC_OCC
+    return e == hipSuccess ? n : -1;
+}
+hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
+    const dim3 grid(ntiles, batch);
+    const int t = mfma_threads(k, false);
+    const size_t l = apply3_lds_bytes(k);
+    switch (k) {
+        case 8: apply_mfma_kernel<8><<<grid, t, l, s>>>(a); break;
+        case 9: apply_mfma_kernel<9><<<grid, t, l, s>>>(a); break;
+        case 10: apply_mfma_kernel<10><<<grid, t, l, s>>>(a); break;
+        case 11: apply_mfma_kernel<11><<<grid, t, l, s>>>(a); break;
+        case 12: apply_mfma_kernel<12><<<grid, t, l, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
+    const dim3 grid(ntiles, batch);
+    const int t = mfma_threads(k, true);
+    const size_t l = sweep3_lds_bytes(k);
+    switch (k) {
+        case 8: sweep_mfma_kernel<8><<<grid, t, l, s>>>(a); break;
+        case 9: sweep_mfma_kernel<9><<<grid, t, l, s>>>(a); break;
+        case 10: sweep_mfma_kernel<10><<<grid, t, l, s>>>(a); break;
+        case 11: sweep_mfma_kernel<11><<<grid, t, l, s>>>(a); break;
+        case 12: sweep_mfma_kernel<12><<<grid, t, l, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s) {
+    if (njobs < 1) return hipSuccess;
+    ubuild_kernel<<<dim3(njobs, batch), 64, 0, s>>>(jobs, thetas, T);
+    return hipGetLastError();
+}
+hipError_t launch_rgrad(const DevSub3* subs, const DevMop* mops, const double* thetas, int T, const void* rpart, int ntiles,
+                        int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s) {
+    if (nsubs_total < 1) return hipSuccess;
+    rgrad_kernel<<<dim3(nsubs_total, batch), 64, 0, s>>>(subs, mops, thetas, T, static_cast<const cplx*>(rpart), ntiles, nsubs_total,
+                                                          static_cast<cplx*>(partial), nslots, from, to, front);
+    return hipGetLastError();
+}
+
+}  // namespace aqc

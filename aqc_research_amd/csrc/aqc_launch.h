@@ -50,6 +50,40 @@ hipError_t init_kernels2();
 hipError_t launch_apply2(int ent, int ntiles, int batch, int k, hipStream_t s, const StageArgs& a);
 hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, int reg_bits, hipStream_t s, const StageArgs& a);
 
+// aqc_kernels3.hip (matrix-core kernels)
+struct Stage3Args {
+    DevStage stage;          // by value: kernel arguments live in the constant address space, so the offset tables are
+                             // scalar loads that no store of the kernel can invalidate
+    const DevSub3* subs;     // all sub-stages of the plan
+    const double* umat;      // [batch][nsubs_total][3][4][64]: MFMA B operands of every sub-stage's 16 x 16 unitary
+    int nsubs_total;
+    const double2* in0;      // apply: src; sweep: w in
+    const double2* in1;      // sweep: z in
+    double2* out0;
+    double2* out1;
+    size_t lane_stride;
+    double2* rpart;          // sweep: [batch][nsubs_total][ntiles][256] per-tile R = Z W^H of every sub-stage
+    int ntiles;
+    int store_out;           // sweep: 0 for the last stage (its w and z are never read again)
+    int debug;               // tuning builds: work-skipping bits for timing experiments (1 LDS writes, 2 LDS reads, 4 R MFMAs, 8 U MFMAs)
+    unsigned long long* stamps;   // tuning builds (-DAQC_TUNING): [workgroup][kStampSlots] s_memtime stamps of wave 0, else null
+};
+constexpr int kStampSlots = 40;
+hipError_t init_kernels3();
+int mfma_threads(int k, bool sweep);
+int mfma_occupancy(int k, bool sweep);
+hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
+hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
+struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
+    const DevSub3* sub;
+    const DevMop* mops;      // the plan's micro-ops
+    double* umat;            // the plan's operand buffer [batch][nsubs][12][64]
+    int index, nsubs;
+};
+hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s);
+hipError_t launch_rgrad(const DevSub3* subs, const DevMop* mops, const double* thetas, int T, const void* rpart, int ntiles,
+                        int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s);
+
 // aqc_mps.hip
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);
 hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,

@@ -377,7 +377,7 @@ def main():
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pj.get("workload") == args.workload and pj.get("batch_per_gpu") == B:
                 for kname, kv in pj["kernels"].items():
-                    if "sweep_stage_kernel" in kname:
+                    if "sweep_stage_kernel" in kname or "sweep_mfma_kernel" in kname:
                         traffic = kv["hbm_bytes_per_launch"]
         except Exception:
             traffic = None

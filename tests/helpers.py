@@ -7,6 +7,9 @@ from oracle import aqc_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-10  # north-star tolerance (complex fp64, absolute)
+# kernel families of the HIP path (AQC_KERNEL_FAMILY): every parity test runs on all of them
+FAMILIES = ["per-group", "register-blocked", "mfma"]
+FAMILY_ENV = {"per-group": "1", "register-blocked": "2", "mfma": "3"}
 
 
 def load(name):

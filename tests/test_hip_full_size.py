@@ -8,17 +8,14 @@ import pytest
 
 from oracle import aqc_oracle as orc
 from oracle import aqc_ref as cref
-from tests.helpers import TOL, maxdiff
+from tests.helpers import FAMILIES, FAMILY_ENV, TOL, maxdiff
 
 pytestmark = pytest.mark.gpu
-
-FAMILIES = ["per-group", "register-blocked"]
-
 
 def _family(monkeypatch, family):
     from aqc_research_amd.engine import HipContext
 
-    monkeypatch.setenv("AQC_KERNEL_FAMILY", {"per-group": "1", "register-blocked": "2", "mfma": "3"}[family])
+    monkeypatch.setenv("AQC_KERNEL_FAMILY", FAMILY_ENV[family])
     HipContext._cache.clear()   # the function-level entry points cache their workspace per structure
 
 
@@ -181,4 +178,35 @@ def test_eval_without_thetas_and_bad_download_buffer_fail_loudly():
         ws.download(BUF_Z, out=np.empty((1, 16), dtype=np.complex64))
     with pytest.raises(ValueError):
         ws.download(BUF_Z, out=np.empty((1, 32), dtype=np.complex128)[:, ::2])
+    ws.close()
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_forced_family_is_the_one_that_runs(family, monkeypatch):
+    """AQC_KERNEL_FAMILY must select the kernels that really execute (no silent fall-back between families)."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    _family(monkeypatch, family)
+    n = 12
+    rng = np.random.default_rng(12)
+    circ = ParametricCircuit(n, "cz", create_ansatz_structure(n, "spin", "full", 25))
+    ws = Workspace(HipContext.of(circ), batch=3)
+    want = int(FAMILY_ENV[family])
+    assert [ws.kernel_family(w) for w in (0, 1, 2)] == [want] * 3
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(3)])
+    y = np.stack([orc.rand_state(n, rng) for _ in range(3)])
+    ws.set_thetas(th)
+    ws.upload(BUF_Y, y)
+    ws.set_basis(BUF_X, [0, 5, 4095])
+    ws.apply(True, BUF_Y, BUF_Z)
+    z = ws.download(BUF_Z)
+    ws.grad((3, 20), False)
+    g = ws.get_grads()
+    for b, xi in enumerate((0, 5, 4095)):
+        zr = cref.v_dagger_mul_vec(circ, th[b], y[b])
+        x = np.zeros(1 << n, complex)
+        x[xi] = 1
+        assert maxdiff(z[b], zr) < TOL and maxdiff(g[b], cref.grad_of_dot_product(circ, th[b], x, zr, (3, 20), False)) < TOL
     ws.close()

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import aqc_oracle as orc
-from tests.helpers import TOL, ansatz_from, load, maxdiff
+from tests.helpers import FAMILIES, FAMILY_ENV, TOL, ansatz_from, load, maxdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -34,13 +34,13 @@ def test_golden_matrix(key):
     assert maxdiff(g, MAT[f"{key}/grad"]) < TOL
 
 
-@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
+@pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("n,ent,depth,k", [(6, "cx", 15, 64), (7, "cp", 12, 5), (8, "cz", 20, 32), (9, "cx", 24, 512)])
 def test_matrix_vs_oracle(n, ent, depth, k, family, monkeypatch):
     import aqc_research_amd.core_op_matrix as com
     from aqc_research_amd.engine import HipContext
 
-    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
+    monkeypatch.setenv("AQC_KERNEL_FAMILY", FAMILY_ENV[family])
     HipContext._cache.clear()  # function-level entry points cache their workspace per structure
 
     rng = np.random.default_rng(n * 31 + k)

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import aqc_oracle as orc
 from oracle import aqc_ref as cref
-from tests.helpers import TOL, maxdiff
+from tests.helpers import FAMILIES, FAMILY_ENV, TOL, maxdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -41,13 +41,13 @@ def _random_case(seed):
     return rng, a, ncols, batch, ka, ks, br, front
 
 
-@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
+@pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("seed", range(30))
 def test_random_configuration(seed, family, monkeypatch):
     from aqc_research_amd import ParametricCircuit, TrotterAnsatz
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
 
-    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
+    monkeypatch.setenv("AQC_KERNEL_FAMILY", FAMILY_ENV[family])
     rng, a, ncols, batch, ka, ks, br, front = _random_case(seed)
     circ = TrotterAnsatz(a.n, a.blocks, second_order=a.second_order) if a.trotter else ParametricCircuit(a.n, a.entangler, a.blocks)
     ws = Workspace(HipContext.of(circ), batch=batch, ncols=ncols, tile_bits_apply=ka, tile_bits_sweep=ks)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import aqc_oracle as orc
-from tests.helpers import TOL, ansatz_from, load, maxdiff
+from tests.helpers import FAMILIES, FAMILY_ENV, TOL, ansatz_from, load, maxdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -59,14 +59,14 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
+@pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("n,ent,depth,ka,ks,batch", CASES)
 def test_oracle_multistage_batched(n, ent, depth, ka, ks, batch, family, monkeypatch):
     """Random generic circuits; small tiles force many stages and many tiles; lanes carry
     different thetas / targets.  Both kernel families (aqc_kernels.hip / aqc_kernels2.hip)."""
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
 
-    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
+    monkeypatch.setenv("AQC_KERNEL_FAMILY", FAMILY_ENV[family])
 
     rng = np.random.default_rng(100 * n + depth)
     blocks = np.stack([rng.permutation(n)[:2] for _ in range(depth)], axis=1).astype(np.int64)
@@ -95,12 +95,12 @@ def test_oracle_multistage_batched(n, ent, depth, ka, ks, batch, family, monkeyp
     ws.close()
 
 
-@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
+@pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("n,layers,order2", [(6, 2, True), (9, 2, True), (12, 2, True), (12, 1, False)])
 def test_trotter_vs_oracle(n, layers, order2, family, monkeypatch):
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
 
-    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
+    monkeypatch.setenv("AQC_KERNEL_FAMILY", FAMILY_ENV[family])
 
     rng = np.random.default_rng(7 * n + layers)
     a = orc.Ansatz(n, "cx", orc.trotter_blocks(n, layers), True, order2)
@@ -126,13 +126,13 @@ def test_trotter_vs_oracle(n, layers, order2, family, monkeypatch):
         ws.close()
 
 
-@pytest.mark.parametrize("family", ["per-group", "register-blocked"])
+@pytest.mark.parametrize("family", FAMILIES)
 def test_headline_size_properties(family, monkeypatch):
     """n=16, L=40 (BASELINE configs[2] geometry): parity vs the oracle plus size-independent
     properties (unitarity, linearity of the gradient in x)."""
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
 
-    monkeypatch.setenv("AQC_KERNEL_V2", "1" if family == "register-blocked" else "0")
+    monkeypatch.setenv("AQC_KERNEL_FAMILY", FAMILY_ENV[family])
 
     n, L = 16, 40
     rng = np.random.default_rng(16)

@@ -20,11 +20,13 @@ int main(int argc, char** argv) {
     std::string e = build_program(n, 0, blocks.data(), L, false, false, prog);
     if (!e.empty()) { printf("err %s\n", e.c_str()); return 1; }
     for (int inv = 0; inv < 2; ++inv)
-    for (int k = 10; k <= 13; ++k) for (int lb = 3; lb >= 2; --lb) for (int mo : {8, 1000}) {
+    for (int k = 10; k <= 13; ++k) for (int lb = 3; lb >= 0; --lb) for (int mo : {1000}) {
         Plan p = make_plan(prog, colbits, k, lb, inv);
         split_substages(prog, p, 4, mo);
         int ns = 0; std::string detail;
         for (auto& st : p.stages) { ns += st.subs.size(); detail += " " + std::to_string(st.ops.size()) + "/" + std::to_string(st.subs.size()); }
-        printf("inv=%d k=%d low=%d maxops=%d stages=%zu subs=%d  [%s ]\n", inv, k, lb, mo, p.stages.size(), ns, detail.c_str());
+        printf("inv=%d k=%d low=%d maxops=%d stages=%zu subs=%d  [%s ]", inv, k, lb, mo, p.stages.size(), ns, detail.c_str());
+        for (auto& st : p.stages) { printf(" {"); for (int b : st.bits) printf("%d,", b); printf("}"); }
+        printf("\n");
     }
 }

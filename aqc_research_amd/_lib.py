@@ -87,6 +87,15 @@ SIGNATURES = {
     "aqc_ws_profile_reset": (c_int, [_P]),
     "aqc_ws_plan_info": (c_int, [_P, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "aqc_ws_kernel_family": (c_int, [_P, c_int]),
+    "aqc_ws_plan_substages": (c_int, [_P, c_int]),
+    "aqc_comm_unique_id": (c_int, [ctypes.c_char_p]),
+    "aqc_comm_create": (c_int, [ctypes.c_char_p, c_int, c_int, c_int, POINTER(_P)]),
+    "aqc_comm_destroy": (c_int, [_P]),
+    "aqc_comm_rank": (c_int, [_P]),
+    "aqc_comm_size": (c_int, [_P]),
+    "aqc_comm_allgather": (c_int, [_P, _D, _D, ctypes.c_size_t]),
+    "aqc_comm_allreduce": (c_int, [_P, _D, ctypes.c_size_t, c_int]),
+    "aqc_comm_barrier": (c_int, [_P]),
     "aqc_plan_query": (
         c_int,
         [_P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],

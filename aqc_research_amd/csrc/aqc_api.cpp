@@ -256,6 +256,10 @@ namespace aqc { int set_error(const std::string& msg) { g_error = msg; return 1;
 struct aqc_ctx {
     Program prog;
     std::mutex mu;
+    // lowered plans (host side: stages, sub-stages, micro-ops) by (which, col_bits, tile bits, low bits, family): workspaces
+    // of the same shape -- one per batch of jobs in the drivers -- share the planning work (the sub-stage search of a
+    // deep Trotter ansatz takes a few tenths of a second)
+    std::map<std::vector<int>, DevPlan> plan_cache;
     std::map<int, aqc_ws*> oneshot;  // ncols -> batch-1 workspace used by the host-pointer entry points
 };
 
@@ -612,9 +616,20 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         return best;
     };
     if (want_v3) { ka = std::min(std::max(ka, 8), 12); ks = std::max(ks, 8); }   // MFMA tiles: 2^8 .. 2^12 amplitudes
-    lower_plan(prog, best_plan(ka, false), ws->fwd, (want_v2 || want_v3) ? 4 : 0, false, want_v3);
-    lower_plan(prog, best_plan(ka, true), ws->inv, (want_v2 || want_v3) ? 4 : 0, false, want_v3);
-    lower_plan(prog, best_plan(ks, false), ws->sweep, want_v3 ? 4 : (want_v2 ? (env_int("AQC_SWEEP_REG_BITS", 4) == 3 ? 3 : 4) : 0), true, want_v3);
+    auto cached_plan = [&](int which, int k, bool inverse, int reg_bits, bool dots, DevPlan& out) {
+        const std::vector<int> key = {which, ws->col_bits, k, low_bits, reg_bits, (int)dots, (int)want_v3};
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto it = ctx->plan_cache.find(key);
+        if (it == ctx->plan_cache.end()) {
+            DevPlan fresh;
+            lower_plan(prog, best_plan(k, inverse), fresh, reg_bits, dots, want_v3);
+            it = ctx->plan_cache.emplace(key, std::move(fresh)).first;
+        }
+        out = it->second;   // host vectors copied; device pointers are null in the cache
+    };
+    cached_plan(2, ka, false, (want_v2 || want_v3) ? 4 : 0, false, ws->fwd);
+    cached_plan(0, ka, true, (want_v2 || want_v3) ? 4 : 0, false, ws->inv);
+    cached_plan(1, ks, false, want_v3 ? 4 : (want_v2 ? (env_int("AQC_SWEEP_REG_BITS", 4) == 3 ? 3 : 4) : 0), true, ws->sweep);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -1415,6 +1430,12 @@ int aqc_ws_plan_info(aqc_ws* ws, int which, int* num_stages, int* tile_bits, int
     if (tile_bits) *tile_bits = p.k;
     if (num_tiles) *num_tiles = p.ntiles;
     return 0;
+}
+
+int aqc_ws_plan_substages(aqc_ws* ws, int which) {
+    if (!ws) return -1;
+    const DevPlan& p = which == 0 ? ws->inv : (which == 1 ? ws->sweep : ws->fwd);
+    return p.v3 ? (int)p.h_subs3.size() : (int)p.h_subs.size();
 }
 
 int aqc_ws_kernel_family(aqc_ws* ws, int which) {

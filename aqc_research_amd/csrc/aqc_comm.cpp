@@ -1,0 +1,179 @@
+// aqc_comm_*: the one collective layer of the path, bound straight to librccl (RCCL over xGMI) -- no torch, no MPI.
+//
+// The fidelity/gradient path shards by independent jobs (seeds x horizons, job_executor.py:136-143): one process
+// per GPU, no data-path collective.  What crosses GPUs is the final gather of fixed-size result records
+// {cost, fidelity, nit, status, theta[T_max]} and, for the optional column-sharded full-unitary AQC objective, one
+// all-reduce of 2 (T + 1) doubles per evaluation.  Both are tiny, so the entry points take HOST buffers and stage
+// them through a small device buffer owned by the communicator.
+//
+// Bootstrap as SURVEY 8e prescribes: rank 0 creates the 128-byte unique id (aqc_comm_unique_id) and hands it to the
+// other ranks through a file or the environment (the Python side does that); every rank then calls aqc_comm_create.
+// librccl is loaded lazily with dlopen, so the core library has no link-time dependency on it and single-GPU users
+// never touch it.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../include/aqc_hip.h"
+#include "aqc_launch.h"
+
+namespace {
+
+// the few RCCL declarations this file needs (rccl.h: ncclResult_t = int, ncclSuccess = 0, ncclFloat64 = 8, ncclSum = 0)
+struct NcclUniqueId { char internal[128]; };
+typedef void* NcclComm;
+typedef int (*GetUniqueIdFn)(NcclUniqueId*);
+typedef int (*CommInitRankFn)(NcclComm*, int, NcclUniqueId, int);
+typedef int (*CommDestroyFn)(NcclComm);
+typedef int (*AllGatherFn)(const void*, void*, size_t, int, NcclComm, hipStream_t);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
+typedef const char* (*GetErrorStringFn)(int);
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;
+
+struct Rccl {
+    void* handle = nullptr;
+    GetUniqueIdFn get_unique_id = nullptr;
+    CommInitRankFn comm_init_rank = nullptr;
+    CommDestroyFn comm_destroy = nullptr;
+    AllGatherFn all_gather = nullptr;
+    AllReduceFn all_reduce = nullptr;
+    GetErrorStringFn error_string = nullptr;
+    std::string error;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    if (r.handle || !r.error.empty()) return r;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { r.error = std::string("cannot load librccl: ") + dlerror(); return r; }
+    r.get_unique_id = (GetUniqueIdFn)dlsym(r.handle, "ncclGetUniqueId");
+    r.comm_init_rank = (CommInitRankFn)dlsym(r.handle, "ncclCommInitRank");
+    r.comm_destroy = (CommDestroyFn)dlsym(r.handle, "ncclCommDestroy");
+    r.all_gather = (AllGatherFn)dlsym(r.handle, "ncclAllGather");
+    r.all_reduce = (AllReduceFn)dlsym(r.handle, "ncclAllReduce");
+    r.error_string = (GetErrorStringFn)dlsym(r.handle, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce) {
+        r.error = "librccl lacks an expected symbol";
+        r.handle = nullptr;
+    }
+    return r;
+}
+
+int comm_fail(const std::string& msg) { return aqc::set_error(msg); }
+int nccl_fail(const char* what, int code) {
+    Rccl& r = rccl();
+    return comm_fail(std::string(what) + " failed: " + (r.error_string ? r.error_string(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+}
+
+}  // namespace
+
+struct aqc_comm {
+    NcclComm comm = nullptr;
+    int nranks = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;
+    double* d_buf = nullptr;   // [send | recv]
+    size_t cap = 0;            // doubles
+};
+
+namespace {
+
+int ensure_cap(aqc_comm* c, size_t doubles) {
+    if (doubles <= c->cap) return 0;
+    if (c->d_buf && hipFree(c->d_buf) != hipSuccess) return comm_fail("hipFree failed");
+    c->d_buf = nullptr;
+    c->cap = 0;
+    if (hipMalloc((void**)&c->d_buf, doubles * sizeof(double)) != hipSuccess) return comm_fail("hipMalloc of the staging buffer failed");
+    c->cap = doubles;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aqc_comm_unique_id(char* out128) {
+    if (!out128) return comm_fail("null output");
+    Rccl& r = rccl();
+    if (!r.handle) return comm_fail(r.error);
+    NcclUniqueId id;
+    const int rc = r.get_unique_id(&id);
+    if (rc != 0) return nccl_fail("ncclGetUniqueId", rc);
+    memcpy(out128, id.internal, sizeof id.internal);
+    return 0;
+}
+
+int aqc_comm_create(const char* id128, int nranks, int rank, int device, aqc_comm** out) {
+    if (!out) return comm_fail("out pointer is null");
+    *out = nullptr;
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return comm_fail("invalid communicator arguments");
+    Rccl& r = rccl();
+    if (!r.handle) return comm_fail(r.error);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return comm_fail("no HIP device available: aqc_comm needs one GPU per rank");
+    if (device < 0 || device >= ndev) return comm_fail("device " + std::to_string(device) + " out of range (" + std::to_string(ndev) + " visible)");
+    if (hipSetDevice(device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    aqc_comm* c = new aqc_comm();
+    c->nranks = nranks; c->rank = rank; c->device = device;
+    NcclUniqueId id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    const int rc = r.comm_init_rank(&c->comm, nranks, id, rank);
+    if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { r.comm_destroy(c->comm); delete c; return comm_fail("hipStreamCreate failed"); }
+    *out = c;
+    return 0;
+}
+
+int aqc_comm_destroy(aqc_comm* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->comm) rccl().comm_destroy(c->comm);
+    delete c;
+    return 0;
+}
+
+int aqc_comm_rank(const aqc_comm* c) { return c ? c->rank : -1; }
+int aqc_comm_size(const aqc_comm* c) { return c ? c->nranks : -1; }
+
+// recv[r * count + i] = send of rank r; count doubles per rank (host pointers)
+int aqc_comm_allgather(aqc_comm* c, const double* send, double* recv, size_t count) {
+    if (!c || !send || !recv || count < 1) return comm_fail("invalid all-gather arguments");
+    if (hipSetDevice(c->device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    if (ensure_cap(c, count * (size_t)(c->nranks + 1))) return 1;
+    double* d_send = c->d_buf;
+    double* d_recv = c->d_buf + count;
+    if (hipMemcpyAsync(d_send, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
+    const int rc = rccl().all_gather(d_send, d_recv, count, kNcclFloat64, c->comm, c->stream);
+    if (rc != 0) return nccl_fail("ncclAllGather", rc);
+    if (hipMemcpyAsync(recv, d_recv, count * c->nranks * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return comm_fail("stream synchronisation failed (collective did not complete)");
+    return 0;
+}
+
+// in place: data[i] <- sum over ranks (or max, op = 1) of data[i]
+int aqc_comm_allreduce(aqc_comm* c, double* data, size_t count, int op) {
+    if (!c || !data || count < 1) return comm_fail("invalid all-reduce arguments");
+    if (op != 0 && op != 2) return comm_fail("op must be 0 (sum) or 2 (max)");
+    if (hipSetDevice(c->device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    if (ensure_cap(c, count)) return 1;
+    if (hipMemcpyAsync(c->d_buf, data, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
+    const int rc = rccl().all_reduce(c->d_buf, c->d_buf, count, kNcclFloat64, op == 0 ? kNcclSum : 2 /* ncclMax */, c->comm, c->stream);
+    if (rc != 0) return nccl_fail("ncclAllReduce", rc);
+    if (hipMemcpyAsync(data, c->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return comm_fail("stream synchronisation failed (collective did not complete)");
+    return 0;
+}
+
+int aqc_comm_barrier(aqc_comm* c) {
+    double token = 1.0;
+    return aqc_comm_allreduce(c, &token, 1, 0);
+}
+
+}  // extern "C"

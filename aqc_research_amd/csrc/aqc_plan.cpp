@@ -170,6 +170,76 @@ Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, b
     return plan;
 }
 
+namespace {
+
+// Beam search for the fewest sub-stages of one stage (matrix-core kernels: a sub-stage costs the same whatever the
+// number of gate groups it absorbs, so the count is what matters).  State = set of executed groups; a move = a set of
+// `r` register bits (for long stages: only those containing the bits of the first pending group), executing everything
+// it can reach in program order.  Returns the chosen register-bit masks, or an empty vector when the stage is too
+// large for the search.
+std::vector<uint64_t> beam_substages(const std::vector<uint64_t>& op_bits, int k, int r, int width) {
+    const int nops = (int)op_bits.size();
+    if (nops == 0 || k <= r || k > 16 || (long long)nops * nops > 4000000) return {};
+    std::vector<uint64_t> masks;
+    for (uint64_t m = 0; m < (1ull << k); ++m)
+        if (popcount64(m) == r) masks.push_back(m);
+    struct State { std::vector<char> done; int ndone; int parent; uint64_t mask; uint64_t hash; };
+    std::vector<std::vector<State>> levels(1);
+    levels[0].push_back({std::vector<char>(nops, 0), 0, -1, 0, 0});
+    auto advance = [&](const std::vector<char>& done, uint64_t mask, std::vector<char>& out) {
+        uint64_t blocked = 0;
+        int count = 0;
+        out = done;
+        for (int i = 0; i < nops; ++i) {
+            if (done[i]) continue;
+            const uint64_t b = op_bits[i];
+            if (b & blocked) blocked |= b;
+            else if ((b & mask) == b) { out[i] = 1; ++count; }
+            else blocked |= b;
+            if ((blocked & mask) == mask) break;
+        }
+        return count;
+    };
+    for (int depth = 0; depth < 4 * nops + 4; ++depth) {
+        const std::vector<State>& cur = levels.back();
+        int finished = -1;
+        for (size_t i = 0; i < cur.size(); ++i)
+            if (cur[i].ndone == nops) { finished = (int)i; break; }
+        if (finished >= 0) {   // walk back
+            std::vector<uint64_t> out;
+            int idx = finished;
+            for (int d = (int)levels.size() - 1; d > 0; --d) { out.push_back(levels[d][idx].mask); idx = levels[d][idx].parent; }
+            std::reverse(out.begin(), out.end());
+            return out;
+        }
+        std::vector<State> next;
+        std::vector<char> tmp;
+        for (size_t i = 0; i < cur.size(); ++i) {
+            int first = 0;
+            while (cur[i].done[first]) ++first;
+            const uint64_t need = nops > 160 ? op_bits[first] : 0;
+            for (uint64_t m : masks) {
+                if ((m & need) != need) continue;
+                const int c = advance(cur[i].done, m, tmp);
+                if (c == 0) continue;
+                uint64_t h = 1469598103934665603ull;
+                for (int q = 0; q < nops; ++q) h = (h ^ (uint64_t)tmp[q]) * 1099511628211ull;
+                bool dup = false;
+                for (const State& s : next)
+                    if (s.hash == h && s.ndone == cur[i].ndone + c && s.done == tmp) { dup = true; break; }
+                if (!dup) next.push_back({tmp, cur[i].ndone + c, (int)i, m, h});
+            }
+        }
+        if (next.empty()) return {};
+        std::stable_sort(next.begin(), next.end(), [](const State& a, const State& b) { return a.ndone > b.ndone; });
+        if ((int)next.size() > width) next.resize(width);
+        levels.push_back(std::move(next));
+    }
+    return {};
+}
+
+}  // namespace
+
 void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops) {
     for (Stage& st : plan.stages) {
         st.subs.clear();
@@ -178,6 +248,15 @@ void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops)
         std::vector<int> local_of(plan.nbits, 0);
         for (int j = 0; j < k; ++j) local_of[st.bits[j]] = j;
         std::vector<int> order = st.ops;
+        // unlimited groups per sub-stage (matrix-core kernels): search for the fewest sub-stages first
+        std::vector<uint64_t> chosen;
+        if (max_ops >= (1 << 20)) {
+            Sim sim{prog, order, plan.col_bits, &local_of};
+            std::vector<uint64_t> op_bits;
+            for (int gi : order) op_bits.push_back(sim.group_bits(prog.groups[gi]));
+            chosen = beam_substages(op_bits, k, r, 64);
+        }
+        size_t next_choice = 0;
         while (!order.empty()) {
             Sim sim{prog, order, plan.col_bits, &local_of, max_ops};
             uint64_t best = 0;
@@ -186,7 +265,9 @@ void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops)
                 const int c = sim.run(m, nullptr, nullptr);
                 if (c > best_count) { best_count = c; best = m; }
             };
-            if (k <= r) {
+            if (next_choice < chosen.size()) {
+                consider(chosen[next_choice++]);
+            } else if (k <= r) {
                 consider((1ull << k) - 1);
             } else {
                 uint64_t m = 0;

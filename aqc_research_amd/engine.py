@@ -272,6 +272,10 @@ class Workspace:
         """1 per-gate-group, 2 register-blocked (both fp64 VALU), 3 fp64 matrix cores."""
         return int(self._L.aqc_ws_kernel_family(self.handle, which))
 
+    def plan_substages(self, which: int = 1) -> int:
+        """Sub-stages of a plan (each is one 16 x 16 complex unitary per lane on the matrix-core path)."""
+        return int(self._L.aqc_ws_plan_substages(self.handle, which))
+
     def family_name(self) -> str:
         return self._FAMILIES[self.kernel_family(1)][0]
 

@@ -142,18 +142,18 @@ class SketchingObjectiveEx:
         self._structure = None
         self._device = device
         self._ws = None
-        # column_shard: under torch.distributed (one process per GPU) every rank runs the gate sequence on its
-        # own slab of the k sketching columns -- columns are independent until the final trace -- and the
-        # per-rank (trace, complex gradient) records are summed with ONE all-reduce of 2(T+1) doubles per
-        # evaluation (RCCL over xGMI with the nccl backend; latency-bound at this size).
+        # column_shard: with one process per GPU every rank runs the gate sequence on its own slab of the k sketching
+        # columns -- columns are independent until the final trace -- and the per-rank (trace, complex gradient)
+        # records are summed with ONE all-reduce of 2(T+1) doubles per evaluation (aqc_comm: RCCL over xGMI bound
+        # directly; latency-bound at this size; the gloo double on CPU).
         self._shard = None
         if column_shard:
-            from ..job_executor import _dist
+            from ..comm import from_environment
 
-            dist = _dist()
-            if dist is not None:
-                k, world, rank = skvecs.num_skvecs, dist.get_world_size(), dist.get_rank()
-                self._shard = (dist, (k * rank) // world, (k * (rank + 1)) // world)
+            comm = from_environment()
+            if comm.size > 1:
+                k, world, rank = skvecs.num_skvecs, comm.size, comm.rank
+                self._shard = (comm, (k * rank) // world, (k * (rank + 1)) // world)
                 if self._shard[2] <= self._shard[1]:
                     raise ValueError("more ranks than sketching columns")
 
@@ -213,9 +213,7 @@ class SketchingObjectiveEx:
 
     def _sharded_eval(self, thetas: np.ndarray):
         """This rank's column slab, then the all-reduce of (trace, gradient)."""
-        import torch
-
-        dist, c0, c1 = self._shard
+        comm, c0, c1 = self._shard
         ctx = HipContext.of(self._circ)
         resident = getattr(self._skvecs, "device_resident", False)
         fresh = self._ws is None or self._structure != ctx.key
@@ -235,11 +233,7 @@ class SketchingObjectiveEx:
         rec[0] = ws.vdot(BUF_X, BUF_Z)[0]
         ws.grad(None, True)
         rec[1:] = ws.get_grads()[0]
-        t = torch.from_numpy(rec.view(np.float64))
-        if dist.get_backend() == "nccl":
-            t = t.to(torch.device("cuda", self._device))
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        rec = t.cpu().numpy().view(np.complex128)
+        comm.allreduce(rec.view(np.float64), "sum")
         return rec[0], rec[1:]
 
     def objective(self, thetas: np.ndarray) -> float:

@@ -42,6 +42,10 @@ WORKLOADS = {
     "mat5_cyc180": dict(n=5, blocks=180, kind="cyclic", ncols=32, desc="5-qubit full AQC (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks), matrix objective+gradient"),
     # config 3 through the MPS front door: every step re-uploads each lane's target as a QiskitMPS (host tensors),
     # contracts it to the dense state on the device (mps_to_vector chain) and runs V^H + gather + sweep on it
+    # config 4: the ASP job mix -- 64 seeds x 8 time horizons of a 20-qubit 2nd-order Trotter ansatz (2h layers at horizon
+    # h), 10 objective+gradient pairs per job -- sharded over the ranks by run_jobs (job j on rank j % world), results
+    # gathered as fixed-size records.  One step = the whole mix.
+    "cfg4_jobs": dict(n=20, kind="jobs", seeds=64, horizons=8, evals=10, desc="20-qubit ASP job mix: 64 seeds x 8 horizons (2nd-order Trotter ansatz, 2h layers), 10 objective+gradient pairs per job, sharded by run_jobs"),
     "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=16 uploaded + densified every evaluation"),
     "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=64 uploaded + densified every evaluation"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=256 uploaded + densified every evaluation"),
@@ -159,6 +163,76 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
     }
 
 
+def _mix_job(job_index, cfg):
+    """One entry of the config-4 mix: `seeds` restarts of horizon h as lanes of one batched objective, `evals`
+    objective+gradient pairs with a fixed-step descent between them (time_evol_best_init.py:197-208's inner loop with the
+    optimizer's line search left out: the workload is the evaluations)."""
+    from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index, trotter_ansatz
+    from oracle import aqc_oracle as orc
+
+    n, h, seeds = cfg["n"], cfg["horizon"], cfg["seeds"]
+    circ = trotter_ansatz(n, 2 * h, True)
+    base = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=1.2 * h, delta=1.0)
+    # synthetic targets: rand_state(20) costs ~60 ms of host time each, 30 s for the mix -- not part of the path.  A pool of
+    # 8 states is drawn once per process; a job's target is a pool state rotated by its seed (still a normalised
+    # uniform[0,1) + i uniform[0,1) state, different for every job)
+    pool = _mix_job.__dict__.setdefault("pool", {})
+    if n not in pool:
+        prng = np.random.default_rng(0x696969)
+        pool[n] = [orc.rand_state(n, prng) for _ in range(8)]
+    targets, starts = [], []
+    for sd in seeds:
+        rng = np.random.default_rng(sd)
+        targets.append(np.roll(pool[n][sd % 8], sd % (1 << n)))
+        starts.append(base + 0.1 * np.pi * (2.0 * rng.random(base.size) - 1.0))
+    bo = BatchedSurrogateObjective(circ, np.stack(targets), base_index=neel_state_index(n), device=cfg["device"])
+    th = np.stack(starts)
+    f = None
+    for _ in range(cfg["evals"]):
+        f, g = bo.value_and_grad(th)
+        th = th - 0.05 * g
+    fid = bo.fidelity.copy()
+    bo.close()
+    return {"cost": float(np.mean(f)), "fidelity": float(np.mean(fid)), "num_iters": cfg["evals"],
+            "num_fun_ev": cfg["evals"] * len(seeds), "num_grad_ev": cfg["evals"] * len(seeds), "thetas": th[0]}
+
+
+def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note):
+    """--workload cfg4_jobs: the whole mix through run_jobs (rank-sharded, fixed-size record gather)."""
+    from aqc_research_amd.job_executor import run_jobs
+
+    chunk = 8   # seeds per job: config index = horizon * (seeds / chunk) + chunk index, so every rank sees every horizon
+    nchunks = w["seeds"] // chunk
+    configs = [{"n": w["n"], "horizon": h, "evals": w["evals"], "device": local_rank,
+                "seeds": [0x696969 + 7 * (c * chunk + s + 1) + 1000 * h for s in range(chunk)]}
+               for h in range(1, w["horizons"] + 1) for c in range(nchunks)]
+    K, W = max(1, min(args.steps, 3)), min(args.warmup, 1)
+    for _ in range(W):
+        run_jobs(configs[: comm.size * 2], 1, _mix_job, records="fixed")   # warm-up: contexts, plans, first launches
+    comm.barrier()
+    t0 = time.perf_counter()
+    results = None
+    for _ in range(K):
+        results = run_jobs(configs, 1, _mix_job, records="fixed")
+    comm.barrier()
+    wall = time.perf_counter() - t0
+    if comm.size > 1:
+        wall = float(comm.allreduce(np.array([wall]), "max")[0])
+    ok = [r for r in results if r["status"].startswith("ok")]
+    njobs = w["seeds"] * w["horizons"]
+    evals = njobs * w["evals"]
+    return {
+        "metric": "objective+gradient evals/sec", "value": evals * K / wall, "unit": "evals/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": w["desc"], "n_qubits": w["n"], "jobs": njobs, "jobs_per_s": njobs * K / wall, "evals_per_job": w["evals"],
+                   "records_ok": len(ok), "records_total": len(results), "mean_fidelity": float(np.mean([r["fidelity"] for r in ok])),
+                   "transport": comm.transport if comm_note is None else comm_note,
+                   "sharding": "run_jobs: config j on rank j % world, 8 seeds per config as lanes of one batched objective"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,26 +253,60 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1 or os.environ.get("AQC_BENCH_FORCE_DIST") == "1":  # one rank per GPU under torch.distributed.run
-        import torch
-        import torch.distributed as dist
+    # Process group: one rank per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    # environment).  The transport is aqc_comm -- librccl bound directly through the C ABI, no torch in the process.
+    # AQC_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than ranks (ranks share a device, records
+    # travel over the gloo test double); AQC_BENCH_BACKEND=torch-nccl forces the torch.distributed nccl backend.  If the
+    # direct binding cannot initialise, the run falls back to torch.distributed nccl and says so in `config.transport`.
+    from aqc_research_amd import comm as aqc_comm
 
+    comm = aqc_comm.Communicator()
+    comm_note = None
+    if world > 1 or os.environ.get("AQC_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # AQC_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than ranks (ranks then share
-        # a device and the tiny timing / record tensors travel over gloo on the CPU); the real path is nccl.
-        backend = os.environ.get("AQC_BENCH_BACKEND", "nccl")
-        ndev = max(1, torch.cuda.device_count())
-        if backend == "nccl":
-            if local_rank >= ndev:
-                raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("AQC_BENCH_BACKEND", "rccl")
+
+        def torch_group(name):
+            import torch
+            import torch.distributed as dist
+
+            ndev = max(1, torch.cuda.device_count())
+            if name == "nccl":
+                if local_rank >= ndev:
+                    raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible")
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=name)
+            return aqc_comm.GlooDouble(dist)
+
+        if backend == "gloo":
+            comm = torch_group("gloo")
+        elif backend == "torch-nccl":
+            comm = torch_group("nccl")
         else:
-            local_rank %= ndev
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend)
-    tdev = f"cuda:{local_rank}" if dist is not None and dist.get_backend() == "nccl" else "cpu"
+            try:
+                os.environ.setdefault("WORLD_SIZE", "1")
+                if world > 1:
+                    comm = aqc_comm.from_environment(prefer="rccl")
+                else:   # AQC_BENCH_FORCE_DIST=1 on one rank: a one-rank RCCL communicator (init + collectives exercised)
+                    import tempfile
+
+                    comm = aqc_comm.RcclCommunicator(0, 1, local_rank, os.path.join(tempfile.gettempdir(), f"aqc_comm_id_bench_{os.getpid()}"))
+            except Exception as exc:  # loud fall-back: the record gather must not take the scaling run down
+                comm_note = f"aqc_comm (direct RCCL) failed to initialise: {exc}; fell back to torch.distributed nccl"
+                print("bench.py: " + comm_note, file=sys.stderr)
+                comm = torch_group("nccl")
+        aqc_comm._current = comm
+    from aqc_research_amd import _lib as aqc_lib
+
+    ndev = aqc_lib.lib().aqc_device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no HIP device visible; the path has no CPU fallback")
+    if local_rank >= ndev:
+        if os.environ.get("AQC_BENCH_BACKEND", "rccl") != "gloo":
+            raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible")
+        local_rank %= ndev   # rehearsal: ranks share devices
     n_gpus = max(args.gpus, world) if world > 1 else args.gpus
     if world == 1 and args.gpus > 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU); running 1 GPU", file=sys.stderr)
@@ -208,6 +316,16 @@ def main():
     from oracle import aqc_oracle as orc
 
     w = WORKLOADS[args.workload]
+    if w["kind"] == "jobs":
+        out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note)
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(out), flush=True)
+            os.dup2(2, 1)
+        comm.barrier()
+        comm.close()
+        return
     circ = build_circuit(w)
     n, T = circ.num_qubits, circ.num_thetas
     ctx = HipContext.of(circ)
@@ -258,12 +376,8 @@ def main():
         ws.grad(None, True)
 
     def barrier():
-        ws.sync()
-        if dist is not None:
-            import torch
-
-            dist.barrier()
-            torch.cuda.synchronize()
+        ws.sync()          # every launch of this rank's stream has completed (the path does not use torch's stream)
+        comm.barrier()
 
     # Settle phase (untimed set-up, tools/hiccup_probe.py): within the first ~50 ms of sustained launches after start-up
     # this stack shows a one-off stall of 50-80 ms (HIP runtime / driver housekeeping); a short burst of the same
@@ -282,23 +396,23 @@ def main():
     ev_ms = ws.timer_stop()
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([wall], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    if comm.size > 1:
+        wall = float(comm.allreduce(np.array([wall]), "max")[0])
 
     # result record of the last step (checked + gathered: the only inter-GPU traffic)
     hs = ws.gather_fetch() if ncols == 1 else ws.vdot_fetch().reshape(B, 1)
     grads = ws.get_grads()
-    record = np.array([np.abs(hs[:, 0]).mean() ** 2, np.linalg.norm(grads.real)], dtype=np.float64)
-    if dist is not None:
-        import torch
+    # the shipped gather: one fixed-size record {cost, fidelity, counts, thetas[T]} per lane through run_jobs' own
+    # packing + ONE all-gather over the communicator (job_executor._gather_records)
+    from aqc_research_amd import job_executor as jex
 
-        rec = torch.from_numpy(record).to(tdev)
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
+    lane_records = [{"job_index": rank + comm.size * b, "seed": 0, "time": 0.0, "status": "ok", "cost": float(1.0 - abs(hs[b, 0]) ** 2),
+                     "fidelity": float(abs(hs[b, 0]) ** 2), "num_iters": K, "num_fun_ev": K, "num_grad_ev": K,
+                     "thetas": bank[(W + K - 1) % nsets][b]} for b in range(B)]
+    gathered = jex._gather_records(lane_records, comm, B * comm.size, "fixed") if comm.size > 1 or comm.transport != "none" else lane_records
+    if len(gathered) != B * comm.size:
+        print(f"bench.py: rank {rank}: gathered {len(gathered)} records, expected {B * comm.size}", file=sys.stderr)
+        os._exit(4)
 
     # ---- the timed work is checked, not assumed: the last step's (hs, gradient) of a few lanes against the C
     # restatement of the reference algorithm (oracle/aqc_ref.c) on the same (theta, target) --------------------
@@ -345,6 +459,9 @@ def main():
         sweep_flops_per_step = float(N) * (80.0 * (G - n) + 60.0 * n) * B
         sweep_flops_per_launch = sweep_flops_per_step * prof_steps / max(sweep_launches, 1)
         sweep_tflops = sweep_flops_per_launch / (sweep_avg_ms * 1e-3) / 1e12 if sweep_avg_ms > 0 else 0.0
+        mfma_tflops = None
+        if ws.kernel_family(1) == 3 and sweep_ms > 0:
+            mfma_tflops = 288.0 * N * B * ws.plan_substages(1) * prof_steps / (sweep_ms * 1e-3) / 1e12
         stages_inv, k_inv, tiles_inv = ws.plan_info(0)
         stages_sw, k_sw, tiles_sw = ws.plan_info(1)
 
@@ -406,6 +523,8 @@ def main():
                 "path": ("MPS front door (mps_dot_objective), dense route" if chi else "state-vector (core_operations)") if ncols == 1 else "matrix (core_op_matrix)",
                 "mps_bond_dimension": chi or None,
                 "columns": ncols,
+                "transport": comm.transport if comm_note is None else comm_note,
+                "records_gathered": len(gathered),
                 "tile_bits": {"vdag": k_inv, "sweep": k_sw},
                 "launches_per_eval_step": {"vdag": stages_inv, "sweep": stages_sw},
             },
@@ -422,6 +541,12 @@ def main():
                 "traffic": traffic,
                 "avg_launch_ms": sweep_avg_ms,
                 "flops_per_launch": sweep_flops_per_launch,
+                # what the matrix pipe really executed: 288 real flops per amplitude and sub-stage (9 real 16x16x16
+                # products per 256 amplitudes).  `achieved` above counts SURVEY 8d's gate-by-gate flops, so frac can
+                # exceed this figure -- and 1 -- when one 16 x 16 unitary absorbs many gates (Trotter triplets).
+                "mfma_issue_TFLOPs": mfma_tflops,
+                "mfma_issue_frac": mfma_tflops / FP64_PEAK_TFLOPS if mfma_tflops is not None else None,
+                "substages": {"vdag": ws.plan_substages(0), "sweep": ws.plan_substages(1)},
             },
             # byte view of the same launches (information only: SURVEY 8d's per-gate-group byte model is not a lower
             # bound for a fused launch; `traffic_bytes_per_launch` is the rocprofv3 PMC measurement)
@@ -458,9 +583,8 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     ws.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == "__main__":

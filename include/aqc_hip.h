@@ -25,6 +25,7 @@
 #ifndef AQC_HIP_H
 #define AQC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -207,12 +208,31 @@ int aqc_ws_profile_reset(aqc_ws* ws);
 /* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
 int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,
                      int* num_stages, int* tile_bits, int* num_tiles);
+/* number of sub-stages (16 x 16 unitaries per lane on the matrix-core path) of plan `which`; 0 for the per-group kernels */
+int aqc_ws_plan_substages(aqc_ws* ws, int which);
 /* kernel family that runs plan `which`: 1 per-gate-group (VALU), 2 register-blocked (VALU), 3 matrix-core (MFMA) */
 int aqc_ws_kernel_family(aqc_ws* ws, int which);
 /* host-only planner introspection (no GPU needed): stage s of plan `which` for the given tiling;
  * ops_out receives gate-group indices (forward program order), bits_out the local address bits */
 int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage,
                    int* num_stages, int* bits_out, int* num_bits, int* ops_out, int* num_ops);
+
+/* ---- multi-GPU: the one collective layer of the path, bound straight to librccl (RCCL over xGMI; loaded lazily).
+ * One process per GPU; jobs are sharded over the ranks (job_executor.py:136-143: joblib processes in the reference) and
+ * only fixed-size result records cross GPUs.  All buffers are HOST pointers (the records are a few KB).
+ * Bootstrap: rank 0 calls aqc_comm_unique_id and passes the 128 bytes to the other ranks (file / environment),
+ * every rank calls aqc_comm_create. */
+typedef struct aqc_comm aqc_comm;
+int aqc_comm_unique_id(char* out128);
+int aqc_comm_create(const char* id128, int nranks, int rank, int device, aqc_comm** out);
+int aqc_comm_destroy(aqc_comm* comm);
+int aqc_comm_rank(const aqc_comm* comm);
+int aqc_comm_size(const aqc_comm* comm);
+/* recv[r * count + i] = send[i] of rank r (the final gather of run_jobs: job_executor.py:141-161) */
+int aqc_comm_allgather(aqc_comm* comm, const double* send, double* recv, size_t count);
+/* in place, op 0 = sum (column-sharded AQC objective: (trace, gradient) record), 2 = max (timing) */
+int aqc_comm_allreduce(aqc_comm* comm, double* data, size_t count, int op);
+int aqc_comm_barrier(aqc_comm* comm);
 
 #ifdef __cplusplus
 }

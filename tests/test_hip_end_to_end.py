@@ -144,3 +144,24 @@ def test_column_sharded_aqc_objective_two_ranks(tmp_path):
                          capture_output=True, text=True, env=env, timeout=280)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ERR") == 2
+
+
+def test_rccl_bound_directly_single_rank(tmp_path):
+    """aqc_comm_*: librccl through the C ABI (no torch): unique id, communicator, all-gather, all-reduce, barrier on a
+    one-rank group -- what a 1-GPU box can exercise of the multi-GPU transport."""
+    from aqc_research_amd.comm import RcclCommunicator
+
+    c = RcclCommunicator(0, 1, 0, str(tmp_path / "id"))
+    assert c.rank == 0 and c.size == 1 and "rccl" in c.transport
+    x = np.linspace(0, 1, 37)
+    assert np.array_equal(c.allgather(x), x[None, :])
+    y = x.copy()
+    assert np.array_equal(c.allreduce(y, "sum"), x) and np.array_equal(c.allreduce(y, "max"), x)
+    c.barrier()
+    from aqc_research_amd import job_executor as jex
+
+    recs = [{"job_index": j, "seed": 7 * j, "time": 0.1, "status": "ok", "cost": 0.5, "fidelity": 0.5, "num_iters": 3,
+             "num_fun_ev": 3, "num_grad_ev": 3, "thetas": np.arange(4.0) + j} for j in range(3)]
+    back = jex._gather_records(recs, c, 3, "fixed")
+    assert [r["job_index"] for r in back] == [0, 1, 2] and np.array_equal(back[2]["thetas"], np.arange(4.0) + 2)
+    c.close()

@@ -245,3 +245,60 @@ def test_lockstep_round_logic_with_stub_workspace(monkeypatch):
         raise KeyError("boom")
     res = batch.run([bad, lambda v: job(v, 1)[0][0][0]])
     assert isinstance(res[0], KeyError) and isinstance(res[1], complex)
+
+
+def test_result_record_roundtrip():
+    """Fixed-size record of run_jobs' final gather: {job_index, seed, ok, time, cost, fidelity, counts, thetas[T_max]}."""
+    from aqc_research_amd import job_executor as jex
+
+    th = np.linspace(-1, 1, 7)
+    r = {"job_index": 5, "seed": 40, "time": 0.25, "status": "ok", "cost": 0.125, "fidelity": 0.875, "num_iters": 12,
+         "num_fun_ev": 15, "num_grad_ev": 15, "thetas": th}
+    back = jex.unpack_record(jex.pack_record(r, 10))
+    assert back["job_index"] == 5 and back["seed"] == 40 and back["status"] == "ok" and back["num_iters"] == 12
+    assert back["cost"] == 0.125 and back["fidelity"] == 0.875 and np.array_equal(back["thetas"], th)
+    failed = jex.unpack_record(jex.pack_record({"job_index": 1, "seed": 2, "time": -1.0, "status": "Traceback ..."}, 3))
+    assert failed["job_index"] == 1 and not failed["status"].startswith("ok") and "thetas" not in failed
+    assert jex._fits_fixed_schema(r) and not jex._fits_fixed_schema(dict(r, extra=1))
+
+
+def test_run_jobs_fixed_records_gloo_world2(tmp_path):
+    """The shipped gather (fixed-size float64 records, one all-gather) over the gloo test double: 5 jobs on 2 ranks,
+    ragged theta sizes, one failing job."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, json
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np, torch.distributed as dist
+        from aqc_research_amd.job_executor import run_jobs
+        from aqc_research_amd import comm
+        dist.init_process_group(backend="gloo")
+        def job(i, cfg):
+            if cfg["a"] == 3:
+                raise ValueError("boom")
+            return {{"cost": 0.5 * cfg["a"], "fidelity": 1 - 0.1 * cfg["a"], "num_iters": cfg["a"], "num_fun_ev": 2 * cfg["a"],
+                     "num_grad_ev": 2 * cfg["a"], "thetas": np.arange(cfg["a"] + 2, dtype=float) + np.random.rand()}}
+        res = run_jobs([{{"a": i}} for i in range(5)], 11, job, records="auto")
+        c = comm.from_environment()
+        out = [(r["job_index"], r["seed"], r["status"].startswith("ok"), r.get("cost"), r.get("num_iters"),
+                None if "thetas" not in r else [float(v) for v in r["thetas"]]) for r in res]
+        open(os.path.join({str(tmp_path)!r}, f"out{{dist.get_rank()}}.json"), "w").write(json.dumps([out, c.transport, c.size]))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+
+    a, ta, sa = json.loads((tmp_path / "out0.json").read_text())
+    b, tb, sb = json.loads((tmp_path / "out1.json").read_text())
+    assert a == b and sa == sb == 2 and "gloo" in ta
+    assert [r[0] for r in a] == [0, 1, 2, 3, 4] and [r[2] for r in a] == [True, True, True, False, True]
+    for i, r in enumerate(a):
+        if i == 3:
+            continue
+        np.random.seed(11 + 7 * (i + 1))
+        assert r[1] == 11 + 7 * (i + 1) and r[3] == 0.5 * i and r[4] == i
+        assert np.allclose(r[5], np.arange(i + 2, dtype=float) + np.random.rand(), atol=0, rtol=0)

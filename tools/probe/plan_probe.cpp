@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     std::string e = build_program(n, 0, blocks.data(), L, false, false, prog);
     if (!e.empty()) { printf("err %s\n", e.c_str()); return 1; }
     for (int inv = 0; inv < 2; ++inv)
-    for (int k = 10; k <= 13; ++k) for (int lb = 3; lb >= 0; --lb) for (int mo : {1000}) {
+    for (int k = 10; k <= 13; ++k) for (int lb = 3; lb >= 0; --lb) for (int mo : {1 << 30}) {
         Plan p = make_plan(prog, colbits, k, lb, inv);
         split_substages(prog, p, 4, mo);
         int ns = 0; std::string detail;

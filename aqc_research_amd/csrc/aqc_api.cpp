@@ -71,7 +71,9 @@ struct DevPlan {
     // matrix-core kernels (family 3)
     bool v3 = false;
     std::vector<DevSub3> h_subs3;
+    std::vector<DevGrp> h_grps;
     DevSub3* d_subs3 = nullptr;
+    DevGrp* d_grps = nullptr;
     double* d_umat = nullptr;     // [batch][nsubs][12][64]
     double2* d_rpart = nullptr;   // sweep plan only: [batch][nsubs][ntiles][256]
     bool u_valid = false;         // d_umat matches the coefficients in use
@@ -152,6 +154,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
     out.h_subs.clear();
     out.h_mops.clear();
     out.h_subs3.clear();
+    out.h_grps.clear();
     out.reg_bits = reg_bits;
     out.v3 = mfma && reg_bits == 4 && (int)plan.stages.front().bits.size() >= 8;
     out.v2 = !out.v3 && reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
@@ -210,11 +213,15 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
                 std::vector<int> reg_of(ds.k, -1);
                 for (int j = 0; j < dsub.nbits; ++j) { dsub.bits[j] = sub.bits[j]; reg_of[sub.bits[j]] = j; }
                 dsub.mop_begin = (int)out.h_mops.size();
+                const int grp_begin = (int)out.h_grps.size();
                 for (int gi : sub.ops) {
                     const GateGroup& g = prog.groups[gi];
                     const int pc = reg_of[local_of[plan.col_bits + g.q0]];
                     const int pt = g.q1 >= 0 ? reg_of[local_of[plan.col_bits + g.q1]] : 0;
                     emit_mops(prog, gi, pc, pt, plan.inverse, with_dots, out.h_mops);
+                    if (out.v3)   // front groups get a dummy second bit so that one code path serves both types
+                        out.h_grps.push_back({g.type, pc, g.q1 >= 0 ? pt : (pc == 0 ? 1 : 0), g.flags, g.theta0,
+                                              with_dots ? gi * kSlotsPerGroup : -1, g.jblock, 0});
                 }
                 dsub.nmops = (int)out.h_mops.size() - dsub.mop_begin;
                 out.h_subs.push_back(dsub);
@@ -224,6 +231,8 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
                     memset(&d3, 0, sizeof d3);
                     d3.mop_begin = dsub.mop_begin;
                     d3.nmops = dsub.nmops;
+                    d3.grp_begin = grp_begin;
+                    d3.ngrp = (int)out.h_grps.size() - grp_begin;
                     std::vector<int> cbits;
                     for (int j = 0; j < ds.k; ++j)
                         if (reg_of[j] < 0) cbits.push_back(j);
@@ -326,6 +335,8 @@ int upload_plan(DevPlan& p) {
     if (p.v3 && !p.h_subs3.empty()) {
         HIP_OK(hipMalloc((void**)&p.d_subs3, p.h_subs3.size() * sizeof(DevSub3)));
         HIP_OK(hipMemcpy(p.d_subs3, p.h_subs3.data(), p.h_subs3.size() * sizeof(DevSub3), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc((void**)&p.d_grps, std::max<size_t>(p.h_grps.size(), 1) * sizeof(DevGrp)));
+        if (!p.h_grps.empty()) HIP_OK(hipMemcpy(p.d_grps, p.h_grps.data(), p.h_grps.size() * sizeof(DevGrp), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -678,7 +689,8 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         std::vector<UJob> jobs;
         for (DevPlan* p : {&ws->inv, &ws->sweep, &ws->fwd})
             if (p->v3)
-                for (size_t i = 0; i < p->h_subs3.size(); ++i) jobs.push_back({p->d_subs3 + i, p->d_mops, p->d_umat, (int)i, (int)p->h_subs3.size()});
+                for (size_t i = 0; i < p->h_subs3.size(); ++i)
+                    jobs.push_back({p->d_subs3 + i, p->d_grps, p->d_umat, (int)i, (int)p->h_subs3.size(), p->plan.inverse ? 1 : 0, prog.entangler});
         if (!jobs.empty()) {
             WS_HIP(hipMalloc((void**)&ws->d_ujobs, sizeof(UJob) * jobs.size()));
             WS_HIP(hipMemcpy(ws->d_ujobs, jobs.data(), sizeof(UJob) * jobs.size(), hipMemcpyHostToDevice));
@@ -714,6 +726,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_subs) (void)hipFree(p->d_subs);
         if (p->d_mops) (void)hipFree(p->d_mops);
         if (p->d_subs3) (void)hipFree(p->d_subs3);
+        if (p->d_grps) (void)hipFree(p->d_grps);
         if (p->d_umat) (void)hipFree(p->d_umat);
         if (p->d_rpart) (void)hipFree(p->d_rpart);
     }
@@ -892,7 +905,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
 #endif
         }
         ProfScope ps(ws, AQC_K_FINALIZE);
-        HIP_OK(launch_rgrad(p.d_subs3, p.d_mops, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
+        HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
                             ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
         HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
                                1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));

@@ -74,10 +74,22 @@ struct DevSub {
 // Matrix-core kernels (aqc_kernels3.hip): LDS slot tables of one sub-stage.  The local index of (amplitude a, chunk c)
 // is deposit(a -> register bits) | deposit(c -> the other local bits); the tables hold swz3() of the three parts
 // (the swizzle is GF(2)-linear, so slot = dep_a[a] ^ dep_clo[c & 15] ^ dep_chi[c >> 4]).
+// One gate group of a sub-stage as the small kernels (U builder, gradient walker) see it: the group is
+// (C (x) T) ENT on register bits (pc, pt) -- or its inverse -- with 2 x 2 matrices C, T built from the thetas.
+struct DevGrp {
+    int32_t type;     // 0 front (Rz Ry Rz on pc; pt is any other register bit), 1 unit-block
+    int32_t pc, pt;   // register bits (0..3) of control / target
+    int32_t flags;    // bit0 Trotter Rz(-pi/2) on control before the block, bit1 Rz(+pi/2) on target after it
+    int32_t theta0;   // index of the group's first theta
+    int32_t slot0;    // first inner-product slot of the group (sweep), -1 otherwise
+    int32_t jblock;   // block index mod L for the block_range test, -1 = front layer
+    int32_t pad;
+};
+
 struct DevSub3 {
     int32_t mop_begin, nmops;
     int32_t bits[4];        // register bits (local bit positions, ascending)
-    int32_t pad[2];
+    int32_t grp_begin, ngrp;  // gate groups of the sub-stage in execution order (DevGrp)
     uint16_t dep_a[16];
     uint16_t dep_clo[16];
     uint16_t dep_chi[64];   // up to 2^14-amplitude tiles

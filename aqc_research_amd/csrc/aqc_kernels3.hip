@@ -400,45 +400,103 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
 }
 
 // ---- small kernels: U of every sub-stage, gradient entries from R -----------------------------------------
-// Both walk the micro-ops of ONE sub-stage over a 16 x 16 complex matrix in LDS with one wave.  The micro-ops are decoded
-// 64 at a time (one per lane, straight from the lane's thetas: sincos of the half angle; no coefficient kernel on this
-// path), so the serial loop only reads LDS.
-struct Gate2 {   // one micro-op: a 2 x 2 rotation on register bit p, or an entangler on bits (p, p2)
-    int kind, p, p2, slot;
-    double c, s;
-    int jblock, pad;
+// Both work on ONE sub-stage's 16 x 16 complex matrix in LDS with one wave, gate GROUP by gate group (not gate by
+// gate: the serial chain is what these kernels cost).  A group is (C (x) T) ENT on register bits (pc, pt): C, T are
+// 2 x 2 products of the group's rotations (Trotter Rz(-+pi/2) folded in -- Rz on the control commutes with every
+// entangler), built by one lane per group straight from the thetas (no coefficient kernel on this path).
+struct Gm {            // one gate group, decoded
+    cplx c[4], t[4];   // C', T' row-major
+    double ec, es;     // CP phase e^{i theta4}
+    double rc[4], rs[4];   // (cos, sin) of the half angles of the group's rotations (gradient walk)
+    int type, pc, pt, flags, slot0, jblock, o0, o1;   // o0 < o1: the two register bits the group does not touch
 };
-__device__ __forceinline__ void stage_gates(Gate2* gates, const DevMop* mops, int begin, int count, const double* thetas, int lane) {
-    if (lane < count) {
-        const DevMop m = mops[begin + lane];
-        Gate2 g;
-        g.kind = m.kind; g.p = m.p; g.p2 = m.p2; g.jblock = m.jblock; g.pad = 0;
-        g.slot = m.kind == MOP_REDUCE ? -1 : m.slot;
-        g.c = 1.0; g.s = 0.0;
-        if (m.kind <= MOP_RX) {          // rotation by theta: (cos, sin) of theta / 2; pad < 0: the Trotter Rz(+-pi/2)
-            const double half = m.pad >= 0 ? 0.5 * thetas[m.pad] : 0.78539816339744831;
-            sincos(half, &g.s, &g.c);
-        } else if (m.kind == MOP_CP) {   // diag(1, 1, 1, e^{i theta})
-            sincos(thetas[m.pad], &g.s, &g.c);
+__device__ __forceinline__ void m2_mul(const cplx (&a)[4], const cplx (&b)[4], cplx (&o)[4]) {   // o = a b
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const cplx x = a[2 * i], y = b[j], u = a[2 * i + 1], v = b[2 + j];
+            o[2 * i + j] = make_double2(x.x * y.x - x.y * y.y + u.x * v.x - u.y * v.y, x.x * y.y + x.y * y.x + u.x * v.y + u.y * v.x);
         }
-        if (m.flags & MOPF_NEG_S) g.s = -g.s;
-        gates[lane] = g;
+}
+__device__ __forceinline__ void m2_ry(double c, double s, cplx (&o)[4]) {
+    o[0] = make_double2(c, 0.0); o[1] = make_double2(-s, 0.0); o[2] = make_double2(s, 0.0); o[3] = make_double2(c, 0.0);
+}
+__device__ __forceinline__ void m2_rz(double c, double s, cplx (&o)[4]) {
+    o[0] = make_double2(c, -s); o[1] = make_double2(0.0, 0.0); o[2] = make_double2(0.0, 0.0); o[3] = make_double2(c, s);
+}
+__device__ __forceinline__ void m2_rx(double c, double s, cplx (&o)[4]) {
+    o[0] = make_double2(c, 0.0); o[1] = make_double2(0.0, -s); o[2] = make_double2(0.0, -s); o[3] = make_double2(c, 0.0);
+}
+// (a0, a1) <- M (a0, a1);  DAG: M^H, TR: M^T
+template <bool DAG, bool TR>
+__device__ __forceinline__ void m2_apply(const cplx (&m)[4], cplx& a0, cplx& a1) {
+    const cplx m00 = m[0], m01 = (DAG || TR) ? m[2] : m[1], m10 = (DAG || TR) ? m[1] : m[2], m11 = m[3];
+    const double sg = DAG ? -1.0 : 1.0;   // conjugate the entries
+    const cplx x = a0, y = a1;
+    a0 = make_double2(m00.x * x.x - sg * m00.y * x.y + m01.x * y.x - sg * m01.y * y.y, m00.x * x.y + sg * m00.y * x.x + m01.x * y.y + sg * m01.y * y.x);
+    a1 = make_double2(m10.x * x.x - sg * m10.y * x.y + m11.x * y.x - sg * m11.y * y.y, m10.x * x.y + sg * m10.y * x.x + m11.x * y.y + sg * m11.y * y.x);
+}
+// decode the groups [begin, begin + count) of a sub-stage, one per lane
+__device__ __forceinline__ void stage_groups(Gm* gm, const DevGrp* grps, int begin, int count, const double* th, int ent, int lane) {
+    if (lane >= count) return;
+    const DevGrp d = grps[begin + lane];
+    Gm g;
+    g.type = d.type; g.pc = d.pc; g.pt = d.pt; g.flags = d.flags; g.slot0 = d.slot0; g.jblock = d.jblock;
+    const int mask = 0xF & ~(1 << d.pc) & ~(1 << d.pt);
+    g.o0 = __ffs(mask) - 1; g.o1 = __ffs(mask & (mask - 1)) - 1;
+    g.ec = 1.0; g.es = 0.0;
+    const int nrot = d.type == 0 ? 3 : 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        g.rc[k] = 1.0; g.rs[k] = 0.0;
+        if (k < nrot) sincos(0.5 * th[d.theta0 + k], &g.rs[k], &g.rc[k]);
+    }
+    cplx a[4], b[4], m[4];
+    if (d.type == 0) {   // Rz(t0) Ry(t1) Rz(t2), rightmost first (core_operations.py:671-677)
+        m2_rz(g.rc[0], g.rs[0], a); m2_ry(g.rc[1], g.rs[1], b); m2_mul(a, b, m);
+        m2_rz(g.rc[2], g.rs[2], b); m2_mul(m, b, g.c);
+        g.t[0] = make_double2(1.0, 0.0); g.t[1] = make_double2(0.0, 0.0); g.t[2] = g.t[1]; g.t[3] = g.t[0];
+    } else {             // control Rz(t1) Ry(t0), target Rs(t3) Ry(t2) (core_operations.py:686-705)
+        m2_rz(g.rc[1], g.rs[1], a); m2_ry(g.rc[0], g.rs[0], b); m2_mul(a, b, g.c);
+        if (d.flags & 1) { m2_rz(kR, -kR, b); m2_mul(g.c, b, m); g.c[0] = m[0]; g.c[1] = m[1]; g.c[2] = m[2]; g.c[3] = m[3]; }
+        if (ent == 0) m2_rx(g.rc[3], g.rs[3], a); else m2_rz(g.rc[3], g.rs[3], a);
+        m2_ry(g.rc[2], g.rs[2], b); m2_mul(a, b, g.t);
+        if (d.flags & 2) { m2_rz(kR, kR, a); m2_mul(a, g.t, m); g.t[0] = m[0]; g.t[1] = m[1]; g.t[2] = m[2]; g.t[3] = m[3]; }
+        if (ent == 2) sincos(th[d.theta0 + 4], &g.es, &g.ec);
+    }
+    gm[lane] = g;
+}
+// index inside the 16 register-bit values: local pair value l = 2 cb + tb on (pc, pt), `rest` on the other two bits
+__device__ __forceinline__ int grp_index(const Gm& g, int l, int rest) {
+    return ((l >> 1) << g.pc) | ((l & 1) << g.pt) | ((rest & 1) << g.o0) | ((rest >> 1) << g.o1);
+}
+// x <- B x (or B^H x, or B^T x) for B = (C (x) T) ENT on the four values x[2 cb + tb]
+template <int MODE>   // 0: B, 1: B^H, 2: B^T
+__device__ __forceinline__ void grp_apply(const Gm& g, int ent, cplx (&x)[4]) {
+    auto entangle = [&](double es) {
+        if (g.type == 0) return;
+        if (ent == 0) { const cplx t = x[2]; x[2] = x[3]; x[3] = t; }
+        else if (ent == 1) x[3] = make_double2(-x[3].x, -x[3].y);
+        else x[3] = cmul(x[3], g.ec, es);
+    };
+    if (MODE == 0) {
+        entangle(g.es);
+        m2_apply<false, false>(g.t, x[0], x[1]); m2_apply<false, false>(g.t, x[2], x[3]);
+        m2_apply<false, false>(g.c, x[0], x[2]); m2_apply<false, false>(g.c, x[1], x[3]);
+    } else {
+        m2_apply<MODE == 1, MODE == 2>(g.c, x[0], x[2]); m2_apply<MODE == 1, MODE == 2>(g.c, x[1], x[3]);
+        m2_apply<MODE == 1, MODE == 2>(g.t, x[0], x[1]); m2_apply<MODE == 1, MODE == 2>(g.t, x[2], x[3]);
+        entangle(MODE == 1 ? -g.es : g.es);
     }
 }
-// x <- G x on the pair (x0: bit clear, x1: bit set) of a rotation (elementary_operations.py:159-251)
-__device__ __forceinline__ void rot_pair(int kind, double c, double s, cplx& x0, cplx& x1) {
-    if (kind == MOP_RY) ry2(x0, x1, c, s);
-    else if (kind == MOP_RZ) rz2(x0, x1, c, s);
-    else rx2(x0, x1, c, s);
-}
-__device__ __forceinline__ int ins0(int v, int p) { return ((v >> p) << (p + 1)) | (v & ((1 << p) - 1)); }
 
-// One unitary per (job, lane): U = product of the sub-stage's micro-ops, written as MFMA B operands
+// One unitary per (job, lane): U = product of the sub-stage's gate groups, written as MFMA B operands
 // umat[lane][sub][plane (re, im - re, re + im)][K-step s][l] = U[l % 16][4 s + l / 16].  Jobs cover the sub-stages of
 // several plans (V^H and the sweep are built by one launch).
 __global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const double* thetas, int T) {
     __shared__ cplx u[256];   // [row = output amplitude][col = input amplitude]
-    __shared__ Gate2 gates[64];
+    __shared__ Gm gm[64];
     const int lane = threadIdx.x, b = blockIdx.y;
     const UJob job = jobs[blockIdx.x];
     const DevSub3 sub = *job.sub;
@@ -448,34 +506,21 @@ __global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const doub
         const int e = lane + 64 * m;
         u[e] = make_double2((e >> 4) == (e & 15) ? 1.0 : 0.0, 0.0);
     }
-    for (int base = 0; base < sub.nmops; base += 64) {
-        const int count = min(64, sub.nmops - base);
+    const int col = lane & 15, rest = lane >> 4;
+    for (int base = 0; base < sub.ngrp; base += 64) {
+        const int count = min(64, sub.ngrp - base);
         __syncthreads();
-        stage_gates(gates, job.mops, sub.mop_begin + base, count, th, lane);
+        stage_groups(gm, job.grps, sub.grp_begin + base, count, th, job.entangler, lane);
         __syncthreads();
-        for (int i = 0; i < count; ++i) {
-            const Gate2 g = gates[i];
-            if (g.kind == MOP_REDUCE) continue;
-            if (g.kind <= MOP_RX) {   // U <- G U: 8 row pairs x 16 columns, two pairs per lane, in place
+        for (int i = 0; i < count; ++i) {   // U <- B U (or B^H U for V^H plans): 4 rows x 16 columns per (col, rest) lane
+            const Gm& g = gm[i];
+            cplx x[4];
+            int idx[4];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int t = lane + 64 * q, col = t & 15, r0 = ins0(t >> 4, g.p), r1 = r0 | (1 << g.p);
-                    cplx x0 = u[r0 * 16 + col], x1 = u[r1 * 16 + col];
-                    rot_pair(g.kind, g.c, g.s, x0, x1);
-                    u[r0 * 16 + col] = x0; u[r1 * 16 + col] = x1;
-                }
-            } else {                  // entanglers: a row permutation (CX) or a phase on the rows with both bits set
-                cplx v[4];
+            for (int l = 0; l < 4; ++l) { idx[l] = grp_index(g, l, rest) * 16 + col; x[l] = u[idx[l]]; }
+            if (job.inverse) grp_apply<1>(g, job.entangler, x); else grp_apply<0>(g, job.entangler, x);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = lane + 64 * q, row = e >> 4, col = e & 15;
-                    const bool cset = row >> g.p & 1, tset = row >> g.p2 & 1;
-                    v[q] = u[((g.kind == MOP_CX && cset) ? row ^ (1 << g.p2) : row) * 16 + col];
-                    if (g.kind != MOP_CX && cset && tset) v[q] = g.kind == MOP_CZ ? make_double2(-v[q].x, -v[q].y) : cmul(v[q], g.c, g.s);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) u[lane + 64 * q] = v[q];   // all reads of the wave precede its writes
-            }
+            for (int l = 0; l < 4; ++l) u[idx[l]] = x[l];
             __syncthreads();
         }
     }
@@ -490,17 +535,56 @@ __global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const doub
     }
 }
 
-// Gradient entries of one sub-stage from its R = Z W^H (summed over tiles in a fixed order).  R belongs to the
-// END of the sub-stage; walking the micro-ops backwards, each inner product is a trace against the current R
-// (the value right after its rotation, core_operations.py:921-935) and the gate is then peeled off both
-// sides, R <- G^H R G.  A rotation on bit p only mixes the four entries (j0|j1, i0|i1) of a 2 x 2 block, so every
-// lane owns one of the 64 blocks: one LDS round trip per micro-op.  One wave per (sub-stage, lane).
-__global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const DevMop* mops, const double* thetas, int T,
+// rho <- G^H rho G for a rotation G (kind, c, s) on local bit LB of a 4 x 4 matrix rho[a * 4 + b] (a: z side, b: w side)
+template <int LB>
+__device__ __forceinline__ void rho_unapply(cplx (&rho)[16], int kind, double c, double s) {
+    constexpr int st = LB == 0 ? 1 : 2, other = LB == 0 ? 2 : 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {   // rows: G^H
+            const int a0 = q * other;
+            if (kind == MOP_RY) ry2(rho[a0 * 4 + b], rho[(a0 + st) * 4 + b], c, -s);
+            else if (kind == MOP_RZ) rz2(rho[a0 * 4 + b], rho[(a0 + st) * 4 + b], c, -s);
+            else rx2(rho[a0 * 4 + b], rho[(a0 + st) * 4 + b], c, -s);
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {   // columns: G^T (Ry^T = Ry(-theta); Rz, Rx symmetric)
+            const int b0 = q * other;
+            if (kind == MOP_RY) ry2(rho[a * 4 + b0], rho[a * 4 + b0 + st], c, -s);
+            else if (kind == MOP_RZ) rz2(rho[a * 4 + b0], rho[a * 4 + b0 + st], c, s);
+            else rx2(rho[a * 4 + b0], rho[a * 4 + b0 + st], c, s);
+        }
+}
+// 0.5j <P w|z> (Ry: 0.5 <Y w|z> / i) of a rotation on local bit LB from rho (core_operations.py:267-351)
+template <int LB>
+__device__ __forceinline__ cplx rho_dot(const cplx (&rho)[16], int kind) {
+    constexpr int st = LB == 0 ? 1 : 2, other = LB == 0 ? 2 : 1;
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i0 = q * other, i1 = i0 + st;
+        if (kind == MOP_RY) { re += rho[i1 * 4 + i0].x - rho[i0 * 4 + i1].x; im += rho[i1 * 4 + i0].y - rho[i0 * 4 + i1].y; }
+        else if (kind == MOP_RZ) { re += rho[i0 * 4 + i0].x - rho[i1 * 4 + i1].x; im += rho[i0 * 4 + i0].y - rho[i1 * 4 + i1].y; }
+        else { re += rho[i0 * 4 + i1].x + rho[i1 * 4 + i0].x; im += rho[i0 * 4 + i1].y + rho[i1 * 4 + i0].y; }
+    }
+    return kind == MOP_RY ? make_double2(0.5 * re, 0.5 * im) : make_double2(-0.5 * im, 0.5 * re);
+}
+
+// Gradient entries of one sub-stage from its R = Z W^H (summed over tiles in a fixed order).  R belongs to the END of
+// the sub-stage.  Walking the gate groups backwards: the group's inner products only involve its two qubits, so they
+// are functions of the 4 x 4 partial trace rho_g of the current R over the other two register bits; rho_g is set aside
+// and the whole group is peeled off R at once, R <- B^H R B (two LDS round trips per group -- this chain is the serial
+// part).  Afterwards one lane per group walks its rho_g through the group's rotations (value right after each
+// rotation, core_operations.py:921-935) and stores the slots.  One wave per (sub-stage, lane).
+__global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
                                                   const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                   int from, int to, int front) {
-    __shared__ cplx R[256];       // R[j * 16 + i] = sum_c z_c[j] conj(w_c[i])
-    __shared__ Gate2 gates[64];
-    __shared__ cplx dterm[64][8];  // per micro-op of the staged batch: the 8 diagonal-block terms of its inner product
+    __shared__ cplx R[16 * 17];    // R[j * 17 + i] = sum_c z_c[j] conj(w_c[i]); rows padded: column walks hit 16 different banks
+    __shared__ Gm gm[64];
+    __shared__ cplx rho_s[64][16];
     const int lane = threadIdx.x, si = blockIdx.x, b = blockIdx.y;
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
@@ -521,75 +605,67 @@ __global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const De
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // MFMA D layout: entry 64 r + l is R[4 r + l / 16][l % 16]
-            R[(4 * r + (lane >> 4)) * 16 + (lane & 15)] = acc[r];
+            R[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[r];
     }
     cplx* out = partial + (size_t)b * nslots;
-    const int jp = lane >> 3, ip = lane & 7;
-    for (int top = sub.nmops; top > 0; top -= 64) {
+    const int lo = lane & 15, hi = lane >> 4;
+    for (int top = sub.ngrp; top > 0; top -= 64) {
         const int base = max(0, top - 64), count = top - base;
         __syncthreads();
-        stage_gates(gates, mops, sub.mop_begin + base, count, th, lane);
+        stage_groups(gm, grps, sub.grp_begin + base, count, th, ent, lane);
         __syncthreads();
         for (int i = count - 1; i >= 0; --i) {
-            const Gate2 g = gates[i];
-            if (g.kind == MOP_REDUCE) continue;
-            if (g.kind <= MOP_RX) {
-                const int j0 = ins0(jp, g.p), j1 = j0 | (1 << g.p), i0 = ins0(ip, g.p), i1 = i0 | (1 << g.p);
-                cplx b00 = R[j0 * 16 + i0], b01 = R[j0 * 16 + i1], b10 = R[j1 * 16 + i0], b11 = R[j1 * 16 + i1];
-                if (jp == ip) {   // diagonal blocks carry the inner product of this rotation (value right after it)
-                    cplx d;
-                    if (g.kind == MOP_RY) d = make_double2(b10.x - b01.x, b10.y - b01.y);        // <Y w|z> / i
-                    else if (g.kind == MOP_RZ) d = make_double2(b00.x - b11.x, b00.y - b11.y);   // <Z w|z>
-                    else d = make_double2(b01.x + b10.x, b01.y + b10.y);                          // <X w|z>
-                    dterm[i][jp] = d;
-                }
-                rot_pair(g.kind, g.c, -g.s, b00, b10);   // rows: G^H on the z side
-                rot_pair(g.kind, g.c, -g.s, b01, b11);
-                const double sc = g.kind == MOP_RY ? -g.s : g.s;   // columns: conj(G^H) = G for Rz / Rx, G^H for Ry
-                rot_pair(g.kind, g.c, sc, b00, b01);
-                rot_pair(g.kind, g.c, sc, b10, b11);
-                R[j0 * 16 + i0] = b00; R[j0 * 16 + i1] = b01; R[j1 * 16 + i0] = b10; R[j1 * 16 + i1] = b11;
-            } else {
-                if (lane < 8) {   // CP: <P11 w|z> = sum of the 4 diagonal entries with both bits set (commutes with the gate)
-                    cplx d = make_double2(0.0, 0.0);
-                    if (lane < 4 && g.kind == MOP_CP) {
-                        const int lo = g.p < g.p2 ? g.p : g.p2, hi = g.p < g.p2 ? g.p2 : g.p;
-                        const int i3 = ins0(ins0(lane, lo), hi) | (1 << g.p) | (1 << g.p2);
-                        d = R[i3 * 16 + i3];
-                    }
-                    dterm[i][lane] = d;
-                }
-                cplx v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {   // R'[j][i] = conj(phi_j) phi_i R[pi(j)][pi(i)]
-                    const int e = lane + 64 * q, j = e >> 4, c = e & 15;
-                    const bool jb = (j >> g.p & 1) && (j >> g.p2 & 1), ib = (c >> g.p & 1) && (c >> g.p2 & 1);
-                    const int js = (g.kind == MOP_CX && (j >> g.p & 1)) ? j ^ (1 << g.p2) : j;
-                    const int is = (g.kind == MOP_CX && (c >> g.p & 1)) ? c ^ (1 << g.p2) : c;
-                    v[q] = R[js * 16 + is];
-                    if (g.kind == MOP_CZ && (jb != ib)) v[q] = make_double2(-v[q].x, -v[q].y);
-                    if (g.kind == MOP_CP) {
-                        if (jb) v[q] = cmul(v[q], g.c, -g.s);
-                        if (ib) v[q] = cmul(v[q], g.c, g.s);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) R[lane + 64 * q] = v[q];   // all reads of the wave precede its writes
+            const Gm& g = gm[i];
+            {   // rho_g[a][b] = sum_o R[(a, o)][(b, o)]: lane = (a, b, o), quad sum over o
+                const int a = lane >> 4, bb = (lane >> 2) & 3, o = lane & 3;
+                cplx v = R[grp_index(g, a, o) * 17 + grp_index(g, bb, o)];
+                v.x += dpp_mov<0xB1, 0xf>(v.x); v.y += dpp_mov<0xB1, 0xf>(v.y);   // quad_perm [1,0,3,2]
+                v.x += dpp_mov<0x4E, 0xf>(v.x); v.y += dpp_mov<0x4E, 0xf>(v.y);   // quad_perm [2,3,0,1]
+                if (o == 0) rho_s[i][a * 4 + bb] = v;
             }
+            cplx x[4];
+            int idx[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { idx[l] = grp_index(g, l, hi) * 17 + lo; x[l] = R[idx[l]]; }   // rows: B^H on the z side
+            grp_apply<1>(g, ent, x);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) R[idx[l]] = x[l];
+            __syncthreads();
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { idx[l] = lo * 17 + grp_index(g, l, hi); x[l] = R[idx[l]]; }   // columns: B^T on the w side
+            grp_apply<2>(g, ent, x);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) R[idx[l]] = x[l];
             __syncthreads();
         }
-        if (lane < count) {   // one micro-op per lane: sum its 8 terms, apply the factor, store the slot
-            const Gate2 g = gates[lane];
+        if (lane < count) {   // one group per lane: walk rho backwards through the group's rotations
+            const Gm& g = gm[lane];
             const bool on = g.jblock < 0 ? (front != 0) : (g.jblock >= from && g.jblock < to);
-            if (g.kind != MOP_REDUCE && g.slot >= 0 && on) {
-                double re = 0.0, im = 0.0;
+            if (on && g.slot0 >= 0) {
+                cplx rho[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { re += dterm[lane][q].x; im += dterm[lane][q].y; }
-                cplx v;   // factors: Ry 0.5, Rz / Rx 0.5j, CP -1j (core_operations.py:267-351,972-975)
-                if (g.kind == MOP_RY) v = make_double2(0.5 * re, 0.5 * im);
-                else if (g.kind == MOP_CP) v = make_double2(im, -re);
-                else v = make_double2(-0.5 * im, 0.5 * re);
-                out[g.slot] = v;
+                for (int e = 0; e < 16; ++e) rho[e] = rho_s[lane][e];
+                if (g.type == 0) {   // Rz(t2) [slot 0], Ry(t1) [slot 1], Rz(t0) [slot 2] on pc (local bit 1)
+                    out[g.slot0 + 2] = rho_dot<1>(rho, MOP_RZ);
+                    rho_unapply<1>(rho, MOP_RZ, g.rc[0], g.rs[0]);
+                    out[g.slot0 + 1] = rho_dot<1>(rho, MOP_RY);
+                    rho_unapply<1>(rho, MOP_RY, g.rc[1], g.rs[1]);
+                    out[g.slot0 + 0] = rho_dot<1>(rho, MOP_RZ);
+                } else {             // Ry(c,t0) [0], Rz(c,t1) [1], Ry(t,t2) [2], Rs(t,t3) [3], CP [4]; rotations on c and t commute
+                    const int ks = ent == 0 ? MOP_RX : MOP_RZ;
+                    if (g.flags & 2) rho_unapply<0>(rho, MOP_RZ, kR, kR);
+                    out[g.slot0 + 3] = rho_dot<0>(rho, ks);
+                    rho_unapply<0>(rho, ks, g.rc[3], g.rs[3]);
+                    out[g.slot0 + 2] = rho_dot<0>(rho, MOP_RY);
+                    out[g.slot0 + 1] = rho_dot<1>(rho, MOP_RZ);
+                    rho_unapply<1>(rho, MOP_RZ, g.rc[1], g.rs[1]);
+                    out[g.slot0 + 0] = rho_dot<1>(rho, MOP_RY);
+                    if (ent == 2) {   // -i <P11 w|z> at the entangler (core_op_matrix.py:430-477): peel the two Ry first
+                        rho_unapply<0>(rho, MOP_RY, g.rc[2], g.rs[2]);
+                        rho_unapply<1>(rho, MOP_RY, g.rc[0], g.rs[0]);
+                        out[g.slot0 + 4] = make_double2(rho[15].y, -rho[15].x);
+                    }
+                }
             }
         }
     }
@@ -660,11 +736,11 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
     ubuild_kernel<<<dim3(njobs, batch), 64, 0, s>>>(jobs, thetas, T);
     return hipGetLastError();
 }
-hipError_t launch_rgrad(const DevSub3* subs, const DevMop* mops, const double* thetas, int T, const void* rpart, int ntiles,
-                        int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s) {
+hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
+                        int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s) {
     if (nsubs_total < 1) return hipSuccess;
-    rgrad_kernel<<<dim3(nsubs_total, batch), 64, 0, s>>>(subs, mops, thetas, T, static_cast<const cplx*>(rpart), ntiles, nsubs_total,
-                                                          static_cast<cplx*>(partial), nslots, from, to, front);
+    rgrad_kernel<<<dim3(nsubs_total, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+                                                          nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front);
     return hipGetLastError();
 }
 

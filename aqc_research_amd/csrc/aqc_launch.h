@@ -76,13 +76,14 @@ hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stag
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
     const DevSub3* sub;
-    const DevMop* mops;      // the plan's micro-ops
+    const DevGrp* grps;      // the plan's gate groups
     double* umat;            // the plan's operand buffer [batch][nsubs][12][64]
     int index, nsubs;
+    int inverse, entangler;  // V^H plans apply every group conjugate-transposed; 0 cx, 1 cz, 2 cp
 };
 hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s);
-hipError_t launch_rgrad(const DevSub3* subs, const DevMop* mops, const double* thetas, int T, const void* rpart, int ntiles,
-                        int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s);
+hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
+                        int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s);
 
 // aqc_mps.hip
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);

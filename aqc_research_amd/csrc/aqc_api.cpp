@@ -302,6 +302,10 @@ struct aqc_ws {
     int nslots = 0, vdot_parts = 0;
     bool coef_valid = false;
     bool need_coef = false;           // something besides the stage kernels reads d_coef (coordinate descent)
+    // aqc_ws_eval as a HIP graph: the whole chain (thetas H2D, U builder, V^H stages, gather, sweep stages, gradient walk,
+    // D2H copies) captured once per call signature and replayed -- one launch instead of ~11 host calls per evaluation
+    std::map<std::vector<long long>, hipGraphExec_t> graphs;
+    bool capturing = false;
     UJob* d_ujobs = nullptr;          // family 3: [V^H subs | sweep subs | V subs]
     struct MpsSlot {
         std::vector<int> dims;          // n + 1 bond dimensions
@@ -603,7 +607,12 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     const size_t big_tiles = (size_t)batch << std::max(0, ws->nbits - 12);
     const bool want_v2 = force_v2 >= 0 ? force_v2 != 0 : big_tiles >= 512;
     auto pick = [&](int kmax) {
-        if (want_v3) return std::min(12, ws->nbits);
+        if (want_v3) {   // 2^12 tiles when they fill the chip (>= 256 workgroups), else down to 2^10: with few lanes the
+                         // latency of an evaluation is the serial chain inside one workgroup (tools/lat_probe.py)
+            int k = std::min(12, ws->nbits);
+            while (k > 10 && ((size_t)batch << (ws->nbits - k)) < 256) --k;
+            return k;
+        }
         if (want_v2) return std::min(kmax, ws->nbits);
         int k = std::min(11, ws->nbits);
         while (k > 10 && ((size_t)batch << (ws->nbits - k)) < 512) --k;
@@ -716,10 +725,13 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     return 0;
 }
 
+static void drop_graphs(aqc_ws* ws);
+
 int aqc_ws_destroy(aqc_ws* ws) {
     if (!ws) return 0;
     (void)hipSetDevice(ws->device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
+    drop_graphs(ws);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         if (p->d_stages) (void)hipFree(p->d_stages);
         if (p->d_ops) (void)hipFree(p->d_ops);
@@ -944,6 +956,11 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
     return 0;
 }
 
+static void drop_graphs(aqc_ws* ws) {
+    for (auto& kv : ws->graphs) (void)hipGraphExecDestroy(kv.second);
+    ws->graphs.clear();
+}
+
 int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered, int x_buf, int block_from, int block_to,
                 int front_layer, double* grads) {
     if (!ws) return fail("null workspace");
@@ -953,26 +970,61 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     double* pin_th = ws->h_pin;
     double* pin_gr = ws->h_pin + ws->pin_thetas;
     double* pin_sm = pin_gr + ws->pin_grads;
-    if (thetas) {
-        memcpy(pin_th, thetas, sizeof(double) * nth);
-        ws->d_thetas = ws->d_thetas_own;
-        HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
-        if (run_coef(ws)) return 1;
-    } else if ((do_vdag || grads) && ensure_coef(ws)) {
-        return 1;
-    }
-    if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
     size_t nsm = 0;
     if (gathered) {
         if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
         nsm = (size_t)ws->batch * ws->gather_count;
         if (2 * nsm > ws->pin_small) return fail("too many gathered amplitudes for the staging buffer");
-        if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
-        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
     }
-    if (grads) {
-        if (aqc_ws_grad_from(ws, x_buf, block_from, block_to, front_layer)) return 1;
-        HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+    if (!thetas && (do_vdag || grads) && ensure_coef(ws)) return 1;
+    if (check_buf(ws, x_buf)) return 1;
+    auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
+        if (thetas) {
+            ws->d_thetas = ws->d_thetas_own;
+            HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
+            if (run_coef(ws)) return 1;
+        }
+        if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        if (gathered) {
+            if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+            HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
+        }
+        if (grads) {
+            if (aqc_ws_grad_from(ws, x_buf, block_from, block_to, front_layer)) return 1;
+            HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+        }
+        return 0;
+    };
+    if (thetas) memcpy(pin_th, thetas, sizeof(double) * nth);
+    static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
+    if (thetas && graphs_on && !ws->profile) {
+        const std::vector<long long> key = {do_vdag, gathered ? 1 : 0, grads ? 1 : 0, x_buf, block_from, block_to, front_layer,
+                                            (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin};
+        auto it = ws->graphs.find(key);
+        if (it == ws->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_OK(hipStreamSynchronize(ws->stream));
+            HIP_OK(hipStreamBeginCapture(ws->stream, hipStreamCaptureModeThreadLocal));
+            ws->capturing = true;
+            const int rc = enqueue();
+            ws->capturing = false;
+            const hipError_t e = hipStreamEndCapture(ws->stream, &graph);
+            if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+            if (e != hipSuccess || !graph) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+            if (ws->graphs.size() >= 16) drop_graphs(ws);
+            it = ws->graphs.emplace(key, exec).first;
+        }
+        ws->d_thetas = ws->d_thetas_own;   // host-side state that enqueue() would have set
+        ws->coef_valid = true;
+        ws->fwd.u_valid = false;
+        ws->inv.u_valid = ws->sweep.u_valid = (do_vdag || grads) && ws->inv.v3 && ws->sweep.v3;
+        HIP_OK(hipGraphLaunch(it->second, ws->stream));
+    } else if (enqueue()) {
+        return 1;
     }
     HIP_OK(hipStreamSynchronize(ws->stream));
     if (gathered) memcpy(gathered, pin_sm, sizeof(double2) * nsm);
@@ -1063,6 +1115,7 @@ int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count) {
         elem[i] = (long long)index[i] << ws->col_bits;
     }
     HIP_OK(hipStreamSynchronize(ws->stream));
+    drop_graphs(ws);   // captured evaluations hold the old index / staging pointers
     if (ensure_index(ws, count) || ensure_small(ws, (size_t)ws->batch * count)) return 1;
     if (2 * (size_t)ws->batch * count > ws->pin_small) {   // aqc_ws_eval stages the gathered amplitudes in pinned memory
         double* pin = nullptr;

@@ -88,6 +88,7 @@ SIGNATURES = {
     "aqc_ws_plan_info": (c_int, [_P, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "aqc_ws_kernel_family": (c_int, [_P, c_int]),
     "aqc_ws_plan_substages": (c_int, [_P, c_int]),
+    "aqc_ws_lbfgs": (c_int, [_P, _D, c_int, c_int, c_double, c_double, c_double, c_int, _D, _D, _D, POINTER(c_int64), POINTER(c_int64)]),
     "aqc_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "aqc_comm_create": (c_int, [ctypes.c_char_p, c_int, c_int, c_int, POINTER(_P)]),
     "aqc_comm_destroy": (c_int, [_P]),

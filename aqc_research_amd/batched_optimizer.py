@@ -108,6 +108,29 @@ class BatchedSurrogateObjective:
             return None            # caller re-evaluates on the device
         return self._assemble(rows_hs, rows_g0, None, True)
 
+    def minimize_on_device(self, x0: np.ndarray, *, maxiter: int = 100, memory: int = 10, gtol: float = 1e-7, ftol: float = 1e-12,
+                           fidelity_thr: float = 0.0, max_backtracks: int = 12) -> Dict:
+        """All lanes minimised by the device-resident L-BFGS (``aqc_ws_lbfgs``): the same algorithm as ``batched_lbfgs``
+        on this objective (two-loop recursion, Armijo backtracking, state update once per accepted step) with thetas,
+        gradients and history resident in HBM -- the host only reads a few flags per step.  Starts from a fresh objective
+        state (weight 1, leading state |state_0>), like a new objective object."""
+        import ctypes
+
+        from . import _lib
+
+        x = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, self.T)
+        xo = np.empty_like(x)
+        f = np.empty(self.batch)
+        fid = np.empty(self.batch)
+        nit = np.zeros(self.batch, dtype=np.int64)
+        nfev = ctypes.c_int64()
+        _lib.check(self.ws._L.aqc_ws_lbfgs(self.ws.handle, _lib.dptr(x), int(maxiter), int(memory), float(gtol), float(ftol),
+                                          float(fidelity_thr), int(max_backtracks), _lib.dptr(xo), _lib.dptr(f), _lib.dptr(fid),
+                                          nit.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.byref(nfev)))
+        self.fidelity = fid
+        self.num_evals += int(nfev.value) * self.batch
+        return {"x": xo, "fun": f, "nit": nit, "nfev": int(nfev.value), "fidelity": fid}
+
     def close(self) -> None:
         self.ws.close()
 

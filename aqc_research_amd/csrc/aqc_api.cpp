@@ -1032,6 +1032,148 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     return 0;
 }
 
+// ---- device-resident multi-start L-BFGS on the lane-batched surrogate objective (aqc_lbfgs.hip) ---------------
+// Preconditions (what BatchedSurrogateObjective sets up): targets in Y, |state_0> one-hot in X, the flip-state indices
+// registered with aqc_ws_gather_setup (state 0 first).  thetas, gradients and the history stay in HBM; per evaluation
+// the host reads one flag word, per line-search trial another.
+int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double gtol, double ftol, double fid_thr, int max_backtracks,
+                 double* x_out, double* f_out, double* fidelity_out, int64_t* nit_out, int64_t* nfev_out) {
+    if (!ws || !x0 || !x_out || !f_out) return fail("null argument");
+    if (ws->ncols != 1) return fail("the L-BFGS driver works on state-vector workspaces");
+    if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called (flip-state indices, state 0 first)");
+    if (memory < 1 || memory > 32 || maxiter < 1 || max_backtracks < 1) return fail("invalid L-BFGS parameters");
+    HIP_OK(hipSetDevice(ws->device));
+    const Program& prog = ws->ctx->prog;
+    const int B = ws->batch, T = prog.num_thetas(), S = ws->gather_count;
+    const size_t BT = (size_t)B * T, BS = (size_t)B * S;
+    hipStream_t st_ = ws->stream;
+    HIP_OK(hipStreamSynchronize(st_));
+    // one allocation for all double arrays, one for the complex ones, one for the integers
+    const size_t nd = BT * (7 + 2 * (size_t)memory) + (size_t)B * (6 + memory + 2 + 2);
+    double* dd = nullptr;
+    double2* dc = nullptr;
+    int* di = nullptr;
+    long long* dl = nullptr;
+    int* h_flags = nullptr;
+    auto cleanup = [&]() {
+        if (dd) (void)hipFree(dd);
+        if (dc) (void)hipFree(dc);
+        if (di) (void)hipFree(di);
+        if (dl) (void)hipFree(dl);
+        if (h_flags) (void)hipHostFree(h_flags);
+    };
+#define LB_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+#define LB_TRY(expr) do { if ((expr) != 0) { cleanup(); return 1; } } while (0)
+    LB_OK(hipMalloc((void**)&dd, nd * sizeof(double)));
+    LB_OK(hipMalloc((void**)&dc, (3 * BT + 3 * BS) * sizeof(double2)));
+    LB_OK(hipMalloc((void**)&di, (size_t)(3 * B + 8) * sizeof(int)));
+    LB_OK(hipMalloc((void**)&dl, (size_t)(2 * B) * sizeof(long long)));
+    LB_OK(hipHostMalloc((void**)&h_flags, 8 * sizeof(int), hipHostMallocDefault));
+    LB_OK(hipMemsetAsync(dd, 0, nd * sizeof(double), st_));
+    LB_OK(hipMemsetAsync(di, 0, (size_t)(3 * B + 8) * sizeof(int), st_));
+    LbState L;
+    double* p = dd;
+    auto take = [&](size_t n) { double* r = p; p += n; return r; };
+    L.B = B; L.T = T; L.S = S; L.memory = memory;
+    L.x = take(BT); L.g = take(BT); L.d = take(BT); L.x_new = take(BT);
+    double* gt = take(BT);        // gradient at the trial points
+    double* g_acc = take(BT);     // gradient at the accepted points under the new state
+    double* spare = take(BT); (void)spare;
+    L.Smem = take(BT * memory); L.Ymem = take(BT * memory);
+    L.f = take(B); L.slope = take(B); L.step = take(B); L.weight = take(B); L.fidelity = take(B);
+    double* ft = take(B);
+    L.rho = take((size_t)B * memory);
+    L.lead_hm = take(2 * (size_t)B);
+    double* f_acc = take(2 * (size_t)B);
+    L.cur_g0 = dc; L.acc_g0 = dc + BT;
+    double2* raw_g0_t = dc + 2 * BT;
+    L.cur_hs = dc + 3 * BT; L.acc_hs = L.cur_hs + BS;
+    double2* raw_hs_t = L.acc_hs + BS;
+    L.active = di; L.done = di + B; L.max_no = di + 2 * B;
+    int* d_flags = di + 3 * B;
+    L.nit = dl;
+    long long* d_prev = dl + B;
+    {   // weight = 1, max_no = 0, active = 1, X2 empty
+        std::vector<double> ones(B, 1.0);
+        std::vector<int> one_i(B, 1);
+        std::vector<long long> neg(2 * (size_t)B, 0);
+        for (int b = 0; b < B; ++b) neg[B + b] = -1;
+        LB_OK(hipMemcpyAsync(L.weight, ones.data(), sizeof(double) * B, hipMemcpyHostToDevice, st_));
+        LB_OK(hipMemcpyAsync(L.active, one_i.data(), sizeof(int) * B, hipMemcpyHostToDevice, st_));
+        LB_OK(hipMemcpyAsync(dl, neg.data(), sizeof(long long) * 2 * B, hipMemcpyHostToDevice, st_));
+        LB_OK(hipMemcpyAsync(L.x, x0, sizeof(double) * BT, hipMemcpyHostToDevice, st_));
+        LB_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st_));
+        LB_OK(hipStreamSynchronize(st_));
+    }
+    int64_t nfev = 0;
+    auto read_flags = [&]() -> int {
+        HIP_OK(hipMemcpyAsync(h_flags, d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st_));
+        HIP_OK(hipStreamSynchronize(st_));
+        return 0;
+    };
+    // f, g at the point in the workspace's theta buffer; raw results to (raw_hs, raw_g0)
+    auto evaluate = [&](int update, double* f_o, double* g_o, double2* raw_hs, double2* raw_g0) -> int {
+        ws->d_thetas = ws->d_thetas_own;
+        if (run_coef(ws)) return 1;
+        if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+        if (aqc_ws_grad_from(ws, AQC_BUF_X, -1, -1, 1)) return 1;
+        HIP_OK(hipMemsetAsync(d_flags, 0, sizeof(int), st_));
+        HIP_OK(lb_assemble1(L, ws->d_small, ws->d_grads, update, f_o, g_o, raw_hs, raw_g0, d_flags, st_));
+        if (read_flags()) return 1;
+        if (h_flags[0]) {   // some lane leads with a flip state other than |state_0>: second sweep from it
+            HIP_OK(lb_set_basis(L, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
+            if (aqc_ws_grad_from(ws, AQC_BUF_X2, -1, -1, 1)) return 1;
+            HIP_OK(lb_assemble2(L, ws->d_grads, g_o, st_));
+        }
+        ++nfev;
+        return 0;
+    };
+    LB_OK(hipMemcpyAsync(ws->d_thetas_own, L.x, sizeof(double) * BT, hipMemcpyDeviceToDevice, st_));
+    LB_TRY(evaluate(1, L.f, L.g, L.cur_hs, L.cur_g0));
+    int count = 0;
+    for (int it = 0; it < maxiter; ++it) {
+        LB_OK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), st_));
+        LB_OK(lb_active(L, gtol, fid_thr, d_flags, st_));
+        LB_TRY(read_flags());
+        if (!h_flags[2]) break;
+        LB_OK(lb_direction(L, count, st_));
+        LB_OK(lb_copy_raw(L, st_));
+        for (int bt = 0; bt < max_backtracks; ++bt) {
+            LB_OK(lb_trial(L, ws->d_thetas_own, st_));
+            LB_TRY(evaluate(0, ft, gt, raw_hs_t, raw_g0_t));
+            LB_OK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), st_));
+            LB_OK(lb_armijo(L, 1e-4, ws->d_thetas_own, ft, raw_hs_t, raw_g0_t, d_flags, st_));
+            LB_TRY(read_flags());
+            if (!h_flags[3]) break;
+        }
+        // state update at the accepted points: from their raw results when no lane would lead with a flip state,
+        // else by a device evaluation at x_new (the second sweep depends on the state chosen now)
+        LB_OK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), st_));
+        LB_OK(lb_probe(L, L.acc_hs, d_flags, st_));
+        LB_TRY(read_flags());
+        if (h_flags[1]) {
+            LB_OK(hipMemcpyAsync(ws->d_thetas_own, L.x_new, sizeof(double) * BT, hipMemcpyDeviceToDevice, st_));
+            LB_TRY(evaluate(1, f_acc, g_acc, L.acc_hs, L.acc_g0));
+        } else {
+            LB_OK(hipMemsetAsync(d_flags, 0, sizeof(int), st_));
+            LB_OK(lb_assemble1(L, L.acc_hs, L.acc_g0, 1, f_acc, g_acc, nullptr, nullptr, d_flags, st_));
+        }
+        LB_OK(lb_history(L, count, ftol, f_acc, g_acc, st_));
+        ++count;
+    }
+    LB_OK(hipMemcpyAsync(x_out, L.x, sizeof(double) * BT, hipMemcpyDeviceToHost, st_));
+    LB_OK(hipMemcpyAsync(f_out, L.f, sizeof(double) * B, hipMemcpyDeviceToHost, st_));
+    if (fidelity_out) LB_OK(hipMemcpyAsync(fidelity_out, L.fidelity, sizeof(double) * B, hipMemcpyDeviceToHost, st_));
+    if (nit_out) LB_OK(hipMemcpyAsync(nit_out, L.nit, sizeof(long long) * B, hipMemcpyDeviceToHost, st_));
+    LB_OK(hipStreamSynchronize(st_));
+    if (nfev_out) *nfev_out = nfev;
+    cleanup();
+#undef LB_OK
+#undef LB_TRY
+    return 0;
+}
+
 int aqc_ws_get_grads(aqc_ws* ws, double* grads) {
     if (!ws || !grads) return fail("null argument");
     HIP_OK(hipSetDevice(ws->device));

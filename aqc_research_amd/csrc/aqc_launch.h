@@ -85,6 +85,33 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s);
 
+// aqc_lbfgs.hip (device-resident multi-start L-BFGS on the lane-batched surrogate objective)
+struct LbState {
+    int B, T, S, memory;          // lanes, parameters, gathered flip states, history length
+    double *x, *g, *f;            // current point, gradient, value (under the current objective state)
+    double *d, *slope, *step;     // search direction, g.d, step length per lane
+    double *x_new;                // accepted trial points of the running line search
+    double *Smem, *Ymem, *rho;    // history [memory][B][T], [memory][B]
+    int *active, *done;
+    long long* nit;
+    double *weight, *fidelity, *lead_hm;   // objective state: smoothed weight, |h_0|^2, coefficient of the second sweep
+    int* max_no;
+    double2 *cur_hs, *cur_g0;     // raw device results of the current point (re-assembled at a state update)
+    double2 *acc_hs, *acc_g0;     // ... of the accepted trial points
+};
+hipError_t lb_assemble1(const LbState& st, const void* hs, const void* g0, int update, double* f_out, double* g_out, void* raw_hs,
+                        void* raw_g0, int* flags, hipStream_t s);
+hipError_t lb_assemble2(const LbState& st, const void* gm, double* g_out, hipStream_t s);
+hipError_t lb_probe(const LbState& st, const void* hs, int* flags, hipStream_t s);
+hipError_t lb_set_basis(const LbState& st, void* x2, size_t lane_stride, const long long* index, long long* prev, hipStream_t s);
+hipError_t lb_active(const LbState& st, double gtol, double fid_thr, int* flags, hipStream_t s);
+hipError_t lb_direction(const LbState& st, int count, hipStream_t s);
+hipError_t lb_trial(const LbState& st, double* thetas, hipStream_t s);
+hipError_t lb_armijo(const LbState& st, double c1, const double* thetas, const double* ft, const void* raw_hs_t, const void* raw_g0_t,
+                     int* flags, hipStream_t s);
+hipError_t lb_copy_raw(const LbState& st, hipStream_t s);
+hipError_t lb_history(const LbState& st, int count, double ftol, const double* f_acc, const double* g_acc, hipStream_t s);
+
 // aqc_mps.hip
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);
 hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,

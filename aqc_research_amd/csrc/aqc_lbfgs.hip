@@ -1,0 +1,303 @@
+// Device-resident multi-start L-BFGS on the lane-batched surrogate objective (one optimisation per lane, all lanes
+// advance together; thetas, gradients and the L-BFGS history never leave HBM -- the host reads a few flags per step).
+//
+// The objective is the reference's surrogate f = 1 - (1 - w) |h_0|^2 - w |h_max|^2 with its 10 % hysteresis on the
+// leading flip state and the smoothed weight (objective_lhs_sur_max.py:82-191); the optimizer stands in for the
+// scipy L-BFGS-B behind the reference's AqcOptimizer (optimizer.py:579-590): two-loop recursion, Armijo
+// backtracking with lane-wise step lengths, the state update once per accepted step.  Same algorithm as the host
+// version in aqc_research_amd/batched_optimizer.py, which stays as its cross-check.
+//
+// One workgroup per lane for everything that reduces over the T parameters.
+#include <hip/hip_runtime.h>
+
+#include "aqc_launch.h"
+#include "aqc_math.h"
+
+namespace aqc {
+
+namespace {
+
+constexpr int kLbThreads = 256;
+
+__device__ __forceinline__ double block_sum(double v, double* red) {   // all threads get the total (fixed order)
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, red[w]);
+    return t;
+}
+
+// First half of an evaluation: from the gathered amplitudes hs[b][S] and the complex gradient g0[b][T] of the sweep
+// from |state_0>: optional state update (hysteresis, weight smoothing), value, the |state_0> part of the gradient,
+// raw copies for a later commit; flags[0] |= some lane leads with a flip state (second sweep needed).
+__global__ __launch_bounds__(kLbThreads) void lb_assemble1_kernel(LbState st, const cplx* hs, const cplx* g0, int update, double* f_out,
+                                                                 double* g_out, cplx* raw_hs, cplx* raw_g0, int* flags) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const cplx* h = hs + (size_t)b * st.S;
+    int max_no = st.max_no[b];
+    double w = st.weight[b];
+    if (update) {   // objective_lhs_sur_max.py:113-117 (10 % hysteresis) and :186 (weight smoothing), every thread alike
+        double best = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
+        for (int i = 0; i < st.S; ++i) {
+            const double v = h[i].x * h[i].x + h[i].y * h[i].y;
+            if (1.1 * best < v) { best = v; max_no = i; }
+        }
+        const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
+        const double f_old = 1.0 - (1.0 - w) * h0 - w * hm;
+        w = w + 0.1 * (sqrt(fabs(f_old)) - w);
+    }
+    const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
+    const bool lead = max_no != 0;
+    const double coef = lead ? -2.0 * (1.0 - w) : -2.0;   // grad = Re(g0 * coef * conj(h0)) [+ Re(gm * (-2 w) conj(hm))]
+    const double cr = coef * h[0].x, ci = -coef * h[0].y;
+    for (int i = t; i < st.T; i += blockDim.x) {
+        const cplx g = g0[(size_t)b * st.T + i];
+        g_out[(size_t)b * st.T + i] = g.x * cr - g.y * ci;
+        if (raw_g0) raw_g0[(size_t)b * st.T + i] = g;
+    }
+    if (raw_hs) for (int i = t; i < st.S; i += blockDim.x) raw_hs[(size_t)b * st.S + i] = h[i];
+    __syncthreads();   // every thread has read the old state
+    if (t == 0) {
+        f_out[b] = 1.0 - (1.0 - w) * h0 - w * hm;
+        if (update) { st.max_no[b] = max_no; st.weight[b] = w; st.fidelity[b] = h0; }
+        st.lead_hm[2 * b] = lead ? -2.0 * w * h[max_no].x : 0.0;   // coefficient of the second sweep's gradient
+        st.lead_hm[2 * b + 1] = lead ? 2.0 * w * h[max_no].y : 0.0;
+        if (lead) atomicOr(&flags[0], 1);
+    }
+}
+// Second half, lanes that lead with a flip state: grad += Re(gm * (-2 w conj(h_max)))
+__global__ __launch_bounds__(kLbThreads) void lb_assemble2_kernel(LbState st, const cplx* gm, double* g_out) {
+    const int b = blockIdx.x;
+    const double cr = st.lead_hm[2 * b], ci = st.lead_hm[2 * b + 1];
+    if (cr == 0.0 && ci == 0.0) return;
+    for (int i = threadIdx.x; i < st.T; i += blockDim.x) {
+        const cplx g = gm[(size_t)b * st.T + i];
+        g_out[(size_t)b * st.T + i] += g.x * cr - g.y * ci;
+    }
+}
+// Probe of the state update on the accepted points (no change of state): flags[1] |= some lane WOULD lead with a flip state
+__global__ void lb_probe_kernel(LbState st, const cplx* hs, int* flags) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    const cplx* h = hs + (size_t)b * st.S;
+    int max_no = st.max_no[b];
+    double best = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
+    for (int i = 0; i < st.S; ++i) {
+        const double v = h[i].x * h[i].x + h[i].y * h[i].y;
+        if (1.1 * best < v) { best = v; max_no = i; }
+    }
+    if (max_no != 0) atomicOr(&flags[1], 1);
+}
+// One-hot |state_max_no> per lane in buffer X2 (clears the previous position)
+__global__ void lb_set_basis_kernel(LbState st, cplx* x2, size_t lane_stride, const long long* index, long long* prev) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    const long long now = index[st.max_no[b]];
+    if (prev[b] >= 0) x2[(size_t)b * lane_stride + (size_t)prev[b]] = make_double2(0.0, 0.0);
+    x2[(size_t)b * lane_stride + (size_t)now] = make_double2(1.0, 0.0);
+    prev[b] = now;
+}
+
+// active &= max|g| > gtol [and fidelity < thr]; flags[2] |= some lane is active
+__global__ __launch_bounds__(kLbThreads) void lb_active_kernel(LbState st, double gtol, double fid_thr, int* flags) {
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    double m = 0.0;
+    for (int i = threadIdx.x; i < st.T; i += blockDim.x) m = fmax(m, fabs(st.g[(size_t)b * st.T + i]));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) {
+        int a = st.active[b];
+        if (!(m > gtol)) a = 0;
+        if (fid_thr > 0.0 && st.fidelity[b] >= fid_thr) a = 0;
+        st.active[b] = a;
+        if (a) atomicOr(&flags[2], 1);
+    }
+}
+
+// Two-loop recursion, search direction, slope; step = active ? 1 : 0, done = !active, x_new = x
+__global__ __launch_bounds__(kLbThreads) void lb_direction_kernel(LbState st, int count) {
+    __shared__ double red[8];
+    __shared__ double alpha[32];
+    const int b = blockIdx.x, t = threadIdx.x, T = st.T, m = st.memory;
+    const size_t off = (size_t)b * T;
+    const int k = count < m ? count : m;
+    double* q = st.d + off;
+    for (int i = t; i < T; i += blockDim.x) q[i] = st.g[off + i];
+    for (int j = k - 1; j >= 0; --j) {
+        const int slot = (count - k + j) % m;
+        const double* s = st.Smem + ((size_t)slot * st.B + b) * T;
+        const double* y = st.Ymem + ((size_t)slot * st.B + b) * T;
+        double acc = 0.0;
+        for (int i = t; i < T; i += blockDim.x) acc += s[i] * q[i];
+        const double a = st.rho[(size_t)slot * st.B + b] * block_sum(acc, red);
+        if (t == 0) alpha[j] = a;
+        for (int i = t; i < T; i += blockDim.x) q[i] -= a * y[i];
+    }
+    if (k) {
+        const int last = (count - 1) % m;
+        const double* y = st.Ymem + ((size_t)last * st.B + b) * T;
+        double acc = 0.0;
+        for (int i = t; i < T; i += blockDim.x) acc += y[i] * y[i];
+        const double yy = block_sum(acc, red), r = st.rho[(size_t)last * st.B + b];
+        const double gamma = (yy > 0.0 && r > 0.0) ? 1.0 / (r * yy) : 1.0;
+        for (int i = t; i < T; i += blockDim.x) q[i] *= gamma;
+    } else {   // first step: at most unit length
+        double acc = 0.0;
+        for (int i = t; i < T; i += blockDim.x) acc += st.g[off + i] * st.g[off + i];
+        const double nrm = sqrt(block_sum(acc, red)), sc = 1.0 / fmax(nrm, 1.0);
+        for (int i = t; i < T; i += blockDim.x) q[i] *= sc;
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const int slot = (count - k + j) % m;
+        const double* s = st.Smem + ((size_t)slot * st.B + b) * T;
+        const double* y = st.Ymem + ((size_t)slot * st.B + b) * T;
+        double acc = 0.0;
+        for (int i = t; i < T; i += blockDim.x) acc += y[i] * q[i];
+        const double beta = st.rho[(size_t)slot * st.B + b] * block_sum(acc, red);
+        const double a = alpha[j];
+        for (int i = t; i < T; i += blockDim.x) q[i] += (a - beta) * s[i];
+    }
+    double acc = 0.0;
+    for (int i = t; i < T; i += blockDim.x) { q[i] = -q[i]; acc += st.g[off + i] * q[i]; }
+    double slope = block_sum(acc, red);
+    if (slope >= 0.0) {   // not a descent direction: steepest descent
+        double gg = 0.0;
+        for (int i = t; i < T; i += blockDim.x) { q[i] = -st.g[off + i]; gg += st.g[off + i] * st.g[off + i]; }
+        slope = -block_sum(gg, red);
+    }
+    for (int i = t; i < T; i += blockDim.x) st.x_new[off + i] = st.x[off + i];
+    if (t == 0) {
+        const int a = st.active[b];
+        st.slope[b] = slope;
+        st.step[b] = a ? 1.0 : 0.0;
+        st.done[b] = a ? 0 : 1;
+    }
+}
+// trial point into the workspace's theta buffer
+__global__ void lb_trial_kernel(LbState st, double* thetas) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)st.B * st.T) return;
+    const int b = (int)(i / st.T);
+    thetas[i] = st.x[i] + st.step[b] * st.d[i];
+}
+// Armijo test per lane; accepted lanes keep the trial point and its raw device results; flags[3] |= some lane not done
+__global__ __launch_bounds__(kLbThreads) void lb_armijo_kernel(LbState st, double c1, const double* thetas, const double* ft,
+                                                              const cplx* raw_hs_t, const cplx* raw_g0_t, int* flags) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const size_t off = (size_t)b * st.T;
+    const bool was_done = st.done[b] != 0;
+    const double step = st.step[b];
+    const bool ok = !was_done && ft[b] <= st.f[b] + c1 * step * st.slope[b];
+    if (ok) {
+        for (int i = t; i < st.T; i += blockDim.x) { st.x_new[off + i] = thetas[off + i]; st.acc_g0[off + i] = raw_g0_t[off + i]; }
+        for (int i = t; i < st.S; i += blockDim.x) st.acc_hs[(size_t)b * st.S + i] = raw_hs_t[(size_t)b * st.S + i];
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (ok) st.done[b] = 1;
+        else if (!was_done) { st.step[b] = 0.5 * step; atomicOr(&flags[3], 1); }
+    }
+}
+// rows of lanes that will not move start as the current point's raw results
+__global__ void lb_copy_raw_kernel(LbState st) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)st.B * st.T) st.acc_g0[i] = st.cur_g0[i];
+    if (i < (size_t)st.B * st.S) st.acc_hs[i] = st.cur_hs[i];
+}
+// History update and convergence flags after the accepted points have been evaluated under the new state
+__global__ __launch_bounds__(kLbThreads) void lb_history_kernel(LbState st, int count, double ftol, const double* f_acc, const double* g_acc) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, t = threadIdx.x, T = st.T;
+    const size_t off = (size_t)b * T;
+    const int slot = count % st.memory;
+    double* s = st.Smem + ((size_t)slot * st.B + b) * T;
+    double* y = st.Ymem + ((size_t)slot * st.B + b) * T;
+    double sy = 0.0, yy = 0.0, moved_any = 0.0;
+    for (int i = t; i < T; i += blockDim.x) {
+        const double si = st.x_new[off + i] - st.x[off + i], yi = g_acc[off + i] - st.g[off + i];
+        s[i] = si; y[i] = yi;
+        sy += si * yi; yy += yi * yi;
+        if (si != 0.0) moved_any = 1.0;
+    }
+    sy = block_sum(sy, red); yy = block_sum(yy, red); moved_any = block_max(moved_any, red);
+    const bool active = st.active[b] != 0;
+    const bool moved = st.done[b] != 0 && active && moved_any > 0.0;
+    const bool good = moved && sy > 1e-12 * yy;
+    if (!good) for (int i = t; i < T; i += blockDim.x) { s[i] = 0.0; y[i] = 0.0; }
+    for (int i = t; i < T; i += blockDim.x) { st.x[off + i] = st.x_new[off + i]; st.g[off + i] = g_acc[off + i]; }
+    for (int i = t; i < T; i += blockDim.x) st.cur_g0[off + i] = st.acc_g0[off + i];
+    for (int i = t; i < st.S; i += blockDim.x) st.cur_hs[(size_t)b * st.S + i] = st.acc_hs[(size_t)b * st.S + i];
+    __syncthreads();
+    if (t == 0) {
+        st.rho[(size_t)slot * st.B + b] = good ? 1.0 / sy : 0.0;
+        const double f = st.f[b], fa = f_acc[b];
+        const bool small = fabs(f - fa) <= ftol * fmax(1.0, fabs(f));
+        if (active) st.nit[b] += 1;
+        st.active[b] = (active && moved && !small) ? 1 : 0;
+        st.f[b] = fa;
+    }
+}
+
+}  // namespace
+
+hipError_t lb_assemble1(const LbState& st, const void* hs, const void* g0, int update, double* f_out, double* g_out, void* raw_hs,
+                        void* raw_g0, int* flags, hipStream_t s) {
+    lb_assemble1_kernel<<<st.B, kLbThreads, 0, s>>>(st, (const cplx*)hs, (const cplx*)g0, update, f_out, g_out, (cplx*)raw_hs, (cplx*)raw_g0, flags);
+    return hipGetLastError();
+}
+hipError_t lb_assemble2(const LbState& st, const void* gm, double* g_out, hipStream_t s) {
+    lb_assemble2_kernel<<<st.B, kLbThreads, 0, s>>>(st, (const cplx*)gm, g_out);
+    return hipGetLastError();
+}
+hipError_t lb_probe(const LbState& st, const void* hs, int* flags, hipStream_t s) {
+    lb_probe_kernel<<<(st.B + 63) / 64, 64, 0, s>>>(st, (const cplx*)hs, flags);
+    return hipGetLastError();
+}
+hipError_t lb_set_basis(const LbState& st, void* x2, size_t lane_stride, const long long* index, long long* prev, hipStream_t s) {
+    lb_set_basis_kernel<<<(st.B + 63) / 64, 64, 0, s>>>(st, (cplx*)x2, lane_stride, index, prev);
+    return hipGetLastError();
+}
+hipError_t lb_active(const LbState& st, double gtol, double fid_thr, int* flags, hipStream_t s) {
+    lb_active_kernel<<<st.B, kLbThreads, 0, s>>>(st, gtol, fid_thr, flags);
+    return hipGetLastError();
+}
+hipError_t lb_direction(const LbState& st, int count, hipStream_t s) {
+    lb_direction_kernel<<<st.B, kLbThreads, 0, s>>>(st, count);
+    return hipGetLastError();
+}
+hipError_t lb_trial(const LbState& st, double* thetas, hipStream_t s) {
+    const size_t n = (size_t)st.B * st.T;
+    lb_trial_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(st, thetas);
+    return hipGetLastError();
+}
+hipError_t lb_armijo(const LbState& st, double c1, const double* thetas, const double* ft, const void* raw_hs_t, const void* raw_g0_t,
+                     int* flags, hipStream_t s) {
+    lb_armijo_kernel<<<st.B, kLbThreads, 0, s>>>(st, c1, thetas, ft, (const cplx*)raw_hs_t, (const cplx*)raw_g0_t, flags);
+    return hipGetLastError();
+}
+hipError_t lb_copy_raw(const LbState& st, hipStream_t s) {
+    const size_t n = (size_t)st.B * (st.T > st.S ? st.T : st.S);
+    lb_copy_raw_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(st);
+    return hipGetLastError();
+}
+hipError_t lb_history(const LbState& st, int count, double ftol, const double* f_acc, const double* g_acc, hipStream_t s) {
+    lb_history_kernel<<<st.B, kLbThreads, 0, s>>>(st, count, ftol, f_acc, g_acc);
+    return hipGetLastError();
+}
+
+}  // namespace aqc

@@ -34,6 +34,7 @@ class UserOptions:
         self.num_seeds = 1                 # random restarts per horizon (lockstep lanes of one workspace)
         self.theta_jitter = 0.1            # restart s > 0 starts from Trotter angles + jitter * pi * U(-1, 1)
         self.vectorised_lbfgs = False      # restarts driven by ONE vectorised L-BFGS (batched_optimizer.py) instead of scipy per lane
+        self.device_lbfgs = False          # ... and that L-BFGS resident on the device (aqc_ws_lbfgs), thetas never leave HBM
         self.__dict__.update(kw)
 
 
@@ -94,7 +95,7 @@ def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
         return {"restart": s, "fidelity": float(res["fidelity"]), "cost": float(res["cost"]),
                 "num_iters": int(res["num_iters"]), "num_fun_ev": int(res["num_fun_ev"]), "thetas": res["thetas"]}
 
-    if opts.vectorised_lbfgs:   # all restarts as lanes of one batched objective, one optimizer for all of them
+    if opts.vectorised_lbfgs or opts.device_lbfgs:   # all restarts as lanes of one batched objective, one optimizer for all of them
         from ..batched_optimizer import BatchedSurrogateObjective, batched_lbfgs
 
         starts = np.tile(trotter_thetas, (opts.num_seeds, 1))
@@ -102,7 +103,10 @@ def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
             rng = np.random.default_rng(opts.seed + 1000 * h + 7 * (s + 1))
             starts[s] += opts.theta_jitter * np.pi * (2.0 * rng.random(trotter_thetas.size) - 1.0)
         bo = BatchedSurrogateObjective(circ, np.tile(target, (opts.num_seeds, 1)), base_index=neel, device=opts.device)
-        res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= opts.fidelity_thr)
+        if opts.device_lbfgs:
+            res = bo.minimize_on_device(starts, maxiter=opts.maxiter, fidelity_thr=opts.fidelity_thr)
+        else:
+            res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= opts.fidelity_thr)
         fids = bo.fidelity.copy()
         evals = bo.num_evals
         bo.close()

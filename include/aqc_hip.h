@@ -217,6 +217,13 @@ int aqc_ws_kernel_family(aqc_ws* ws, int which);
 int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage,
                    int* num_stages, int* bits_out, int* num_bits, int* ops_out, int* num_ops);
 
+/* ---- device-resident multi-start L-BFGS on the lane-batched surrogate objective: one optimisation per lane, thetas /
+ * gradients / history stay in HBM (stand-in for the scipy L-BFGS-B behind AqcOptimizer.optimize, optimizer.py:579-590,
+ * on objective_lhs_sur_max.py:82-191).  Preconditions: targets in buffer Y, |state_0> one-hot in X, flip-state indices
+ * registered with aqc_ws_gather_setup (state 0 first).  x0 / x_out: [batch][T]; f / fidelity / nit: [batch]. */
+int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double gtol, double ftol, double fid_thr,
+                 int max_backtracks, double* x_out, double* f_out, double* fidelity_out, int64_t* nit_out, int64_t* nfev_out);
+
 /* ---- multi-GPU: the one collective layer of the path, bound straight to librccl (RCCL over xGMI; loaded lazily).
  * One process per GPU; jobs are sharded over the ranks (job_executor.py:136-143: joblib processes in the reference) and
  * only fixed-size result records cross GPUs.  All buffers are HOST pointers (the records are a few KB).

@@ -311,7 +311,10 @@ struct aqc_ws {
         std::vector<int> dims;          // n + 1 bond dimensions
         std::vector<size_t> offset;     // element offset of site q inside d_t
         double2* d_t = nullptr;         // [q][2][dims[q]][dims[q+1]], lambda folded in
+        size_t cap = 0;                 // capacity of d_t (grow-only: re-uploads of the same shape allocate nothing)
     } mps[AQC_MPS_SLOTS];
+    double* d_mps_lam = nullptr;        // staging of the packed Schmidt vectors (grow-only)
+    size_t mps_lam_cap = 0;
     double2* d_mps_scratch = nullptr;
     size_t mps_scratch_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
@@ -749,6 +752,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
     for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
+    if (ws->d_mps_lam) (void)hipFree(ws->d_mps_lam);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1}) if (ev) (void)hipEventDestroy(ev);
     if (ws->stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
@@ -1475,61 +1479,113 @@ static int check_mps_slot(const aqc_ws* ws, int slot, bool need_data) {
 int aqc_ws_mps_upload(aqc_ws* ws, int slot, const int32_t* dims, const double* gammas, const double* lambdas) {
     if (check_mps_slot(ws, slot, false)) return 1;
     const int n = ws->ctx->prog.n;
+    if (n > 64) return fail("MPS helpers of the workspace serve up to 64 qubits");
     if (!dims || !gammas || (n > 1 && !lambdas)) return fail("null MPS argument");
     if (dims[0] != 1 || dims[n] != 1) return fail("MPS boundary bond dimensions must be 1");
     HIP_OK(hipSetDevice(ws->device));
     aqc_ws::MpsSlot& m = ws->mps[slot];
     m.dims.assign(dims, dims + n + 1);
     m.offset.assign(n + 1, 0);
+    MpsSites sites;
+    memset(&sites, 0, sizeof sites);
+    sites.n = n;
     size_t total = 0, lam_total = 0;
     for (int q = 0; q < n; ++q) {
         if (dims[q] < 1 || dims[q + 1] < 1) return fail("MPS bond dimensions must be positive");
         m.offset[q] = total;
+        sites.offset[q] = total;
+        sites.cols[q] = dims[q + 1];
+        sites.lam_offset[q] = (int)lam_total;
         total += (size_t)2 * dims[q] * dims[q + 1];
         if (q < n - 1) lam_total += dims[q + 1];
     }
     m.offset[n] = total;
-    HIP_OK(hipStreamSynchronize(ws->stream));
-    if (m.d_t) HIP_OK(hipFree(m.d_t));
-    m.d_t = nullptr;
-    HIP_OK(hipMalloc((void**)&m.d_t, total * sizeof(double2)));
-    double* d_lam = nullptr;
-    HIP_OK(hipMalloc((void**)&d_lam, std::max<size_t>(lam_total, 1) * sizeof(double)));
-    HIP_OK(hipMemcpyAsync(m.d_t, gammas, total * sizeof(double2), hipMemcpyHostToDevice, ws->stream));
-    if (lam_total) HIP_OK(hipMemcpyAsync(d_lam, lambdas, lam_total * sizeof(double), hipMemcpyHostToDevice, ws->stream));
-    size_t lo = 0;
-    for (int q = 0; q < n - 1; ++q) {
-        ProfScope ps(ws, AQC_K_MISC);
-        HIP_OK(launch_mps_scale(m.d_t + m.offset[q], d_lam + lo, 2 * dims[q], dims[q + 1], ws->stream));
-        lo += dims[q + 1];
+    sites.offset[n] = total;
+    sites.total = total;
+    if (total > m.cap || lam_total > ws->mps_lam_cap) {   // grow-only device buffers
+        HIP_OK(hipStreamSynchronize(ws->stream));
+        if (total > m.cap) {
+            if (m.d_t) HIP_OK(hipFree(m.d_t));
+            m.d_t = nullptr; m.cap = 0;
+            HIP_OK(hipMalloc((void**)&m.d_t, total * sizeof(double2)));
+            m.cap = total;
+        }
+        if (lam_total > ws->mps_lam_cap) {
+            if (ws->d_mps_lam) HIP_OK(hipFree(ws->d_mps_lam));
+            ws->d_mps_lam = nullptr; ws->mps_lam_cap = 0;
+            HIP_OK(hipMalloc((void**)&ws->d_mps_lam, std::max<size_t>(lam_total, 1) * sizeof(double)));
+            ws->mps_lam_cap = std::max<size_t>(lam_total, 1);
+        }
     }
-    HIP_OK(hipStreamSynchronize(ws->stream));
-    HIP_OK(hipFree(d_lam));
+    HIP_OK(hipMemcpyAsync(m.d_t, gammas, total * sizeof(double2), hipMemcpyHostToDevice, ws->stream));
+    if (lam_total) {
+        HIP_OK(hipMemcpyAsync(ws->d_mps_lam, lambdas, lam_total * sizeof(double), hipMemcpyHostToDevice, ws->stream));
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_mps_scale_all(m.d_t, ws->d_mps_lam, sites, ws->stream));   // _preprocess_mps: lambda on the right bond
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));   // the host arrays (and the shared lambda staging) may be reused right away
     return 0;
 }
 
+// MPS -> dense state (mps_to_vector, mps_operations.py:159-189; index bit q <-> site q), contracted from both ends:
+//   L[lo][chi]   = sites 0 .. h-1       (rows grow by appending the next site as the next HIGHER bit)
+//   Rt[chi][i]   = sites n-1 .. h       (columns grow likewise, so i is the BIT-REVERSED high part of the index)
+//   G = L Rt, then out[(rev(i) << h) + lo] = G[lo][i].
+// O(2^(n/2) chi^2 + 2^n chi) flops instead of the O(2^n chi^2) of a one-sided sweep; both values of the site's bit go
+// through one batched GEMM launch.
 int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
     if (check_mps_slot(ws, slot, true) || check_buf(ws, buf)) return 1;
     if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
     HIP_OK(hipSetDevice(ws->device));
     const aqc_ws::MpsSlot& m = ws->mps[slot];
     const int n = ws->ctx->prog.n;
-    size_t need = 0;
-    for (int q = 0; q < n - 1; ++q) need = std::max(need, ((size_t)2 << q) * m.dims[q + 1]);
-    if (mps_scratch(ws, 2 * need)) return 1;
-    double2* ping = ws->d_mps_scratch;
-    double2* pong = ws->d_mps_scratch + need;
+    const int h = n / 2, mh = n - h;     // low bits from sites 0..h-1, high bits from sites h..n-1
+    size_t need_l = 2, need_r = 2;
+    for (int q = 0; q < h; ++q) need_l = std::max(need_l, ((size_t)2 << q) * m.dims[q + 1]);
+    for (int q = n - 1; q >= h; --q) need_r = std::max(need_r, ((size_t)2 << (n - 1 - q)) * m.dims[q]);
+    const size_t need_g = (size_t)1 << n;
+    if (mps_scratch(ws, 2 * need_l + 2 * need_r + need_g)) return 1;
+    double2* lbuf[2] = {ws->d_mps_scratch, ws->d_mps_scratch + need_l};
+    double2* rbuf[2] = {lbuf[1] + need_l, lbuf[1] + need_l + need_r};
+    double2* g = rbuf[1] + need_r;
     double2* out = ws->bufs[buf] + (size_t)lane * ws->lane_elems;
-    const double2* acc = m.d_t;  // site 0: (2 x chi_0), rows = bit 0
-    for (int q = 1; q < n; ++q) {
-        double2* dst = (q == n - 1) ? out : ((q & 1) ? ping : pong);
+    // left part: L_q[idx + 2^q b][chi'] = sum_chi L[idx][chi] T_q[b][chi][chi']; site 0 is L_0 = T_0 viewed as (2 x chi_1)
+    const double2* L = m.d_t;
+    for (int q = 1; q < h; ++q) {
+        double2* dst = lbuf[q & 1];
         const int rows = 1 << q, kk = m.dims[q], nn = m.dims[q + 1];
-        for (int b = 0; b < 2; ++b) {  // new index = idx + 2^q b  (mps_operations.py:178-186)
-            ProfScope ps(ws, AQC_K_MISC);
-            HIP_OK(launch_zgemm(false, false, rows, nn, kk, acc, kk, m.d_t + m.offset[q] + (size_t)b * kk * nn, nn,
-                                dst + (size_t)b * rows * nn, nn, ws->stream));
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_zgemm_batched(false, false, rows, nn, kk, L, kk, m.d_t + m.offset[q], nn, dst, nn, 0, (size_t)kk * nn,
+                                    (size_t)rows * nn, 2, ws->stream));
+        L = dst;
+    }
+    // right part: Rt_q[chi_l][i + 2^j b] = sum_chi_r T_q[b][chi_l][chi_r] Rt[chi_r][i], j = n - 1 - q; the last site is
+    // Rt = T_{n-1} viewed as (chi x 2): element [chi][b] = T[b][chi][0]  -> built by the same recurrence from Rt = [1]
+    const double2* Rt = nullptr;
+    for (int q = n - 1; q >= h; --q) {
+        const int j = n - 1 - q, cols = 1 << j, chil = m.dims[q], chir = m.dims[q + 1];
+        double2* dst = rbuf[j & 1];
+        ProfScope ps(ws, AQC_K_MISC);
+        if (j == 0) {   // Rt[chi_l][b] = T[b][chi_l][0]: a (chi_l x 1)(1 x 1) product per b with the constant 1
+            HIP_OK(hipMemcpy2DAsync(dst, 2 * sizeof(double2), m.d_t + m.offset[q], sizeof(double2), sizeof(double2), chil,
+                                    hipMemcpyDeviceToDevice, ws->stream));
+            HIP_OK(hipMemcpy2DAsync(dst + 1, 2 * sizeof(double2), m.d_t + m.offset[q] + chil, sizeof(double2), sizeof(double2), chil,
+                                    hipMemcpyDeviceToDevice, ws->stream));
+        } else {
+            HIP_OK(launch_zgemm_batched(false, false, chil, cols, chir, m.d_t + m.offset[q], chir, Rt, cols, dst, 2 * cols,
+                                        (size_t)chil * chir, 0, (size_t)cols, 2, ws->stream));
         }
-        acc = dst;
+        Rt = dst;
+    }
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        if (h == 0) {   // n == 1: the state is Rt itself
+            HIP_OK(hipMemcpyAsync(out, Rt, sizeof(double2) * 2, hipMemcpyDeviceToDevice, ws->stream));
+        } else {
+            const int chi = m.dims[h];
+            HIP_OK(launch_zgemm(false, false, 1 << h, 1 << mh, chi, L, chi, Rt, 1 << mh, g, 1 << mh, ws->stream));
+            HIP_OK(launch_mps_permute(g, out, h, mh, ws->stream));
+        }
     }
     return 0;
 }

@@ -404,6 +404,8 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
 // gate: the serial chain is what these kernels cost).  A group is (C (x) T) ENT on register bits (pc, pt): C, T are
 // 2 x 2 products of the group's rotations (Trotter Rz(-+pi/2) folded in -- Rz on the control commutes with every
 // entangler), built by one lane per group straight from the thetas (no coefficient kernel on this path).
+constexpr int kGrpChunk = 16;   // groups decoded per batch: keeps the LDS footprint of a workgroup (one wave) near 12 KB, so
+                                // that a CU holds a dozen of them instead of four
 struct Gm {            // one gate group, decoded
     cplx c[4], t[4];   // C', T' row-major
     double ec, es;     // CP phase e^{i theta4}
@@ -496,7 +498,7 @@ __device__ __forceinline__ void grp_apply(const Gm& g, int ent, cplx (&x)[4]) {
 // several plans (V^H and the sweep are built by one launch).
 __global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const double* thetas, int T) {
     __shared__ cplx u[256];   // [row = output amplitude][col = input amplitude]
-    __shared__ Gm gm[64];
+    __shared__ Gm gm[kGrpChunk];
     const int lane = threadIdx.x, b = blockIdx.y;
     const UJob job = jobs[blockIdx.x];
     const DevSub3 sub = *job.sub;
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const doub
         u[e] = make_double2((e >> 4) == (e & 15) ? 1.0 : 0.0, 0.0);
     }
     const int col = lane & 15, rest = lane >> 4;
-    for (int base = 0; base < sub.ngrp; base += 64) {
-        const int count = min(64, sub.ngrp - base);
+    for (int base = 0; base < sub.ngrp; base += kGrpChunk) {
+        const int count = min(kGrpChunk, sub.ngrp - base);
         __syncthreads();
         stage_groups(gm, job.grps, sub.grp_begin + base, count, th, job.entangler, lane);
         __syncthreads();
@@ -583,8 +585,8 @@ __global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const De
                                                   const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                   int from, int to, int front) {
     __shared__ cplx R[16 * 17];    // R[j * 17 + i] = sum_c z_c[j] conj(w_c[i]); rows padded: column walks hit 16 different banks
-    __shared__ Gm gm[64];
-    __shared__ cplx rho_s[64][16];
+    __shared__ Gm gm[kGrpChunk];
+    __shared__ cplx rho_s[kGrpChunk][16];
     const int lane = threadIdx.x, si = blockIdx.x, b = blockIdx.y;
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
@@ -609,8 +611,8 @@ __global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const De
     }
     cplx* out = partial + (size_t)b * nslots;
     const int lo = lane & 15, hi = lane >> 4;
-    for (int top = sub.ngrp; top > 0; top -= 64) {
-        const int base = max(0, top - 64), count = top - base;
+    for (int top = sub.ngrp; top > 0; top -= kGrpChunk) {
+        const int base = max(0, top - kGrpChunk), count = top - base;
         __syncthreads();
         stage_groups(gm, grps, sub.grp_begin + base, count, th, ent, lane);
         __syncthreads();

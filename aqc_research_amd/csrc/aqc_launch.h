@@ -116,6 +116,17 @@ hipError_t lb_history(const LbState& st, int count, double ftol, const double* f
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);
 hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                         void* C, int ldc, hipStream_t s);
+hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                void* C, int ldc, size_t stride_a, size_t stride_b, size_t stride_c, int nbatch, hipStream_t s);
+struct MpsSites {            // site table of one MPS (by value in the kernel arguments)
+    int n;
+    size_t total;            // complex elements of all site tensors
+    size_t offset[65];       // element offset of site q
+    int lam_offset[64];      // offset of lambda_q inside the packed Schmidt vectors
+    int cols[64];            // right bond dimension of site q
+};
+hipError_t launch_mps_scale_all(void* t, const double* lam, const MpsSites& sites, hipStream_t s);
+hipError_t launch_mps_permute(const void* g, void* out, int h, int m, hipStream_t s);
 
 // aqc_cd.hip
 int cd_num_parts(size_t npairs);

@@ -19,6 +19,27 @@ __global__ void mps_scale_kernel(cplx* g, const double* lam, int rows, int cols)
     }
 }
 
+// all sites of an MPS at once: gamma_q[b][l][r] *= lambda_q[r] for q < n - 1 (one launch instead of n - 1)
+__global__ void mps_scale_all_kernel(cplx* t, const double* lam, MpsSites sites) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sites.total) return;
+    int q = 0;
+    while (q + 1 < sites.n && i >= sites.offset[q + 1]) ++q;
+    if (q >= sites.n - 1) return;   // the last site has no Schmidt vector on its right
+    const size_t local = i - sites.offset[q];
+    const double sc = lam[sites.lam_offset[q] + (int)(local % (size_t)sites.cols[q])];
+    t[i].x *= sc;
+    t[i].y *= sc;
+}
+// out[(rev(i) << h) + lo] = g[lo * 2^m + i], rev = bit reversal over m bits (final step of the MPS -> dense contraction)
+__global__ void mps_permute_kernel(const cplx* g, cplx* out, int h, int m) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ((size_t)1 << (h + m))) return;
+    const unsigned i = (unsigned)(e & (((size_t)1 << m) - 1)), lo = (unsigned)(e >> m);
+    const unsigned r = m ? (__brev(i) >> (32 - m)) : 0u;
+    out[((size_t)r << h) + lo] = g[e];
+}
+
 // C[M x N] (+)= op(A) * B, row-major.  CONJ_T: op(A)[m][k] = conj(A[k][m]) with A stored (K x M).
 //
 // fp64 matrix cores: one v_mfma_f64_16x16x4_f64 multiplies a 16x4 by a 4x16 real tile.  Operand layout
@@ -30,7 +51,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int TM = 64, TN = 64, TK = 16;
 template <bool CONJ_T, bool ACCUM>
 __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const cplx* __restrict__ A, int lda,
-                                                    const cplx* __restrict__ B, int ldb, cplx* __restrict__ C, int ldc) {
+                                                    const cplx* __restrict__ B, int ldb, cplx* __restrict__ C, int ldc,
+                                                    size_t stride_a, size_t stride_b, size_t stride_c) {
+    A += (size_t)blockIdx.z * stride_a; B += (size_t)blockIdx.z * stride_b; C += (size_t)blockIdx.z * stride_c;   // batched
     __shared__ double sar[TK][TM + 4], sai[TK][TM + 4];
     __shared__ double sbr[TK][TN + 4], sbi[TK][TN + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,18 +116,35 @@ hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipS
     return hipGetLastError();
 }
 
+hipError_t launch_mps_scale_all(void* t, const double* lam, const MpsSites& sites, hipStream_t s) {
+    if (sites.total == 0) return hipSuccess;
+    mps_scale_all_kernel<<<(unsigned)((sites.total + 255) / 256), 256, 0, s>>>(static_cast<cplx*>(t), lam, sites);
+    return hipGetLastError();
+}
+hipError_t launch_mps_permute(const void* g, void* out, int h, int m, hipStream_t s) {
+    const size_t total = (size_t)1 << (h + m);
+    mps_permute_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<const cplx*>(g), static_cast<cplx*>(out), h, m);
+    return hipGetLastError();
+}
+
 hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                         void* C, int ldc, hipStream_t s) {
-    const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM);
+    return launch_zgemm_batched(conj_t, accum, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, s);
+}
+
+// `nbatch` products in one launch: operand / result pointers advance by the strides (in elements) per product
+hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                void* C, int ldc, size_t sa, size_t sb, size_t sc, int nbatch, hipStream_t s) {
+    const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch);
     const cplx* a = static_cast<const cplx*>(A);
     const cplx* b = static_cast<const cplx*>(B);
     cplx* c = static_cast<cplx*>(C);
     if (conj_t) {
-        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc);
-        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc);
+        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
+        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
     } else {
-        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc);
-        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc);
+        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
+        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
     }
     return hipGetLastError();
 }

@@ -44,3 +44,24 @@ def free_port() -> int:
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         return sock.getsockname()[1]
+
+
+def canonical_mps(vec, cap):
+    """Canonical Vidal form (Gamma, lambda) of a dense state by successive SVDs -- what Aer hands the reference
+    (mps_operations.py:216-243) -- with the bonds capped at `cap` and the kept Schmidt values renormalised."""
+    nq = int(np.log2(vec.size))
+    rest = vec.reshape([2] * nq).transpose(list(range(nq - 1, -1, -1))).reshape(1, -1)   # axes (b_0, ..., b_{n-1})
+    gam, lam, prev = [], [], np.ones(1)
+    for _ in range(nq - 1):
+        chi_l = rest.shape[0]
+        u, s, vh = np.linalg.svd(rest.reshape(chi_l * 2, -1), full_matrices=False)
+        k = min(cap, int((s > 1e-14 * s[0]).sum()))
+        u, s, vh = u[:, :k], s[:k] / np.linalg.norm(s[:k]), vh[:k]
+        a = u.reshape(chi_l, 2, k)
+        gam.append((a[:, 0, :] / prev[:, None], a[:, 1, :] / prev[:, None]))
+        lam.append(s.copy())
+        prev = s
+        rest = s[:, None] * vh
+    a = rest.reshape(rest.shape[0], 2, 1)
+    gam.append((a[:, 0, :] / prev[:, None], a[:, 1, :] / prev[:, None]))
+    return gam, lam

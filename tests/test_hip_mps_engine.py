@@ -132,6 +132,36 @@ def test_truncation_contract_and_large_register():
         assert abs((f[0] - f[1]) / 2e-5 - g[t]) < 1e-7
 
 
+def test_bond_256_at_16_qubits_matches_the_dense_route():
+    """Config 3 at its largest bond (n = 16, 40 blocks, chi <= 256, trunc_thr = 1e-16): V^H|phi> and the
+    gate-by-gate gradient on the engine equal the dense route to 1e-10.  2 chi = 512 > 64 columns takes the
+    multi-launch Jacobi path.  The target is a canonical MPS, as Aer produces them; the discard rule is stated in the
+    canonical gauge (sum of squared Schmidt values), so a non-canonical input (oracle random_mps) is outside the
+    contract -- and Aer's own truncation arithmetic at trunc_thr = 1e-6 stays parity-unpinned."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.mps_engine import DeviceMPS, fast_dot_gradient_mps, v_dagger_mul_mps
+    from oracle import aqc_ref as cref
+    from tests.helpers import canonical_mps
+
+    n = 16
+    rng = np.random.default_rng(1)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", 40))
+    th = orc.rand_thetas(circ.num_thetas, rng)
+    raw = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    phi = canonical_mps(raw / np.linalg.norm(raw), 256)
+    assert max(l.size for l in phi[1]) == 256
+    dense = orc.mps_to_vector(phi)
+    vh = v_dagger_mul_mps(circ, th, DeviceMPS.from_qiskit(phi), trunc_thr=1e-16)
+    assert vh.bond_dims.max() == 256
+    ref = cref.v_dagger_mul_vec(circ, th, dense)
+    assert maxdiff(_dense(vh), ref) < TOL
+    g = fast_dot_gradient_mps(circ, th, DeviceMPS.basis_state(n, 0), vh, trunc_thr=1e-16)
+    x = np.zeros(1 << n, complex)
+    x[0] = 1
+    assert maxdiff(g, cref.grad_of_dot_product(circ, th, x, ref)) < TOL
+
+
 def test_reference_signature_functions_route_to_the_engine(monkeypatch):
     """fast_dot_gradient / v_dagger_mul_mps / cx_mul_mps with the reference signatures: the native engine
     (forced here on a small register) gives what the dense route gives."""

@@ -19,3 +19,5 @@ for w in sv12_trotter2 sv20_l40 sv20_trotter2 mat10_l40 mat5_cyc180 mps16_l40_ch
   python bench.py --workload $w --steps 40 --warmup 10 > $O/bench_$w.json 2> $O/bench_$w.err
   echo "bench $w done"
 done
+timeout -k 10 400 python bench.py --workload cfg4_jobs --steps 2 --warmup 1 > $O/bench_cfg4_jobs.json 2> $O/bench_cfg4_jobs.err || echo "cfg4_jobs failed"
+echo "bench cfg4_jobs done"

@@ -116,6 +116,9 @@ hipError_t lb_history(const LbState& st, int count, double ftol, const double* f
 hipError_t launch_mps_scale(void* g, const double* lam, int rows, int cols, hipStream_t s);
 hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                         void* C, int ldc, hipStream_t s);
+hipError_t launch_zgemm_bh(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                           void* C, int ldc, hipStream_t s);   // C = op(A) . B^H, B stored (N x K)
+hipError_t launch_mps_env_dot(const void* e, const void* rc, size_t count, void* out, hipStream_t s);
 hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                 void* C, int ldc, size_t stride_a, size_t stride_b, size_t stride_c, int nbatch, hipStream_t s);
 struct MpsSites {            // site table of one MPS (by value in the kernel arguments)
@@ -156,6 +159,10 @@ hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, con
 bool svd_fits_small(int rows, int cols);
 hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
                                int* sweeps_out, hipStream_t s);
+bool svd_fits_block(int rows, int cols);
+int svd_block_size();
+hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void* bpairs, int rounds, int per_round, double tol, int max_sweeps,
+                               int* rot, unsigned* bar, int* status, hipStream_t s);
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
 hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,

@@ -52,7 +52,7 @@ constexpr int TM = 64, TN = 64, TK = 16;
 template <bool CONJ_T, bool ACCUM>
 __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const cplx* __restrict__ A, int lda,
                                                     const cplx* __restrict__ B, int ldb, cplx* __restrict__ C, int ldc,
-                                                    size_t stride_a, size_t stride_b, size_t stride_c) {
+                                                    size_t stride_a, size_t stride_b, size_t stride_c, int b_herm) {
     A += (size_t)blockIdx.z * stride_a; B += (size_t)blockIdx.z * stride_b; C += (size_t)blockIdx.z * stride_c;   // batched
     __shared__ double sar[TK][TM + 4], sai[TK][TM + 4];
     __shared__ double sbr[TK][TN + 4], sbi[TK][TN + 4];
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const c
         for (int e = threadIdx.x; e < TK * TN; e += 256) {
             const int kk = e / TN, nn = e % TN;
             const int gk = k0 + kk, gn = n0 + nn;
-            const cplx v = (gk < K && gn < N) ? B[(size_t)gk * ldb + gn] : make_double2(0.0, 0.0);
+            cplx v = make_double2(0.0, 0.0);
+            if (gk < K && gn < N) {
+                if (b_herm) { v = B[(size_t)gn * ldb + gk]; v.y = -v.y; } else { v = B[(size_t)gk * ldb + gn]; }   // b_herm: B holds (N x K), used as B^H
+            }
             sbr[kk][nn] = v.x;
             sbi[kk][nn] = v.y;
         }
@@ -127,25 +130,61 @@ hipError_t launch_mps_permute(const void* g, void* out, int h, int m, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                        void* C, int ldc, hipStream_t s) {
-    return launch_zgemm_batched(conj_t, accum, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, s);
-}
-
-// `nbatch` products in one launch: operand / result pointers advance by the strides (in elements) per product
-hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                                void* C, int ldc, size_t sa, size_t sb, size_t sc, int nbatch, hipStream_t s) {
+namespace {
+hipError_t zgemm_launch(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, size_t sa,
+                        size_t sb, size_t sc, int nbatch, int b_herm, hipStream_t s) {
+    if (M <= 0 || N <= 0 || nbatch <= 0) return hipSuccess;
     const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch);
     const cplx* a = static_cast<const cplx*>(A);
     const cplx* b = static_cast<const cplx*>(B);
     cplx* c = static_cast<cplx*>(C);
     if (conj_t) {
-        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
-        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
+        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
+        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
     } else {
-        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
-        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc);
+        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
+        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
     }
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_zgemm(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                        void* C, int ldc, hipStream_t s) {
+    return zgemm_launch(conj_t, accum, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, 0, s);
+}
+// C (M x N) = op(A) . B^H with B stored (N x K) row-major
+hipError_t launch_zgemm_bh(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                           void* C, int ldc, hipStream_t s) {
+    return zgemm_launch(conj_t, accum, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, 1, s);
+}
+
+// `nbatch` products in one launch: operand / result pointers advance by the strides (in elements) per product
+hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                void* C, int ldc, size_t sa, size_t sb, size_t sc, int nbatch, hipStream_t s) {
+    return zgemm_launch(conj_t, accum, M, N, K, A, lda, B, ldb, C, ldc, sa, sb, sc, nbatch, 0, s);
+}
+
+// out = sum_i e[i] conj(rc[i]): closes an inner product between a left environment and a (conjugated) right one;
+// one workgroup, fixed-order reduction
+__global__ __launch_bounds__(256) void mps_env_dot_kernel(const cplx* __restrict__ e, const cplx* __restrict__ rc, size_t count, cplx* __restrict__ out) {
+    __shared__ double sr[256], si[256];
+    double re = 0.0, im = 0.0;
+    for (size_t i = threadIdx.x; i < count; i += 256) {
+        const cplx a = e[i], b = rc[i];
+        re += a.x * b.x + a.y * b.y;
+        im += a.y * b.x - a.x * b.y;
+    }
+    sr[threadIdx.x] = re; si[threadIdx.x] = im;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sr[threadIdx.x] += sr[threadIdx.x + s]; si[threadIdx.x] += si[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = make_double2(sr[0], si[0]);
+}
+hipError_t launch_mps_env_dot(const void* e, const void* rc, size_t count, void* out, hipStream_t s) {
+    mps_env_dot_kernel<<<1, 256, 0, s>>>(static_cast<const cplx*>(e), static_cast<const cplx*>(rc), count, static_cast<cplx*>(out));
     return hipGetLastError();
 }
 

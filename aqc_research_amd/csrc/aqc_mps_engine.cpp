@@ -16,8 +16,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -82,36 +84,69 @@ void tournament(int cols, std::vector<int>& pairs, int& rounds, int& per_round) 
 struct SvdWork {
     Scratch pairs, flag, sigma;
     std::vector<int> h_pairs;
-    int cached_cols = -1, rounds = 0, per_round = 0;
+    int cached_cols = -1, cached_blocked = -1, rounds = 0, per_round = 0;
     void release() { pairs.release(); flag.release(); sigma.release(); }
 };
+
+// Tournament over column blocks: a block without a partner (odd number of blocks) still plays, alone (.y = -1).
+void block_tournament(int nblocks, std::vector<int>& pairs, int& rounds, int& per_round) {
+    const int n2 = nblocks + (nblocks & 1);
+    rounds = std::max(n2 - 1, 1);
+    per_round = std::max(n2 / 2, 1);
+    pairs.assign((size_t)rounds * per_round * 2, -1);
+    if (nblocks == 1) { pairs[0] = 0; return; }
+    std::vector<int> ring(n2);
+    std::iota(ring.begin(), ring.end(), 0);
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = 0; i < per_round; ++i) {
+            int a = ring[i], b = ring[n2 - 1 - i];
+            if (a > b) std::swap(a, b);
+            pairs[((size_t)r * per_round + i) * 2] = a;
+            pairs[((size_t)r * per_round + i) * 2 + 1] = b < nblocks ? b : -1;
+        }
+        std::rotate(ring.begin() + 1, ring.end() - 1, ring.end());
+    }
+}
 
 // Orthogonalises the columns of the column-major W (rows x cols) in place, accumulating V (cols x cols);
 // returns the column norms in h_sigma.  `sweeps_out` reports the number of sweeps used.
 int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st, std::vector<double>& h_sigma, int* sweeps_out) {
-    if (sw.cached_cols != cols) {
-        tournament(cols, sw.h_pairs, sw.rounds, sw.per_round);
+    const char* env_blocked = getenv("AQC_SVD_BLOCKED");   // 0: round-per-launch cross-check
+    const bool blocked_ok = !(env_blocked && atoi(env_blocked) == 0);
+    const bool small = svd_fits_small(rows, cols);
+    const bool blocked = !small && blocked_ok && svd_fits_block(rows, cols);
+    if (sw.cached_cols != cols || sw.cached_blocked != (int)blocked) {
+        if (blocked) block_tournament((cols + svd_block_size() - 1) / svd_block_size(), sw.h_pairs, sw.rounds, sw.per_round);
+        else tournament(cols, sw.h_pairs, sw.rounds, sw.per_round);
         if (sw.pairs.reserve(std::max<size_t>(sw.h_pairs.size(), 2) * sizeof(int))) return 1;
         if (!sw.h_pairs.empty()) HIP_OK(hipMemcpyAsync(sw.pairs.p, sw.h_pairs.data(), sw.h_pairs.size() * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_OK(hipStreamSynchronize(st));
         sw.cached_cols = cols;
+        sw.cached_blocked = (int)blocked;
     }
-    if (sw.flag.reserve(sizeof(int)) || sw.sigma.reserve(sizeof(double) * std::max(cols, 1))) return 1;
+    constexpr int kFlagInts = 64 + 4;   // [0..63] rotations per sweep | [64] barrier | [65] sweeps used | [66] barrier timeout
+    if (sw.flag.reserve(sizeof(int) * kFlagInts) || sw.sigma.reserve(sizeof(double) * std::max(cols, 1))) return 1;
+    int* flag = static_cast<int*>(sw.flag.p);
     const double tol = 1e-15;
     int sweeps = 0;
-    if (svd_fits_small(rows, cols)) {   // one launch: matrix and V live in the LDS of one workgroup
-        HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, static_cast<int*>(sw.flag.p), st));
-        HIP_OK(hipMemcpyAsync(&sweeps, sw.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    int status[2] = {0, 0};
+    if (small) {   // one launch: matrix and V live in the LDS of one workgroup
+        HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, st));
+        HIP_OK(hipMemcpyAsync(&sweeps, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    } else if (blocked) {   // one cooperative launch: persistent workgroups, 16 columns at a time in LDS
+        HIP_OK(launch_svd_identity(V, cols, st));
+        HIP_OK(hipMemsetAsync(flag, 0, sizeof(int) * kFlagInts, st));
+        HIP_OK(launch_jacobi_block(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, reinterpret_cast<unsigned*>(flag + 64), flag + 65, st));
+        HIP_OK(hipMemcpyAsync(status, flag + 65, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     } else {
         HIP_OK(launch_svd_identity(V, cols, st));
     }
-    for (; !svd_fits_small(rows, cols) && sweeps < 60 && cols > 1; ++sweeps) {
-        HIP_OK(hipMemsetAsync(sw.flag.p, 0, sizeof(int), st));
+    for (; !small && !blocked && sweeps < 60 && cols > 1; ++sweeps) {
+        HIP_OK(hipMemsetAsync(flag, 0, sizeof(int), st));
         for (int r = 0; r < sw.rounds; ++r)
-            HIP_OK(launch_jacobi_round(W, rows, V, cols, static_cast<int*>(sw.pairs.p) + (size_t)r * sw.per_round * 2, sw.per_round, tol,
-                                       static_cast<int*>(sw.flag.p), st));
+            HIP_OK(launch_jacobi_round(W, rows, V, cols, static_cast<int*>(sw.pairs.p) + (size_t)r * sw.per_round * 2, sw.per_round, tol, flag, st));
         int rotations = 0;
-        HIP_OK(hipMemcpyAsync(&rotations, sw.flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(&rotations, flag, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         if (rotations == 0) { ++sweeps; break; }
     }
@@ -119,7 +154,11 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
     HIP_OK(launch_svd_norms(W, rows, cols, static_cast<double*>(sw.sigma.p), st));
     HIP_OK(hipMemcpyAsync(h_sigma.data(), sw.sigma.p, sizeof(double) * cols, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (sweeps_out) *sweeps_out = sweeps;   // the single-launch path delivers its count with this synchronisation
+    if (blocked) {
+        if (status[1] != 0) return failf("Jacobi SVD: a grid barrier of the persistent kernel timed out (%d x %d)", rows, cols);
+        sweeps = status[0];
+    }
+    if (sweeps_out) *sweeps_out = sweeps;   // the single-launch paths deliver their count with this synchronisation
     return 0;
 }
 
@@ -128,6 +167,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
 struct aqc_mps {
     int device = 0, n = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     std::vector<int> dims;                    // n + 1 bond dimensions, dims[0] = dims[n] = 1
     std::vector<double2*> t;                  // per site: [2][dims[q]][dims[q+1]]
     std::vector<size_t> t_cap, lam_cap;       // allocated elements (buffers only grow)
@@ -173,7 +213,7 @@ void destroy(aqc_mps* m) {
     for (double2* p : m->t) if (p) (void)hipFree(p);
     for (double* p : m->d_lam) if (p) (void)hipFree(p);
     m->theta.release(); m->work.release(); m->vmat.release(); m->ord.release(); m->tmp.release(); m->svd.release();
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->stream && m->owns_stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 
@@ -257,6 +297,252 @@ void permute_gate(const double* g, bool flip, double* out) {   // flip: swap the
             out[2 * (4 * i + j)] = g[2 * (4 * si + sj)];
             out[2 * (4 * i + j) + 1] = g[2 * (4 * si + sj) + 1];
         }
+}
+
+
+int gate1_site(aqc_mps* m, int q, const double* g8) {
+    HIP_OK(launch_gate1q(m->t[q], m->t[q], 1, (size_t)m->dims[q] * m->dims[q + 1], 0, g8, m->stream));
+    return 0;
+}
+
+// 4x4 gate (index 2 * bit_ctrl + bit_targ) on any pair of qubits
+int gate2_pair(aqc_mps* m, int ctrl, int targ, const double* gate, double trunc_thr, int max_bond) {
+    static const double swap_gate[32] = {1, 0, 0, 0, 0, 0, 0, 0,  0, 0, 0, 0, 1, 0, 0, 0,  0, 0, 1, 0, 0, 0, 0, 0,  0, 0, 0, 0, 0, 0, 1, 0};
+    const int lo = std::min(ctrl, targ), hi = std::max(ctrl, targ);
+    // bring qubit `hi` down to position lo + 1 by swaps, apply, swap back (the route Aer takes as well)
+    for (int p = hi - 1; p > lo; --p)
+        if (gate_adjacent(m, p, swap_gate, trunc_thr, max_bond)) return 1;
+    double g[32];
+    permute_gate(gate, ctrl > targ, g);      // site lo carries the lower qubit: flip when ctrl is the upper one
+    if (gate_adjacent(m, lo, g, trunc_thr, max_bond)) return 1;
+    for (int p = lo + 1; p < hi; ++p)
+        if (gate_adjacent(m, p, swap_gate, trunc_thr, max_bond)) return 1;
+    return 0;
+}
+
+// ---- the ansatz, gate by gate (host side of aqc_mps_apply_circuit / aqc_mps_fast_dot_gradient) ----------
+typedef std::complex<double> cd;
+struct M2 { cd m[4]; };   // row-major 2x2
+M2 operator*(const M2& x, const M2& y) {
+    return {{x.m[0] * y.m[0] + x.m[1] * y.m[2], x.m[0] * y.m[1] + x.m[1] * y.m[3], x.m[2] * y.m[0] + x.m[3] * y.m[2], x.m[2] * y.m[1] + x.m[3] * y.m[3]}};
+}
+M2 rz_m(double t) { return {{std::polar(1.0, -0.5 * t), 0.0, 0.0, std::polar(1.0, 0.5 * t)}}; }
+M2 ry_m(double t) { const double c = std::cos(0.5 * t), s = std::sin(0.5 * t); return {{c, -s, s, c}}; }
+M2 rx_m(double t) { const double c = std::cos(0.5 * t), s = std::sin(0.5 * t); return {{c, cd(0, -s), cd(0, -s), c}}; }
+const M2 kPauliX = {{0.0, 1.0, 1.0, 0.0}}, kPauliY = {{0.0, cd(0, -1), cd(0, 1), 0.0}}, kPauliZ = {{1.0, 0.0, 0.0, -1.0}}, kProj1 = {{0.0, 0.0, 0.0, 1.0}};
+void pack(const M2& g, double* out8) { for (int i = 0; i < 4; ++i) { out8[2 * i] = g.m[i].real(); out8[2 * i + 1] = g.m[i].imag(); } }
+int gate1(aqc_mps* m, int q, const M2& g) { double g8[8]; pack(g, g8); return gate1_site(m, q, g8); }
+
+void entangler_matrix(int ent, double angle, double* out32) {   // |0><0| x I + |1><1| x {X, Z, diag(1, e^{i angle})}, index 2 c + t
+    std::fill(out32, out32 + 32, 0.0);
+    out32[0] = 1.0; out32[2 * 5] = 1.0;
+    if (ent == AQC_CX) { out32[2 * 11] = 1.0; out32[2 * 14] = 1.0; }
+    else if (ent == AQC_CZ) { out32[2 * 10] = 1.0; out32[2 * 15] = -1.0; }
+    else { out32[2 * 10] = 1.0; out32[2 * 15] = std::cos(angle); out32[2 * 15 + 1] = std::sin(angle); }
+}
+
+struct BlockRef { int i, j, c, t; };   // running index, parameter block, control, target
+int check_circuit(const aqc_circuit* c, int n) {
+    if (!c || !c->blocks) return failf("null circuit description");
+    if (c->num_qubits != n) return failf("circuit and MPS differ in the number of qubits");
+    if (c->entangler != AQC_CX && c->entangler != AQC_CZ && c->entangler != AQC_CP) return failf("unknown entangler");
+    if (c->num_blocks < 0) return failf("negative number of blocks");
+    for (int b = 0; b < c->num_blocks; ++b) {
+        const int ct = c->blocks[b], tg = c->blocks[c->num_blocks + b];
+        if (ct < 0 || ct >= n || tg < 0 || tg >= n || ct == tg) return failf("block %d couples invalid qubits", b);
+    }
+    return 0;
+}
+// incl. the virtual trailing half-layer of a 2nd-order Trotter ansatz (parametric_circuit.py:328-333)
+std::vector<BlockRef> blocks_of(const aqc_circuit* c) {
+    const int L = c->num_blocks, tail = (c->trotter && c->second_order) ? 3 * (c->num_qubits / 2) : 0;
+    std::vector<BlockRef> out;
+    for (int i = 0; i < L + tail && L > 0; ++i) out.push_back({i, i % L, c->blocks[i % L], c->blocks[L + i % L]});
+    return out;
+}
+
+int apply_circuit(aqc_mps* m, const aqc_circuit* c, const double* th, bool inverse, double trunc_thr, int max_bond) {
+    const int n = m->n, tpb = c->entangler == AQC_CP ? 5 : 4;
+    const double* t2 = th + 3 * n;
+    const bool cx = c->entangler == AQC_CX;
+    const std::vector<BlockRef> blocks = blocks_of(c);
+    const double half_pi = 1.5707963267948966;
+    double ent[32];
+    if (!inverse) {   // core_operations.py:671-708
+        for (int q = 0; q < n; ++q)
+            if (gate1(m, q, rz_m(th[3 * q]) * ry_m(th[3 * q + 1]) * rz_m(th[3 * q + 2]))) return 1;
+        for (const BlockRef& b : blocks) {
+            const double* p = t2 + (size_t)tpb * b.j;
+            if (c->trotter && b.i % 3 == 0 && gate1(m, b.c, rz_m(-half_pi))) return 1;
+            entangler_matrix(c->entangler, tpb == 5 ? p[4] : 0.0, ent);
+            if (gate2_pair(m, b.c, b.t, ent, trunc_thr, max_bond)) return 1;
+            if (gate1(m, b.c, rz_m(p[1]) * ry_m(p[0]))) return 1;
+            if (gate1(m, b.t, (cx ? rx_m(p[3]) : rz_m(p[3])) * ry_m(p[2]))) return 1;
+            if (c->trotter && b.i % 3 == 2 && gate1(m, b.t, rz_m(half_pi))) return 1;
+        }
+    } else {          // core_operations.py:787-818
+        for (auto it = blocks.rbegin(); it != blocks.rend(); ++it) {
+            const BlockRef& b = *it;
+            const double* p = t2 + (size_t)tpb * b.j;
+            if (c->trotter && b.i % 3 == 2 && gate1(m, b.t, rz_m(-half_pi))) return 1;
+            if (gate1(m, b.t, ry_m(-p[2]) * (cx ? rx_m(-p[3]) : rz_m(-p[3])))) return 1;
+            if (gate1(m, b.c, ry_m(-p[0]) * rz_m(-p[1]))) return 1;
+            entangler_matrix(c->entangler, tpb == 5 ? -p[4] : 0.0, ent);
+            if (gate2_pair(m, b.c, b.t, ent, trunc_thr, max_bond)) return 1;
+            if (c->trotter && b.i % 3 == 0 && gate1(m, b.c, rz_m(half_pi))) return 1;
+        }
+        for (int q = 0; q < n; ++q)
+            if (gate1(m, q, rz_m(-th[3 * q + 2]) * ry_m(-th[3 * q + 1]) * rz_m(-th[3 * q]))) return 1;
+    }
+    return 0;
+}
+
+// Environments of the pair (w, z) for <(ops) w|z>: L[q] = contraction of the sites < q ([chi_w][chi_z]), Rc[q] = the
+// CONJUGATE of the contraction of the sites > q.  A gate on sites [lo, hi] leaves L[<= lo] and Rc[>= hi] valid, so
+// the ~T inner products of one gradient cost a few site steps each instead of a full chain of n.
+struct Environments {
+    aqc_mps* w; aqc_mps* z;
+    int n, valid_l, valid_r;
+    std::vector<Scratch> L, R;
+    Scratch t, e0, e1, bsite, vals;
+    hipStream_t st;
+    int init(aqc_mps* w_, aqc_mps* z_, int nvals) {
+        w = w_; z = z_; n = w->n; st = w->stream;
+        L.resize(n + 1); R.resize(n);
+        valid_l = 0; valid_r = n - 1;
+        const double one[2] = {1.0, 0.0};
+        if (L[0].reserve(sizeof(double2)) || R[n - 1].reserve(sizeof(double2)) || vals.reserve(sizeof(double2) * std::max(nvals, 1))) return 1;
+        HIP_OK(hipMemcpyAsync(L[0].p, one, sizeof one, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(R[n - 1].p, one, sizeof one, hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+        return 0;
+    }
+    void release() { for (Scratch& x : L) x.release(); for (Scratch& x : R) x.release(); t.release(); e0.release(); e1.release(); bsite.release(); vals.release(); }
+    void touched(int lo, int hi) { valid_l = std::min(valid_l, lo); valid_r = std::max(valid_r, hi); }
+    // site p of z, seen through G^H when an operator G sits on w's side there (<G w|z> = <w|G^H z>)
+    int z_site(int p, const M2* op, const double2** out) {
+        *out = z->t[p];
+        if (!op) return 0;
+        const size_t ne = (size_t)z->dims[p] * z->dims[p + 1];
+        if (bsite.reserve(sizeof(double2) * 2 * ne)) return 1;
+        const M2 gh = {{std::conj(op->m[0]), std::conj(op->m[2]), std::conj(op->m[1]), std::conj(op->m[3])}};
+        double g8[8]; pack(gh, g8);
+        HIP_OK(launch_gate1q(z->t[p], bsite.p, 1, ne, 0, g8, st));
+        *out = static_cast<const double2*>(bsite.p);
+        return 0;
+    }
+    // out[u][v] = sum_bit sum_xy conj(A_p[bit][x][u]) in[x][y] B_p[bit][y][v]
+    int step_left(int p, const void* in, const M2* op, Scratch& out) {
+        const int xa = w->dims[p], ua = w->dims[p + 1], yb = z->dims[p], vb = z->dims[p + 1];
+        const double2* bq = nullptr;
+        if (z_site(p, op, &bq)) return 1;
+        if (t.reserve(sizeof(double2) * (size_t)xa * vb) || out.reserve(sizeof(double2) * (size_t)ua * vb)) return 1;
+        for (int bit = 0; bit < 2; ++bit) {
+            HIP_OK(launch_zgemm(false, false, xa, vb, yb, in, yb, bq + (size_t)bit * yb * vb, vb, t.p, vb, st));
+            HIP_OK(launch_zgemm(true, bit == 1, ua, vb, xa, w->t[p] + (size_t)bit * xa * ua, ua, t.p, vb, out.p, vb, st));
+        }
+        return 0;
+    }
+    // Rc[p-1][x][y] = sum_bit A_p[bit][x][u] (Rc[p] B_p[bit]^H)[u][y]
+    int step_right(int p) {
+        const int xa = w->dims[p], ua = w->dims[p + 1], yb = z->dims[p], vb = z->dims[p + 1];
+        if (t.reserve(sizeof(double2) * (size_t)ua * yb) || R[p - 1].reserve(sizeof(double2) * (size_t)xa * yb)) return 1;
+        for (int bit = 0; bit < 2; ++bit) {
+            HIP_OK(launch_zgemm_bh(false, false, ua, yb, vb, R[p].p, vb, z->t[p] + (size_t)bit * yb * vb, vb, t.p, yb, st));
+            HIP_OK(launch_zgemm(false, bit == 1, xa, yb, ua, w->t[p] + (size_t)bit * xa * ua, ua, t.p, yb, R[p - 1].p, yb, st));
+        }
+        return 0;
+    }
+    // vals[slot] = <(G_1 on q_1)(G_2 on q_2) w | z>, q_1 < q_2 (nops = 1: only q_1)
+    int dot(int slot, int nops, const int* q, const M2* const* g) {
+        const int lo = q[0], hi = q[nops - 1];
+        for (; valid_l < lo; ++valid_l)
+            if (step_left(valid_l, L[valid_l].p, nullptr, L[valid_l + 1])) return 1;
+        for (; valid_r > hi; --valid_r)
+            if (step_right(valid_r)) return 1;
+        const void* cur = L[lo].p;
+        Scratch* pp[2] = {&e0, &e1};
+        for (int p = lo; p <= hi; ++p) {
+            const M2* op = p == q[0] ? g[0] : (nops > 1 && p == q[1] ? g[1] : nullptr);
+            Scratch& out = *pp[(p - lo) & 1];
+            if (step_left(p, cur, op, out)) return 1;
+            cur = out.p;
+        }
+        HIP_OK(launch_mps_env_dot(cur, R[hi].p, (size_t)w->dims[hi + 1] * z->dims[hi + 1], static_cast<double2*>(vals.p) + slot, st));
+        return 0;
+    }
+};
+
+int fast_dot_gradient(const aqc_circuit* c, aqc_mps* w, aqc_mps* z, const double* th, double trunc_thr, int max_bond, int lo_blk, int hi_blk,
+                      bool front_layer, double* grad) {
+    const int n = w->n, tpb = c->entangler == AQC_CP ? 5 : 4, L = c->num_blocks, T = 3 * n + tpb * L;
+    const bool cx = c->entangler == AQC_CX;
+    const std::vector<BlockRef> blocks = blocks_of(c);
+    const double half_pi = 1.5707963267948966;
+    // every recorded inner product: (theta index, factor); several may add into one theta (Trotter tail)
+    std::vector<std::pair<int, cd>> rec;
+    rec.reserve((size_t)3 * n + (size_t)tpb * blocks.size());
+    Environments env;
+    if (env.init(w, z, 3 * n + tpb * (int)blocks.size())) { env.release(); return 1; }
+    auto both = [&](int q, const M2& g) -> int {
+        if (gate1(w, q, g) || gate1(z, q, g)) return 1;
+        env.touched(q, q);
+        return 0;
+    };
+    auto record = [&](int tindex, cd factor, int nops, const int* q, const M2* const* g) -> int {
+        if (env.dot((int)rec.size(), nops, q, g)) return 1;
+        rec.emplace_back(tindex, factor);
+        return 0;
+    };
+    int rc = 1;
+    do {
+        bool bad = false;
+        // front layer: Rz(t2), Ry(t1), Rz(t0), rightmost first (core_operations.py:921-935)
+        for (int q = 0; q < n && !bad; ++q) {
+            const int slots[3] = {2, 1, 0};
+            for (int k = 0; k < 3 && !bad; ++k) {
+                const int slot = slots[k];
+                const bool is_y = slot == 1;
+                if (both(q, is_y ? ry_m(th[3 * q + slot]) : rz_m(th[3 * q + slot]))) { bad = true; break; }
+                const M2* op = is_y ? &kPauliY : &kPauliZ;
+                if (front_layer && record(3 * q + slot, cd(0, 0.5), 1, &q, &op)) bad = true;
+            }
+        }
+        double ent[32];
+        for (size_t bi = 0; bi < blocks.size() && !bad; ++bi) {
+            const BlockRef& b = blocks[bi];
+            const double* p = th + 3 * n + (size_t)tpb * b.j;
+            const int base = 3 * n + tpb * b.j;
+            const bool live = lo_blk <= b.j && b.j < hi_blk;
+            if (c->trotter && b.i % 3 == 0 && both(b.c, rz_m(-half_pi))) { bad = true; break; }
+            if (live && tpb == 5) {   // -1j <P11 w|z> before the gate (core_op_matrix.py:430-477)
+                const int qq[2] = {std::min(b.c, b.t), std::max(b.c, b.t)};
+                const M2* gg[2] = {&kProj1, &kProj1};
+                if (record(base + 4, cd(0, -1.0), 2, qq, gg)) { bad = true; break; }
+            }
+            entangler_matrix(c->entangler, tpb == 5 ? p[4] : 0.0, ent);
+            if (gate2_pair(z, b.c, b.t, ent, trunc_thr, max_bond) || gate2_pair(w, b.c, b.t, ent, trunc_thr, max_bond)) { bad = true; break; }
+            env.touched(std::min(b.c, b.t), std::max(b.c, b.t));
+            const int qs[4] = {b.c, b.c, b.t, b.t};
+            const M2 gs[4] = {ry_m(p[0]), rz_m(p[1]), ry_m(p[2]), cx ? rx_m(p[3]) : rz_m(p[3])};
+            const M2* ps[4] = {&kPauliY, &kPauliZ, &kPauliY, cx ? &kPauliX : &kPauliZ};
+            for (int k = 0; k < 4 && !bad; ++k) {
+                if (both(qs[k], gs[k])) { bad = true; break; }
+                if (live && record(base + k, cd(0, 0.5), 1, &qs[k], &ps[k])) bad = true;
+            }
+            if (!bad && c->trotter && b.i % 3 == 2 && both(b.t, rz_m(half_pi))) bad = true;
+        }
+        if (bad) break;
+        std::vector<cd> vals(rec.size());
+        if (!rec.empty() && hipMemcpyAsync(vals.data(), env.vals.p, sizeof(cd) * rec.size(), hipMemcpyDeviceToHost, env.st) != hipSuccess) { failf("gradient download failed"); break; }
+        if (hipStreamSynchronize(env.st) != hipSuccess) { failf("stream synchronisation failed"); break; }
+        std::vector<cd> g(T, cd(0.0, 0.0));
+        for (size_t i = 0; i < rec.size(); ++i) g[rec[i].first] += rec[i].second * vals[i];
+        std::memcpy(grad, g.data(), sizeof(cd) * T);
+        rc = 0;
+    } while (false);
+    env.release();
+    return rc;
 }
 
 }  // namespace
@@ -351,8 +637,7 @@ int aqc_mps_gate1(aqc_mps* m, int qubit, const double* gate) {
     if (!m || !gate) return failf("null argument");
     if (qubit < 0 || qubit >= m->n) return failf("qubit out of range");
     HIP_OK(hipSetDevice(m->device));
-    HIP_OK(launch_gate1q(m->t[qubit], m->t[qubit], 1, (size_t)m->dims[qubit] * m->dims[qubit + 1], 0, gate, m->stream));
-    return 0;
+    return gate1_site(m, qubit, gate);
 }
 
 /* 4x4 gate (index 2 * bit_ctrl + bit_targ) on any pair of qubits */
@@ -361,17 +646,40 @@ int aqc_mps_gate2(aqc_mps* m, int ctrl, int targ, const double* gate, double tru
     if (ctrl < 0 || ctrl >= m->n || targ < 0 || targ >= m->n || ctrl == targ) return failf("invalid qubit pair");
     if (!(trunc_thr >= 0.0)) return failf("trunc_thr must be non-negative");
     HIP_OK(hipSetDevice(m->device));
-    static const double swap_gate[32] = {1, 0, 0, 0, 0, 0, 0, 0,  0, 0, 0, 0, 1, 0, 0, 0,  0, 0, 1, 0, 0, 0, 0, 0,  0, 0, 0, 0, 0, 0, 1, 0};
-    const int lo = std::min(ctrl, targ), hi = std::max(ctrl, targ);
-    // bring qubit `hi` down to position lo + 1 by swaps, apply, swap back (the route Aer takes as well)
-    for (int p = hi - 1; p > lo; --p)
-        if (gate_adjacent(m, p, swap_gate, trunc_thr, max_bond)) return 1;
-    double g[32];
-    permute_gate(gate, ctrl > targ, g);      // site lo carries the lower qubit: flip when ctrl is the upper one
-    if (gate_adjacent(m, lo, g, trunc_thr, max_bond)) return 1;
-    for (int p = lo + 1; p < hi; ++p)
-        if (gate_adjacent(m, p, swap_gate, trunc_thr, max_bond)) return 1;
-    return 0;
+    return gate2_pair(m, ctrl, targ, gate, trunc_thr, max_bond);
+}
+
+/* V(thetas)|mps> (inverse = 0) or V(thetas)^H|mps> (inverse = 1) in place, the whole ansatz in one call
+ * (mps_operations.py:326-371: v_mul_mps / v_dagger_mul_mps) */
+int aqc_mps_apply_circuit(aqc_mps* m, const aqc_circuit* circ, const double* thetas, int inverse, double trunc_thr, int max_bond) {
+    if (!m || !thetas) return failf("null argument");
+    if (check_circuit(circ, m->n)) return 1;
+    if (!(trunc_thr >= 0.0)) return failf("trunc_thr must be non-negative");
+    HIP_OK(hipSetDevice(m->device));
+    return apply_circuit(m, circ, thetas, inverse != 0, trunc_thr, max_bond);
+}
+
+/* complex gradient of <V lvec|phi> given vh_phi = V^H|phi>, the whole gate-by-gate walk in one call
+ * (mps_dot_objective.py:41-242 fast_dot_gradient); block_from < 0: all blocks.  The operands are left intact. */
+int aqc_mps_fast_dot_gradient(const aqc_circuit* circ, const aqc_mps* lvec, const aqc_mps* vh_phi, const double* thetas, double trunc_thr,
+                              int max_bond, int block_from, int block_to, int front_layer, double* grad) {
+    if (!lvec || !vh_phi || !thetas || !grad) return failf("null argument");
+    if (lvec->n != vh_phi->n || lvec->device != vh_phi->device) return failf("MPS operands differ in size or device");
+    if (check_circuit(circ, lvec->n)) return 1;
+    if (!(trunc_thr >= 0.0)) return failf("trunc_thr must be non-negative");
+    if (block_from < 0) { block_from = 0; block_to = circ->num_blocks; }
+    if (block_from > block_to || block_to > circ->num_blocks) return failf("invalid block range");
+    HIP_OK(hipSetDevice(lvec->device));
+    aqc_mps *w = nullptr, *z = nullptr;
+    if (aqc_mps_clone(lvec, &w)) return 1;
+    if (aqc_mps_clone(vh_phi, &z)) { destroy(w); return 1; }
+    (void)hipStreamDestroy(z->stream);   // one stream orders the gates on both operands and the environments
+    z->stream = w->stream;
+    z->owns_stream = false;
+    const int rc = fast_dot_gradient(circ, w, z, thetas, trunc_thr, max_bond, block_from, block_to, front_layer != 0, grad);
+    destroy(z);
+    destroy(w);
+    return rc;
 }
 
 /* <(prod_i G_i on qubit_i) a | b> by transfer matrices (mps_dot, mps_operations.py:192-213; with one Pauli this is

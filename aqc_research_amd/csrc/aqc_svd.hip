@@ -7,6 +7,8 @@
 // Everything is deterministic: fixed pair order, fixed-order block reductions, no float atomics.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "aqc_launch.h"
 #include "aqc_math.h"
 
@@ -150,6 +152,258 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
     for (int i = tid; i < rows * cols; i += blockDim.x) W[i] = sw[i];
     for (int i = tid; i < cols * cols; i += blockDim.x) V[i] = sv[i];
     if (tid == 0) *sweeps_out = sweep;
+}
+
+// Two-level (block) Jacobi for work matrices beyond one workgroup's LDS (64 < columns, rows <= 512: bond dimensions
+// up to 256, the cap of config 3).  The columns are cut into blocks of 8; one outer round pairs the blocks by a
+// round-robin tournament and gives every block pair to one workgroup, which pulls its 16 columns of W into LDS,
+// runs a complete inner tournament over them (15 rounds x 8 column pairs, one wave per pair, workgroup barriers
+// only), and accumulates the 16x16 unitary Q of its rotations.  W goes back once; the 16 columns of V are updated
+// as V <- V Q on the fp64 matrix cores.  The whole SVD -- all sweeps, all outer rounds, the convergence test -- is
+// ONE cooperative launch: the workgroups are persistent and meet at a grid barrier after every outer round
+// (511 dependent launches per sweep at 512 columns before, 63 barriers now).  Every wait is bounded: a barrier that
+// does not fill raises `fail` and every workgroup leaves.
+constexpr int kBlk = 8, kBlk2 = 2 * kBlk, kBlockThreads = 64 * kBlk, kBlockMaxRows = 512, kBlockMaxSweeps = 64;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct BlockJacobi {
+    cplx* W; cplx* V;
+    const int2* bpairs;   // [rounds][per_round] block pairs; .y = -1: the block plays alone (odd number of blocks)
+    int rows, cols, rounds, per_round, max_sweeps;
+    double tol;
+    int* rot;             // [kBlockMaxSweeps] rotations per sweep, zeroed by the host
+    unsigned* bar;        // grid barrier counter, zeroed by the host
+    int* status;          // [0] sweeps used, [1] != 0: a barrier timed out
+    int debug;            // tuning builds: 1 no inner rounds, 2 no V update, 4 no grid barrier, 8 no W traffic, 16 run 10 sweeps regardless
+};
+#ifdef AQC_TUNING
+#define SVD_DBG(a, bit) ((a).debug & (bit))
+#else
+#define SVD_DBG(a, bit) 0
+#endif
+
+__device__ __forceinline__ int block_col(int2 bp, int lc, int cols) {
+    const int blk = lc < kBlk ? bp.x : bp.y;
+    const int c = blk * kBlk + (lc & (kBlk - 1));
+    return (blk >= 0 && c < cols) ? c : -1;
+}
+
+// One outer round of one block pair.  `full`: the inner tournament covers all 120 pairs of the 16 columns (first outer
+// round of a sweep: this is where the pairs inside a block are met); otherwise only the 64 cross pairs (8 rounds), so
+// that a sweep visits every column pair exactly once.  The rotation count goes to *s_rot.
+__device__ void block_round(const BlockJacobi& a, int2 bp, bool full, cplx* sw, cplx* sq, int* s_rot) {
+    constexpr int kIt = kBlockMaxRows / 64, kVt = kBlockMaxRows / (16 * (kBlockThreads / 64));
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, rows = a.rows, cols = a.cols;
+    // LDS columns are padded to a multiple of 64 rows (zeros): the loops below run whole waves, without lane guards.
+    // Global loads use clamped (always valid) addresses and select afterwards, so that all of them are in flight at once.
+    const int nit = (rows + 63) >> 6, ldw = nit << 6;
+    {   // the two columns of this wave
+        cplx ld[2][kIt];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = SVD_DBG(a, 8) ? -1 : block_col(bp, 2 * w + h, cols);
+            const cplx* src = a.W + (size_t)(c >= 0 ? c : 0) * rows;
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                const int i = lane + 64 * it;
+                const cplx val = src[i < rows ? i : rows - 1];
+                ld[h][it] = (c >= 0 && i < rows) ? val : make_double2(0.0, 0.0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int it = 0; it < kIt; ++it)
+                if (it < nit) sw[(2 * w + h) * ldw + lane + 64 * it] = ld[h][it];
+    }
+    if (tid < kBlk2 * kBlk2) sq[tid] = make_double2((tid / kBlk2) == (tid % kBlk2) ? 1.0 : 0.0, 0.0);
+    // the V operands of the update at the end do not depend on the inner sweep: fetch them now, under its shadow.
+    // B[k][row] = V[col(k)][row]; lane l feeds B[l/16 (+4 kk)][l%16]; wave w owns the row tiles w, w + 8, ...
+    int ck[4];
+    cplx v[kVt][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ck[kk] = block_col(bp, 4 * kk + (lane >> 4), cols);
+#pragma unroll
+    for (int vt = 0; vt < kVt; ++vt) {
+        const int row = 16 * (w + (kBlockThreads / 64) * vt) + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const cplx val = a.V[(size_t)(ck[kk] >= 0 ? ck[kk] : 0) * cols + (row < cols ? row : cols - 1)];
+            v[vt][kk] = (ck[kk] >= 0 && row < cols && !SVD_DBG(a, 2)) ? val : make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    const int nrounds = SVD_DBG(a, 1) ? 0 : (full ? kBlk2 - 1 : kBlk);
+    // Cross rounds: wave w keeps column w of the first block (x) in registers for all 8 rounds -- only the partner
+    // column goes through LDS -- and tracks |x|^2 through the rotations' own update.
+    cplx x[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) x[it] = (!full && it < nit) ? sw[w * ldw + lane + 64 * it] : make_double2(0.0, 0.0);
+    for (int r = 0; r < nrounds; ++r) {
+        int p, q;
+        if (full) {   // circle method: player 15 stays, the others rotate
+            p = w == 0 ? kBlk2 - 1 : (r + w) % (kBlk2 - 1);
+            q = w == 0 ? r : (r + (kBlk2 - 1) - w) % (kBlk2 - 1);
+        } else {      // column w of the first block against column (w + r) mod 8 of the second
+            p = w;
+            q = kBlk + ((w + r) & (kBlk - 1));
+        }
+        if (block_col(bp, p, cols) >= 0 && block_col(bp, q, cols) >= 0) {
+            cplx* wp = sw + p * ldw + lane;
+            cplx* wq = sw + q * ldw + lane;
+            cplx y[kIt];
+            double sa = 0.0, sb = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                if (full && it < nit) x[it] = wp[64 * it];
+                y[it] = it < nit ? wq[64 * it] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                sa += x[it].x * x[it].x + x[it].y * x[it].y;
+                sb += y[it].x * y[it].x + y[it].y * y[it].y;
+                gr += x[it].x * y[it].x + x[it].y * y[it].y;      // conj(x) * y
+                gi += x[it].x * y[it].y - x[it].y * y[it].x;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64);
+                gr += __shfl_xor(gr, off, 64); gi += __shfl_xor(gi, off, 64);
+            }
+            const double g2 = gr * gr + gi * gi;
+            if (g2 > a.tol * a.tol * sa * sb && g2 != 0.0) {
+                if (lane == 0) atomicAdd(s_rot, 1);
+                const double inv_g = rsqrt(g2);
+                const double zeta = 0.5 * (sb - sa) * inv_g;
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = rsqrt(1.0 + t * t), s = c * t;
+                const double er = gr * inv_g, ei = -gi * inv_g;             // e^{-i phi}, phi = arg(gamma)
+#pragma unroll
+                for (int it = 0; it < kIt; ++it) {
+                    if (it < nit) {
+                        const cplx yy = make_double2(y[it].x * er - y[it].y * ei, y[it].x * ei + y[it].y * er);
+                        const cplx xn = make_double2(c * x[it].x - s * yy.x, c * x[it].y - s * yy.y);
+                        if (full) wp[64 * it] = xn;
+                        wq[64 * it] = make_double2(s * x[it].x + c * yy.x, s * x[it].y + c * yy.y);
+                        x[it] = xn;
+                    }
+                }
+                if (lane < kBlk2) {   // the same rotation on the columns of Q
+                    const cplx xx = sq[p * kBlk2 + lane], y0 = sq[q * kBlk2 + lane];
+                    const cplx yy = make_double2(y0.x * er - y0.y * ei, y0.x * ei + y0.y * er);
+                    sq[p * kBlk2 + lane] = make_double2(c * xx.x - s * yy.x, c * xx.y - s * yy.y);
+                    sq[q * kBlk2 + lane] = make_double2(s * xx.x + c * yy.x, s * xx.y + c * yy.y);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!full && nrounds > 0) {   // column w goes back to LDS for the store below
+#pragma unroll
+        for (int it = 0; it < kIt; ++it)
+            if (it < nit) sw[w * ldw + lane + 64 * it] = x[it];
+        __syncthreads();
+    }
+    if (!SVD_DBG(a, 8))
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = block_col(bp, 2 * w + h, cols);
+            if (c >= 0)
+                for (int i = lane; i < rows; i += 64) a.W[(size_t)c * rows + i] = sw[(2 * w + h) * ldw + i];
+        }
+    if ((*s_rot == 0 && !SVD_DBG(a, 16)) || SVD_DBG(a, 2)) return;   // Q = 1 (uniform: read after the barrier above)
+    // V[:, col(n)] <- sum_k V[:, col(k)] Q[k][n] on the matrix cores: D[n][row] = sum_k A[n][k] B[k][row] with
+    // A[n][k] = Q[k][n] = sq[n * 16 + k]; lane l feeds A[l%16][l/16] and owns D[4 j + l/16][l%16].  Complex by four
+    // real products.
+    double qr[4], qi[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const cplx qv = sq[(lane & 15) * kBlk2 + 4 * kk + (lane >> 4)];
+        qr[kk] = qv.x; qi[kk] = qv.y;
+    }
+#pragma unroll
+    for (int vt = 0; vt < kVt; ++vt) {
+        const int row0 = 16 * (w + (kBlockThreads / 64) * vt);
+        if (row0 >= cols) break;
+        const int row = row0 + (lane & 15);
+        double4_t dre = {0.0, 0.0, 0.0, 0.0}, dim = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            dre = __builtin_amdgcn_mfma_f64_16x16x4f64(qr[kk], v[vt][kk].x, dre, 0, 0, 0);
+            dre = __builtin_amdgcn_mfma_f64_16x16x4f64(-qi[kk], v[vt][kk].y, dre, 0, 0, 0);
+            dim = __builtin_amdgcn_mfma_f64_16x16x4f64(qi[kk], v[vt][kk].x, dim, 0, 0, 0);
+            dim = __builtin_amdgcn_mfma_f64_16x16x4f64(qr[kk], v[vt][kk].y, dim, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // D rows 4 j + l/16 are the columns ck[j]
+            if (ck[j] >= 0 && row < cols) a.V[(size_t)ck[j] * cols + row] = make_double2(dre[j], dim[j]);
+    }
+}
+
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* s_fail) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // release: this workgroup's W and V columns are visible device-wide (L2 written back) before the arrival counts
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > 4000000L) { *s_fail = 1; break; }   // bounded: seconds, a round takes microseconds
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave drops its stale lines of the other workgroups' columns
+    return *s_fail == 0;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void jacobi_block_kernel(const BlockJacobi a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* sw = reinterpret_cast<cplx*>(smem);       // [16][rows]
+    cplx* sq = sw + (size_t)kBlk2 * (((a.rows + 63) >> 6) << 6);   // [16][16], behind the padded columns
+    __shared__ int s_rot, s_fail;
+    if (threadIdx.x == 0) { s_rot = 0; s_fail = 0; }
+    __syncthreads();
+    unsigned epoch = 0;
+    int sweep = 0;
+    for (; sweep < a.max_sweeps; ++sweep) {
+        for (int r = 0; r < a.rounds; ++r) {
+            const int2 bp = a.bpairs[(size_t)r * a.per_round + blockIdx.x];
+            if (bp.x >= 0) block_round(a, bp, r == 0, sw, sq, &s_rot);
+            __syncthreads();
+            if (threadIdx.x == 0 && s_rot) { atomicAdd(a.rot + sweep, s_rot); s_rot = 0; }
+            ++epoch;
+            if (!SVD_DBG(a, 4) && !grid_barrier(a.bar, epoch * gridDim.x, &s_fail)) {
+                if (threadIdx.x == 0) a.status[1] = 1;
+                return;
+            }
+        }
+        const int any = __hip_atomic_load(a.rot + sweep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // the same on every workgroup
+        if (SVD_DBG(a, 16)) { if (sweep == 9) { ++sweep; break; } continue; }
+        if (any == 0) { ++sweep; break; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.status[0] = sweep;
+}
+
+bool svd_fits_block(int rows, int cols) { return rows <= kBlockMaxRows && cols <= rows && cols >= 2; }
+int svd_block_size() { return kBlk; }
+hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void* bpairs, int rounds, int per_round, double tol, int max_sweeps,
+                               int* rot, unsigned* bar, int* status, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(cplx) * (kBlk2 * kBlockMaxRows + kBlk2 * kBlk2)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (max_sweeps > kBlockMaxSweeps) max_sweeps = kBlockMaxSweeps;
+    BlockJacobi a{static_cast<cplx*>(W), static_cast<cplx*>(V), static_cast<const int2*>(bpairs), rows, cols, rounds, per_round, max_sweeps, tol, rot, bar, status, 0};
+#ifdef AQC_TUNING
+    if (const char* e = getenv("AQC_SVD_DEBUG")) a.debug = atoi(e);
+#endif
+    void* args[] = {&a};
+    const size_t lds = sizeof(cplx) * ((size_t)kBlk2 * (((rows + 63) >> 6) << 6) + kBlk2 * kBlk2);
+    // cooperative: the runtime refuses the launch unless all workgroups are resident together (the barrier needs that)
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(jacobi_block_kernel), dim3(per_round), dim3(kBlockThreads), args, (unsigned)lds, s);
 }
 
 // Generic entry (aqc_svd): A row-major (m x n) -> Jacobi work matrix, and (W, V, order, sigma) -> U (m x k), Vh (k x n).

@@ -8,6 +8,7 @@ reference that runs inside qiskit-aer's ``matrix_product_state`` simulator (``mp
 circuit applications of ``mps_operations.py:326-371``.  With ``trunc_thr -> 0`` everything is exact (tested
 against the dense oracle); Aer's truncation arithmetic itself is third party and parity unpinned.
 """
+import ctypes
 from ctypes import POINTER, byref, c_int, c_int32, c_void_p
 from typing import Optional, Tuple
 
@@ -173,7 +174,40 @@ def _blocks_of(circ):
     return trotter, [(i, i % L, int(circ.blocks[0, i % L]), int(circ.blocks[1, i % L])) for i in range(L + tail)]
 
 
+class _CircuitDesc(ctypes.Structure):
+    """``aqc_circuit`` of include/aqc_hip.h."""
+
+    _fields_ = [("num_qubits", c_int32), ("entangler", c_int32), ("num_blocks", c_int32), ("trotter", c_int32),
+                ("second_order", c_int32), ("blocks", POINTER(c_int32))]
+
+
+def _describe(circ):
+    """(aqc_circuit, keep-alive array) of a ParametricCircuit / TrotterAnsatz."""
+    blocks = np.ascontiguousarray(circ.blocks, dtype=np.int32)
+    trotter = hasattr(circ, "is_second_order")
+    desc = _CircuitDesc(circ.num_qubits, _lib.ENTANGLERS[circ.entangler], circ.num_blocks, int(trotter),
+                        int(trotter and circ.is_second_order), blocks.ctypes.data_as(POINTER(c_int32)))
+    return desc, blocks
+
+
+def _thetas(circ, thetas) -> np.ndarray:
+    th = np.ascontiguousarray(thetas, dtype=np.float64)
+    if th.shape != (circ.num_thetas,):
+        raise ValueError(f"expected {circ.num_thetas} thetas, got an array of shape {th.shape}")
+    return th
+
+
 def _apply_circuit(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: float, max_bond: int) -> DeviceMPS:
+    """The whole ansatz in ONE ABI call (``aqc_mps_apply_circuit``)."""
+    desc, keep = _describe(circ)
+    th = _thetas(circ, thetas)
+    check(_lib.lib().aqc_mps_apply_circuit(mps.handle, byref(desc), dptr(th), int(inverse), float(trunc_thr), int(max_bond)))
+    del keep
+    return mps
+
+
+def _apply_circuit_gatewise(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: float, max_bond: int) -> DeviceMPS:
+    """The same walk with one ABI call per gate -- the cross-check of the C-side loop used by the tests."""
     n = circ.num_qubits
     th = np.asarray(thetas, dtype=np.float64)
     t1 = th[: 3 * n].reshape(n, 3)
@@ -222,7 +256,25 @@ def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, t
                           block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> np.ndarray:
     """Complex gradient of <V lvec|phi> given vh_phi = V^H|phi>, gate by gate on two MPS
     (mps_dot_objective.py:41-242): w <- lvec, z <- vh_phi; every gate is applied to both and each parametrised
-    rotation records 0.5j <P w|z>; the CPhase derivative is -1j <P11 w|z> taken before the gate."""
+    rotation records 0.5j <P w|z>; the CPhase derivative is -1j <P11 w|z> taken before the gate.
+    ONE ABI call (``aqc_mps_fast_dot_gradient``): the walk, the cached environments behind the inner products and the
+    single download of all of them live on the C side."""
+    desc, keep = _describe(circ)
+    th = _thetas(circ, thetas)
+    lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+    if block_range is not None and not 0 <= lo <= hi <= circ.num_blocks:
+        raise ValueError("invalid block range")
+    grad = np.zeros(circ.num_thetas, dtype=np.complex128)
+    check(_lib.lib().aqc_mps_fast_dot_gradient(byref(desc), lvec.handle, vh_phi.handle, dptr(th), float(trunc_thr), int(max_bond),
+                                               lo, hi, int(bool(front_layer)), dptr(grad)))
+    del keep
+    return grad
+
+
+def fast_dot_gradient_mps_gatewise(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, trunc_thr: float = 0.0, max_bond: int = 0,
+                                   block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> np.ndarray:
+    """The same sweep with one ABI call per gate and one full transfer-matrix chain per inner product -- the
+    cross-check of the C-side walk used by the tests."""
     n = circ.num_qubits
     th = np.asarray(thetas, dtype=np.float64)
     tpb = 5 if circ.entangler == "cp" else 4

@@ -188,6 +188,21 @@ int aqc_mps_dot(aqc_mps* a, aqc_mps* b, double* out /* 1 c128 */);
 /* <(prod_i G_i on qubits[i]) a|b> without forming G.a: dot_{x,y,z} (mps_dot_objective.py:471-516) up to the factor
  * 0.5j with one Pauli; two projectors |1><1| give the CPhase derivative term.  gates: nops 2x2 matrices (4 c128 each) */
 int aqc_mps_dot_ops(aqc_mps* a, aqc_mps* b, int nops, const int32_t* qubits, const double* gates, double* out);
+/* ansatz description for the MPS entry points (ParametricCircuit / TrotterAnsatz, parametric_circuit.py:24-70,267-333);
+ * unlike aqc_ctx it is not limited to dense-reachable registers.  blocks: int32[2][num_blocks], row 0 = control */
+typedef struct aqc_circuit {
+    int32_t num_qubits, entangler /* AQC_CX / AQC_CZ / AQC_CP */, num_blocks, trotter, second_order;
+    const int32_t* blocks;
+} aqc_circuit;
+/* v_mul_mps / v_dagger_mul_mps(circ, thetas, mps, trunc_thr) (mps_operations.py:326-371): the whole ansatz (inverse = 1:
+ * its conjugate transpose) applied in place, one call instead of one per gate */
+int aqc_mps_apply_circuit(aqc_mps* mps, const aqc_circuit* circ, const double* thetas, int inverse, double trunc_thr, int max_bond);
+/* fast_dot_gradient(circ, thetas, lvec, vh_phi, trunc_thr, block_range, front_layer) (mps_dot_objective.py:41-242):
+ * complex gradient (c128[num_thetas]) of <V lvec|phi> from vh_phi = V^H|phi>.  One call walks all gates on device copies
+ * of both operands; the ~num_thetas inner products 0.5j<P w|z> reuse cached left / right environments of the pair and
+ * come back in a single transfer.  block_from < 0: all blocks.  lvec and vh_phi are left intact. */
+int aqc_mps_fast_dot_gradient(const aqc_circuit* circ, const aqc_mps* lvec, const aqc_mps* vh_phi, const double* thetas,
+                              double trunc_thr, int max_bond, int block_from, int block_to, int front_layer, double* grad);
 /* one-sided Jacobi SVD on the device (the kernel behind aqc_mps_gate2): A (m x n row-major) = U diag(S) Vh,
  * k = min(m, n), S descending, U (m x k), Vh (k x n); *sweeps (optional) = Jacobi sweeps used */
 int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, double* vh, int* sweeps);

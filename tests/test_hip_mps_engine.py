@@ -10,8 +10,11 @@ from tests.helpers import TOL, maxdiff
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 3), (3, 7), (16, 16), (40, 64), (64, 40), (128, 128)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 3), (3, 7), (16, 16), (40, 64), (64, 40), (128, 128), (200, 72), (66, 300), (512, 512),
+                                   (100, 513)])
 def test_jacobi_svd(shape):
+    """1..64: one workgroup in LDS; up to 512 rows: the persistent two-level kernel (also 72 = 9 blocks, an odd
+    tournament, and 66 = a ragged last block); beyond: one launch per round."""
     from aqc_research_amd.mps_engine import svd
 
     rng = np.random.default_rng(sum(shape))
@@ -21,12 +24,25 @@ def test_jacobi_svd(shape):
         a[:, 9] = 0
     u, s, vh, sweeps = svd(a)
     k = min(shape)
-    assert sweeps < 40 and np.all(np.diff(s) <= 1e-13)
+    assert (sweeps > 0 or k == 1) and sweeps < 40 and np.all(np.diff(s) <= 1e-13)
     assert maxdiff(s, np.linalg.svd(a, compute_uv=False)) < 1e-11 * max(1.0, s[0])
     assert maxdiff((u * s) @ vh, a) < 1e-11 * max(1.0, s[0])
     good = s > 1e-12 * s[0]
     assert maxdiff(u[:, good].conj().T @ u[:, good], np.eye(int(good.sum()))) < 1e-11
     assert maxdiff(vh[good] @ vh[good].conj().T, np.eye(int(good.sum()))) < 1e-11
+
+
+def test_blocked_jacobi_agrees_with_round_per_launch(monkeypatch):
+    """The persistent two-level kernel and the plain one-launch-per-round tournament give the same decomposition."""
+    from aqc_research_amd.mps_engine import svd
+
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((160, 96)) + 1j * rng.standard_normal((160, 96))
+    u1, s1, vh1, _ = svd(a)
+    monkeypatch.setenv("AQC_SVD_BLOCKED", "0")
+    u0, s0, vh0, _ = svd(a)
+    assert maxdiff(s0, s1) < 1e-12 * s0[0]
+    assert maxdiff((u0 * s0) @ vh0, (u1 * s1) @ vh1) < 1e-11 * s0[0]
 
 
 def _dense(mps):
@@ -69,6 +85,7 @@ def test_gates_exact_against_dense():
 @pytest.mark.parametrize("kind", ["cx", "cz", "cp", "trotter2"])
 def test_native_gradient_and_circuit_against_oracle(kind):
     from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+    from aqc_research_amd import mps_engine as eng
     from aqc_research_amd.mps_engine import DeviceMPS, fast_dot_gradient_mps, v_dagger_mul_mps, v_mul_mps
 
     n = 6
@@ -93,6 +110,10 @@ def test_native_gradient_and_circuit_against_oracle(kind):
     br = (2, min(7, a.num_blocks))
     gp = fast_dot_gradient_mps(circ, th, xm, vhy, block_range=br, front_layer=False)
     assert maxdiff(gp, orc.grad_of_dot_product(a, th, x, vhy_ref, br, False)) < 100 * TOL
+    # the C-side walk (one ABI call, cached environments) against the gate-per-call walk with full chains
+    assert maxdiff(g, eng.fast_dot_gradient_mps_gatewise(circ, th, xm, vhy)) < TOL
+    assert maxdiff(gp, eng.fast_dot_gradient_mps_gatewise(circ, th, xm, vhy, block_range=br, front_layer=False)) < TOL
+    assert maxdiff(_dense(vhy), _dense(eng._apply_circuit_gatewise(circ, th, ym.clone(), True, 0.0, 0))) < TOL
 
 
 def test_truncation_contract_and_large_register():

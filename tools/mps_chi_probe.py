@@ -38,8 +38,9 @@ raw = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
 phi = canonical_mps(raw / np.linalg.norm(raw), chi)
 dense = orc.mps_to_vector(phi)
 print("canonical MPS bonds", max(l.size for l in phi[1]), "norm", np.linalg.norm(dense), flush=True)
-t0 = time.perf_counter()
 m = eng.DeviceMPS.from_qiskit(phi)
+vh = eng.v_dagger_mul_mps(circ, th, m, trunc_thr=1e-16)   # warm-up (module load, buffer growth)
+t0 = time.perf_counter()
 vh = eng.v_dagger_mul_mps(circ, th, m, trunc_thr=1e-16)
 t1 = time.perf_counter()
 ref = cref.v_dagger_mul_vec(circ, th, dense)
@@ -47,9 +48,14 @@ from aqc_research_amd.mps_operations import mps_to_vector
 got = mps_to_vector(vh.to_qiskit())
 print(f"chi={chi} L={L}: V^H on the engine {t1 - t0:.2f} s, bonds {vh.bond_dims.max()}, max |diff| vs dense {np.abs(got - ref).max():.2e}", flush=True)
 zero = eng.DeviceMPS.basis_state(n, 0)
+g = eng.fast_dot_gradient_mps(circ, th, zero, vh, trunc_thr=1e-16)
 t0 = time.perf_counter()
 g = eng.fast_dot_gradient_mps(circ, th, zero, vh, trunc_thr=1e-16)
 t1 = time.perf_counter()
+if os.environ.get("AQC_PROBE_GATEWISE"):
+    t2 = time.perf_counter()
+    g2 = eng.fast_dot_gradient_mps_gatewise(circ, th, zero, vh, trunc_thr=1e-16)
+    print(f"   gate-per-call walk {time.perf_counter() - t2:.2f} s, max |diff| {np.abs(g - g2).max():.2e}")
 x = np.zeros(1 << n, complex); x[0] = 1
 gref = cref.grad_of_dot_product(circ, th, x, ref)
 print(f"   gradient {t1 - t0:.2f} s, max |diff| {np.abs(g - gref).max():.2e}", flush=True)

@@ -288,6 +288,8 @@ struct aqc_ws {
     size_t pin_thetas = 0, pin_grads = 0, pin_small = 0;
     double2* d_partial = nullptr;
     double2* d_grads = nullptr;
+    double* mirror_grads = nullptr;    // set by aqc_ws_eval around its launches: pinned host copies written by the kernels
+    double* mirror_small = nullptr;
     double2* d_small = nullptr;  // gather / vdot results
     double2* d_vdot_part = nullptr;
     double2* d_vdot_out = nullptr;
@@ -477,6 +479,7 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
             a.out0 = ws->bufs[dst_buf];
             a.lane_stride = ws->lane_elems;
             a.ntiles = p.ntiles;
+            a.batch = ws->batch;
             ProfScope ps(ws, AQC_K_APPLY);
             HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
         }
@@ -879,6 +882,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
             a.lane_stride = ws->lane_elems;
             a.rpart = p.d_rpart;
             a.ntiles = p.ntiles;
+            a.batch = ws->batch;
             a.store_out = s + 1 < p.h_stages.size() ? 1 : 0;
 #ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the sweep workgroups of this launch, on stderr
             static unsigned long long* d_stamps = nullptr;
@@ -900,23 +904,29 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                 HIP_OK(hipStreamSynchronize(ws->stream));
                 HIP_OK(hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
                 const int ns = p.h_stages[s].nsubs;
-                double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0;
+                // the 2^12 sweep is persistent: a workgroup's per-sub-stage stamps are those of its LAST item, slot S-4 its end,
+                // slots S-6 / S-5 bracket its last hand-over to a prefetched tile
+                double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0, turn = 0;
+                size_t live = 0;
                 for (size_t w = 0; w < nwg; ++w) {
                     const unsigned long long* t = h.data() + w * kStampSlots;
+                    if (t[kStampSlots - 4] == 0) continue;   // no workgroup with this index (persistent grid)
+                    ++live;
                     load += (double)(t[1] - t[0]);
                     store += (double)(t[kStampSlots - 1] - t[kStampSlots - 2]);
-                    total += (double)(t[kStampSlots - 1] - t[0]);
-                    for (int i = 0; i < ns && 5 + 4 * i < kStampSlots - 2; ++i) {
-                        top += (double)(t[2 + 4 * i] - (i ? t[5 + 4 * (i - 1)] : t[1]));
+                    total += (double)(t[kStampSlots - 4] - t[0]);
+                    if (t[kStampSlots - 5]) turn += (double)(t[kStampSlots - 5] - t[kStampSlots - 6]);
+                    for (int i = 0; i < ns && 5 + 4 * i < kStampSlots - 6; ++i) {
+                        if (i) top += (double)(t[2 + 4 * i] - t[5 + 4 * (i - 1)]);
                         mf += (double)(t[3 + 4 * i] - t[2 + 4 * i]);
                         bar += (double)(t[4 + 4 * i] - t[3 + 4 * i]);
                         red += (double)(t[5 + 4 * i] - t[4 + 4 * i]);
                     }
                 }
-                const double n = (double)nwg;
-                fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups): total %.0f cycles = load %.0f + per sub-stage "
-                        "[top barrier %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f\n", s, ns, nwg, total / n, load / n,
-                        top / n / ns, mf / n / ns, bar / n / ns, red / n / ns, store / n);
+                const double n = (double)std::max<size_t>(live, 1), items = (double)nwg / n;
+                fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups x %.1f items): total %.0f cycles per item = first load %.0f/items + "
+                        "per sub-stage [top %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f + hand-over %.0f\n", s, ns, live, items,
+                        total / n / items, load / n, top / n / std::max(ns - 1, 1), mf / n / ns, bar / n / ns, red / n / ns, store / n, turn / n);
             }
 #endif
         }
@@ -924,7 +934,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
         HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
                             ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
         HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
-                               1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
+                               1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
         return 0;
     }
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
@@ -956,7 +966,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
     }
     ProfScope ps(ws, AQC_K_FINALIZE);
     HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
-                           p.ntiles, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
+                           p.ntiles, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
     return 0;
 }
 
@@ -982,6 +992,14 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     }
     if (!thetas && (do_vdag || grads) && ensure_coef(ws)) return 1;
     if (check_buf(ws, x_buf)) return 1;
+    // Small results skip the device-to-host copy nodes: the producing kernels write a second copy straight into the pinned
+    // staging buffer (two nodes and their dependencies less on the single-evaluation critical path).
+    const bool zero_copy = sizeof(double2) * (nth + nsm) <= 65536;
+    struct MirrorScope {
+        aqc_ws* w;
+        MirrorScope(aqc_ws* w_, double* g, double* s) : w(w_) { w->mirror_grads = g; w->mirror_small = s; }
+        ~MirrorScope() { w->mirror_grads = nullptr; w->mirror_small = nullptr; }
+    } mirror_scope(ws, zero_copy ? pin_gr : nullptr, zero_copy ? pin_sm : nullptr);
     auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
         if (thetas) {
             ws->d_thetas = ws->d_thetas_own;
@@ -991,11 +1009,11 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
         if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
         if (gathered) {
             if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
-            HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
+            if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
         }
         if (grads) {
             if (aqc_ws_grad_from(ws, x_buf, block_from, block_to, front_layer)) return 1;
-            HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+            if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
         }
         return 0;
     };
@@ -1282,7 +1300,7 @@ int aqc_ws_gather_launch(aqc_ws* ws, int buf) {
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
     HIP_OK(hipSetDevice(ws->device));
     ProfScope ps(ws, AQC_K_MISC);
-    HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream));
+    HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream, ws->mirror_small));
     return 0;
 }
 

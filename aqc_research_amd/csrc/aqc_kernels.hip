@@ -371,8 +371,10 @@ __global__ void sign_kernel(double* coef, int n, int nblocks, int tail) {
 }
 
 // grads[b][t] = sum over the (<=2) slots feeding theta t, over tiles, in a fixed order.
+// `mirror` (may be null): a second copy of the result written straight into pinned host memory -- the one-call
+// evaluation path uses it instead of a device-to-host copy node for small batches.
 __global__ void finalize_kernel(const cplx* partial, const int* theta_slots, const int* slot_ntiles, cplx* grads,
-                                int T, int nslots, int ntiles_max, int n, int tpb, int from, int to, int front) {
+                                int T, int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, cplx* mirror) {
     const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const bool on = t < 3 * n ? (front != 0) : ((t - 3 * n) / tpb >= from && (t - 3 * n) / tpb < to);
     double re = 0.0, im = 0.0;
@@ -387,7 +389,10 @@ __global__ void finalize_kernel(const cplx* partial, const int* theta_slots, con
     }
     re = wave_sum(re);
     im = wave_sum(im);
-    if (lane == 0) grads[(size_t)b * T + t] = make_double2(re, im);
+    if (lane == 0) {
+        grads[(size_t)b * T + t] = make_double2(re, im);
+        if (mirror) mirror[(size_t)b * T + t] = make_double2(re, im);
+    }
 }
 
 __global__ void scatter_one_kernel(cplx* buf, size_t lane_stride, int batch, const long long* elem) {
@@ -403,11 +408,14 @@ __global__ void set_identity_kernel(cplx* buf, size_t lane_stride, int dim, int 
     }
 }
 
-__global__ void gather_kernel(const cplx* buf, size_t lane_stride, const long long* elem, int count, int batch, cplx* out) {
+__global__ void gather_kernel(const cplx* buf, size_t lane_stride, const long long* elem, int count, int batch, cplx* out,
+                              cplx* mirror) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < batch * count) {
         const int b = idx / count, i = idx % count;
-        out[idx] = buf[(size_t)b * lane_stride + (size_t)elem[i]];
+        const cplx v = buf[(size_t)b * lane_stride + (size_t)elem[i]];
+        out[idx] = v;
+        if (mirror) mirror[idx] = v;   // pinned host copy (see finalize_kernel)
     }
 }
 
@@ -498,9 +506,10 @@ hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, i
 
 hipError_t launch_finalize(const void* partial, const int* theta_slots, const int* slot_ntiles, void* grads, int T,
                            int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, int batch,
-                           hipStream_t s) {
+                           hipStream_t s, void* mirror) {
     finalize_kernel<<<dim3(T, batch), 64, 0, s>>>(static_cast<const cplx*>(partial), theta_slots, slot_ntiles,
-                                                   static_cast<cplx*>(grads), T, nslots, ntiles_max, n, tpb, from, to, front);
+                                                   static_cast<cplx*>(grads), T, nslots, ntiles_max, n, tpb, from, to, front,
+                                                   static_cast<cplx*>(mirror));
     return hipGetLastError();
 }
 
@@ -516,10 +525,10 @@ hipError_t launch_set_identity(void* buf, size_t lane_stride, int dim, int pitch
 }
 
 hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* elem, int count, int batch, void* out,
-                         hipStream_t s) {
+                         hipStream_t s, void* mirror) {
     const int total = batch * count;
     gather_kernel<<<(total + 127) / 128, 128, 0, s>>>(static_cast<const cplx*>(buf), lane_stride, elem, count, batch,
-                                                      static_cast<cplx*>(out));
+                                                      static_cast<cplx*>(out), static_cast<cplx*>(mirror));
     return hipGetLastError();
 }
 

@@ -177,9 +177,8 @@ __device__ __forceinline__ void store_tile3(const cplx* tile, cplx* dst, const D
         dst[lo + st.dhi[wave + i * NW]] = tile[slot];
     }
 }
-__device__ __forceinline__ size_t tile_base3(const DevStage& st) {
+__device__ __forceinline__ size_t tile_base3(const DevStage& st, unsigned tile) {
     size_t base = 0;
-    const unsigned tile = blockIdx.x;
     for (int i = 0; i < st.nub; ++i) base |= (size_t)((tile >> i) & 1u) << st.ubits[i];
     return base;
 }
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     if (lds_base & ((16u << K) - 1)) __builtin_trap();   // XOR addressing needs the tile aligned to its own size
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tile_base3(st);
+    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tile_base3(st, blockIdx.x);
     const double* umat = a.umat + (size_t)blockIdx.y * a.nsubs_total * 12 * 64;
     const unsigned lo = st.dlo[lane];
     SubRegs cur, nxt;
@@ -273,21 +272,59 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     unsigned* done = reinterpret_cast<unsigned*>(scratch + kSlots * 256);   // kFlag only (sweep3_lds_bytes)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tile_base3(st);
-    const double* umat = a.umat + (size_t)blockIdx.y * a.nsubs_total * 12 * 64;
-    cplx* rpart = a.rpart + (((size_t)blockIdx.y * a.nsubs_total + st.sub_begin) * a.ntiles + blockIdx.x) * 256;
+    // Work items = (tile, lane of the batch), item wi on workgroup wi mod gridDim.x.  2^12 tiles leave room for ONE
+    // workgroup per CU, so nothing else would hide its HBM traffic: there the grid is one workgroup per CU, each walks
+    // over its items and fetches the NEXT item's w and z tiles into registers (2 x 16 x 16 B per lane, in four chunks
+    // behind the operand fetch of sub-stages 0..3) while the current one computes; the stores of a finished tile drain
+    // under the next one as well.  Smaller tiles run two workgroups per CU, which overlap by themselves (grid = items).
+    constexpr bool kPersist = K >= 12;
+    constexpr int NL = TS::kLoads, NW = TS::kWaves;
+    const int nwork = a.ntiles * a.batch;
     const unsigned lo = st.dlo[lane];
     SubRegs cur, nxt;
+    // The prefetched tiles live in ACCUMULATION registers (the sub-stage pipeline fills all 256 architectural VGPRs; left
+    // to itself the allocator spills a prefetch array to scratch memory): global_load with an AGPR destination, LDS write
+    // with an AGPR source, both as inline assembly; the compiler does not track these loads, so the wait before the LDS
+    // writes is explicit.
+    dbl2_t pw[NL], pz[NL];
+    unsigned done_base = 0;
     AQC_STAMP(0);
     if (kFlag && threadIdx.x == 0) *done = 0;
-    if (st.nsubs > 0) fetch_sub<TS::kGpw>(cur, a.subs, umat, st.sub_begin, lane, wave, TS::kWaves);
-    load_tiles3<K, 2>(tw, tz, a.in0 + lane_off, a.in1 + lane_off, st, lo, wave);
+    int wi = blockIdx.x;
+    {
+        const size_t off0 = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
+        if (st.nsubs > 0) fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)(wi / a.ntiles) * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+        load_tiles3<K, 2>(tw, tz, a.in0 + off0, a.in1 + off0, st, lo, wave);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see apply_mfma_kernel
     __syncthreads();
     AQC_STAMP(1);
+    for (;;) {
+    const int bl = wi / a.ntiles, tile = wi - bl * a.ntiles;
+    const size_t lane_off = (size_t)bl * a.lane_stride + tile_base3(st, tile);
+    const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
+    cplx* rpart = a.rpart + (((size_t)bl * a.nsubs_total + st.sub_begin) * a.ntiles + tile) * 256;
+    const int nwi = wi + (int)gridDim.x;
+    const bool more = kPersist && nwi < nwork;
+    const int nbl = more ? nwi / a.ntiles : 0;
+    const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
     for (int si = 0; si < st.nsubs; ++si) {
         AQC_STAMP(2 + 4 * si);
-        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, TS::kWaves);
+        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
+        else if (more) fetch_sub<TS::kGpw>(nxt, a.subs, a.umat + (size_t)nbl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+        if (kPersist && more) {   // a quarter of the next item's tiles, issued BEHIND the operand fetch (loads retire in order)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (si == (c < st.nsubs ? c : st.nsubs - 1)) {
+#pragma unroll
+                    for (int i = c * (NL / 4); i < (c + 1) * (NL / 4); ++i) {
+                        const size_t off = next_off + lo + st.dhi[wave + i * NW];
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(pw[i]) : "v"(a.in0 + off) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(pz[i]) : "v"(a.in1 + off) : "memory");
+                    }
+                }
+            }
+        }
         double4_t t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
         // Software pipeline over the wave's groups, written as CLUSTERS that the compiler may not interleave
         // (sched_barrier): on gfx950 an fp64 MFMA and vector-ALU instructions of the same SIMD do not overlap, and every
@@ -354,7 +391,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         }
         AQC_STAMP(3 + 4 * si);
         if (kFlag && si > 0) {   // the previous sub-stage's scratch has been read by everyone (bounded wait, see above)
-            const unsigned want = (unsigned)(si * kSlots);
+            const unsigned want = done_base + (unsigned)(si * kSlots);
             for (int spin = 0; spin < 4096 && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)
                 __builtin_amdgcn_s_sleep(1);
         }
@@ -389,7 +426,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         if (kFlag) { if (lane == 0 && wave < kSlots) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         else __syncthreads();
         AQC_STAMP(5 + 4 * si);
-        if (si + 1 < st.nsubs) cur = nxt;
+        if (si + 1 < st.nsubs || more) cur = nxt;
     }
     AQC_STAMP(kStampSlots - 2);
     if (a.store_out) {   // the last stage's w and z are never read again (only the gradient entries are results)
@@ -397,6 +434,23 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         store_tile3<K, true>(tz, a.out1 + lane_off, st, lo, wave);
     }
     AQC_STAMP(kStampSlots - 1);
+    if (!more) break;
+    AQC_STAMP(kStampSlots - 6);
+    __syncthreads();   // every wave has finished with the LDS tiles (sub-stage reads, scratch, the stores' LDS reads)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the prefetched tiles have arrived
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const unsigned slot = swz3((unsigned)((wave + i * NW) << 6) | (threadIdx.x & 63u));
+        asm volatile("ds_write_b128 %0, %1" : : "v"(lds_base + (slot << 4)), "a"(pw[i]) : "memory");
+        asm volatile("ds_write_b128 %0, %1" : : "v"(lds_base + ((slot + tsize) << 4)), "a"(pz[i]) : "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes above are not tracked by the compiler either
+    __syncthreads();
+    AQC_STAMP(kStampSlots - 5);
+    wi = nwi;
+    done_base += (unsigned)(st.nsubs * kSlots);
+    }
+    AQC_STAMP(kStampSlots - 4);
 }
 
 // ---- small kernels: U of every sub-stage, gradient entries from R -----------------------------------------
@@ -581,29 +635,46 @@ __device__ __forceinline__ cplx rho_dot(const cplx (&rho)[16], int kind) {
 // and the whole group is peeled off R at once, R <- B^H R B (two LDS round trips per group -- this chain is the serial
 // part).  Afterwards one lane per group walks its rho_g through the group's rotations (value right after each
 // rotation, core_operations.py:921-935) and stores the slots.  One wave per (sub-stage, lane).
-__global__ __launch_bounds__(64) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
-                                                  const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
-                                                  int from, int to, int front) {
+// WAVES = 4 (many tiles per lane of the batch, i.e. few lanes: the single-evaluation regime): three helper waves share
+// the sum over the tiles -- the dependent-load chain that otherwise dominates this kernel -- and retire; wave 0 adds the
+// four partial sums in a fixed order and walks the groups alone.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
+                                                           const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
+                                                           int from, int to, int front) {
     __shared__ cplx R[16 * 17];    // R[j * 17 + i] = sum_c z_c[j] conj(w_c[i]); rows padded: column walks hit 16 different banks
     __shared__ Gm gm[kGrpChunk];
     __shared__ cplx rho_s[kGrpChunk][16];
-    const int lane = threadIdx.x, si = blockIdx.x, b = blockIdx.y;
+    __shared__ cplx psum[WAVES > 1 ? WAVES - 1 : 1][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, si = blockIdx.x, b = blockIdx.y;
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
     const cplx* rp = rpart + ((size_t)b * nsubs_total + si) * ntiles * 256;
-    {   // fixed-order sum over the tiles, 8 tiles (32 loads per lane) in flight at a time
+    {   // fixed-order sum over the tiles (wave w: tiles w, w + WAVES, ...), 8 tiles (32 loads per lane) in flight at a time
         cplx acc[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
-        for (int t0 = 0; t0 < ntiles; t0 += 8) {
+        for (int t0 = wave; t0 < ntiles; t0 += 8 * WAVES) {
             cplx v[8][4];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    v[u][r] = t0 + u < ntiles ? rp[(size_t)(t0 + u) * 256 + 64 * r + lane] : make_double2(0.0, 0.0);
+                    v[u][r] = t0 + u * WAVES < ntiles ? rp[(size_t)(t0 + u * WAVES) * 256 + 64 * r + lane] : make_double2(0.0, 0.0);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc[r].x += v[u][r].x; acc[r].y += v[u][r].y; }
+        }
+        if (WAVES > 1) {
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) psum[wave - 1][64 * r + lane] = acc[r];
+            }
+            __syncthreads();
+            if (wave > 0) return;   // s_barrier only waits for the surviving waves of a workgroup
+#pragma unroll
+            for (int w = 0; w < WAVES - 1; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const cplx p = psum[w][64 * r + lane]; acc[r].x += p.x; acc[r].y += p.y; }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // MFMA D layout: entry 64 r + l is R[4 r + l / 16][l % 16]
@@ -719,8 +790,23 @@ hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stag
     }
     return hipGetLastError();
 }
+// workgroups of the persistent 2^12 sweep: one per CU of the current device (the occupancy its 144 KiB of LDS allows)
+static long persistent_sweep_grid() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    if (const char* e = getenv("AQC_SWEEP_GRID")) { const long v = atol(e); if (v > 0) return v; }   // experiments
+    return cus[dev];
+}
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
-    const dim3 grid(ntiles, batch);
+    if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
+    // 2^12 tiles: one persistent workgroup per CU walking over its items (see the kernel); smaller tiles: one item each
+    const long nwork = (long)ntiles * batch;
+    const dim3 grid((unsigned)(k >= 12 ? std::min<long>(nwork, persistent_sweep_grid()) : nwork));
     const int t = mfma_threads(k, true);
     const size_t l = sweep3_lds_bytes(k);
     switch (k) {
@@ -741,8 +827,12 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s) {
     if (nsubs_total < 1) return hipSuccess;
-    rgrad_kernel<<<dim3(nsubs_total, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
-                                                          nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front);
+    if (ntiles >= 32)
+        rgrad_kernel<4><<<dim3(nsubs_total, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front);
+    else
+        rgrad_kernel<1><<<dim3(nsubs_total, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+                                                                 nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front);
     return hipGetLastError();
 }
 

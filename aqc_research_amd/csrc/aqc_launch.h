@@ -37,11 +37,11 @@ hipError_t launch_sweep(int ent, int ntiles, int batch, int threads, int k, hipS
 hipError_t launch_coef(const double* thetas, double* coef, int n, int nblocks, int tpb, int tail, int batch, hipStream_t s);
 hipError_t launch_finalize(const void* partial, const int* theta_slots, const int* slot_ntiles, void* grads, int T,
                            int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, int batch,
-                           hipStream_t s);
+                           hipStream_t s, void* mirror = nullptr);   // mirror: optional pinned host copy of the result
 hipError_t launch_scatter_one(void* buf, size_t lane_stride, int batch, const long long* elem, hipStream_t s);
 hipError_t launch_set_identity(void* buf, size_t lane_stride, int dim, int pitch, int batch, hipStream_t s);
 hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* elem, int count, int batch, void* out,
-                         hipStream_t s);
+                         hipStream_t s, void* mirror = nullptr);
 hipError_t launch_vdot(const void* a, const void* b, size_t lane_stride, size_t count, int batch, void* part, int nparts,
                        void* out, hipStream_t s);
 
@@ -64,6 +64,7 @@ struct Stage3Args {
     size_t lane_stride;
     double2* rpart;          // sweep: [batch][nsubs_total][ntiles][256] per-tile R = Z W^H of every sub-stage
     int ntiles;
+    int batch;               // lanes of the batch (sweep: work items = ntiles x batch)
     int store_out;           // sweep: 0 for the last stage (its w and z are never read again)
     int debug;               // tuning builds: work-skipping bits for timing experiments (1 LDS writes, 2 LDS reads, 4 R MFMAs, 8 U MFMAs)
     unsigned long long* stamps;   // tuning builds (-DAQC_TUNING): [workgroup][kStampSlots] s_memtime stamps of wave 0, else null

@@ -300,6 +300,8 @@ struct aqc_ws {
     long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
     size_t small_cap = 0, index_cap = 0;
     int* d_theta_slots = nullptr;
+    int* d_slot_theta = nullptr;       // slot -> theta when every theta has exactly one slot (grads_direct), see rgrad_kernel
+    bool grads_direct = false;
     int* d_slot_ntiles = nullptr;
     int nslots = 0, vdot_parts = 0;
     bool coef_valid = false;
@@ -320,6 +322,8 @@ struct aqc_ws {
     double2* d_mps_scratch = nullptr;
     size_t mps_scratch_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    const double* theta_host = nullptr;      // aqc_ws_eval: pinned thetas the next U build reads directly (and copies to d_thetas)
+    bool gather_rides = false;               // aqc_ws_eval: the next gradient walk also performs the registered gather (see there)
     bool profile = false;
     int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
     double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
@@ -447,7 +451,10 @@ int ensure_umat(aqc_ws* ws, DevPlan& p) {
         HIP_OK(launch_ubuild(ws->d_ujobs + ninv + nsw, nfwd, ws->d_thetas, T, ws->batch, ws->stream));
         p.u_valid = true;
     } else {
-        HIP_OK(launch_ubuild(ws->d_ujobs, ninv + nsw, ws->d_thetas, T, ws->batch, ws->stream));
+        // aqc_ws_eval (small batches): the thetas are read from its pinned staging buffer and land in HBM through this kernel
+        HIP_OK(launch_ubuild(ws->d_ujobs, ninv + nsw, ws->theta_host ? ws->theta_host : ws->d_thetas, T, ws->batch, ws->stream,
+                             ws->theta_host ? ws->d_thetas : nullptr));
+        ws->theta_host = nullptr;
         ws->inv.u_valid = ws->sweep.u_valid = true;
     }
     return 0;
@@ -680,6 +687,12 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         }
     }
 
+    std::vector<int> slot_theta((size_t)std::max(ws->nslots, 1), -1);
+    ws->grads_direct = ws->sweep.v3 && T > 0 && env_int("AQC_GRADS_DIRECT", 1) != 0;
+    for (int t = 0; t < T; ++t) {
+        if (theta_slots[2 * t] < 0 || theta_slots[2 * t + 1] >= 0) { ws->grads_direct = false; break; }
+        slot_theta[theta_slots[2 * t]] = t;
+    }
     if (env_int("AQC_VERBOSE", 0) && want_v3)
         fprintf(stderr, "aqc_hip: matrix-core kernels, tiles 2^%d (V / V^H, %d workgroups per CU) / 2^%d (sweep, %d per CU), sub-stages %zu / %zu / %zu\n",
                 ws->inv.k, mfma_occupancy(ws->inv.k, false), ws->sweep.k, mfma_occupancy(ws->sweep.k, true), ws->fwd.h_subs3.size(),
@@ -717,6 +730,8 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     WS_HIP(hipMalloc((void**)&ws->d_theta_slots, sizeof(int) * theta_slots.size()));
     WS_HIP(hipMalloc((void**)&ws->d_slot_ntiles, sizeof(int) * slot_ntiles.size()));
     WS_HIP(hipMemcpy(ws->d_theta_slots, theta_slots.data(), sizeof(int) * theta_slots.size(), hipMemcpyHostToDevice));
+    WS_HIP(hipMalloc((void**)&ws->d_slot_theta, sizeof(int) * slot_theta.size()));
+    WS_HIP(hipMemcpy(ws->d_slot_theta, slot_theta.data(), sizeof(int) * slot_theta.size(), hipMemcpyHostToDevice));
     WS_HIP(hipMemcpy(ws->d_slot_ntiles, slot_ntiles.data(), sizeof(int) * slot_ntiles.size(), hipMemcpyHostToDevice));
     ws->pin_thetas = (size_t)batch * std::max(T, 1);
     ws->pin_grads = 2 * (size_t)batch * std::max(T, 1);
@@ -749,7 +764,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
         if (p->d_rpart) (void)hipFree(p->d_rpart);
     }
     void* ptrs[] = {ws->d_thetas_own, ws->d_theta_bank, ws->d_coef, ws->d_partial, ws->d_grads, ws->d_small, ws->d_vdot_part, ws->d_index, ws->d_tmp_index, ws->d_tmp_small,
-                    ws->d_theta_slots, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out, ws->d_ujobs};
+                    ws->d_theta_slots, ws->d_slot_theta, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out, ws->d_ujobs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
@@ -932,9 +947,13 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
         }
         ProfScope ps(ws, AQC_K_FINALIZE);
         HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
-                            ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream));
-        HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
-                               1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
+                            ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream,
+                            ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads, ws->mirror_grads,
+                            ws->gather_rides ? GatherJob{ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->d_small, ws->mirror_small}
+                                             : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr}));
+        if (!ws->grads_direct)   // some theta collects two slots (2nd-order Trotter half-layers, core_operations.py:966-968)
+            HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
+                                   1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
         return 0;
     }
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
@@ -1003,18 +1022,29 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
         if (thetas) {
             ws->d_thetas = ws->d_thetas_own;
-            HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
+            // matrix-core path, small batch: no copy node -- the U builder (first kernel of V^H or of the sweep) reads the pinned
+            // thetas over the bus and stores them to HBM for the gradient walk
+            const bool direct_thetas = zero_copy && (do_vdag || grads) && ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef &&
+                                       (do_vdag ? ws->inv.v3 : true);
+            if (!direct_thetas) HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
             if (run_coef(ws)) return 1;
+            ws->theta_host = direct_thetas ? pin_th : nullptr;
         }
         if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
-        if (gathered) {
+        // with a gradient in the same call the gather (it only reads Z, which the sweep leaves intact) rides along as one
+        // extra workgroup per lane of the gradient-walk kernel: one node less on the single-evaluation critical path
+        const bool ride = gathered && grads && zero_copy && ws->sweep.v3;
+        if (gathered && !ride) {
             if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
             if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
         }
+        ws->gather_rides = ride;
         if (grads) {
             if (aqc_ws_grad_from(ws, x_buf, block_from, block_to, front_layer)) return 1;
             if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
         }
+        ws->gather_rides = false;
+        ws->theta_host = nullptr;
         return 0;
     };
     if (thetas) memcpy(pin_th, thetas, sizeof(double) * nth);

@@ -550,13 +550,17 @@ __device__ __forceinline__ void grp_apply(const Gm& g, int ent, cplx (&x)[4]) {
 // One unitary per (job, lane): U = product of the sub-stage's gate groups, written as MFMA B operands
 // umat[lane][sub][plane (re, im - re, re + im)][K-step s][l] = U[l % 16][4 s + l / 16].  Jobs cover the sub-stages of
 // several plans (V^H and the sweep are built by one launch).
-__global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const double* thetas, int T) {
+// `thetas` may be pinned HOST memory (the one-call evaluation path hands the parameters over without a copy node);
+// `thetas_copy` (may be null) then receives them in HBM for the kernels that follow: job 0 of every lane copies its lane's.
+__global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const double* thetas, int T, double* thetas_copy) {
     __shared__ cplx u[256];   // [row = output amplitude][col = input amplitude]
     __shared__ Gm gm[kGrpChunk];
     const int lane = threadIdx.x, b = blockIdx.y;
     const UJob job = jobs[blockIdx.x];
     const DevSub3 sub = *job.sub;
     const double* th = thetas + (size_t)b * T;
+    if (thetas_copy && blockIdx.x == 0)
+        for (int i = lane; i < T; i += 64) thetas_copy[(size_t)b * T + i] = th[i];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int e = lane + 64 * m;
@@ -641,7 +645,17 @@ __device__ __forceinline__ cplx rho_dot(const cplx (&rho)[16], int kind) {
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
-                                                           int from, int to, int front) {
+                                                           int from, int to, int front, const int* slot_theta, cplx* grads, cplx* mirror,
+                                                           const GatherJob gj) {
+    if ((int)blockIdx.x == nsubs_total) {   // the passenger (see GatherJob): one extra workgroup per lane of the batch
+        const cplx* src = static_cast<const cplx*>(gj.buf) + (size_t)blockIdx.y * gj.lane_stride;
+        for (int i = threadIdx.x; i < gj.count; i += 64 * WAVES) {
+            const cplx v = src[(size_t)gj.elem[i]];
+            static_cast<cplx*>(gj.out)[(size_t)blockIdx.y * gj.count + i] = v;
+            if (gj.mirror) static_cast<cplx*>(gj.mirror)[(size_t)blockIdx.y * gj.count + i] = v;
+        }
+        return;
+    }
     __shared__ cplx R[16 * 17];    // R[j * 17 + i] = sum_c z_c[j] conj(w_c[i]); rows padded: column walks hit 16 different banks
     __shared__ Gm gm[kGrpChunk];
     __shared__ cplx rho_s[kGrpChunk][16];
@@ -681,6 +695,19 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
             R[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[r];
     }
     cplx* out = partial + (size_t)b * nslots;
+    // slot_theta != null: every theta is fed by exactly one slot, so the entry is final here -- it goes straight into the
+    // gradient (and its pinned host copy) and finalize_kernel is not launched; entries outside block_range / front_layer
+    // are written as zeros
+    auto put = [&](int slot, cplx v) {
+        out[slot] = v;
+        if (slot_theta) {
+            const int t = slot_theta[slot];
+            if (t >= 0) {
+                grads[(size_t)b * T + t] = v;
+                if (mirror) mirror[(size_t)b * T + t] = v;
+            }
+        }
+    };
     const int lo = lane & 15, hi = lane >> 4;
     for (int top = sub.ngrp; top > 0; top -= kGrpChunk) {
         const int base = max(0, top - kGrpChunk), count = top - base;
@@ -719,26 +746,28 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) rho[e] = rho_s[lane][e];
                 if (g.type == 0) {   // Rz(t2) [slot 0], Ry(t1) [slot 1], Rz(t0) [slot 2] on pc (local bit 1)
-                    out[g.slot0 + 2] = rho_dot<1>(rho, MOP_RZ);
+                    put(g.slot0 + 2, rho_dot<1>(rho, MOP_RZ));
                     rho_unapply<1>(rho, MOP_RZ, g.rc[0], g.rs[0]);
-                    out[g.slot0 + 1] = rho_dot<1>(rho, MOP_RY);
+                    put(g.slot0 + 1, rho_dot<1>(rho, MOP_RY));
                     rho_unapply<1>(rho, MOP_RY, g.rc[1], g.rs[1]);
-                    out[g.slot0 + 0] = rho_dot<1>(rho, MOP_RZ);
+                    put(g.slot0 + 0, rho_dot<1>(rho, MOP_RZ));
                 } else {             // Ry(c,t0) [0], Rz(c,t1) [1], Ry(t,t2) [2], Rs(t,t3) [3], CP [4]; rotations on c and t commute
                     const int ks = ent == 0 ? MOP_RX : MOP_RZ;
                     if (g.flags & 2) rho_unapply<0>(rho, MOP_RZ, kR, kR);
-                    out[g.slot0 + 3] = rho_dot<0>(rho, ks);
+                    put(g.slot0 + 3, rho_dot<0>(rho, ks));
                     rho_unapply<0>(rho, ks, g.rc[3], g.rs[3]);
-                    out[g.slot0 + 2] = rho_dot<0>(rho, MOP_RY);
-                    out[g.slot0 + 1] = rho_dot<1>(rho, MOP_RZ);
+                    put(g.slot0 + 2, rho_dot<0>(rho, MOP_RY));
+                    put(g.slot0 + 1, rho_dot<1>(rho, MOP_RZ));
                     rho_unapply<1>(rho, MOP_RZ, g.rc[1], g.rs[1]);
-                    out[g.slot0 + 0] = rho_dot<1>(rho, MOP_RY);
+                    put(g.slot0 + 0, rho_dot<1>(rho, MOP_RY));
                     if (ent == 2) {   // -i <P11 w|z> at the entangler (core_op_matrix.py:430-477): peel the two Ry first
                         rho_unapply<0>(rho, MOP_RY, g.rc[2], g.rs[2]);
                         rho_unapply<1>(rho, MOP_RY, g.rc[0], g.rs[0]);
-                        out[g.slot0 + 4] = make_double2(rho[15].y, -rho[15].x);
+                        put(g.slot0 + 4, make_double2(rho[15].y, -rho[15].x));
                     }
                 }
+            } else if (slot_theta && g.slot0 >= 0) {
+                for (int k = 0; k < 5; ++k) put(g.slot0 + k, make_double2(0.0, 0.0));
             }
         }
     }
@@ -819,20 +848,24 @@ hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stag
     }
     return hipGetLastError();
 }
-hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s) {
+hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s, double* thetas_copy) {
     if (njobs < 1) return hipSuccess;
-    ubuild_kernel<<<dim3(njobs, batch), 64, 0, s>>>(jobs, thetas, T);
+    ubuild_kernel<<<dim3(njobs, batch), 64, 0, s>>>(jobs, thetas, T, thetas_copy);
     return hipGetLastError();
 }
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
-                        int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s) {
+                        int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
+                        const int* slot_theta, void* grads, void* mirror, GatherJob gather) {
     if (nsubs_total < 1) return hipSuccess;
+    const int extra = gather.count > 0 && gather.buf ? 1 : 0;
     if (ntiles >= 32)
-        rgrad_kernel<4><<<dim3(nsubs_total, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
-                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front);
+        rgrad_kernel<4><<<dim3(nsubs_total + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
+                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather);
     else
-        rgrad_kernel<1><<<dim3(nsubs_total, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
-                                                                 nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front);
+        rgrad_kernel<1><<<dim3(nsubs_total + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+                                                                 nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
+                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather);
     return hipGetLastError();
 }
 

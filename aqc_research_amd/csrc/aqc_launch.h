@@ -82,9 +82,14 @@ struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` o
     int index, nsubs;
     int inverse, entangler;  // V^H plans apply every group conjugate-transposed; 0 cx, 1 cz, 2 cp
 };
-hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s);
+hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s, double* thetas_copy = nullptr);
+struct GatherJob {           // optional passenger of the gradient walk: out[lane][i] = buf[lane][elem[i]] (+ pinned host copy)
+    const void* buf; size_t lane_stride; const long long* elem; int count; void* out; void* mirror;
+};
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
-                        int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s);
+                        int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
+                        const int* slot_theta = nullptr, void* grads = nullptr, void* mirror = nullptr,
+                        GatherJob gather = GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr});   // slot_theta: direct mode, see rgrad_kernel
 
 // aqc_lbfgs.hip (device-resident multi-start L-BFGS on the lane-batched surrogate objective)
 struct LbState {

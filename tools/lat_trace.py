@@ -23,3 +23,18 @@ for r in range(5):
         ws.eval(ths[i], vdag=True, gather=True, grad=True)
     best = min(best, (time.perf_counter() - t0) / 280 * 1e3)
 print(f"n={n}: {best:.4f} ms per evaluation; tiles {ws.plan_info(0)}/{ws.plan_info(1)}")
+# the same through the raw ABI with prebuilt pointers: what the Python wrapper itself costs
+from aqc_research_amd import _lib
+L = _lib.lib()
+hs = np.empty((1, ws._gather_count), dtype=np.complex128); g = np.empty((1, circ.num_thetas), dtype=np.complex128)
+ptrs = [_lib.dptr(np.ascontiguousarray(ths[i])) for i in range(300)]
+keep = [np.ascontiguousarray(ths[i]) for i in range(300)]
+ptrs = [_lib.dptr(k) for k in keep]
+phs, pg = _lib.dptr(hs), _lib.dptr(g)
+best = 1e9
+for r in range(5):
+    t0 = time.perf_counter()
+    for i in range(20, 300):
+        L.aqc_ws_eval(ws.handle, ptrs[i], 1, phs, BUF_X, -1, -1, 1, pg)
+    best = min(best, (time.perf_counter() - t0) / 280 * 1e3)
+print(f"n={n}: {best:.4f} ms per evaluation through the raw ABI")

@@ -624,6 +624,10 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
                          // latency of an evaluation is the serial chain inside one workgroup (tools/lat_probe.py)
             int k = std::min(12, ws->nbits);
             while (k > 10 && ((size_t)batch << (ws->nbits - k)) < 256) --k;
+            // matrices: column bits are pure batch bits, so a tile may shrink to "all qubit bits + 3 column bits" without
+            // adding a stage; with few lanes that spreads one lane over several CUs (config 1 at 64 lanes: 2^8 tiles, +15 %)
+            const int kmin = std::max(8, prog.n + std::min(ws->col_bits, 3));
+            while (ws->col_bits > 0 && k > kmin && ((size_t)batch << (ws->nbits - k)) < 256) --k;
             return k;
         }
         if (want_v2) return std::min(kmax, ws->nbits);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 template <int N, int KIND>
 __global__ __launch_bounds__(256) void shadow(double* out, int iters) {
@@ -17,8 +18,10 @@ __global__ __launch_bounds__(256) void shadow(double* out, int iters) {
     for (int i = 0; i < 6; ++i) c[i] = double4_t{0, 0, 0, 0};
     double f[8] = {1, 2, 3, 4, 5, 6, 7, 8};
     unsigned x[8] = {1, 2, 3, 4, 5, 6, 7, 8};
-    double2 ld[4];
+    d2_t ld[4];
     const unsigned addr = (unsigned)(size_t)(&lds[l & 255]);
+    const unsigned addr2 = (unsigned)(size_t)(&lds[((l & 15) * 16 + ((l >> 4) & 15)) & 255]);   // transposed: lanes 0..15 are 256 B apart
+    ld[0] = ld[1] = ld[2] = ld[3] = d2_t{1.0, 2.0};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
@@ -27,10 +30,13 @@ __global__ __launch_bounds__(256) void shadow(double* out, int iters) {
             for (int k = 0; k < N; ++k) {
                 if (KIND == 0) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[k & 7]) : "v"(a));
                 else if (KIND == 1) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[k & 7]) : "v"(l));
-                else asm volatile("ds_read_b128 %0, %1" : "=v"(ld[k & 3]) : "v"(addr));
+                else if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[k & 3]) : "v"(addr));
+                else if (KIND == 3) asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(ld[k & 3]) : "memory");
+                else if (KIND == 4) asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(f[k & 7]) : "memory");
+                else asm volatile("ds_write_b128 %0, %1" : : "v"(addr2), "v"(ld[k & 3]) : "memory");   // 16-lane stride pattern
             }
         }
-        if (KIND == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (KIND >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     double s = 0;
     for (int i = 0; i < 6; ++i) for (int r = 0; r < 4; ++r) s += c[i][r];
@@ -66,5 +72,8 @@ int main(int argc, char** argv) {
     run<16, 0>(d, "v_add_f64   ");
     run<4, 1>(d, "v_xor_b32   "); run<8, 1>(d, "v_xor_b32   "); run<16, 1>(d, "v_xor_b32   "); run<32, 1>(d, "v_xor_b32   ");
     run<1, 2>(d, "ds_read_b128"); run<2, 2>(d, "ds_read_b128"); run<4, 2>(d, "ds_read_b128");
+    run<1, 3>(d, "ds_write_b128"); run<2, 3>(d, "ds_write_b128"); run<4, 3>(d, "ds_write_b128");
+    run<2, 4>(d, "ds_write_b64 "); run<4, 4>(d, "ds_write_b64 "); run<8, 4>(d, "ds_write_b64 ");
+    run<1, 5>(d, "ds_write_b128 transposed"); run<2, 5>(d, "ds_write_b128 transposed");
     return 0;
 }

@@ -285,6 +285,30 @@ def test_full_size_direct_parity_headline_batch():
     ws.close()
 
 
+@pytest.mark.parametrize("n,B", [(13, 150), (14, 70), (12, 300)])
+def test_persistent_sweep_uneven_work(n, B):
+    """The 2^12 sweep runs one persistent workgroup per CU over (tile, lane) items with the next tile prefetched into
+    registers: item counts that are not a multiple of the grid (300 / 280 / 300 items on 256 CUs: some workgroups take two
+    items, most one) and a per-lane theta, every lane against the compiled CPU restatement."""
+    from oracle import aqc_ref as cref
+    from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
+
+    rng = np.random.default_rng(n * 1000 + B)
+    a = orc.Ansatz(n, "cz", orc.spin_blocks(n, 17))
+    thetas = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(B)])
+    y = orc.rand_state(n, rng)
+    ws = Workspace(HipContext.of(make_circ(a)), batch=B)
+    assert ws.plan_info(1)[1] == 12 and ws.kernel_family(1) == 3
+    ws.broadcast(BUF_Y, y)
+    ws.set_basis(BUF_X, 3)
+    ws.gather_setup([3])
+    hs, grads = ws.eval(thetas, gather=True)
+    hs_ref, g_ref = cref.eval_batch(a, thetas, y, 3, threads=8)
+    assert maxdiff(hs[:, 0], hs_ref) < TOL
+    assert maxdiff(grads, g_ref) < TOL
+    ws.close()
+
+
 @pytest.mark.parametrize("order2", [True, False])
 def test_full_size_direct_parity_20_qubits(order2):
     """BASELINE configs[3] size (2^20 amplitudes, Trotter ansatz, Neel basis state): direct comparison."""

@@ -250,6 +250,13 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
                     }
                     for (unsigned g = 0; g < 64; ++g)
                         d3.dep_chi[g] = nc > 4 && g < (1u << (nc - 4)) ? (uint16_t)swz3_host(deposit(g, cbits.data() + 4, nc - 4)) : 0;
+                    for (unsigned l = 0; l < 64; ++l)
+                        d3.lane12[l] = (uint32_t)(d3.dep_clo[l & 15] ^ d3.dep_a[l >> 4]) | ((uint32_t)(d3.dep_a[l & 15] ^ d3.dep_clo[l >> 4]) << 16);
+                    for (unsigned g = 0; g < 16; ++g)
+                        for (unsigned s = 0; s < 4; ++s) {
+                            d3.kk[g][s] = (uint32_t)(d3.dep_a[4 * s] ^ d3.dep_chi[g]) << 4;
+                            d3.kk[g][4 + s] = (uint32_t)(d3.dep_clo[4 * s] ^ d3.dep_chi[g]) << 4;
+                        }
                     out.h_subs3.push_back(d3);
                 }
             }

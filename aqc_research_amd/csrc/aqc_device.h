@@ -93,6 +93,10 @@ struct DevSub3 {
     uint16_t dep_a[16];
     uint16_t dep_clo[16];
     uint16_t dep_chi[64];   // up to 2^14-amplitude tiles
+    // the same tables in the form the stage kernels consume (so that a sub-stage's address set-up is one vector load and
+    // a few scalar loads instead of 16 loads, 13 readfirstlanes and ~70 scalar operations):
+    uint32_t lane12[64];    // per lane: low half = L1 slot (dep_clo[l % 16] ^ dep_a[l / 16]), high half = L2 slot
+    uint32_t kk[16][8];     // per group g: [s] = (dep_a[4 s] ^ dep_chi[g]) << 4 (L1, K-step s), [4 + r] = (dep_clo[4 r] ^ dep_chi[g]) << 4
 };
 
 constexpr int kMaxMopsPerSub = 64;   // 8 gate groups x (7 micro-ops + 1 reduction)

@@ -88,12 +88,9 @@ template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape 
     static constexpr int kLoads = (1 << (K - 6)) / kWaves;             // 16-byte HBM accesses per thread and vector
 };
 
-struct SubRegs {   // everything a lane needs for one sub-stage, fetched one sub-stage ahead (no load on the critical path)
+struct SubRegs {   // what a lane needs for one sub-stage from vector memory, fetched one sub-stage ahead (no load on the critical path)
     double u0[4], u1[4], u2[4];
-    unsigned l1a, l1b, l2a, l2b;  // L1 slot of this lane = l1a ^ l1b, L2 slot = l2a ^ l2b (combined only at the point of use
-                                  // so that the prefetch is not waited for early)
-    unsigned sa[4], sc[4];        // step terms: amplitude 4s (L1), chunk 4r (L2)   (wave-uniform)
-    unsigned gt[4];               // group terms of this wave's groups                (wave-uniform)
+    unsigned lane12;              // L1 slot of this lane (low half) and L2 slot (high half), DevSub3::lane12
 };
 
 template <int GPW>
@@ -107,34 +104,33 @@ __device__ __forceinline__ void fetch_sub(SubRegs& x, const DevSub3* subs, const
         x.u1[s] = up[(1 * 4 + s) * 64 + lane];
         x.u2[s] = up[(2 * 4 + s) * 64 + lane];
     }
-    x.l1a = sub->dep_clo[lane & 15]; x.l1b = sub->dep_a[lane >> 4];
-    x.l2a = sub->dep_a[lane & 15];   x.l2b = sub->dep_clo[lane >> 4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { x.sa[s] = sub->dep_a[4 * s]; x.sc[s] = sub->dep_clo[4 * s]; }
-#pragma unroll
-    for (int j = 0; j < GPW; ++j) x.gt[j] = sub->dep_chi[wave + j * nwaves];
+    x.lane12 = sub->lane12[lane];
 }
 
 // LDS byte addresses of one sub-stage: one per-lane base for each layout and wave-uniform XOR terms kept in SGPRs
-// (16 << slot arithmetic done once; every access is then a single v_xor_b32 with a scalar operand).
+// (every access is then a single v_xor_b32 with a scalar operand).  The uniform terms come precomputed from the plan
+// (DevSub3::kk) by SCALAR loads -- the plan tables are never written by a kernel, hence the constant address space --
+// issued right after the previous sub-stage's matrix work, straight into the registers that work has just released.
 template <int GPW>
 struct SubAddr {
     unsigned a1, a2;                 // per lane: L1 / L2 byte address inside a tile
     unsigned k1[GPW][4], k2[GPW][4];  // uniform: ((step term ^ group term) << 4) for L1 (K-step s) and L2 (register r)
 };
+typedef unsigned uint8v_t __attribute__((ext_vector_type(8)));
 template <int GPW>
-__device__ __forceinline__ void sub_addr(SubAddr<GPW>& x, const SubRegs& c, unsigned lds_base) {
-    x.a1 = ((c.l1a ^ c.l1b) << 4) + lds_base;
-    x.a2 = ((c.l2a ^ c.l2b) << 4) + lds_base;
-    unsigned sa[4], sc[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { sa[s] = __builtin_amdgcn_readfirstlane(c.sa[s]); sc[s] = __builtin_amdgcn_readfirstlane(c.sc[s]); }
+__device__ __forceinline__ void fetch_k(SubAddr<GPW>& x, const DevSub3* subs, int sub_index, int wave, int nwaves) {
 #pragma unroll
     for (int j = 0; j < GPW; ++j) {
-        const unsigned g = __builtin_amdgcn_readfirstlane(c.gt[j]);
+        const uint8v_t kv = *reinterpret_cast<const __attribute__((address_space(4))) uint8v_t*>(
+            (const __attribute__((address_space(4))) void*)(const void*)&subs[sub_index].kk[wave + j * nwaves][0]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { x.k1[j][s] = (sa[s] ^ g) << 4; x.k2[j][s] = (sc[s] ^ g) << 4; }
+        for (int s = 0; s < 4; ++s) { x.k1[j][s] = kv[s]; x.k2[j][s] = kv[4 + s]; }
     }
+}
+template <int GPW>
+__device__ __forceinline__ void sub_addr(SubAddr<GPW>& x, const SubRegs& c, unsigned lds_base) {
+    x.a1 = ((c.lane12 & 0xffffu) << 4) + lds_base;
+    x.a2 = ((c.lane12 >> 16) << 4) + lds_base;
 }
 // LDS accesses by absolute 32-bit LDS address (the tile region starts at LDS address `lds_base`, checked once per
 // kernel to be a multiple of the XOR span, so base + (a ^ k) == (base + a) ^ k and no add is left on the access path).
@@ -198,7 +194,11 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     const double* umat = a.umat + (size_t)blockIdx.y * a.nsubs_total * 12 * 64;
     const unsigned lo = st.dlo[lane];
     SubRegs cur, nxt;
-    if (st.nsubs > 0) fetch_sub<TS::kGpw>(cur, a.subs, umat, st.sub_begin, lane, wave, TS::kWaves);
+    SubAddr<TS::kGpw> ad;   // clustered software pipeline, see sweep_mfma_kernel
+    if (st.nsubs > 0) {
+        fetch_sub<TS::kGpw>(cur, a.subs, umat, st.sub_begin, lane, wave, TS::kWaves);
+        fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, TS::kWaves);
+    }
     load_tiles3<K, 1>(tw, nullptr, a.in0 + lane_off, nullptr, st, lo, wave);
     // Every load so far has landed before the loop: otherwise the compiler's wait-count analysis, merging the loop
     // entry with the back edge, makes the first use of `cur` inside the loop wait for the prefetch of `nxt` as well.
@@ -206,7 +206,6 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     for (int si = 0; si < st.nsubs; ++si) {
         __syncthreads();
         if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, TS::kWaves);
-        SubAddr<TS::kGpw> ad;   // clustered software pipeline, see sweep_mfma_kernel
         sub_addr(ad, cur, lds_base);
         cplx v[2][4];
         Acc3 acc;
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
                 for (int r = 0; r < 4; ++r) lds_put(ad.a2 ^ ad.k2[j - 1][r], o[r]);
             }
         }
-        if (si + 1 < st.nsubs) cur = nxt;
+        if (si + 1 < st.nsubs) { cur = nxt; fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin + si + 1, wave, TS::kWaves); }
     }
     __syncthreads();
     store_tile3<K, false>(tw, a.out0 + lane_off, st, lo, wave);
@@ -282,6 +281,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     const int nwork = a.ntiles * a.batch;
     const unsigned lo = st.dlo[lane];
     SubRegs cur, nxt;
+    SubAddr<TS::kGpw> ad;
     // The prefetched tiles live in ACCUMULATION registers (the sub-stage pipeline fills all 256 architectural VGPRs; left
     // to itself the allocator spills a prefetch array to scratch memory): global_load with an AGPR destination, LDS write
     // with an AGPR source, both as inline assembly; the compiler does not track these loads, so the wait before the LDS
@@ -293,7 +293,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     int wi = blockIdx.x;
     {
         const size_t off0 = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
-        if (st.nsubs > 0) fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)(wi / a.ntiles) * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+        if (st.nsubs > 0) {
+            fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)(wi / a.ntiles) * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+            fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, NW);
+        }
         load_tiles3<K, 2>(tw, tz, a.in0 + off0, a.in1 + off0, st, lo, wave);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see apply_mfma_kernel
@@ -332,7 +335,6 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         // the fp64 adds bunched between them.  Per iteration j:  LDS reads of group j + 1 (issue only) | adds: operand
         // sums of group j, complex results of group j - 1 | 36 MFMAs: U w and U z of group j, then Z' W'^H of group
         // j - 1 | LDS writes of group j - 1.
-        SubAddr<TS::kGpw> ad;
         sub_addr(ad, cur, lds_base);
         constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
         const unsigned a1z = ad.a1 | ZOFF, a2z = ad.a2 | ZOFF;
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             }
         }
         AQC_STAMP(3 + 4 * si);
+        if (si + 1 < st.nsubs || more) fetch_k<TS::kGpw>(ad, a.subs, si + 1 < st.nsubs ? st.sub_begin + si + 1 : st.sub_begin, wave, NW);
         if (kFlag && si > 0) {   // the previous sub-stage's scratch has been read by everyone (bounded wait, see above)
             const unsigned want = done_base + (unsigned)(si * kSlots);
             for (int spin = 0; spin < 4096 && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 --pmc passes on one kernel family (AQC_KERNEL_FAMILY): the headline shape
-(16 qubits, 40 blocks, 64 lanes), three V^H + sweep steps."""
+(16 qubits, 40 blocks, bench.py's default number of lanes), three V^H + sweep steps."""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from aqc_research_amd import ParametricCircuit  # noqa: E402
 from aqc_research_amd.circuit_structures import create_ansatz_structure  # noqa: E402
 from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace  # noqa: E402
 
-n, L, B = 16, 40, 64
+n, L, B = 16, 40, int(os.environ.get("AQC_PROF_BATCH", "256"))   # bench.py's default lanes per GPU at this size
 circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", L))
 ctx = HipContext.of(circ)
 rng = np.random.default_rng(0)

@@ -6,6 +6,7 @@ mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || true
 tail -3 $O/gpu_tests.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --batch 64 --no-cpu-baseline > $O/bench_b64.json 2> $O/bench_b64.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency > $O/bench_under_rocprof.json 2> $O/kt.err
 echo "kernel trace done"

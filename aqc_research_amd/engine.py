@@ -181,9 +181,9 @@ class Workspace:
         hs = np.empty((self.batch, self._gather_count), dtype=np.complex128) if gather else None
         g = np.empty((self.batch, self.T), dtype=np.complex128) if grad else None
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
-        check(self._L.aqc_ws_eval(self.handle, None if th is None else dptr(th), int(bool(vdag)),
-                                  None if hs is None else dptr(hs), x_buf, lo, hi, int(bool(front_layer)),
-                                  None if g is None else dptr(g)))
+        check(self._L.aqc_ws_eval(self.handle, None if th is None else th.ctypes.data, int(bool(vdag)),
+                                  None if hs is None else hs.ctypes.data, x_buf, lo, hi, int(bool(front_layer)),
+                                  None if g is None else g.ctypes.data))
         return hs, g
 
     def grad_from(self, x_buf: int, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:

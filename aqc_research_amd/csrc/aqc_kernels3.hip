@@ -496,21 +496,36 @@ __device__ __forceinline__ void m2_apply(const cplx (&m)[4], cplx& a0, cplx& a1)
     a0 = make_double2(m00.x * x.x - sg * m00.y * x.y + m01.x * y.x - sg * m01.y * y.y, m00.x * x.y + sg * m00.y * x.x + m01.x * y.y + sg * m01.y * y.x);
     a1 = make_double2(m10.x * x.x - sg * m10.y * x.y + m11.x * y.x - sg * m11.y * y.y, m10.x * x.y + sg * m10.y * x.x + m11.x * y.y + sg * m11.y * y.x);
 }
-// decode the groups [begin, begin + count) of a sub-stage, one per lane
+// decode the groups [begin, begin + count) of a sub-stage (count <= kGrpChunk = 16).  The half-angle sincos of the up to four
+// rotations of a group -- the long part -- are taken by four lanes per group in parallel (lane = 4 group + rotation), the
+// 2 x 2 products by one lane per group afterwards.  Called by ONE whole wave (its LDS instructions execute in order, so
+// the hand-over between the two phases needs no workgroup barrier).
 __device__ __forceinline__ void stage_groups(Gm* gm, const DevGrp* grps, int begin, int count, const double* th, int ent, int lane) {
+    {
+        const int gi = lane >> 2, k = lane & 3;
+        if (gi < count) {
+            const DevGrp d = grps[begin + gi];
+            double c = 1.0, s = 0.0;
+            if (k < (d.type == 0 ? 3 : 4)) sincos(0.5 * th[d.theta0 + k], &s, &c);
+            gm[gi].rc[k] = c; gm[gi].rs[k] = s;
+            if (k == 0) {
+                double ec = 1.0, es = 0.0;
+                if (ent == 2 && d.type != 0) sincos(th[d.theta0 + 4], &es, &ec);
+                gm[gi].ec = ec; gm[gi].es = es;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (lane >= count) return;
     const DevGrp d = grps[begin + lane];
     Gm g;
     g.type = d.type; g.pc = d.pc; g.pt = d.pt; g.flags = d.flags; g.slot0 = d.slot0; g.jblock = d.jblock;
     const int mask = 0xF & ~(1 << d.pc) & ~(1 << d.pt);
     g.o0 = __ffs(mask) - 1; g.o1 = __ffs(mask & (mask - 1)) - 1;
-    g.ec = 1.0; g.es = 0.0;
-    const int nrot = d.type == 0 ? 3 : 4;
+    g.ec = gm[lane].ec; g.es = gm[lane].es;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        g.rc[k] = 1.0; g.rs[k] = 0.0;
-        if (k < nrot) sincos(0.5 * th[d.theta0 + k], &g.rs[k], &g.rc[k]);
-    }
+    for (int k = 0; k < 4; ++k) { g.rc[k] = gm[lane].rc[k]; g.rs[k] = gm[lane].rs[k]; }
     cplx a[4], b[4], m[4];
     if (d.type == 0) {   // Rz(t0) Ry(t1) Rz(t2), rightmost first (core_operations.py:671-677)
         m2_rz(g.rc[0], g.rs[0], a); m2_ry(g.rc[1], g.rs[1], b); m2_mul(a, b, m);
@@ -522,7 +537,6 @@ __device__ __forceinline__ void stage_groups(Gm* gm, const DevGrp* grps, int beg
         if (ent == 0) m2_rx(g.rc[3], g.rs[3], a); else m2_rz(g.rc[3], g.rs[3], a);
         m2_ry(g.rc[2], g.rs[2], b); m2_mul(a, b, g.t);
         if (d.flags & 2) { m2_rz(kR, kR, a); m2_mul(a, g.t, m); g.t[0] = m[0]; g.t[1] = m[1]; g.t[2] = m[2]; g.t[3] = m[3]; }
-        if (ent == 2) sincos(th[d.theta0 + 4], &g.es, &g.ec);
     }
     gm[lane] = g;
 }
@@ -667,17 +681,22 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
     const cplx* rp = rpart + ((size_t)b * nsubs_total + si) * ntiles * 256;
-    {   // fixed-order sum over the tiles (wave w: tiles w, w + WAVES, ...), 8 tiles (32 loads per lane) in flight at a time
+    {   // fixed-order sum over the tiles (wave w: tiles w, w + WAVES, ...), 8 tiles (32 loads per lane) in flight at a time;
+        // in the few-lane variant wave 0 decodes the last chunk of groups (the first one the walk needs) while its first batch
+        // of loads is in flight
         cplx acc[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
-        for (int t0 = wave; t0 < ntiles; t0 += 8 * WAVES) {
-            cplx v[8][4];
+        constexpr int TB = 8;
+        for (int t0 = wave; t0 < ntiles; t0 += TB * WAVES) {
+            cplx v[TB][4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < TB; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     v[u][r] = t0 + u * WAVES < ntiles ? rp[(size_t)(t0 + u * WAVES) * 256 + 64 * r + lane] : make_double2(0.0, 0.0);
+            if (WAVES > 1 && t0 == wave && wave == 0 && sub.ngrp > 0)   // latency regime only: the live loads cost occupancy
+                stage_groups(gm, grps, sub.grp_begin + max(0, sub.ngrp - kGrpChunk), min(sub.ngrp, kGrpChunk), th, ent, lane);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < TB; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc[r].x += v[u][r].x; acc[r].y += v[u][r].y; }
         }
@@ -715,7 +734,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     for (int top = sub.ngrp; top > 0; top -= kGrpChunk) {
         const int base = max(0, top - kGrpChunk), count = top - base;
         __syncthreads();
-        stage_groups(gm, grps, sub.grp_begin + base, count, th, ent, lane);
+        if (WAVES == 1 || top != sub.ngrp) stage_groups(gm, grps, sub.grp_begin + base, count, th, ent, lane);   // WAVES > 1: the first chunk was decoded above
         __syncthreads();
         for (int i = count - 1; i >= 0; --i) {
             const Gm& g = gm[i];

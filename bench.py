@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=0, help="independent evaluations resident per GPU (default: 256 state vectors up to 16 qubits, 64 beyond, 8-64 matrices)")
+    ap.add_argument("--batch", type=int, default=0, help="independent evaluations resident per GPU (default: 256 state vectors up to 16 qubits, 64 beyond, 32-64 matrices)")
     ap.add_argument("--workload", default="sv16_l40", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -335,7 +335,7 @@ def main():
     chi = w.get("chi", 0)
     # lanes per GPU: 256 for state vectors up to 2^16 amplitudes (the persistent sweep walks 16 tiles per workgroup: launch
     # ramp and tail are amortised; 64 lanes give 135.9k evals/s at the headline, 256 give 150k -- DESIGN 6), 64 otherwise
-    B = args.batch if args.batch > 0 else (8 if chi else ((256 if n <= 16 else 64) if ncols == 1 else (8 if ncols >= 256 else 64)))
+    B = args.batch if args.batch > 0 else (8 if chi else ((256 if n <= 16 else 64) if ncols == 1 else (32 if ncols >= 256 else 64)))
     K, W = args.steps, args.warmup
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule

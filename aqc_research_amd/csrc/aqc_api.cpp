@@ -934,10 +934,14 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                 // slots S-6 / S-5 bracket its last hand-over to a prefetched tile
                 double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0, turn = 0;
                 size_t live = 0;
+                unsigned long long first_start = ~0ull, last_start = 0, first_end = ~0ull, last_end = 0, wg_min = ~0ull, wg_max = 0;
                 for (size_t w = 0; w < nwg; ++w) {
                     const unsigned long long* t = h.data() + w * kStampSlots;
                     if (t[kStampSlots - 4] == 0) continue;   // no workgroup with this index (persistent grid)
                     ++live;
+                    first_start = std::min(first_start, t[0]); last_start = std::max(last_start, t[0]);
+                    first_end = std::min(first_end, t[kStampSlots - 4]); last_end = std::max(last_end, t[kStampSlots - 4]);
+                    wg_min = std::min(wg_min, t[kStampSlots - 4] - t[0]); wg_max = std::max(wg_max, t[kStampSlots - 4] - t[0]);
                     load += (double)(t[1] - t[0]);
                     store += (double)(t[kStampSlots - 1] - t[kStampSlots - 2]);
                     total += (double)(t[kStampSlots - 4] - t[0]);
@@ -953,6 +957,8 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                 fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups x %.1f items): total %.0f cycles per item = first load %.0f/items + "
                         "per sub-stage [top %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f + hand-over %.0f\n", s, ns, live, items,
                         total / n / items, load / n, top / n / std::max(ns - 1, 1), mf / n / ns, bar / n / ns, red / n / ns, store / n, turn / n);
+                fprintf(stderr, "aqc_hip stamps: stage %zu workgroup lifetimes (s_memtime ticks): min %llu max %llu; starts spread over %llu, ends over %llu; "
+                        "first start -> last end %llu\n", s, wg_min, wg_max, last_start - first_start, last_end - first_end, last_end - first_start);
             }
 #endif
         }

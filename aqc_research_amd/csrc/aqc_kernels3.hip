@@ -77,6 +77,10 @@ __device__ __forceinline__ void u_combine(const Acc3& t, cplx (&o)[4]) {
 #define AQC_DBG_TEST(x) false
 #endif
 
+// sweep kernels: R scratch double-buffered (one barrier per sub-stage) where the second buffer costs no occupancy: the
+// persistent 2^12 kernel (one workgroup per CU anyway) and tiles up to 2^9 (scratch of a few KiB)
+__host__ __device__ constexpr bool sweep_scratch_double(int k) { return k >= 12 || k <= 9; }
+constexpr int kSweepSpread = 2, kApplySpread = 1;   // MFMAs between two LDS writes inside a matrix run (sweep / V, V^H)
 template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
     // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
     // work itself runs at 64 cycles per MFMA either way, and the per-wave cost of a sub-stage (operand prefetch, address
@@ -225,6 +229,15 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
                 for (int s = 0; s < 4; ++s) sv[s] = v[j & 1][s].x + v[j & 1][s].y;
             }
             if (j > 0) u_combine(acc, o);
+            unsigned wa[4];   // LDS write addresses of group j - 1, taken here in the vector-ALU bunch
+            if (j < TS::kGpw) {   // (pinned: IR-level sinking otherwise moves the sums in between the MFMAs below)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(sv[s]));
+            }
+            if (j > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { wa[r] = ad.a2 ^ ad.k2[j - 1][r]; asm volatile("" : "+v"(wa[r])); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (j < TS::kGpw) {
                 acc.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; acc.k2 = acc.k1; acc.k3 = acc.k1;
@@ -235,11 +248,18 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
                     acc.k3 = mfma(v[j & 1][s].y, cur.u2[s], acc.k3);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (j > 0) {
+            if (j > 0) {   // the LDS writes of group j - 1 ride inside the MFMA run (see sweep_mfma_kernel)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds_put(ad.a2 ^ ad.k2[j - 1][r], o[r]);
+                for (int r = 0; r < 4; ++r) lds_put(wa[r], o[r]);
+                if (j < TS::kGpw) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, kApplySpread, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (si + 1 < st.nsubs) { cur = nxt; fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin + si + 1, wave, TS::kWaves); }
     }
@@ -249,11 +269,11 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
 
 // ---- forward w / z sweep with R = Z W^H per sub-stage ------------------------------------------------------
 // One barrier per sub-stage: the per-wave R of sub-stage s goes to an LDS scratch before it, the fixed-order sum over
-// the waves (64 entries per wave) right after it.  The scratch is written again only at the end of the NEXT
-// sub-stage's matrix work; `done` (an LDS counter every wave bumps after its scratch reads) makes that formally
-// safe without a second barrier -- the wait never spins in practice and is bounded.  2^11 tiles are the exception:
-// two workgroups share a CU only if each stays within exactly 80 KiB (tiles + scratch), so there the 4 bytes of the
-// counter are not affordable and a second barrier takes its place.
+// the waves (64 entries per wave) right after it.  The scratch is DOUBLE-BUFFERED by sub-stage parity: the buffer of
+// sub-stage s is written again in sub-stage s + 2, and every wave has finished its reads of it before it arrives at
+// the barrier of sub-stage s + 1, which every writer has passed -- no second barrier, no counter.  2^10 and 2^11 tiles
+// are the exception (sweep_scratch_double): a second buffer would cost them a resident workgroup per CU (2^11: two
+// workgroups share a CU only if each stays within exactly 80 KiB), so there a second barrier per sub-stage takes its place.
 template <int K> struct SweepShape : TileShape<K, true> {};   // (no comma inside the __launch_bounds__ macro arguments)
 template <int K>
 __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void sweep_mfma_kernel(const Stage3Args a) {
@@ -264,11 +284,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     const DevStage& st = a.stage;
     cplx* tw = reinterpret_cast<cplx*>(smem);
     cplx* tz = tw + tsize;
-    cplx* scratch = tz + tsize;   // [kWaves][4][64]: per-wave R of the current sub-stage
-    constexpr bool kFlag = K != 11;
+    cplx* scratch = tz + tsize;   // [2 if kDouble][kSlots][4][64]: per-wave R of the current sub-stage
+    constexpr bool kDouble = sweep_scratch_double(K);
     const unsigned lds_base = lds_address(smem);
     if (lds_base & ((32u << K) - 1)) __builtin_trap();   // XOR addressing needs the two tiles aligned to their joint size
-    unsigned* done = reinterpret_cast<unsigned*>(scratch + kSlots * 256);   // kFlag only (sweep3_lds_bytes)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Work items = (tile, lane of the batch), item wi on workgroup wi mod gridDim.x.  2^12 tiles leave room for ONE
@@ -280,6 +299,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     constexpr int NL = TS::kLoads, NW = TS::kWaves;
     const int nwork = a.ntiles * a.batch;
     const unsigned lo = st.dlo[lane];
+    const unsigned lo16 = lo << 4;   // byte offset of this lane inside a run of the tile (dlo < 2^28 elements)
     SubRegs cur, nxt;
     SubAddr<TS::kGpw> ad;
     // The prefetched tiles live in ACCUMULATION registers (the sub-stage pipeline fills all 256 architectural VGPRs; left
@@ -287,9 +307,8 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     // with an AGPR source, both as inline assembly; the compiler does not track these loads, so the wait before the LDS
     // writes is explicit.
     dbl2_t pw[NL], pz[NL];
-    unsigned done_base = 0;
+    unsigned parity = 0;   // scratch buffer of the running sub-stage (kDouble)
     AQC_STAMP(0);
-    if (kFlag && threadIdx.x == 0) *done = 0;
     int wi = blockIdx.x;
     {
         const size_t off0 = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
@@ -320,10 +339,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             for (int c = 0; c < 4; ++c) {
                 if (si == (c < st.nsubs ? c : st.nsubs - 1)) {
 #pragma unroll
-                    for (int i = c * (NL / 4); i < (c + 1) * (NL / 4); ++i) {
-                        const size_t off = next_off + lo + st.dhi[wave + i * NW];
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(pw[i]) : "v"(a.in0 + off) : "memory");
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(pz[i]) : "v"(a.in1 + off) : "memory");
+                    for (int i = c * (NL / 4); i < (c + 1) * (NL / 4); ++i) {   // scalar base + 32-bit lane offset: no vector address arithmetic
+                        const size_t ub = next_off + st.dhi[wave + i * NW];
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(lo16), "s"(a.in0 + ub) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(lo16), "s"(a.in1 + ub) : "memory");
                     }
                 }
             }
@@ -364,6 +383,23 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { zs[r] = oz[r].x + oz[r].y; wd[r] = ow[r].x - ow[r].y; }
             }
+            // the sums are pinned HERE (IR-level sinking otherwise moves them in between the MFMAs of the cluster below)
+            if (j < TS::kGpw) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { asm volatile("" : "+v"(sw[s])); asm volatile("" : "+v"(sz[s])); }
+            }
+            if (j > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { asm volatile("" : "+v"(zs[r])); asm volatile("" : "+v"(wd[r])); }
+            }
+            unsigned wa[4], za[4];   // LDS write addresses of group j - 1, taken in the vector-ALU bunch
+            if (j > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    wa[r] = ad.a2 ^ ad.k2[j - 1][r]; za[r] = a2z ^ ad.k2[j - 1][r];
+                    asm volatile("" : "+v"(wa[r])); asm volatile("" : "+v"(za[r]));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (j < TS::kGpw) {
                 aw.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; aw.k2 = aw.k1; aw.k3 = aw.k1; az.k1 = aw.k1; az.k2 = aw.k1; az.k3 = aw.k1;
@@ -385,49 +421,58 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                     t3 = mfma(zs[r], wd[r], t3);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // The 8 LDS writes of group j - 1 ride INSIDE the MFMA run, one after every kSweepSpread MFMAs: an LDS write
+            // issued between two MFMAs costs ~1.5 cycles (tools/ubench/mfma_f64_shadow.hip), while the same writes bunched
+            // after the run -- all four waves at once -- run into the 64-79 B/clk the CU accepts for 128-bit stores
+            // (1.7k cycles per sub-stage).  Measured at the headline: sweep launch pair 1.215 -> 1.092 ms.
             if (j > 0 AQC_DBG_AND(!(a.debug & 1))) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { lds_put(ad.a2 ^ ad.k2[j - 1][r], ow[r]); lds_put(a2z ^ ad.k2[j - 1][r], oz[r]); }
+                for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, kSweepSpread, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // DS write
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         AQC_STAMP(3 + 4 * si);
         if (si + 1 < st.nsubs || more) fetch_k<TS::kGpw>(ad, a.subs, si + 1 < st.nsubs ? st.sub_begin + si + 1 : st.sub_begin, wave, NW);
-        if (kFlag && si > 0) {   // the previous sub-stage's scratch has been read by everyone (bounded wait, see above)
-            const unsigned want = done_base + (unsigned)(si * kSlots);
-            for (int spin = 0; spin < 4096 && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spin)
-                __builtin_amdgcn_s_sleep(1);
-        }
         cplx rr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rr[r] = make_double2(t1[r] + t2[r], t3[r] - t1[r] + t2[r]);   // Re R = T1 + T2, Im R = T3 - T1 + T2
+        cplx* scr = scratch + (kDouble ? parity * (kSlots * 256) : 0);
+        parity ^= 1u;
         if (TS::kWaves > 4) {   // 8 waves: wave w + 4 hands its R to wave w through the scratch, wave w publishes the pair's sum
             if (wave >= 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scratch[((wave - 4) * 4 + r) * 64 + lane] = rr[r];
+                for (int r = 0; r < 4; ++r) scr[((wave - 4) * 4 + r) * 64 + lane] = rr[r];
             }
             __syncthreads();   // the sub-stage's tile updates are visible as well
             if (wave < 4) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const cplx p = scratch[(wave * 4 + r) * 64 + lane];
-                    scratch[(wave * 4 + r) * 64 + lane] = make_double2(rr[r].x + p.x, rr[r].y + p.y);
+                    const cplx p = scr[(wave * 4 + r) * 64 + lane];
+                    scr[(wave * 4 + r) * 64 + lane] = make_double2(rr[r].x + p.x, rr[r].y + p.y);
                 }
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scratch[(wave * 4 + r) * 64 + lane] = rr[r];
+            for (int r = 0; r < 4; ++r) scr[(wave * 4 + r) * 64 + lane] = rr[r];
         }
         __syncthreads();   // the sub-stage's tile updates and every slot of the scratch are visible
         AQC_STAMP(4 + 4 * si);
-        for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {   // fixed-order sum over the slots
-            double re = 0.0, im = 0.0;
+        for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {   // fixed-order sum over the slots; the reads go out together
+            cplx p[kSlots];
 #pragma unroll
-            for (int w = 0; w < kSlots; ++w) { const cplx p = scratch[w * 256 + e]; re += p.x; im += p.y; }
+            for (int w = 0; w < kSlots; ++w) p[w] = scr[w * 256 + e];
+            __builtin_amdgcn_sched_group_barrier(0x100, kSlots, 0);   // all DS reads first (one LDS latency, not kSlots)
+            double re = p[0].x, im = p[0].y;
+#pragma unroll
+            for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
             rpart[(size_t)si * a.ntiles * 256 + e] = make_double2(re, im);
         }
-        if (kFlag) { if (lane == 0 && wave < kSlots) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        else __syncthreads();
+        if (!kDouble) __syncthreads();
         AQC_STAMP(5 + 4 * si);
         if (si + 1 < st.nsubs || more) cur = nxt;
     }
@@ -451,7 +496,6 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     __syncthreads();
     AQC_STAMP(kStampSlots - 5);
     wi = nwi;
-    done_base += (unsigned)(st.nsubs * kSlots);
     }
     AQC_STAMP(kStampSlots - 4);
 }
@@ -798,8 +842,8 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
 // ---- launchers -----------------------------------------------------------------------------------------------
 int mfma_threads(int k, bool sweep) { return (sweep && k == 12) ? 64 * SweepShape<12>::kWaves : 64 * std::min(4, 1 << std::max(0, k - 8)); }
 size_t apply3_lds_bytes(int k) { return (size_t)16 << k; }
-size_t sweep3_lds_bytes(int k) {   // two tiles + R scratch of up to 4 slots (+ the `done` counter, except for 2^11 tiles)
-    return ((size_t)32 << k) + (size_t)std::min(4, mfma_threads(k, true) / 64) * 256 * sizeof(cplx) + (k != 11 ? 16 : 0);
+size_t sweep3_lds_bytes(int k) {   // two tiles + R scratch of up to 4 slots, double-buffered where sweep_scratch_double says so
+    return ((size_t)32 << k) + (size_t)(sweep_scratch_double(k) ? 2 : 1) * std::min(4, mfma_threads(k, true) / 64) * 256 * sizeof(cplx);
 }
 
 template <typename F>
@@ -855,6 +899,8 @@ static long persistent_sweep_grid() {
 }
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
+    for (int l = 0; l < 64; ++l)   // the persistent sweep addresses its prefetch with a 32-bit byte offset per lane
+        if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
     // 2^12 tiles: one persistent workgroup per CU walking over its items (see the kernel); smaller tiles: one item each
     const long nwork = (long)ntiles * batch;
     const dim3 grid((unsigned)(k >= 12 ? std::min<long>(nwork, persistent_sweep_grid()) : nwork));

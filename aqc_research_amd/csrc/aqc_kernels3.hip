@@ -149,6 +149,13 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
     return (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)p);
 }
 
+// a wave-uniform pointer as a scalar register pair (an "s" operand of inline assembly must not end up in vector registers)
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+
 // HBM <-> LDS: 16 B per lane, runs of the stage's low local bits are contiguous in HBM.  l & 63 == lane for
 // every element a thread touches and l >> 6 is wave-uniform; all loads of a thread are in flight together.
 template <int K, int NV>
@@ -330,6 +337,15 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     const bool more = kPersist && nwi < nwork;
     const int nbl = more ? nwi / a.ntiles : 0;
     const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
+    constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
+    cplx vw[2][4], vz[2][4];   // operands of group j (slot j & 1) and j + 1; group 0 of a sub-stage is requested right after the
+                               // barrier that ends the previous one, ahead of the R reduction (its latency hides there)
+    constexpr bool kEarly = K >= 11;   // (smaller tiles: the ten extra live registers would cost a resident wave per SIMD)
+    if (kEarly && st.nsubs > 0) {
+        sub_addr(ad, cur, lds_base);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
+    }
     for (int si = 0; si < st.nsubs; ++si) {
         AQC_STAMP(2 + 4 * si);
         if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
@@ -341,8 +357,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
 #pragma unroll
                     for (int i = c * (NL / 4); i < (c + 1) * (NL / 4); ++i) {   // scalar base + 32-bit lane offset: no vector address arithmetic
                         const size_t ub = next_off + st.dhi[wave + i * NW];
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(lo16), "s"(a.in0 + ub) : "memory");
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(lo16), "s"(a.in1 + ub) : "memory");
+                        // (s_nop: the hazard recogniser does not look inside inline assembly -- a scalar base that was written by
+                        // v_readfirstlane needs 5 wait states before a vector-memory instruction may read it)
+                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(lo16), "s"(uniform_ptr(a.in0 + ub)) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(lo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
                     }
                 }
             }
@@ -354,13 +372,13 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         // the fp64 adds bunched between them.  Per iteration j:  LDS reads of group j + 1 (issue only) | adds: operand
         // sums of group j, complex results of group j - 1 | 36 MFMAs: U w and U z of group j, then Z' W'^H of group
         // j - 1 | LDS writes of group j - 1.
-        sub_addr(ad, cur, lds_base);
-        constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
-        const unsigned a1z = ad.a1 | ZOFF, a2z = ad.a2 | ZOFF;
-        cplx vw[2][4], vz[2][4];   // operands of group j (slot j & 1) and j + 1
-        Acc3 aw, az;               // products of group j - 1 until they are combined, then of group j
+        if (!kEarly) {
+            sub_addr(ad, cur, lds_base);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get(a1z ^ ad.k1[0][s]); }
+            for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
+        }
+        const unsigned a1z = ad.a1 | ZOFF, a2z = ad.a2 | ZOFF;
+        Acc3 aw, az;               // products of group j - 1 until they are combined, then of group j
 #pragma unroll
         for (int j = 0; j <= TS::kGpw; ++j) {
             if (j + 1 < TS::kGpw AQC_DBG_AND(!(a.debug & 2))) {
@@ -462,19 +480,42 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         }
         __syncthreads();   // the sub-stage's tile updates and every slot of the scratch are visible
         AQC_STAMP(4 + 4 * si);
-        for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {   // fixed-order sum over the slots; the reads go out together
+        // fixed-order sum over the slots.  With four waves (one entry per thread) the reads go out first, then -- if the item
+        // goes on -- the next sub-stage's addresses and the LDS reads of its group 0, then the sum: one LDS latency is paid
+        // where three were (scratch, scratch again, operands)
+        const bool go_on = si + 1 < st.nsubs;
+        if (kEarly) {
             cplx p[kSlots];
 #pragma unroll
-            for (int w = 0; w < kSlots; ++w) p[w] = scr[w * 256 + e];
-            __builtin_amdgcn_sched_group_barrier(0x100, kSlots, 0);   // all DS reads first (one LDS latency, not kSlots)
+            for (int w = 0; w < kSlots; ++w) p[w] = scr[w * 256 + threadIdx.x];
+            __builtin_amdgcn_sched_barrier(0);
+            if (go_on) {
+                cur = nxt;
+                sub_addr(ad, cur, lds_base);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             double re = p[0].x, im = p[0].y;
 #pragma unroll
             for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
-            rpart[(size_t)si * a.ntiles * 256 + e] = make_double2(re, im);
+            rpart[(size_t)si * a.ntiles * 256 + threadIdx.x] = make_double2(re, im);
+            if (!kDouble) __syncthreads();
+        } else {
+            for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {
+                cplx p[kSlots];
+#pragma unroll
+                for (int w = 0; w < kSlots; ++w) p[w] = scr[w * 256 + e];
+                double re = p[0].x, im = p[0].y;
+#pragma unroll
+                for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
+                rpart[(size_t)si * a.ntiles * 256 + e] = make_double2(re, im);
+            }
+            if (!kDouble) __syncthreads();
+            if (go_on) cur = nxt;
         }
-        if (!kDouble) __syncthreads();
         AQC_STAMP(5 + 4 * si);
-        if (si + 1 < st.nsubs || more) cur = nxt;
+        if (!go_on && more) cur = nxt;
     }
     AQC_STAMP(kStampSlots - 2);
     if (a.store_out) {   // the last stage's w and z are never read again (only the gradient entries are results)

@@ -43,7 +43,9 @@ SIGNATURES = {
     "aqc_ws_broadcast": (c_int, [_P, c_int, _D]),
     "aqc_ws_download": (c_int, [_P, c_int, _D]),
     "aqc_ws_download_lane": (c_int, [_P, c_int, c_int, _D]),
+    "aqc_ws_copy_lane": (c_int, [_P, c_int, c_int, _P, c_int, c_int]),
     "aqc_ws_set_basis": (c_int, [_P, c_int, POINTER(c_int64)]),
+    "aqc_ws_set_combo": (c_int, [_P, c_int, POINTER(c_int64), _D]),
     "aqc_ws_set_identity": (c_int, [_P, c_int]),
     "aqc_ws_apply": (c_int, [_P, c_int, c_int, c_int]),
     "aqc_ws_grad": (c_int, [_P, c_int, c_int, c_int]),
@@ -84,6 +86,8 @@ SIGNATURES = {
     "aqc_ws_gather_fetch": (c_int, [_P, _D]),
     "aqc_ws_vdot_launch": (c_int, [_P, c_int, c_int]),
     "aqc_ws_vdot_fetch": (c_int, [_P, _D]),
+    "aqc_ws_results_async": (c_int, [_P]),
+    "aqc_ws_results_fetch": (c_int, [_P, _D, _D]),
     "aqc_ws_timer_start": (c_int, [_P]),
     "aqc_ws_timer_stop": (c_int, [_P, POINTER(c_float)]),
     "aqc_ws_profile_enable": (c_int, [_P, c_int]),
@@ -92,7 +96,8 @@ SIGNATURES = {
     "aqc_ws_plan_info": (c_int, [_P, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "aqc_ws_kernel_family": (c_int, [_P, c_int]),
     "aqc_ws_plan_substages": (c_int, [_P, c_int]),
-    "aqc_ws_lbfgs": (c_int, [_P, _D, c_int, c_int, c_double, c_double, c_double, c_int, _D, _D, _D, POINTER(c_int64), POINTER(c_int64)]),
+    "aqc_ws_lbfgs": (c_int, [_P, _D, c_int, c_int, c_double, c_double, c_double, c_int, c_int, c_int, c_int, _D, _D, _D, POINTER(c_int64),
+                     POINTER(c_int64), _D, POINTER(c_int64)]),
     "aqc_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "aqc_comm_create": (c_int, [ctypes.c_char_p, c_int, c_int, c_int, POINTER(_P)]),
     "aqc_comm_destroy": (c_int, [_P]),

@@ -27,83 +27,109 @@ class BatchedSurrogateObjective:
 
     _gamma = 0.1  # objective_lhs_sur_max.py:40
 
-    def __init__(self, circ, targets: np.ndarray, *, max_flips: int = 1, base_index: int = 0,
-                 block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, device: int = 0):
-        targets = np.ascontiguousarray(targets, dtype=np.complex128)
-        if targets.ndim != 2 or targets.shape[1] != circ.dimension:
-            raise ValueError("targets must have shape (lanes, 2^n)")
-        self.circ, self.batch, self.T = circ, targets.shape[0], circ.num_thetas
+    def __init__(self, circ, targets: Optional[np.ndarray], *, max_flips: int = 1, base_index: int = 0,
+                 block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, device: Optional[int] = None,
+                 lanes: Optional[int] = None):
+        """``targets`` may be None when ``lanes`` is given: the lanes' targets are then handed over on the device
+        (``target_from``) -- how a driver re-uses one objective for the jobs of a horizon."""
+        if targets is not None:
+            targets = np.ascontiguousarray(targets, dtype=np.complex128)
+            if targets.ndim != 2 or targets.shape[1] != circ.dimension:
+                raise ValueError("targets must have shape (lanes, 2^n)")
+            lanes = targets.shape[0]
+        elif lanes is None or lanes < 1:
+            raise ValueError("give the targets or the number of lanes")
+        self.circ, self.batch, self.T = circ, int(lanes), circ.num_thetas
         self._states = ThinStateHandler(circ.num_qubits, max_flips, base_index=base_index)
         self._idx = np.asarray(self._states.state_indices, dtype=np.int64)
         self._block_range = None if block_range is None else (int(block_range[0]), int(block_range[1]))
         self._front = bool(front_layer or block_range is None or tuple(block_range) == (0, circ.num_blocks))
         self.ws = Workspace(HipContext.of(circ), batch=self.batch, ncols=1, device=device)
-        self.ws.upload(BUF_Y, targets)
+        if targets is not None:
+            self.ws.upload(BUF_Y, targets)
         self.ws.set_basis(BUF_X, int(self._idx[0]))
         self.ws.gather_setup(self._idx)
+        self.num_evals = 0
+        self.reset_state()
+
+    def reset_state(self) -> None:
+        """A fresh objective (weight 1, |state_0> leads) on the same workspace: the next job of a driver."""
         self.weight = np.ones(self.batch)
         self.max_no = np.zeros(self.batch, dtype=np.int64)
         self.fidelity = np.full(self.batch, -1.0)
-        self.num_evals = 0
+        self.last_raw = None
+
+    def target_from(self, lane: int, src: Workspace, src_buf: int, src_lane: int) -> None:
+        """Lane ``lane``'s target <- lane ``src_lane`` of buffer ``src_buf`` of another workspace, on the device."""
+        self.ws.copy_lane_from(src, src_buf, src_lane, BUF_Y, lane)
 
     def value_and_grad(self, thetas: np.ndarray, update_state: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         """f[B], g[B][T] at thetas[B][T].  ``update_state=False`` evaluates with the current weights / leading states
         without touching them (line-search trials); ``True`` first applies the hysteresis and the weight smoothing --
-        once per accepted step, as an objective()/gradient() pair does -- and evaluates under the new state."""
+        once per accepted step, as an objective()/gradient() pair does -- and evaluates under the new state.
+
+        While every lane leads with |state_0> one native call does V^H, the amplitudes and the sweep from |state_0>.  As soon
+        as some lane leads with a flip state, the sweep waits for the amplitudes: its lhs is then the combination
+        conj(c_0)|state_0> + conj(c_max)|state_max> per lane, whose gradient IS c_0 g_0 + c_max g_max (the gradient of <V x|y>
+        is conjugate-linear in x) -- one sweep where objective_lhs_sur_max.py:147-175 runs two."""
         th = np.ascontiguousarray(thetas, dtype=np.float64).reshape(self.batch, self.T)
-        hs, g0 = self.ws.eval(th, vdag=True, gather=True, grad=True, x_buf=BUF_X, block_range=self._block_range,
-                              front_layer=self._front)
         self.num_evals += self.batch
-        return self._assemble(hs, g0, None, update_state)
+        if not (self.max_no != 0).any():
+            hs, g0 = self.ws.eval(th, vdag=True, gather=True, grad=True, x_buf=BUF_X, block_range=self._block_range,
+                                  front_layer=self._front)
+            return self._assemble(hs, g0, None, update_state)
+        hs, _ = self.ws.eval(th, vdag=True, gather=True, grad=False, x_buf=BUF_X, block_range=self._block_range, front_layer=self._front)
+        return self._assemble(hs, None, None, update_state)
 
-    def _assemble(self, hs, g0, gm_in, update_state: bool):
-        """Value and gradient from the device results (hs, g0[, gm]) under the current / the updated state; keeps the
-        raw results so that ``commit`` can re-assemble accepted trial points without another device evaluation."""
-        hs2 = np.abs(hs) ** 2
+    def _update(self, hs2: np.ndarray):
+        """10 % hysteresis (objective_lhs_sur_max.py:113-117) and weight smoothing (:186), lane-wise; returns (max_no, w)."""
         lanes = np.arange(self.batch)
-        max_no = self.max_no
-        if update_state:   # 10 % hysteresis (objective_lhs_sur_max.py:113-117), lane-wise
-            max_no = self.max_no.copy()
-            best = hs2[lanes, max_no]
-            for i in range(hs2.shape[1]):
-                better = 1.1 * best < hs2[:, i]
-                best = np.where(better, hs2[:, i], best)
-                max_no = np.where(better, i, max_no)
-        w = self.weight
-        if update_state:   # smoothed weight from the value under the old one (objective_lhs_sur_max.py:186); the value and
-            f_old = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[lanes, max_no]          # gradient returned below use the NEW
-            w = w + self._gamma * (np.sqrt(np.abs(f_old)) - w)                   # state, so that all trial points of the
-            self.max_no, self.weight, self.fidelity = max_no, w, hs2[:, 0].copy()  # next line search see one function
-        f = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[lanes, max_no]
-        h0 = hs[:, 0]
-        lead = max_no != 0
-        grad = np.where(lead[:, None], (g0 * (-2.0 * (1.0 - w) * np.conj(h0))[:, None]).real,
-                        (g0 * (-2.0 * np.conj(h0))[:, None]).real)
-        gm = gm_in
-        if lead.any():     # second sweep from the leading flip state, only where it is not |state_0>
-            if gm is None:
-                self.ws.set_basis(BUF_X2, self._idx[max_no])
-                _, gm = self.ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=self._block_range,
-                                     front_layer=self._front)
-                self._gm_states = max_no.copy()
-            hm = hs[lanes, max_no]
-            grad = grad + np.where(lead[:, None], (gm * (-2.0 * w * np.conj(hm))[:, None]).real, 0.0)
-        self.last_raw = (hs, g0, gm, max_no.copy())
-        return f, grad
-
-    def commit(self, rows_hs: np.ndarray, rows_g0: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-        """State update (hysteresis + weight smoothing) at points whose device results are already known -- the trial
-        points a line search accepted, lane by lane -- and the value / gradient under the new state, assembled on the
-        host.  Returns None when some lane would lead with a flip state other than |state_0>: its second sweep depends
-        on the state chosen now, so the caller evaluates on the device instead."""
-        hs2 = np.abs(rows_hs) ** 2
-        lanes = np.arange(self.batch)
-        probe = self.max_no.copy()
-        best = hs2[lanes, probe]
+        max_no = self.max_no.copy()
+        best = hs2[lanes, max_no]
         for i in range(hs2.shape[1]):
             better = 1.1 * best < hs2[:, i]
             best = np.where(better, hs2[:, i], best)
-            probe = np.where(better, i, probe)
+            max_no = np.where(better, i, max_no)
+        w = self.weight
+        f_old = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[lanes, max_no]      # the value under the OLD weight feeds the smoothing
+        return max_no, w + self._gamma * (np.sqrt(np.abs(f_old)) - w)
+
+    def _assemble(self, hs, g0, gm_in, update_state: bool):
+        """Value and gradient from the device results under the current / the updated state.  ``g0`` (complex gradient of the
+        sweep from |state_0>) may be None: then -- and whenever some lane leads with a flip state -- the gradient comes from
+        one sweep over the combined lhs states.  Keeps the raw results so that ``commit`` can re-assemble accepted trial
+        points without another device evaluation while |state_0> leads everywhere."""
+        hs2 = np.abs(hs) ** 2
+        lanes = np.arange(self.batch)
+        max_no, w = self.max_no, self.weight
+        if update_state:   # the value and gradient returned below use the NEW state, so that all trial points of the next line
+            max_no, w = self._update(hs2)                                          # search see one function
+            self.max_no, self.weight, self.fidelity = max_no, w, hs2[:, 0].copy()
+        f = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[lanes, max_no]
+        h0 = hs[:, 0]
+        lead = max_no != 0
+        if g0 is not None and not lead.any():
+            grad = (g0 * (-2.0 * np.conj(h0))[:, None]).real
+            self.last_raw = (hs, g0, None, max_no.copy())
+            return f, grad
+        hm = hs[lanes, max_no]
+        c0 = np.where(lead, -2.0 * (1.0 - w), -2.0) * np.conj(h0)
+        cm = np.where(lead, -2.0 * w, 0.0) * np.conj(hm)
+        idx = np.stack([np.full(self.batch, self._idx[0]), np.where(lead, self._idx[max_no], -1)], axis=1)
+        self.ws.set_combo(BUF_X2, idx, np.stack([np.conj(c0), np.conj(cm)], axis=1))
+        _, gc = self.ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=self._block_range,
+                             front_layer=self._front)
+        self.last_raw = (hs, None, None, max_no.copy())
+        return f, gc.real.copy()
+
+    def commit(self, rows_hs: np.ndarray, rows_g0: Optional[np.ndarray]) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        """State update (hysteresis + weight smoothing) at points whose device results are already known -- the trial
+        points a line search accepted, lane by lane -- and the value / gradient under the new state, assembled on the
+        host.  Returns None when some lane leads (or would lead) with a flip state other than |state_0>: the sweep then
+        depends on the state chosen now, so the caller evaluates on the device instead."""
+        if rows_g0 is None or (self.max_no != 0).any():
+            return None
+        probe, _ = self._update(np.abs(rows_hs) ** 2)
         if (probe != 0).any():
             return None            # caller re-evaluates on the device
         return self._assemble(rows_hs, rows_g0, None, True)
@@ -122,12 +148,19 @@ class BatchedSurrogateObjective:
         xo = np.empty_like(x)
         f = np.empty(self.batch)
         fid = np.empty(self.batch)
+        w = np.empty(self.batch)
         nit = np.zeros(self.batch, dtype=np.int64)
+        max_no = np.zeros(self.batch, dtype=np.int64)
         nfev = ctypes.c_int64()
+        lo, hi = (-1, -1) if self._block_range is None else self._block_range
+        i64 = ctypes.POINTER(ctypes.c_int64)
         _lib.check(self.ws._L.aqc_ws_lbfgs(self.ws.handle, _lib.dptr(x), int(maxiter), int(memory), float(gtol), float(ftol),
-                                          float(fidelity_thr), int(max_backtracks), _lib.dptr(xo), _lib.dptr(f), _lib.dptr(fid),
-                                          nit.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.byref(nfev)))
-        self.fidelity = fid
+                                          float(fidelity_thr), int(max_backtracks), int(lo), int(hi), int(self._front),
+                                          _lib.dptr(xo), _lib.dptr(f), _lib.dptr(fid), nit.ctypes.data_as(i64), ctypes.byref(nfev),
+                                          _lib.dptr(w), max_no.ctypes.data_as(i64)))
+        # the objective's state follows the device's: later host-side evaluations continue from where the optimizer stopped
+        self.fidelity, self.weight, self.max_no = fid, w, max_no
+        self.last_raw = None
         self.num_evals += int(nfev.value) * self.batch
         return {"x": xo, "fun": f, "nit": nit, "nfev": int(nfev.value), "fidelity": fid}
 
@@ -188,7 +221,8 @@ def batched_lbfgs(fun: Callable[[np.ndarray, bool], Tuple[np.ndarray, np.ndarray
         f_new, g_new, x_new = f.copy(), g.copy(), x.copy()
         owner = getattr(fun, "__self__", None)          # objectives that expose their raw device results can commit
         raw_hs = raw_g0 = None                          # accepted trial points on the host (no second evaluation)
-        can_commit = owner is not None and hasattr(owner, "commit") and getattr(owner, "last_raw", None) is not None
+        can_commit = (owner is not None and hasattr(owner, "commit") and getattr(owner, "last_raw", None) is not None
+                      and owner.last_raw[1] is not None)
         if can_commit:
             raw_hs, raw_g0 = owner.last_raw[0].copy(), owner.last_raw[1].copy()   # rows of lanes that do not move
         for _bt in range(max_backtracks):
@@ -197,6 +231,8 @@ def batched_lbfgs(fun: Callable[[np.ndarray, bool], Tuple[np.ndarray, np.ndarray
             nfev += 1
             ok = (~done) & (ft <= f + c1 * step * slope)
             f_new[ok], g_new[ok], x_new[ok] = ft[ok], gt[ok], trial[ok]
+            if can_commit and owner.last_raw[1] is None:
+                can_commit = False    # (cannot happen while the state is frozen during the trials; stay safe)
             if can_commit:
                 raw_hs[ok], raw_g0[ok] = owner.last_raw[0][ok], owner.last_raw[1][ok]
             done |= ok
@@ -231,7 +267,7 @@ class BatchedSketchingObjective:
     ``FullRangeSketchingVectors``, sk_core.py:167-326): random restarts and / or different target unitaries on one
     workspace.  ``targets``: (B, d, d) complex128, or (d, d) shared by all ``lanes``."""
 
-    def __init__(self, circ, targets: np.ndarray, lanes: Optional[int] = None, device: int = 0):
+    def __init__(self, circ, targets: np.ndarray, lanes: Optional[int] = None, device: Optional[int] = None):
         t = np.ascontiguousarray(targets, dtype=np.complex128)
         d = circ.dimension
         if t.shape == (d, d):

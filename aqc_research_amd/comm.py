@@ -1,9 +1,8 @@
 """
 Process-group layer of the job-sharded path: one process per GPU, fixed-size float64 records, two collectives
 (all-gather of result records, all-reduce of small sums).  The production transport is ``aqc_comm_*`` of the C ABI --
-librccl (RCCL over xGMI) bound directly, no torch.  ``GlooDouble`` is the CPU test double used by the world_size-2
-tests in this repository and by rehearsals on boxes with fewer GPUs than ranks; it speaks the same interface over
-``torch.distributed`` with the gloo backend.
+librccl (RCCL over xGMI) bound directly, no torch.  (The CPU tests and rehearsals of this repository install a test
+double with the same interface over ``torch.distributed``/gloo through ``use()``: ``tests/gloo_double.py``.)
 
 Rendezvous ("unique id passed via file/env, no MPI"): ranks are told their place by the environment that
 ``torch.distributed.run`` / any launcher sets (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT); rank 0 writes the 128-byte
@@ -19,7 +18,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Communicator", "RcclCommunicator", "GlooDouble", "from_environment"]
+__all__ = ["Communicator", "RcclCommunicator", "from_environment", "use", "reset"]
 
 
 class Communicator:
@@ -51,6 +50,10 @@ class RcclCommunicator(Communicator):
         L = _lib.lib()
         self._L, self.rank, self.size, self.device = L, int(rank), int(size), int(device)
         if rank == 0:
+            try:
+                os.remove(id_file)   # a crashed earlier launch may have left one behind
+            except OSError:
+                pass
             buf = ctypes.create_string_buffer(128)
             _lib.check(L.aqc_comm_unique_id(buf))
             tmp = id_file + f".tmp{os.getpid()}"
@@ -111,69 +114,33 @@ class RcclCommunicator(Communicator):
             pass
 
 
-class GlooDouble(Communicator):
-    """CPU test double with the same interface over an already initialised torch.distributed group."""
-
-    def __init__(self, dist):
-        self._dist = dist
-        self.rank, self.size = dist.get_rank(), dist.get_world_size()
-        self.transport = f"torch.distributed ({dist.get_backend()})"
-
-    def _device(self):
-        import torch
-
-        if self._dist.get_backend() == "nccl":
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        return torch.device("cpu")
-
-    def allgather(self, send: np.ndarray) -> np.ndarray:
-        import torch
-
-        s = torch.from_numpy(np.ascontiguousarray(send, dtype=np.float64).ravel().copy()).to(self._device())
-        outs = [torch.empty_like(s) for _ in range(self.size)]
-        self._dist.all_gather(outs, s)
-        return np.stack([o.cpu().numpy() for o in outs])
-
-    def allreduce(self, data: np.ndarray, op: str = "sum") -> np.ndarray:
-        import torch
-
-        t = torch.from_numpy(data).to(self._device())
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX)
-        np.copyto(data, t.cpu().numpy())
-        return data
-
-    def barrier(self) -> None:
-        self._dist.barrier()
-
-
 _current: Optional[Communicator] = None
 
 
-def _initialised_torch_group():
-    import sys
-
-    dist = sys.modules.get("torch.distributed")   # never import torch on behalf of the caller
-    if dist is None:
-        return None
-    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+def use(communicator: Optional[Communicator]) -> None:
+    """Install the process group of this run (tests and rehearsals hand in their double; None forgets it)."""
+    global _current
+    _current = communicator
 
 
-def from_environment(prefer: str = "auto") -> Communicator:
-    """The process group of this run: an already initialised torch.distributed group is wrapped (that is how the CPU
-    tests and rehearsals drive the path); otherwise, under a launcher (WORLD_SIZE > 1), RCCL is bound directly;
-    a single process gets the trivial communicator.  The result is cached per process."""
+def launch_tag() -> str:
+    """Names one launch: all ranks share the launcher as parent process and its rendezvous port; a restarted attempt of an
+    elastic launcher (same agent, same port) gets a new name through its restart count / run id."""
+    env = os.environ
+    return "_".join([env.get("MASTER_PORT", "0"), str(os.getppid()), env.get("AQC_COMM_TAG", "0"),
+                     env.get("TORCHELASTIC_RUN_ID", "0"), env.get("TORCHELASTIC_RESTART_COUNT", "0")])
+
+
+def from_environment() -> Communicator:
+    """The process group of this run: whatever ``use()`` installed; otherwise, under a launcher (WORLD_SIZE > 1), RCCL
+    bound directly; a single process gets the trivial communicator.  The result is cached per process."""
     global _current
     if _current is not None:
         return _current
-    dist = _initialised_torch_group()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if dist is not None and prefer != "rccl":
-        _current = GlooDouble(dist)
-    elif world > 1:
+    if world > 1:
         rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-        # all ranks of one launch share the launcher as parent process: port + parent pid name the launch
-        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('AQC_COMM_TAG', '0')}"
-        id_file = os.environ.get("AQC_COMM_FILE", os.path.join(tempfile.gettempdir(), f"aqc_comm_id_{tag}"))
+        id_file = os.environ.get("AQC_COMM_FILE", os.path.join(tempfile.gettempdir(), f"aqc_comm_id_{launch_tag()}"))
         _current = RcclCommunicator(rank, world, local % max(1, _lib.lib().aqc_device_count()), id_file)
     else:
         _current = Communicator()

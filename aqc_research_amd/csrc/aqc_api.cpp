@@ -305,6 +305,10 @@ struct aqc_ws {
     double2* d_tmp_small = nullptr;
     size_t tmp_index_cap = 0, tmp_small_cap = 0;
     long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
+    long long* d_combo_prev[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // set_combo: positions written last time
+    bool combo_valid[AQC_NUM_BUFS] = {false, false, false, false, false, false};   // buffer holds exactly that sparse pattern
+    long long* d_combo_index = nullptr;   // [batch][2] staging of set_combo
+    double2* d_combo_coef = nullptr;      // [batch][2]
     size_t small_cap = 0, index_cap = 0;
     int* d_theta_slots = nullptr;
     int* d_slot_theta = nullptr;       // slot -> theta when every theta has exactly one slot (grads_direct), see rgrad_kernel
@@ -778,6 +782,9 @@ int aqc_ws_destroy(aqc_ws* ws) {
                     ws->d_theta_slots, ws->d_slot_theta, ws->d_slot_ntiles, ws->d_basis_index, ws->d_vdot_out, ws->d_ujobs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
+    for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->d_combo_prev[b]) (void)hipFree(ws->d_combo_prev[b]);
+    if (ws->d_combo_index) (void)hipFree(ws->d_combo_index);
+    if (ws->d_combo_coef) (void)hipFree(ws->d_combo_coef);
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
     for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
@@ -801,6 +808,7 @@ int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas) {
 
 int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
     if (check_buf(ws, buf)) return 1;
+    ws->combo_valid[buf] = false;
     if (!src) return fail("null source");
     HIP_OK(hipSetDevice(ws->device));
     return copy_in(ws, ws->bufs[buf], src, (size_t)ws->batch << ws->ctx->prog.n);
@@ -808,6 +816,7 @@ int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
 
 int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src) {
     if (check_buf(ws, buf)) return 1;
+    ws->combo_valid[buf] = false;
     if (!src) return fail("null source");
     if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
     HIP_OK(hipSetDevice(ws->device));
@@ -816,12 +825,28 @@ int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src) {
 
 int aqc_ws_broadcast(aqc_ws* ws, int buf, const double* src) {
     if (check_buf(ws, buf)) return 1;
+    ws->combo_valid[buf] = false;
     if (!src) return fail("null source");
     HIP_OK(hipSetDevice(ws->device));
     if (copy_in(ws, ws->bufs[buf], src, (size_t)1 << ws->ctx->prog.n)) return 1;
     for (int b = 1; b < ws->batch; ++b)
         HIP_OK(hipMemcpyAsync(ws->bufs[buf] + (size_t)b * ws->lane_elems, ws->bufs[buf], ws->lane_elems * sizeof(double2),
                               hipMemcpyDeviceToDevice, ws->stream));
+    return 0;
+}
+
+// dst_ws.buf[dst_lane] <- src_ws.buf[src_lane], device to device (both workspaces on the same device, same lane size): how a
+// driver hands device-resident targets (e.g. synthesised by another workspace, model_sp_lhs/trotter) to an objective's lanes
+int aqc_ws_copy_lane(aqc_ws* dst_ws, int dst_buf, int dst_lane, aqc_ws* src_ws, int src_buf, int src_lane) {
+    if (check_buf(dst_ws, dst_buf) || check_buf(src_ws, src_buf)) return 1;
+    if (dst_ws->device != src_ws->device) return fail("copy_lane: the two workspaces live on different devices");
+    if (dst_ws->lane_elems != src_ws->lane_elems) return fail("copy_lane: lane sizes differ");
+    if (dst_lane < 0 || dst_lane >= dst_ws->batch || src_lane < 0 || src_lane >= src_ws->batch) return fail("lane out of range");
+    HIP_OK(hipSetDevice(dst_ws->device));
+    dst_ws->combo_valid[dst_buf] = false;
+    if (src_ws->stream != dst_ws->stream) HIP_OK(hipStreamSynchronize(src_ws->stream));   // the source is complete
+    HIP_OK(hipMemcpyAsync(dst_ws->bufs[dst_buf] + (size_t)dst_lane * dst_ws->lane_elems, src_ws->bufs[src_buf] + (size_t)src_lane * src_ws->lane_elems,
+                          sizeof(double2) * dst_ws->lane_elems, hipMemcpyDeviceToDevice, dst_ws->stream));
     return 0;
 }
 
@@ -842,6 +867,7 @@ int aqc_ws_download_lane(aqc_ws* ws, int buf, int lane, double* dst) {
 
 int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
     if (check_buf(ws, buf)) return 1;
+    ws->combo_valid[buf] = false;
     if (!index) return fail("null index");
     HIP_OK(hipSetDevice(ws->device));
     const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
@@ -861,6 +887,7 @@ int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
 
 int aqc_ws_set_identity(aqc_ws* ws, int buf) {
     if (check_buf(ws, buf)) return 1;
+    ws->combo_valid[buf] = false;
     const int dim = 1 << ws->ctx->prog.n;
     if (ws->ncols != dim) return fail("identity needs a square workspace (ncols == 2^n)");
     HIP_OK(hipSetDevice(ws->device));
@@ -870,8 +897,45 @@ int aqc_ws_set_identity(aqc_ws* ws, int buf) {
     return 0;
 }
 
+// buffer[lane] = coef[lane][0] |index[lane][0]> + coef[lane][1] |index[lane][1]>   (index[lane][1] < 0: one term).
+// The gradient of <V x|y> is conjugate-linear in x, so the surrogate objective's two sweeps -- from |state_0> and from
+// the leading flip state, combined as c_0 g_0 + c_max g_max (objective_lhs_sur_max.py:147-191) -- are ONE sweep from
+// x = conj(c_0) |state_0> + conj(c_max) |state_max>.  Only the positions written by the previous call are cleared
+// (the buffer is 2^n amplitudes per lane); any other writer of the buffer makes the next call clear all of it.
+int aqc_ws_set_combo(aqc_ws* ws, int buf, const int64_t* index, const double* coef) {
+    if (check_buf(ws, buf)) return 1;
+    if (!index || !coef) return fail("null argument");
+    if (buf == AQC_BUF_W || buf == AQC_BUF_ZW || buf == AQC_BUF_Z) return fail("set_combo targets an lhs buffer (X, X2) or Y");
+    HIP_OK(hipSetDevice(ws->device));
+    const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
+    const int B = ws->batch;
+    std::vector<long long> elem(2 * (size_t)B);
+    for (int b = 0; b < B; ++b) {
+        const int64_t i0 = index[2 * b], i1 = index[2 * b + 1];
+        if (i0 < 0 || i0 >= dim || i1 >= dim) return fail("basis index out of range");
+        if (i1 == i0) return fail("the two basis states of a lane must differ");
+        elem[2 * b] = (long long)i0 << ws->col_bits;
+        elem[2 * b + 1] = i1 < 0 ? -1 : (long long)i1 << ws->col_bits;
+    }
+    if (!ws->d_combo_index) HIP_OK(hipMalloc((void**)&ws->d_combo_index, sizeof(long long) * 2 * B));
+    if (!ws->d_combo_coef) HIP_OK(hipMalloc((void**)&ws->d_combo_coef, sizeof(double2) * 2 * B));
+    if (!ws->d_combo_prev[buf]) { HIP_OK(hipMalloc((void**)&ws->d_combo_prev[buf], sizeof(long long) * 2 * B)); ws->combo_valid[buf] = false; }
+    HIP_OK(hipMemcpyAsync(ws->d_combo_index, elem.data(), sizeof(long long) * 2 * B, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipMemcpyAsync(ws->d_combo_coef, coef, sizeof(double2) * 2 * B, hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));   // `elem` and the caller's array may go away
+    if (!ws->combo_valid[buf]) {
+        HIP_OK(hipMemsetAsync(ws->bufs[buf], 0, sizeof(double2) * (size_t)B * ws->lane_elems, ws->stream));
+        HIP_OK(hipMemsetAsync(ws->d_combo_prev[buf], 0xff, sizeof(long long) * 2 * B, ws->stream));   // -1: nothing to clear
+    }
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(launch_scatter_two(ws->bufs[buf], ws->lane_elems, B, ws->d_combo_index, ws->d_combo_coef, ws->d_combo_prev[buf], ws->stream));
+    ws->combo_valid[buf] = true;
+    return 0;
+}
+
 int aqc_ws_apply(aqc_ws* ws, int inverse, int src_buf, int dst_buf) {
     if (check_buf(ws, src_buf) || check_buf(ws, dst_buf)) return 1;
+    ws->combo_valid[dst_buf] = false;
     if (ensure_coef(ws)) return 1;
     HIP_OK(hipSetDevice(ws->device));
     return run_apply(ws, inverse != 0, src_buf, dst_buf);
@@ -1106,8 +1170,12 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
 // registered with aqc_ws_gather_setup (state 0 first).  thetas, gradients and the history stay in HBM; per evaluation
 // the host reads one flag word, per line-search trial another.
 int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double gtol, double ftol, double fid_thr, int max_backtracks,
-                 double* x_out, double* f_out, double* fidelity_out, int64_t* nit_out, int64_t* nfev_out) {
+                 int block_from, int block_to, int front_layer, double* x_out, double* f_out, double* fidelity_out, int64_t* nit_out,
+                 int64_t* nfev_out, double* weight_out, int64_t* max_no_out) {
     if (!ws || !x0 || !x_out || !f_out) return fail("null argument");
+    if (block_from < 0) { block_from = 0; block_to = ws->ctx->prog.num_blocks; }
+    if (ws->ctx->prog.num_blocks > 0 && !(0 <= block_from && block_from < block_to && block_to <= ws->ctx->prog.num_blocks))
+        return fail("invalid block_range [%d, %d)", block_from, block_to);
     if (ws->ncols != 1) return fail("the L-BFGS driver works on state-vector workspaces");
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called (flip-state indices, state 0 first)");
     if (memory < 1 || memory > 32 || maxiter < 1 || max_backtracks < 1) return fail("invalid L-BFGS parameters");
@@ -1136,7 +1204,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     LB_OK(hipMalloc((void**)&dd, nd * sizeof(double)));
     LB_OK(hipMalloc((void**)&dc, (3 * BT + 3 * BS) * sizeof(double2)));
     LB_OK(hipMalloc((void**)&di, (size_t)(3 * B + 8) * sizeof(int)));
-    LB_OK(hipMalloc((void**)&dl, (size_t)(2 * B) * sizeof(long long)));
+    LB_OK(hipMalloc((void**)&dl, (size_t)(3 * B) * sizeof(long long)));
     LB_OK(hipHostMalloc((void**)&h_flags, 8 * sizeof(int), hipHostMallocDefault));
     LB_OK(hipMemsetAsync(dd, 0, nd * sizeof(double), st_));
     LB_OK(hipMemsetAsync(di, 0, (size_t)(3 * B + 8) * sizeof(int), st_));
@@ -1152,7 +1220,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     L.f = take(B); L.slope = take(B); L.step = take(B); L.weight = take(B); L.fidelity = take(B);
     double* ft = take(B);
     L.rho = take((size_t)B * memory);
-    L.lead_hm = take(2 * (size_t)B);
+    (void)take(2 * (size_t)B);
     double* f_acc = take(2 * (size_t)B);
     L.cur_g0 = dc; L.acc_g0 = dc + BT;
     double2* raw_g0_t = dc + 2 * BT;
@@ -1161,17 +1229,18 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     L.active = di; L.done = di + B; L.max_no = di + 2 * B;
     int* d_flags = di + 3 * B;
     L.nit = dl;
-    long long* d_prev = dl + B;
+    long long* d_prev = dl + B;   // [B][2]: positions of X2 written by the previous evaluation
     {   // weight = 1, max_no = 0, active = 1, X2 empty
         std::vector<double> ones(B, 1.0);
         std::vector<int> one_i(B, 1);
-        std::vector<long long> neg(2 * (size_t)B, 0);
-        for (int b = 0; b < B; ++b) neg[B + b] = -1;
+        std::vector<long long> neg(3 * (size_t)B, 0);
+        for (int b = 0; b < 2 * B; ++b) neg[B + b] = -1;
         LB_OK(hipMemcpyAsync(L.weight, ones.data(), sizeof(double) * B, hipMemcpyHostToDevice, st_));
         LB_OK(hipMemcpyAsync(L.active, one_i.data(), sizeof(int) * B, hipMemcpyHostToDevice, st_));
-        LB_OK(hipMemcpyAsync(dl, neg.data(), sizeof(long long) * 2 * B, hipMemcpyHostToDevice, st_));
+        LB_OK(hipMemcpyAsync(dl, neg.data(), sizeof(long long) * 3 * B, hipMemcpyHostToDevice, st_));
         LB_OK(hipMemcpyAsync(L.x, x0, sizeof(double) * BT, hipMemcpyHostToDevice, st_));
         LB_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st_));
+        ws->combo_valid[AQC_BUF_X2] = false;
         LB_OK(hipStreamSynchronize(st_));
     }
     int64_t nfev = 0;
@@ -1180,21 +1249,16 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
         HIP_OK(hipStreamSynchronize(st_));
         return 0;
     };
-    // f, g at the point in the workspace's theta buffer; raw results to (raw_hs, raw_g0)
-    auto evaluate = [&](int update, double* f_o, double* g_o, double2* raw_hs, double2* raw_g0) -> int {
+    // f, g at the point in the workspace's theta buffer; raw results to (raw_hs, raw_g).  V^H, the amplitudes, the lane's
+    // combined lhs state (lb_prepare) and ONE sweep from it -- no host round trip inside an evaluation.
+    auto evaluate = [&](int update, double* f_o, double* g_o, double2* raw_hs, double2* raw_g) -> int {
         ws->d_thetas = ws->d_thetas_own;
         if (run_coef(ws)) return 1;
         if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
-        if (aqc_ws_grad_from(ws, AQC_BUF_X, -1, -1, 1)) return 1;
-        HIP_OK(hipMemsetAsync(d_flags, 0, sizeof(int), st_));
-        HIP_OK(lb_assemble1(L, ws->d_small, ws->d_grads, update, f_o, g_o, raw_hs, raw_g0, d_flags, st_));
-        if (read_flags()) return 1;
-        if (h_flags[0]) {   // some lane leads with a flip state other than |state_0>: second sweep from it
-            HIP_OK(lb_set_basis(L, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
-            if (aqc_ws_grad_from(ws, AQC_BUF_X2, -1, -1, 1)) return 1;
-            HIP_OK(lb_assemble2(L, ws->d_grads, g_o, st_));
-        }
+        HIP_OK(lb_prepare(L, ws->d_small, update, f_o, raw_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
+        if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
+        HIP_OK(lb_take(L, ws->d_grads, g_o, raw_g, st_));
         ++nfev;
         return 0;
     };
@@ -1225,8 +1289,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
             LB_OK(hipMemcpyAsync(ws->d_thetas_own, L.x_new, sizeof(double) * BT, hipMemcpyDeviceToDevice, st_));
             LB_TRY(evaluate(1, f_acc, g_acc, L.acc_hs, L.acc_g0));
         } else {
-            LB_OK(hipMemsetAsync(d_flags, 0, sizeof(int), st_));
-            LB_OK(lb_assemble1(L, L.acc_hs, L.acc_g0, 1, f_acc, g_acc, nullptr, nullptr, d_flags, st_));
+            LB_OK(lb_commit0(L, L.acc_hs, L.acc_g0, f_acc, g_acc, st_));
         }
         LB_OK(lb_history(L, count, ftol, f_acc, g_acc, st_));
         ++count;
@@ -1235,7 +1298,11 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     LB_OK(hipMemcpyAsync(f_out, L.f, sizeof(double) * B, hipMemcpyDeviceToHost, st_));
     if (fidelity_out) LB_OK(hipMemcpyAsync(fidelity_out, L.fidelity, sizeof(double) * B, hipMemcpyDeviceToHost, st_));
     if (nit_out) LB_OK(hipMemcpyAsync(nit_out, L.nit, sizeof(long long) * B, hipMemcpyDeviceToHost, st_));
+    if (weight_out) LB_OK(hipMemcpyAsync(weight_out, L.weight, sizeof(double) * B, hipMemcpyDeviceToHost, st_));
+    std::vector<int> h_max_no(B, 0);
+    if (max_no_out) LB_OK(hipMemcpyAsync(h_max_no.data(), L.max_no, sizeof(int) * B, hipMemcpyDeviceToHost, st_));
     LB_OK(hipStreamSynchronize(st_));
+    if (max_no_out) for (int b = 0; b < B; ++b) max_no_out[b] = h_max_no[b];
     if (nfev_out) *nfev_out = nfev;
     cleanup();
 #undef LB_OK
@@ -1614,6 +1681,7 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
     double2* rbuf[2] = {lbuf[1] + need_l, lbuf[1] + need_l + need_r};
     double2* g = rbuf[1] + need_r;
     double2* out = ws->bufs[buf] + (size_t)lane * ws->lane_elems;
+    ws->combo_valid[buf] = false;
     // left part: L_q[idx + 2^q b][chi'] = sum_chi L[idx][chi] T_q[b][chi][chi']; site 0 is L_0 = T_0 viewed as (2 x chi_1)
     const double2* L = m.d_t;
     for (int q = 1; q < h; ++q) {
@@ -1707,6 +1775,38 @@ int aqc_ws_vdot_fetch(aqc_ws* ws, double* out) {
     HIP_OK(hipSetDevice(ws->device));
     HIP_OK(hipMemcpyAsync(out, ws->d_vdot_out, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+// Results of the evaluation just enqueued -> pinned host memory, asynchronously on the workspace's stream (what an optimizer
+// on the host consumes every evaluation: gradients, gathered amplitudes, <A|B>); aqc_ws_results_fetch waits and hands them out.
+int aqc_ws_results_async(aqc_ws* ws) {
+    if (!ws) return fail("null workspace");
+    HIP_OK(hipSetDevice(ws->device));
+    const size_t nth = (size_t)ws->batch * ws->ctx->prog.num_thetas();
+    double* pin_gr = ws->h_pin + ws->pin_thetas;
+    double* pin_sm = pin_gr + ws->pin_grads;
+    HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+    if (ws->gather_count > 0 && 2 * (size_t)ws->batch * ws->gather_count <= ws->pin_small)
+        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * (size_t)ws->batch * ws->gather_count, hipMemcpyDeviceToHost, ws->stream));
+    else if (ws->d_vdot_out && 2 * (size_t)ws->batch <= ws->pin_small)
+        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_vdot_out, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
+    return 0;
+}
+
+int aqc_ws_results_fetch(aqc_ws* ws, double* small_out, double* grads_out) {
+    if (!ws) return fail("null workspace");
+    HIP_OK(hipSetDevice(ws->device));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    const size_t nth = (size_t)ws->batch * ws->ctx->prog.num_thetas();
+    const double* pin_gr = ws->h_pin + ws->pin_thetas;
+    const double* pin_sm = pin_gr + ws->pin_grads;
+    if (grads_out) memcpy(grads_out, pin_gr, sizeof(double2) * nth);
+    if (small_out) {
+        const size_t count = ws->gather_count > 0 ? (size_t)ws->gather_count : 1;
+        if (2 * (size_t)ws->batch * count > ws->pin_small) return fail("gathered amplitudes do not fit the staging buffer");
+        memcpy(small_out, pin_sm, sizeof(double2) * (size_t)ws->batch * count);
+    }
     return 0;
 }
 

@@ -400,6 +400,20 @@ __global__ void scatter_one_kernel(cplx* buf, size_t lane_stride, int batch, con
     if (b < batch) buf[(size_t)b * lane_stride + (size_t)elem[b]] = make_double2(1.0, 0.0);
 }
 
+// lane b: clear the two positions written last time, then buf[elem[2b]] = coef[2b], buf[elem[2b+1]] = coef[2b+1] (elem < 0: none)
+__global__ void scatter_two_kernel(cplx* buf, size_t lane_stride, int batch, const long long* elem, const cplx* coef, long long* prev) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    cplx* x = buf + (size_t)b * lane_stride;
+    for (int k = 0; k < 2; ++k)
+        if (prev[2 * b + k] >= 0) x[(size_t)prev[2 * b + k]] = make_double2(0.0, 0.0);
+    for (int k = 0; k < 2; ++k) {
+        const long long e = elem[2 * b + k];
+        if (e >= 0) x[(size_t)e] = coef[2 * b + k];
+        prev[2 * b + k] = e;
+    }
+}
+
 __global__ void set_identity_kernel(cplx* buf, size_t lane_stride, int dim, int pitch, int batch) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (size_t)batch * dim) {
@@ -515,6 +529,11 @@ hipError_t launch_finalize(const void* partial, const int* theta_slots, const in
 
 hipError_t launch_scatter_one(void* buf, size_t lane_stride, int batch, const long long* elem, hipStream_t s) {
     scatter_one_kernel<<<(batch + 63) / 64, 64, 0, s>>>(static_cast<cplx*>(buf), lane_stride, batch, elem);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_two(void* buf, size_t lane_stride, int batch, const long long* elem, const void* coef, long long* prev, hipStream_t s) {
+    scatter_two_kernel<<<(batch + 63) / 64, 64, 0, s>>>(static_cast<cplx*>(buf), lane_stride, batch, elem, static_cast<const cplx*>(coef), prev);
     return hipGetLastError();
 }
 

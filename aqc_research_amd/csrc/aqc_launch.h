@@ -39,6 +39,7 @@ hipError_t launch_finalize(const void* partial, const int* theta_slots, const in
                            int nslots, int ntiles_max, int n, int tpb, int from, int to, int front, int batch,
                            hipStream_t s, void* mirror = nullptr);   // mirror: optional pinned host copy of the result
 hipError_t launch_scatter_one(void* buf, size_t lane_stride, int batch, const long long* elem, hipStream_t s);
+hipError_t launch_scatter_two(void* buf, size_t lane_stride, int batch, const long long* elem, const void* coef, long long* prev, hipStream_t s);
 hipError_t launch_set_identity(void* buf, size_t lane_stride, int dim, int pitch, int batch, hipStream_t s);
 hipError_t launch_gather(const void* buf, size_t lane_stride, const long long* elem, int count, int batch, void* out,
                          hipStream_t s, void* mirror = nullptr);
@@ -100,16 +101,16 @@ struct LbState {
     double *Smem, *Ymem, *rho;    // history [memory][B][T], [memory][B]
     int *active, *done;
     long long* nit;
-    double *weight, *fidelity, *lead_hm;   // objective state: smoothed weight, |h_0|^2, coefficient of the second sweep
+    double *weight, *fidelity;   // objective state: smoothed weight, |h_0|^2
     int* max_no;
-    double2 *cur_hs, *cur_g0;     // raw device results of the current point (re-assembled at a state update)
+    double2 *cur_hs, *cur_g0;     // raw device results of the current point: amplitudes, complex gradient of its one sweep
     double2 *acc_hs, *acc_g0;     // ... of the accepted trial points
 };
-hipError_t lb_assemble1(const LbState& st, const void* hs, const void* g0, int update, double* f_out, double* g_out, void* raw_hs,
-                        void* raw_g0, int* flags, hipStream_t s);
-hipError_t lb_assemble2(const LbState& st, const void* gm, double* g_out, hipStream_t s);
+hipError_t lb_prepare(const LbState& st, const void* hs, int update, double* f_out, void* raw_hs, void* x2, size_t lane_stride,
+                      const long long* index, long long* prev, hipStream_t s);
+hipError_t lb_take(const LbState& st, const void* grads, double* g_out, void* raw_g, hipStream_t s);
 hipError_t lb_probe(const LbState& st, const void* hs, int* flags, hipStream_t s);
-hipError_t lb_set_basis(const LbState& st, void* x2, size_t lane_stride, const long long* index, long long* prev, hipStream_t s);
+hipError_t lb_commit0(const LbState& st, const void* hs, const void* raw_g, double* f_out, double* g_out, hipStream_t s);
 hipError_t lb_active(const LbState& st, double gtol, double fid_thr, int* flags, hipStream_t s);
 hipError_t lb_direction(const LbState& st, int count, hipStream_t s);
 hipError_t lb_trial(const LbState& st, double* thetas, hipStream_t s);

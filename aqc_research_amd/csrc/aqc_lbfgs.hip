@@ -41,75 +41,80 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     return t;
 }
 
-// First half of an evaluation: from the gathered amplitudes hs[b][S] and the complex gradient g0[b][T] of the sweep
-// from |state_0>: optional state update (hysteresis, weight smoothing), value, the |state_0> part of the gradient,
-// raw copies for a later commit; flags[0] |= some lane leads with a flip state (second sweep needed).
-__global__ __launch_bounds__(kLbThreads) void lb_assemble1_kernel(LbState st, const cplx* hs, const cplx* g0, int update, double* f_out,
-                                                                 double* g_out, cplx* raw_hs, cplx* raw_g0, int* flags) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    const cplx* h = hs + (size_t)b * st.S;
-    int max_no = st.max_no[b];
-    double w = st.weight[b];
-    if (update) {   // objective_lhs_sur_max.py:113-117 (10 % hysteresis) and :186 (weight smoothing), every thread alike
-        double best = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
-        for (int i = 0; i < st.S; ++i) {
-            const double v = h[i].x * h[i].x + h[i].y * h[i].y;
-            if (1.1 * best < v) { best = v; max_no = i; }
-        }
-        const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
-        const double f_old = 1.0 - (1.0 - w) * h0 - w * hm;
-        w = w + 0.1 * (sqrt(fabs(f_old)) - w);
-    }
-    const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
-    const bool lead = max_no != 0;
-    const double coef = lead ? -2.0 * (1.0 - w) : -2.0;   // grad = Re(g0 * coef * conj(h0)) [+ Re(gm * (-2 w) conj(hm))]
-    const double cr = coef * h[0].x, ci = -coef * h[0].y;
-    for (int i = t; i < st.T; i += blockDim.x) {
-        const cplx g = g0[(size_t)b * st.T + i];
-        g_out[(size_t)b * st.T + i] = g.x * cr - g.y * ci;
-        if (raw_g0) raw_g0[(size_t)b * st.T + i] = g;
-    }
-    if (raw_hs) for (int i = t; i < st.S; i += blockDim.x) raw_hs[(size_t)b * st.S + i] = h[i];
-    __syncthreads();   // every thread has read the old state
-    if (t == 0) {
-        f_out[b] = 1.0 - (1.0 - w) * h0 - w * hm;
-        if (update) { st.max_no[b] = max_no; st.weight[b] = w; st.fidelity[b] = h0; }
-        st.lead_hm[2 * b] = lead ? -2.0 * w * h[max_no].x : 0.0;   // coefficient of the second sweep's gradient
-        st.lead_hm[2 * b + 1] = lead ? 2.0 * w * h[max_no].y : 0.0;
-        if (lead) atomicOr(&flags[0], 1);
-    }
-}
-// Second half, lanes that lead with a flip state: grad += Re(gm * (-2 w conj(h_max)))
-__global__ __launch_bounds__(kLbThreads) void lb_assemble2_kernel(LbState st, const cplx* gm, double* g_out) {
-    const int b = blockIdx.x;
-    const double cr = st.lead_hm[2 * b], ci = st.lead_hm[2 * b + 1];
-    if (cr == 0.0 && ci == 0.0) return;
-    for (int i = threadIdx.x; i < st.T; i += blockDim.x) {
-        const cplx g = gm[(size_t)b * st.T + i];
-        g_out[(size_t)b * st.T + i] += g.x * cr - g.y * ci;
-    }
-}
-// Probe of the state update on the accepted points (no change of state): flags[1] |= some lane WOULD lead with a flip state
-__global__ void lb_probe_kernel(LbState st, const cplx* hs, int* flags) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= st.B) return;
-    const cplx* h = hs + (size_t)b * st.S;
-    int max_no = st.max_no[b];
+// State update of one lane from its amplitudes: 10 % hysteresis on the leading flip state and the smoothed weight
+// (objective_lhs_sur_max.py:113-117, :186).
+__device__ __forceinline__ void lb_update(const cplx* h, int S, int& max_no, double& w) {
     double best = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
-    for (int i = 0; i < st.S; ++i) {
+    for (int i = 0; i < S; ++i) {
         const double v = h[i].x * h[i].x + h[i].y * h[i].y;
         if (1.1 * best < v) { best = v; max_no = i; }
     }
-    if (max_no != 0) atomicOr(&flags[1], 1);
+    const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
+    const double f_old = 1.0 - (1.0 - w) * h0 - w * hm;
+    w = w + 0.1 * (sqrt(fabs(f_old)) - w);
 }
-// One-hot |state_max_no> per lane in buffer X2 (clears the previous position)
-__global__ void lb_set_basis_kernel(LbState st, cplx* x2, size_t lane_stride, const long long* index, long long* prev) {
+
+// First half of an evaluation (one thread per lane): from the gathered amplitudes hs[b][S] the optional state update, the
+// value, and the lhs state of the lane's ONE sweep.  The surrogate's gradient is Re(c_0 g_0 + c_max g_max) with
+// c_0 = -2 (1 - w) conj(h_0) (-2 conj(h_0) while |state_0> leads), c_max = -2 w conj(h_max), g_s the complex gradient of
+// the sweep from |state_s> (objective_lhs_sur_max.py:147-191).  That gradient is conjugate-linear in the lhs state, so the
+// sum is the gradient of the sweep from conj(c_0)|state_0> + conj(c_max)|state_max>: the two amplitudes go into X2 here
+// (the previous call's positions are cleared), and the sweep that follows delivers the combination directly.
+__global__ void lb_prepare_kernel(LbState st, const cplx* hs, int update, double* f_out, cplx* raw_hs, cplx* x2, size_t lane_stride,
+                                  const long long* index, long long* prev) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= st.B) return;
-    const long long now = index[st.max_no[b]];
-    if (prev[b] >= 0) x2[(size_t)b * lane_stride + (size_t)prev[b]] = make_double2(0.0, 0.0);
-    x2[(size_t)b * lane_stride + (size_t)now] = make_double2(1.0, 0.0);
-    prev[b] = now;
+    const cplx* h = hs + (size_t)b * st.S;
+    int max_no = st.max_no[b];
+    double w = st.weight[b];
+    if (update) lb_update(h, st.S, max_no, w);
+    const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
+    const bool lead = max_no != 0;
+    f_out[b] = 1.0 - (1.0 - w) * h0 - w * hm;
+    if (update) { st.max_no[b] = max_no; st.weight[b] = w; st.fidelity[b] = h0; }
+    cplx* x = x2 + (size_t)b * lane_stride;
+    for (int k = 0; k < 2; ++k)
+        if (prev[2 * b + k] >= 0) x[(size_t)prev[2 * b + k]] = make_double2(0.0, 0.0);
+    const double k0 = lead ? -2.0 * (1.0 - w) : -2.0;
+    const long long i0 = index[0], im = lead ? index[max_no] : -1;
+    x[(size_t)i0] = make_double2(k0 * h[0].x, k0 * h[0].y);                      // conj(c_0) = k0 h_0
+    if (lead) x[(size_t)im] = make_double2(-2.0 * w * h[max_no].x, -2.0 * w * h[max_no].y);   // conj(c_max) = -2 w h_max
+    prev[2 * b] = i0; prev[2 * b + 1] = im;
+    if (raw_hs) for (int i = 0; i < st.S; ++i) raw_hs[(size_t)b * st.S + i] = h[i];
+}
+// Second half: the real gradient and a copy of the complex one
+__global__ void lb_take_kernel(LbState st, const cplx* grads, double* g_out, cplx* raw_g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)st.B * st.T) return;
+    const cplx g = grads[i];
+    g_out[i] = g.x;
+    if (raw_g) raw_g[i] = g;
+}
+// Probe of the state update on the accepted points (no change of state): flags[1] |= some lane leads with a flip state now
+// or WOULD after the update -- the accepted points' gradients then have to be swept again under the new state
+__global__ void lb_probe_kernel(LbState st, const cplx* hs, int* flags) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    int max_no = st.max_no[b];
+    double w = st.weight[b];
+    const bool lead_now = max_no != 0;
+    lb_update(hs + (size_t)b * st.S, st.S, max_no, w);
+    if (lead_now || max_no != 0) atomicOr(&flags[1], 1);
+}
+// State update at the accepted points while |state_0> leads everywhere (before and after): the value 1 - |h_0|^2 and the
+// gradient Re(-2 conj(h_0) g_0) do not depend on the weight, so the raw results of the accepted trials are final
+__global__ void lb_commit0_kernel(LbState st, const cplx* hs, const cplx* raw_g, double* f_out, double* g_out) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const cplx* h = hs + (size_t)b * st.S;
+    for (int i = t; i < st.T; i += blockDim.x) g_out[(size_t)b * st.T + i] = raw_g[(size_t)b * st.T + i].x;
+    if (t == 0) {
+        int max_no = st.max_no[b];
+        double w = st.weight[b];
+        lb_update(h, st.S, max_no, w);
+        const double h0 = h[0].x * h[0].x + h[0].y * h[0].y;
+        f_out[b] = 1.0 - h0;
+        st.max_no[b] = max_no; st.weight[b] = w; st.fidelity[b] = h0;
+    }
 }
 
 // active &= max|g| > gtol [and fidelity < thr]; flags[2] |= some lane is active
@@ -255,21 +260,22 @@ __global__ __launch_bounds__(kLbThreads) void lb_history_kernel(LbState st, int 
 
 }  // namespace
 
-hipError_t lb_assemble1(const LbState& st, const void* hs, const void* g0, int update, double* f_out, double* g_out, void* raw_hs,
-                        void* raw_g0, int* flags, hipStream_t s) {
-    lb_assemble1_kernel<<<st.B, kLbThreads, 0, s>>>(st, (const cplx*)hs, (const cplx*)g0, update, f_out, g_out, (cplx*)raw_hs, (cplx*)raw_g0, flags);
+hipError_t lb_prepare(const LbState& st, const void* hs, int update, double* f_out, void* raw_hs, void* x2, size_t lane_stride,
+                      const long long* index, long long* prev, hipStream_t s) {
+    lb_prepare_kernel<<<(st.B + 63) / 64, 64, 0, s>>>(st, (const cplx*)hs, update, f_out, (cplx*)raw_hs, (cplx*)x2, lane_stride, index, prev);
     return hipGetLastError();
 }
-hipError_t lb_assemble2(const LbState& st, const void* gm, double* g_out, hipStream_t s) {
-    lb_assemble2_kernel<<<st.B, kLbThreads, 0, s>>>(st, (const cplx*)gm, g_out);
+hipError_t lb_take(const LbState& st, const void* grads, double* g_out, void* raw_g, hipStream_t s) {
+    const size_t n = (size_t)st.B * st.T;
+    lb_take_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(st, (const cplx*)grads, g_out, (cplx*)raw_g);
     return hipGetLastError();
 }
 hipError_t lb_probe(const LbState& st, const void* hs, int* flags, hipStream_t s) {
     lb_probe_kernel<<<(st.B + 63) / 64, 64, 0, s>>>(st, (const cplx*)hs, flags);
     return hipGetLastError();
 }
-hipError_t lb_set_basis(const LbState& st, void* x2, size_t lane_stride, const long long* index, long long* prev, hipStream_t s) {
-    lb_set_basis_kernel<<<(st.B + 63) / 64, 64, 0, s>>>(st, (cplx*)x2, lane_stride, index, prev);
+hipError_t lb_commit0(const LbState& st, const void* hs, const void* raw_g, double* f_out, double* g_out, hipStream_t s) {
+    lb_commit0_kernel<<<st.B, kLbThreads, 0, s>>>(st, (const cplx*)hs, (const cplx*)raw_g, f_out, g_out);
     return hipGetLastError();
 }
 hipError_t lb_active(const LbState& st, double gtol, double fid_thr, int* flags, hipStream_t s) {

@@ -107,9 +107,10 @@ class HipContext:
 class Workspace:
     """``batch`` independent evaluations resident in HBM (aqc_ws_*)."""
 
-    def __init__(self, ctx: HipContext, batch: int = 1, ncols: int = 1, device: int = 0,
+    def __init__(self, ctx: HipContext, batch: int = 1, ncols: int = 1, device: Optional[int] = None,
                  tile_bits_apply: int = 0, tile_bits_sweep: int = 0):
-        self.ctx, self.batch, self.ncols, self.device = ctx, int(batch), int(ncols), int(device)
+        device = default_device() if device is None else int(device)   # one process per GPU: LOCAL_RANK's device
+        self.ctx, self.batch, self.ncols, self.device = ctx, int(batch), int(ncols), device
         self.dim = 1 << ctx.num_qubits
         self.T = ctx.num_thetas
         self._L = _lib.lib()
@@ -158,9 +159,19 @@ class Workspace:
             check(self._L.aqc_ws_download_lane(self.handle, buf, lane, dptr(res)))
         return res
 
+    def copy_lane_from(self, src: "Workspace", src_buf: int, src_lane: int, dst_buf: int, dst_lane: int) -> None:
+        """this.dst_buf[dst_lane] <- src.src_buf[src_lane], device to device (targets that are already resident)."""
+        check(self._L.aqc_ws_copy_lane(self.handle, dst_buf, dst_lane, src.handle, src_buf, src_lane))
+
     def set_basis(self, buf: int, index) -> None:
         idx = np.ascontiguousarray(np.broadcast_to(np.asarray(index, dtype=np.int64), (self.batch,)))
         check(self._L.aqc_ws_set_basis(self.handle, buf, idx.ctypes.data_as(ctypes.POINTER(c_int64))))
+
+    def set_combo(self, buf: int, index, coef) -> None:
+        """buffer[lane] = coef[lane][0] |index[lane][0]> + coef[lane][1] |index[lane][1]>  (index[lane][1] < 0: one term)."""
+        idx = np.ascontiguousarray(np.asarray(index, dtype=np.int64).reshape(self.batch, 2))
+        cf = np.ascontiguousarray(np.asarray(coef, dtype=np.complex128).reshape(self.batch, 2))
+        check(self._L.aqc_ws_set_combo(self.handle, buf, idx.ctypes.data_as(ctypes.POINTER(c_int64)), dptr(cf)))
 
     def set_identity(self, buf: int) -> None:
         check(self._L.aqc_ws_set_identity(self.handle, buf))
@@ -238,6 +249,17 @@ class Workspace:
         out = np.empty(self.batch, dtype=np.complex128)
         check(self._L.aqc_ws_vdot_fetch(self.handle, dptr(out)))
         return out
+
+    def results_async(self) -> None:
+        """Enqueue the copies of this evaluation's gradients and gathered amplitudes (or <A|B>) into pinned host memory."""
+        check(self._L.aqc_ws_results_async(self.handle))
+
+    def results_fetch(self, small: bool = True, grads: bool = True):
+        """Wait for the stream; returns (gathered amplitudes / <A|B> or None, gradients or None) of the last results_async."""
+        hs = np.empty((self.batch, max(self._gather_count, 1)), dtype=np.complex128) if small else None
+        g = np.empty((self.batch, self.T), dtype=np.complex128) if grads else None
+        check(self._L.aqc_ws_results_fetch(self.handle, None if hs is None else dptr(hs), None if g is None else dptr(g)))
+        return hs, g
 
     def sync(self) -> None:
         check(self._L.aqc_ws_sync(self.handle))

@@ -25,20 +25,14 @@ def _job_function_wrapper(job_index: int, config: Dict, seed: int, job_function:
         result = job_function(job_index, config)
         result.update({"time": perf_counter() - tic, "status": "ok", "job_index": job_index, "seed": seed})
     except Exception:
-        print(f"exception in job={job_index},\n", flush=True)
-        result = {"time": float(-1), "status": traceback.format_exc(), "job_index": job_index, "seed": seed}
+        status = traceback.format_exc()
+        # printed HERE, on the rank that ran the job: a fixed-size record of the final gather cannot carry the text
+        print(f"exception in job={job_index}:\n{status}", flush=True)
+        result = {"time": float(-1), "status": status, "job_index": job_index, "seed": seed}
     finally:
         sys.stderr.flush()
         sys.stdout.flush()
     return result
-
-
-def _dist():
-    """An initialised torch.distributed group with more than one rank, else None (torch is never imported here)."""
-    dist = sys.modules.get("torch.distributed")
-    if dist is None:
-        return None
-    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
 
 
 def local_device() -> int:

@@ -53,7 +53,14 @@ class LaneView:
 
     def set_basis(self, buf: int, index) -> None:
         with self._owner._cv:
-            self._owner._basis[buf][self.lane] = int(np.asarray(index).ravel()[0])
+            self._owner._combo_idx[buf][self.lane] = (int(np.asarray(index).ravel()[0]), -1)
+            self._owner._combo_coef[buf][self.lane] = (1.0, 0.0)
+            self._owner._basis_dirty[buf] = True
+
+    def set_combo(self, buf: int, index, coef) -> None:
+        with self._owner._cv:
+            self._owner._combo_idx[buf][self.lane] = np.asarray(index, dtype=np.int64).ravel()[:2]
+            self._owner._combo_coef[buf][self.lane] = np.asarray(coef, dtype=np.complex128).ravel()[:2]
             self._owner._basis_dirty[buf] = True
 
     def gather_setup(self, index) -> None:
@@ -95,17 +102,19 @@ class LaneView:
 class LockstepBatch:
     """``nlanes`` independent clients of one ``nlanes``-lane workspace, served round by round."""
 
-    def __init__(self, circ, nlanes: int, device: int = 0):
+    def __init__(self, circ, nlanes: int, device: Optional[int] = None):
         if nlanes < 1:
             raise ValueError("nlanes must be positive")
-        self.ws = Workspace(HipContext.of(circ), batch=int(nlanes), ncols=1, device=int(device))
+        self.ws = Workspace(HipContext.of(circ), batch=int(nlanes), ncols=1, device=device)
         self.nlanes = int(nlanes)
         self._cv = threading.Condition(threading.RLock())
         self._pending: Dict[int, _Request] = {}
         self._results: Dict[int, Any] = {}
         self._active = 0
         self._thetas = np.zeros((self.nlanes, self.ws.T))
-        self._basis = {b: np.zeros(self.nlanes, dtype=np.int64) for b in (BUF_X, BUF_X2)}
+        # lhs state of every lane as a two-term combination of basis states (one term: second index -1)
+        self._combo_idx = {b: np.tile(np.array([0, -1], dtype=np.int64), (self.nlanes, 1)) for b in (BUF_X, BUF_X2)}
+        self._combo_coef = {b: np.tile(np.array([1.0, 0.0], dtype=np.complex128), (self.nlanes, 1)) for b in (BUF_X, BUF_X2)}
         self._basis_dirty = {BUF_X: True, BUF_X2: True}
         self._gather_idx: Optional[np.ndarray] = None
         self._error: Optional[BaseException] = None
@@ -147,7 +156,11 @@ class LockstepBatch:
             for sig in sorted(groups, key=lambda s: (not s[0], repr(s))):
                 vdag, gather, grad, x_buf, br, front = sig
                 if grad and self._basis_dirty.get(x_buf, False):
-                    self.ws.set_basis(x_buf, self._basis[x_buf])
+                    idx, cf = self._combo_idx[x_buf], self._combo_coef[x_buf]
+                    if (idx[:, 1] < 0).all() and (cf[:, 0] == 1.0).all():
+                        self.ws.set_basis(x_buf, idx[:, 0].copy())
+                    else:
+                        self.ws.set_combo(x_buf, idx, cf)
                     self._basis_dirty[x_buf] = False
                 hs, g = self.ws.eval(self._thetas, vdag=vdag, gather=gather, grad=grad, x_buf=x_buf,
                                      block_range=br, front_layer=front)
@@ -203,7 +216,7 @@ def run_jobs_lockstep(
     job_function: Callable[[int, Dict, LaneView], Dict],
     *,
     nlanes: int = 64,
-    device: int = 0,
+    device: Optional[int] = None,
 ) -> List[Dict]:
     """``run_jobs`` for jobs that share the ansatz ``circ`` (e.g. the seeds of one time horizon):
     chunks of ``nlanes`` jobs advance in lockstep on one GPU.  ``job_function(job_index, config,

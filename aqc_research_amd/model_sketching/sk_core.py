@@ -121,7 +121,7 @@ class SketchingObjectiveEx:
     gradient amplifier are duck-typed host objects."""
 
     def __init__(self, circ: ParametricCircuit, skvecs: SketchingVectorsBase, *, enable_stats: bool = False,
-                 grad_scaler=None, stop_timeout=None, stop_stagnant=None, stop_small_fobj=None, logger=None, device: int = 0,
+                 grad_scaler=None, stop_timeout=None, stop_stagnant=None, stop_small_fobj=None, logger=None, device=None,
                  column_shard: bool = False):
         if not isinstance(skvecs, SketchingVectorsBase):
             raise TypeError("skvecs must derive from SketchingVectorsBase")

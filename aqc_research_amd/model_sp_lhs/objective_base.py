@@ -131,7 +131,7 @@ class SpService:
 
     def on_end_gradient(self, fobj: float, fidelity: float, grad: np.ndarray, hs2: np.ndarray, weight: float):
         self._num_grad_ev += 1
-        if self._stats:
+        if "hs2" in self._stats:   # enabled by enable_optim_stats (callers may add keys of their own to the dictionary)
             s = self._stats
             s["hs2"] = np.vstack((s["hs2"], hs2.astype(np.float16)[None, :]))
             s["weight"] = np.append(s["weight"], np.float16(weight))
@@ -204,7 +204,7 @@ class SpLHSObjectiveBase:
         if self._native_mps:
             pass
         elif self._ws is None:
-            self._ws = Workspace(HipContext.of(circuit), batch=1, ncols=1, device=int(user_parameters.get("device", 0)))
+            self._ws = Workspace(HipContext.of(circuit), batch=1, ncols=1, device=user_parameters.get("device"))
         elif self._ws.T != circuit.num_thetas or self._ws.dim != circuit.dimension:
             raise ValueError("user_parameters['workspace'] belongs to a different ansatz")
 

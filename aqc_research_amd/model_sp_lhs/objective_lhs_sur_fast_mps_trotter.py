@@ -52,9 +52,15 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
             return
         from ..mps_engine import DeviceMPS
 
-        self._target_dev = DeviceMPS.from_qiskit(target, device=int(self._params.get("device", 0)))
+        self._target_dev = DeviceMPS.from_qiskit(target, device=self._mps_device())
         self._vh = None
         self._basis_dev = {}
+
+    def _mps_device(self) -> int:
+        from ..engine import default_device
+
+        d = self._params.get("device")
+        return default_device() if d is None else int(d)
 
     # ---- native MPS mode: no dense state anywhere (objective_lhs_sur_fast_mps_trotter.py:114-227) ----------
     def _basis(self, state_no: int):
@@ -62,7 +68,7 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
 
         if state_no not in self._basis_dev:
             self._basis_dev[state_no] = DeviceMPS.basis_state(self._circuit.num_qubits, int(self._state_handler.state_indices[state_no]),
-                                                              device=int(self._params.get("device", 0)))
+                                                              device=self._mps_device())
         return self._basis_dev[state_no]
 
     def _evaluate(self, thetas) -> None:
@@ -84,3 +90,9 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
 
         return fast_dot_gradient_mps(self._circuit, self._last_thetas, self._basis(state_no), self._vh, trunc_thr=self._trunc_thr,
                                      block_range=self._block_range, front_layer=front)
+
+    def _sweep_combined(self, c_0: complex, c_max: complex, front: bool):
+        if not self._native_mps:
+            return super()._sweep_combined(c_0, c_max, front)
+        # native MPS engine: the two product-state sweeps of the reference (a combined lhs would be a bond-2 MPS)
+        return c_0 * self._sweep(0, front) + c_max * self._sweep(self._max_no, front)

@@ -77,10 +77,13 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
             self._hs[:] = self._projections()
             self._grad0 = None
         else:
-            hs, g = ws.eval(thetas, vdag=True, gather=True, grad=self._speculative, x_buf=BUF_X,
+            # the sweep from |state_0> rides along only while |state_0> leads: otherwise gradient() runs ONE sweep from the
+            # combination of |state_0> and the leading state (see gradient), and a speculative one would be wasted
+            spec = self._speculative and self._max_no == 0
+            hs, g = ws.eval(thetas, vdag=True, gather=True, grad=spec, x_buf=BUF_X,
                             block_range=self._block_range, front_layer=front)
             self._hs[:] = hs[0]
-            self._grad0 = g[0] if self._speculative else None
+            self._grad0 = g[0] if spec else None
 
     def objective(self, thetas: np.ndarray) -> float:
         if self._target is None:
@@ -116,17 +119,34 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
             self._x2_state = state_no
         return ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=self._block_range, front_layer=front)[1][0]
 
+    def _sweep_combined(self, c_0: complex, c_max: complex, front: bool) -> np.ndarray:
+        """c_0 g(|state_0>) + c_max g(|state_max>) as one sweep from the combined lhs state."""
+        ws = self._ws
+        self._grad0 = None
+        if self._dense:
+            x = np.conj(c_0) * self._state_handler.init_state(0) + np.conj(c_max) * self._state_handler.init_state(self._max_no)
+            ws.upload(BUF_X, x)
+            ws.grad(self._block_range, front)
+            return ws.get_grads()[0]
+        idx = self._state_handler.state_indices
+        ws.set_combo(BUF_X2, [[int(idx[0]), int(idx[self._max_no])]], [[np.conj(c_0), np.conj(c_max)]])
+        self._x2_state = -1
+        return ws.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=self._block_range, front_layer=front)[1][0]
+
     def gradient(self, thetas: np.ndarray) -> np.ndarray:
         self._service.on_begin_gradient(self._fobj, thetas, self._fidelity)  # may raise (stoppers)
         self._calc_objective_before_gradient(thetas)
         front = bool(self._front_layer or self._block_range == (0, self._circuit.num_blocks))
-        grad_0 = self._sweep(0, front)
         if self._max_no == 0:
+            grad_0 = self._sweep(0, front)
             full_grad = (grad_0 * (-2 * np.conj(self._hs[0]))).real.copy()
         else:
-            full_grad = (grad_0 * (-2 * (1 - self._weight) * np.conj(self._hs[0]))).real.copy()
-            grad_max = self._sweep(self._max_no, front)
-            full_grad += (grad_max * (-2 * self._weight * np.conj(self._hs[self._max_no]))).real
+            # objective_lhs_sur_max.py:147-175 runs two sweeps and combines them as c_0 g_0 + c_max g_max.  The gradient of
+            # <V x|y> is conjugate-linear in x, so that sum IS the gradient from x = conj(c_0)|state_0> + conj(c_max)|state_max>:
+            # one sweep, the same number up to rounding in the last place
+            c_0 = -2 * (1 - self._weight) * np.conj(self._hs[0])
+            c_max = -2 * self._weight * np.conj(self._hs[self._max_no])
+            full_grad = self._sweep_combined(c_0, c_max, front).real.copy()
         if self._grad_scaler:
             full_grad *= self._grad_scaler.estimate(self._fobj)
         self._weight += self._gamma * (float(np.sqrt(abs(self._fobj))) - self._weight)

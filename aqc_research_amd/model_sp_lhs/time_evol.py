@@ -30,7 +30,7 @@ class UserOptions:
         self.fidelity_thr = 0.9999
         self.time_limit = -1
         self.seed = 1234
-        self.device = 0
+        self.device = None                  # None: this rank's GPU (LOCAL_RANK under a one-process-per-GPU launcher)
         self.num_seeds = 1                 # random restarts per horizon (lockstep lanes of one workspace)
         self.theta_jitter = 0.1            # restart s > 0 starts from Trotter angles + jitter * pi * U(-1, 1)
         self.vectorised_lbfgs = False      # restarts driven by ONE vectorised L-BFGS (batched_optimizer.py) instead of scipy per lane

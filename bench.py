@@ -163,53 +163,96 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
     }
 
 
+# ---- config 4: the ASP job mix ---------------------------------------------------------------------------------------
+# What a horizon's jobs share stays resident between them (time_evol_best_init.py:337-382 builds everything per job): the
+# ansatz context and its plans (HipContext cache), ONE batched objective per (horizon, lanes) whose lanes are the seeds of a
+# job, and the synthetic targets, which live in a target bank on the device and reach an objective's lanes by
+# device-to-device copies (in a real run they are synthesised on the device, model_sp_lhs/trotter).
+_MIX = {"setup": {}, "pool": {}, "bank": {}, "objective": {}}
+
+
+def _mix_setup(n, h):
+    """(ansatz, Trotter-initialised parameters, Neel index) of horizon h: 2nd-order Trotter ansatz with 2h layers."""
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index, trotter_ansatz
+
+    if (n, h) not in _MIX["setup"]:
+        circ = trotter_ansatz(n, 2 * h, True)
+        base = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=1.2 * h, delta=1.0)
+        _MIX["setup"][(n, h)] = (circ, base, neel_state_index(n))
+    return _MIX["setup"][(n, h)]
+
+
+def _mix_pool(n):
+    """8 synthetic targets, utils.rand_state(n) (uniform[0,1) + i uniform[0,1), normalised; utils.py:71-79), seed 0x696969."""
+    from oracle import aqc_oracle as orc
+
+    if n not in _MIX["pool"]:
+        prng = np.random.default_rng(0x696969)
+        _MIX["pool"][n] = [orc.rand_state(n, prng) for _ in range(8)]
+    return _MIX["pool"][n]
+
+
+def _mix_target(n, seed):
+    return _mix_pool(n)[seed % 8]
+
+
+def _mix_start(base, seed):
+    return base + 0.1 * np.pi * (2.0 * np.random.default_rng(seed).random(base.size) - 1.0)
+
+
 def _mix_job(job_index, cfg):
-    """One entry of the config-4 mix: `seeds` restarts of horizon h as lanes of one batched objective, `evals`
+    """One entry of the config-4 mix: the seeds of the entry are the lanes of one batched objective of horizon h; `evals`
     objective+gradient pairs with a fixed-step descent between them (time_evol_best_init.py:197-208's inner loop with the
     optimizer's line search left out: the workload is the evaluations)."""
     from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective
-    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index, trotter_ansatz
-    from oracle import aqc_oracle as orc
+    from aqc_research_amd.engine import BUF_Y, HipContext, Workspace
 
-    n, h, seeds = cfg["n"], cfg["horizon"], cfg["seeds"]
-    circ = trotter_ansatz(n, 2 * h, True)
-    base = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=1.2 * h, delta=1.0)
-    # synthetic targets: rand_state(20) costs ~60 ms of host time each, 30 s for the mix -- not part of the path.  A pool of
-    # 8 states is drawn once per process; a job's target is a pool state rotated by its seed (still a normalised
-    # uniform[0,1) + i uniform[0,1) state, different for every job)
-    pool = _mix_job.__dict__.setdefault("pool", {})
-    if n not in pool:
-        prng = np.random.default_rng(0x696969)
-        pool[n] = [orc.rand_state(n, prng) for _ in range(8)]
-    targets, starts = [], []
-    for sd in seeds:
-        rng = np.random.default_rng(sd)
-        targets.append(np.roll(pool[n][sd % 8], sd % (1 << n)))
-        starts.append(base + 0.1 * np.pi * (2.0 * rng.random(base.size) - 1.0))
-    bo = BatchedSurrogateObjective(circ, np.stack(targets), base_index=neel_state_index(n), device=cfg["device"])
-    th = np.stack(starts)
+    n, h, seeds, device = cfg["n"], cfg["horizon"], cfg["seeds"], cfg["device"]
+    circ, base, neel = _mix_setup(n, h)
+    if (n, device) not in _MIX["bank"]:   # the target bank: a workspace of the shallowest ansatz whose Y lanes hold the pool
+        bank = Workspace(HipContext.of(_mix_setup(n, 1)[0]), batch=8, device=device)
+        bank.upload(BUF_Y, np.stack(_mix_pool(n)))
+        _MIX["bank"][(n, device)] = bank
+    bank = _MIX["bank"][(n, device)]
+    key = (n, h, len(seeds), device)
+    if key not in _MIX["objective"]:
+        _MIX["objective"][key] = BatchedSurrogateObjective(circ, None, lanes=len(seeds), base_index=neel, device=device)
+    bo = _MIX["objective"][key]
+    bo.reset_state()
+    for lane, sd in enumerate(seeds):
+        bo.target_from(lane, bank, BUF_Y, sd % 8)
+    th = np.stack([_mix_start(base, sd) for sd in seeds])
     f = None
     for _ in range(cfg["evals"]):
         f, g = bo.value_and_grad(th)
         th = th - 0.05 * g
-    fid = bo.fidelity.copy()
-    bo.close()
-    return {"cost": float(np.mean(f)), "fidelity": float(np.mean(fid)), "num_iters": cfg["evals"],
+    return {"cost": float(np.mean(f)), "fidelity": float(np.mean(bo.fidelity)), "num_iters": cfg["evals"],
             "num_fun_ev": cfg["evals"] * len(seeds), "num_grad_ev": cfg["evals"] * len(seeds), "thetas": th[0]}
+
+
+def _mix_release():
+    for kind in ("objective", "bank"):
+        for o in _MIX[kind].values():
+            o.close()
+        _MIX[kind].clear()
 
 
 def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note):
     """--workload cfg4_jobs: the whole mix through run_jobs (rank-sharded, fixed-size record gather)."""
     from aqc_research_amd.job_executor import run_jobs
 
-    chunk = 8   # seeds per job: config index = horizon * (seeds / chunk) + chunk index, so every rank sees every horizon
-    nchunks = w["seeds"] // chunk
+    # one entry = (horizon, a chunk of the 64 seeds); entry index = horizon * chunks + chunk and run_jobs puts entry j on
+    # rank j % world, so with chunks = world every rank works on every horizon (the horizons differ 8x in depth)
+    nchunks = max(1, comm.size)
+    while w["seeds"] % nchunks:
+        nchunks += 1
+    chunk = w["seeds"] // nchunks
     configs = [{"n": w["n"], "horizon": h, "evals": w["evals"], "device": local_rank,
                 "seeds": [0x696969 + 7 * (c * chunk + s + 1) + 1000 * h for s in range(chunk)]}
                for h in range(1, w["horizons"] + 1) for c in range(nchunks)]
     K, W = max(1, min(args.steps, 3)), min(args.warmup, 1)
-    for _ in range(W):
-        run_jobs(configs[: comm.size * 2], 1, _mix_job, records="fixed")   # warm-up: contexts, plans, first launches
+    for _ in range(W):   # warm-up: contexts, plans, objectives and first launches of every horizon (2 evaluation pairs each)
+        run_jobs([dict(c, evals=2) for c in configs], 1, _mix_job, records="fixed")
     comm.barrier()
     t0 = time.perf_counter()
     results = None
@@ -219,6 +262,7 @@ def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note):
     wall = time.perf_counter() - t0
     if comm.size > 1:
         wall = float(comm.allreduce(np.array([wall]), "max")[0])
+    _mix_release()
     ok = [r for r in results if r["status"].startswith("ok")]
     njobs = w["seeds"] * w["horizons"]
     evals = njobs * w["evals"]
@@ -229,8 +273,135 @@ def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note):
         "config": {"workload": w["desc"], "n_qubits": w["n"], "jobs": njobs, "jobs_per_s": njobs * K / wall, "evals_per_job": w["evals"],
                    "records_ok": len(ok), "records_total": len(results), "mean_fidelity": float(np.mean([r["fidelity"] for r in ok])),
                    "transport": comm.transport if comm_note is None else comm_note,
-                   "sharding": "run_jobs: config j on rank j % world, 8 seeds per config as lanes of one batched objective"},
+                   "lanes_per_entry": chunk, "entries": len(configs),
+                   "sharding": "run_jobs: entry j = (horizon j // chunks, seed chunk j % chunks) on rank j % world; chunks = world, so "
+                               "every rank holds every horizon; the seeds of an entry are the lanes of one batched objective",
+                   "evaluation": "V^H + flip-state amplitudes + ONE sweep from the combined lhs state per lane (aqc_ws_set_combo)"},
     }
+
+
+def launch_ranks(n_ranks, argv):
+    """`bench.py --gpus N` started as ONE plain process: it becomes the launcher -- N fresh child processes of this script,
+    one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / AQC_COMM_FILE in their environment, exactly what
+    torch.distributed.run would set), rank 0's JSON line relayed.  The launcher itself never touches the GPU (no HIP call,
+    no library of the package loaded) and never replaces itself by another program.  Non-zero exit if any rank fails; the
+    other ranks are terminated then (a dead rank would otherwise leave them waiting in a collective until its time-out)."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tmp = tempfile.mkdtemp(prefix="aqc_bench_")
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AQC_COMM_FILE=os.path.join(tmp, "rccl_unique_id"),
+                   AQC_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc, out0 = 0, b""
+    try:
+        pending = set(range(n_ranks))
+        while pending and rc == 0:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if code != 0:
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                    rc = code if code > 0 else 1
+            if pending and rc == 0:
+                if 0 in pending:   # keep rank 0's pipe drained (one line; it cannot fill, but do not rely on that)
+                    pass
+                time.sleep(0.05)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        for q in procs:
+            try:
+                q.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                q.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
+    if rc == 0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+    return rc
+
+
+def objective_object_rates(circ, targets, rng, device):
+    """Evaluations per second through the objective objects a user of the reference holds (one evaluation = one
+    objective(theta) + gradient(theta) pair on the object, objective_lhs_sur_max.py:82-191, consumed by optimizer.py:579-590):
+    the drop-in SpSurrogateObjectiveMax under AqcOptimizer(lbfgs) (one lane, host optimizer), the lane-batched surrogate's
+    value_and_grad (64 lanes) and the device-resident multi-start L-BFGS on it."""
+    from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax
+    from aqc_research_amd.optimizer import AqcOptimizer
+
+    n, T = circ.num_qubits, circ.num_thetas
+    out = {}
+    user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: 0, enable_optim_stats=False, verbose=0, maxiter=40, device=device)
+    objv = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+    objv.set_target(targets[0])
+    th0 = 0.2 * np.pi * (2 * rng.random(T) - 1)
+    AqcOptimizer(optimizer_name="lbfgs", maxiter=3).optimize(objv, circ, th0)   # warm-up (graph capture, first launches)
+    t0 = time.perf_counter()
+    res = AqcOptimizer(optimizer_name="lbfgs", maxiter=40).optimize(objv, circ, th0)
+    dt = time.perf_counter() - t0
+    out["SpSurrogateObjectiveMax_under_AqcOptimizer_lbfgs"] = {"lanes": 1, "evals_per_s": res["num_fun_ev"] / dt, "pairs": int(res["num_fun_ev"]),
+                                                              "seconds": dt, "final_fidelity": float(res["fidelity"])}
+    lanes = min(64, targets.shape[0])
+    bo = BatchedSurrogateObjective(circ, targets[:lanes], base_index=0, device=device)
+    th = 0.2 * np.pi * (2 * rng.random((lanes, T)) - 1)
+    f, g = bo.value_and_grad(th)
+    t0 = time.perf_counter()
+    calls = 0
+    while calls < 20 or time.perf_counter() - t0 < 0.5:
+        th = th - 0.05 * g
+        f, g = bo.value_and_grad(th)
+        calls += 1
+    dt = time.perf_counter() - t0
+    out["BatchedSurrogateObjective_value_and_grad"] = {"lanes": lanes, "evals_per_s": calls * lanes / dt, "calls": calls, "seconds": dt,
+                                                     "lanes_led_by_a_flip_state": int((bo.max_no != 0).sum())}
+    bo.reset_state()
+    bo.minimize_on_device(th, maxiter=2)   # warm-up
+    bo.reset_state()
+    t0 = time.perf_counter()
+    dev = bo.minimize_on_device(th, maxiter=20)
+    dt = time.perf_counter() - t0
+    out["minimize_on_device"] = {"lanes": lanes, "evals_per_s": dev["nfev"] * lanes / dt, "batched_evaluations": dev["nfev"], "seconds": dt,
+                                 "mean_fidelity": float(np.mean(dev["fidelity"]))}
+    bo.close()
+    return out
+
+
+def rank_echo(args):
+    """Launcher self-test (CPU, no HIP): every rank joins a gloo group from its environment and rank 0 prints who is there."""
+    real_stdout = os.dup(1)   # one JSON line on stdout, library chatter to stderr (as in main)
+    os.dup2(2, 1)
+    import torch.distributed as dist
+
+    if os.environ.get("AQC_BENCH_ECHO_FAIL_RANK") == os.environ.get("RANK"):
+        os._exit(7)   # launcher self-test: this rank dies before the rendezvous
+    dist.init_process_group(backend="gloo")
+    seen = [None] * dist.get_world_size()
+    dist.all_gather_object(seen, (int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), os.environ.get("AQC_COMM_FILE", "")))
+    if dist.get_rank() == 0:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"n_gpus": args.gpus, "world_size": dist.get_world_size(), "ranks_seen": sorted(r for r, _, _ in seen),
+                          "local_ranks": sorted(l for _, l, _ in seen), "comm_files": len({f for _, _, f in seen})}), flush=True)
+        os.dup2(2, 1)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -242,7 +413,14 @@ def main():
     ap.add_argument("--workload", default="sv16_l40", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--rank-echo", action="store_true", help=argparse.SUPPRESS)   # launcher self-test: no GPU work, see tests/
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained-rate loop after the timed one (0 = off)")
+    ap.add_argument("--no-objective-object", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.rank_echo:
+        return rank_echo(args)
     if os.environ.get("AQC_DEBUG_SKIP"):   # a work-skipping switch of tuning builds: never time with it
         raise SystemExit("bench.py: AQC_DEBUG_SKIP is set; refusing to time a run that may skip work")
 
@@ -253,11 +431,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Process group: one rank per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
-    # environment).  The transport is aqc_comm -- librccl bound directly through the C ABI, no torch in the process.
-    # AQC_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than ranks (ranks share a device, records
-    # travel over the gloo test double); AQC_BENCH_BACKEND=torch-nccl forces the torch.distributed nccl backend.  If the
-    # direct binding cannot initialise, the run falls back to torch.distributed nccl and says so in `config.transport`.
+    # Process group: one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, set by launch_ranks
+    # above or by torch.distributed.run).  The transport is aqc_comm -- librccl bound directly through the C ABI, no torch
+    # in the process; if it cannot initialise the run FAILS (non-zero exit).  AQC_BENCH_BACKEND=gloo is the rehearsal mode
+    # for boxes with fewer GPUs than ranks: ranks share a device and the records travel over the test double of tests/.
     from aqc_research_amd import comm as aqc_comm
 
     comm = aqc_comm.Communicator()
@@ -265,39 +442,27 @@ def main():
     if world > 1 or os.environ.get("AQC_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("AQC_BENCH_BACKEND", "rccl")
-
-        def torch_group(name):
-            import torch
+        if backend == "gloo":
             import torch.distributed as dist
 
-            ndev = max(1, torch.cuda.device_count())
-            if name == "nccl":
-                if local_rank >= ndev:
-                    raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible")
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(backend=name)
-            return aqc_comm.GlooDouble(dist)
+            from tests.gloo_double import GlooDouble
 
-        if backend == "gloo":
-            comm = torch_group("gloo")
-        elif backend == "torch-nccl":
-            comm = torch_group("nccl")
-        else:
+            dist.init_process_group(backend="gloo")
+            comm = GlooDouble(dist)
+        elif backend == "rccl":
             try:
-                os.environ.setdefault("WORLD_SIZE", "1")
                 if world > 1:
-                    comm = aqc_comm.from_environment(prefer="rccl")
+                    comm = aqc_comm.from_environment()
                 else:   # AQC_BENCH_FORCE_DIST=1 on one rank: a one-rank RCCL communicator (init + collectives exercised)
                     import tempfile
 
                     comm = aqc_comm.RcclCommunicator(0, 1, local_rank, os.path.join(tempfile.gettempdir(), f"aqc_comm_id_bench_{os.getpid()}"))
-            except Exception as exc:  # loud fall-back: the record gather must not take the scaling run down
-                comm_note = f"aqc_comm (direct RCCL) failed to initialise: {exc}; fell back to torch.distributed nccl"
-                print("bench.py: " + comm_note, file=sys.stderr)
-                comm = torch_group("nccl")
-        aqc_comm._current = comm
+            except Exception as exc:
+                print(f"bench.py: rank {rank}: aqc_comm (direct RCCL) failed to initialise: {exc}", file=sys.stderr)
+                os._exit(5)
+        else:
+            raise SystemExit(f"bench.py: unknown AQC_BENCH_BACKEND {backend!r} (rccl | gloo)")
+        aqc_comm.use(comm)
     from aqc_research_amd import _lib as aqc_lib
 
     ndev = aqc_lib.lib().aqc_device_count()
@@ -307,10 +472,14 @@ def main():
         if os.environ.get("AQC_BENCH_BACKEND", "rccl") != "gloo":
             raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible")
         local_rank %= ndev   # rehearsal: ranks share devices
-    n_gpus = max(args.gpus, world) if world > 1 else args.gpus
-    if world == 1 and args.gpus > 1:
-        print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU); running 1 GPU", file=sys.stderr)
-        n_gpus = 1
+    n_gpus = world
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    # who is really there: every rank's id through the communicator (one all-gather) -> config.ranks_seen
+    ranks_seen = sorted(int(v) for v in comm.allgather(np.array([float(rank)]))[:, 0]) if comm.size > 1 else [0]
+    if ranks_seen != list(range(world)):
+        print(f"bench.py: rank {rank}: the process group holds ranks {ranks_seen}, expected 0..{world - 1}", file=sys.stderr)
+        os._exit(6)
 
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, HipContext, Workspace
     from oracle import aqc_oracle as orc
@@ -318,6 +487,7 @@ def main():
     w = WORKLOADS[args.workload]
     if w["kind"] == "jobs":
         out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note)
+        out["config"]["ranks_seen"] = ranks_seen
         if rank == 0:
             sys.stdout.flush()
             os.dup2(real_stdout, 1)
@@ -376,6 +546,7 @@ def main():
         else:
             ws.vdot_launch(BUF_X, BUF_Z)  # <X|V^H Y>  (sk_core.py:192)
         ws.grad(None, True)
+        ws.results_async()   # gradients + amplitudes of THIS step -> pinned host memory (what an optimizer reads every evaluation)
 
     def barrier():
         ws.sync()          # every launch of this rank's stream has completed (the path does not use torch's stream)
@@ -402,8 +573,30 @@ def main():
         wall = float(comm.allreduce(np.array([wall]), "max")[0])
 
     # result record of the last step (checked + gathered: the only inter-GPU traffic)
-    hs = ws.gather_fetch() if ncols == 1 else ws.vdot_fetch().reshape(B, 1)
-    grads = ws.get_grads()
+    hs, grads = ws.results_fetch()   # the host copies the last timed step delivered
+    hs = hs.reshape(B, -1)
+
+    # sustained rate: the same step for >= --sustain-seconds of wall clock after the driver-sized loop (power / clock settling)
+    sustained = None
+    if args.sustain_seconds > 0:
+        barrier()
+        t1 = time.perf_counter()
+        done_steps = 0
+        while True:
+            for i in range(50):
+                step(W + K + done_steps + i)
+            done_steps += 50
+            ws.sync()
+            flag = np.array([1.0 if time.perf_counter() - t1 < args.sustain_seconds else 0.0])
+            if comm.size > 1:
+                comm.allreduce(flag, "max")   # all ranks stop after the same number of steps
+            if flag[0] == 0.0:
+                break
+        barrier()
+        t_sus = time.perf_counter() - t1
+        if comm.size > 1:
+            t_sus = float(comm.allreduce(np.array([t_sus]), "max")[0])
+        sustained = (done_steps * B * n_gpus / t_sus, t_sus, done_steps)
     # the shipped gather: one fixed-size record {cost, fidelity, counts, thetas[T]} per lane through run_jobs' own
     # packing + ONE all-gather over the communicator (job_executor._gather_records)
     from aqc_research_amd import job_executor as jex
@@ -464,6 +657,8 @@ def main():
         mfma_tflops = None
         if ws.kernel_family(1) == 3 and sweep_ms > 0:
             mfma_tflops = 288.0 * N * B * ws.plan_substages(1) * prof_steps / (sweep_ms * 1e-3) / 1e12
+        exec_tflops = mfma_tflops if mfma_tflops is not None else sweep_tflops
+        exec_flops_per_launch = (288.0 * N * B * ws.plan_substages(1) * prof_steps / max(sweep_launches, 1)) if mfma_tflops is not None else sweep_flops_per_launch
         stages_inv, k_inv, tiles_inv = ws.plan_info(0)
         stages_sw, k_sw, tiles_sw = ws.plan_info(1)
 
@@ -489,17 +684,24 @@ def main():
             latency_rounds = rounds
             ws1.close()
 
+        # ---- the metric as SURVEY 8(d) words it: objective(theta) + gradient(theta) on the objective OBJECT ----------------
+        objective_object = None
+        if not args.no_objective_object and ncols == 1 and not chi:
+            objective_object = objective_object_rates(circ, targets, rng, local_rank)
+
         # measured HBM traffic of the dominant kernel (rocprofv3 --pmc passes, tools/pmc_summary.py), if the
         # committed profile was taken on this workload / batch
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pj.get("workload") == args.workload and pj.get("batch_per_gpu") == B:
                 for kname, kv in pj["kernels"].items():
                     if "sweep_stage_kernel" in kname or "sweep_mfma_kernel" in kname:
                         traffic = kv["hbm_bytes_per_launch"]
+                        traffic_source = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_run3.py, "
+                                          f"committed as profiles/pmc_traffic.json ({pj.get('date', 'undated')}, {pj.get('source', 'builder-run')})")
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         evals = K * B * n_gpus
         value = evals / wall
         out = {
@@ -527,27 +729,33 @@ def main():
                 "columns": ncols,
                 "transport": comm.transport if comm_note is None else comm_note,
                 "records_gathered": len(gathered),
+                "ranks_seen": ranks_seen,
+                "launcher": os.environ.get("AQC_BENCH_LAUNCHER", "external" if world > 1 else "none"),
                 "tile_bits": {"vdag": k_inv, "sweep": k_sw},
                 "launches_per_eval_step": {"vdag": stages_inv, "sweep": stages_sw},
             },
-            # The sweep launches fuse many gate groups per HBM round trip, so what bounds them is fp64 arithmetic, not
-            # HBM: achieved = SURVEY 8(d)'s useful flops of one sweep launch / its average duration (HIP events on the
-            # workspace stream), against the 78.6 TFLOP/s fp64 peak (vector = matrix on gfx950).
+            # The sweep launches fuse many gate groups per HBM round trip, so what bounds them is fp64 arithmetic on the matrix
+            # cores, not HBM.  `achieved` = flops the matrix pipe EXECUTED in one sweep launch (288 real flops per amplitude
+            # and sub-stage: 9 real 16x16x16 products per 256 amplitudes) / its average duration (HIP events on the
+            # workspace stream), against the 78.6 TFLOP/s fp64 MFMA peak: a true bound, frac <= 1 on every workload.
+            # SURVEY 8(d)'s gate-by-gate flop count (what the reference's algorithm would spend) rides along as
+            # `algorithmic_*`; it is NOT a bound for a kernel that fuses whole gate groups into one 16 x 16 unitary.
             "roofline": {
-                "bound": ws.family_name(),
+                "bound": "mfma",
                 "kernel": ws.sweep_kernel_name(),
-                "achieved": sweep_tflops,
+                "achieved": exec_tflops,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": sweep_tflops / FP64_PEAK_TFLOPS,
+                "frac": exec_tflops / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_launch_ms": sweep_avg_ms,
-                "flops_per_launch": sweep_flops_per_launch,
-                # what the matrix pipe really executed: 288 real flops per amplitude and sub-stage (9 real 16x16x16
-                # products per 256 amplitudes).  `achieved` above counts SURVEY 8d's gate-by-gate flops, so frac can
-                # exceed this figure -- and 1 -- when one 16 x 16 unitary absorbs many gates (Trotter triplets).
-                "mfma_issue_TFLOPs": mfma_tflops,
-                "mfma_issue_frac": mfma_tflops / FP64_PEAK_TFLOPS if mfma_tflops is not None else None,
+                "flops_per_launch": exec_flops_per_launch,
+                "flop_convention": "executed MFMA flops (288 per amplitude and sub-stage)" if mfma_tflops is not None else
+                                   "SURVEY 8d gate-by-gate flops (VALU kernel family: no fused unitaries)",
+                "algorithmic_TFLOPs": sweep_tflops,
+                "algorithmic_frac": sweep_tflops / FP64_PEAK_TFLOPS,
+                "algorithmic_note": "SURVEY 8d unfused flop count / launch time; not a bound (exceeds 1 when one unitary absorbs many gates)",
                 "substages": {"vdag": ws.plan_substages(0), "sweep": ws.plan_substages(1)},
             },
             # byte view of the same launches (information only: SURVEY 8d's per-gate-group byte model is not a lower
@@ -572,6 +780,11 @@ def main():
                 "frac": N * (108.0 * (G - n) + 74.0 * n) * value / n_gpus / 1e12 / FP64_PEAK_TFLOPS,
                 "flops_per_eval": N * (108.0 * (G - n) + 74.0 * n),
             },
+            "sustained_evals_per_s": None if sustained is None else sustained[0],
+            "sustained": None if sustained is None else {"seconds": sustained[1], "steps": sustained[2]},
+            "results_to_host": "every timed step ends with asynchronous copies of its gradients (batch x T complex128) and amplitudes "
+                               "into pinned host memory on the workspace stream (aqc_ws_results_async); the last step's copies are the checked ones",
+            "objective_object": objective_object,
             "kernel_ms_per_step": {k: v[1] / prof_steps for k, v in prof.items()},
             "device_ms_per_step_events": ev_ms / K,
             "latency_batch1_ms": latency,

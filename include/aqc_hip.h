@@ -91,7 +91,14 @@ int aqc_ws_broadcast(aqc_ws* ws, int buf, const double* src /* [2^n][ncols] c128
 int aqc_ws_download(aqc_ws* ws, int buf, double* dst);
 int aqc_ws_download_lane(aqc_ws* ws, int buf, int lane, double* dst);
 /* X_lane <- one-hot basis state |index[lane]>  (ThinStateHandler.init_state, objective_base.py:99-116) */
+/* dst_ws.buf[dst_lane] <- src_ws.buf[src_lane] on the device (same device, same lane size; asynchronous on dst's stream) */
+int aqc_ws_copy_lane(aqc_ws* dst_ws, int dst_buf, int dst_lane, aqc_ws* src_ws, int src_buf, int src_lane);
 int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index /* [batch] */);
+/* buffer[lane] = coef[lane][0] |index[lane][0]> + coef[lane][1] |index[lane][1]> (index[lane][1] < 0: one term).  The
+ * gradient of <V x|y> is conjugate-linear in x, so the two sweeps of the surrogate objective (|state_0> and the leading
+ * flip state, objective_lhs_sur_max.py:147-155,167-175) combined as c_0 g_0 + c_max g_max are ONE sweep from
+ * x = conj(c_0) |state_0> + conj(c_max) |state_max>. */
+int aqc_ws_set_combo(aqc_ws* ws, int buf, const int64_t* index /* [batch][2] */, const double* coef /* [batch][2] c128 */);
 /* X <- identity matrix (FullRangeSketchingVectors.generate, sk_core.py:317-326); needs ncols == 2^n */
 int aqc_ws_set_identity(aqc_ws* ws, int buf);
 /* dst <- V src (inverse=0) or V^H src (inverse=1), per lane, with the lane's thetas */
@@ -127,6 +134,12 @@ int aqc_ws_gather_launch(aqc_ws* ws, int buf);
 int aqc_ws_gather_fetch(aqc_ws* ws, double* out /* [batch][count] c128 */);
 int aqc_ws_vdot_launch(aqc_ws* ws, int buf_a, int buf_b);
 int aqc_ws_vdot_fetch(aqc_ws* ws, double* out /* [batch] c128 */);
+/* what the optimizer on the host reads after every evaluation (optimizer.py:579-590 consumes objective(theta) and
+ * gradient(theta)): aqc_ws_results_async enqueues the copies of the gradients and of the gathered amplitudes (or of <A|B>
+ * after aqc_ws_vdot_launch) into pinned host memory behind the kernels already on the stream, without synchronising;
+ * aqc_ws_results_fetch waits for the stream and hands them out (either pointer may be NULL). */
+int aqc_ws_results_async(aqc_ws* ws);
+int aqc_ws_results_fetch(aqc_ws* ws, double* small_out /* [batch][count] c128 */, double* grads_out /* [batch][T] c128 */);
 
 /* ---- MPS helpers (state-vector workspaces only).  An MPS arrives in the reference's QiskitMPS
  * layout (mps_operations.py:33,87-123): site q has Gamma^0, Gamma^1 of shape (dims[q], dims[q+1]),
@@ -234,10 +247,14 @@ int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bi
 
 /* ---- device-resident multi-start L-BFGS on the lane-batched surrogate objective: one optimisation per lane, thetas /
  * gradients / history stay in HBM (stand-in for the scipy L-BFGS-B behind AqcOptimizer.optimize, optimizer.py:579-590,
- * on objective_lhs_sur_max.py:82-191).  Preconditions: targets in buffer Y, |state_0> one-hot in X, flip-state indices
- * registered with aqc_ws_gather_setup (state 0 first).  x0 / x_out: [batch][T]; f / fidelity / nit: [batch]. */
+ * on objective_lhs_sur_max.py:82-191).  Preconditions: targets in buffer Y, flip-state indices registered with
+ * aqc_ws_gather_setup (state 0 first); buffer X2 is used for the lhs states.  An evaluation is V^H, the amplitudes and ONE
+ * sweep from conj(c_0)|state_0> + conj(c_max)|state_max> (see aqc_ws_set_combo).  block_from / block_to / front_layer as in
+ * aqc_ws_grad (block_from < 0: all blocks).  x0 / x_out: [batch][T]; f / fidelity / nit / weight / max_no: [batch]; the
+ * last two are the objective's state at exit (smoothed weight, index of the leading state), either may be NULL. */
 int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double gtol, double ftol, double fid_thr,
-                 int max_backtracks, double* x_out, double* f_out, double* fidelity_out, int64_t* nit_out, int64_t* nfev_out);
+                 int max_backtracks, int block_from, int block_to, int front_layer, double* x_out, double* f_out,
+                 double* fidelity_out, int64_t* nit_out, int64_t* nfev_out, double* weight_out, int64_t* max_no_out);
 
 /* ---- multi-GPU: the one collective layer of the path, bound straight to librccl (RCCL over xGMI; loaded lazily).
  * One process per GPU; jobs are sharded over the ranks (job_executor.py:136-143: joblib processes in the reference) and

@@ -121,6 +121,7 @@ def test_column_sharded_aqc_objective_two_ranks(tmp_path):
         from aqc_research_amd.circuit_structures import create_ansatz_structure
         from aqc_research_amd.model_sketching.sk_core import FullRangeSketchingVectors, SketchingObjectiveEx
         dist.init_process_group(backend="gloo")
+        from tests.gloo_double import install; install(dist)
         n = 5
         circ = ParametricCircuit(n, "cz", create_ansatz_structure(n, "spin", "full", 11))
         rng = np.random.default_rng(42)

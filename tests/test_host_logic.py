@@ -45,6 +45,7 @@ def test_run_jobs_gloo_world2(tmp_path):
         import numpy as np, torch.distributed as dist
         from aqc_research_amd.job_executor import run_jobs
         dist.init_process_group(backend="gloo")
+        from tests.gloo_double import install; install(dist)
         def job(i, cfg):
             return {{"value": cfg["a"] + np.random.rand(), "rank": dist.get_rank(), "arr": np.arange(cfg["a"] + 1)}}
         res = run_jobs([{{"a": i}} for i in range(7)], 5, job)
@@ -273,6 +274,7 @@ def test_run_jobs_fixed_records_gloo_world2(tmp_path):
         from aqc_research_amd.job_executor import run_jobs
         from aqc_research_amd import comm
         dist.init_process_group(backend="gloo")
+        from tests.gloo_double import install; install(dist)
         def job(i, cfg):
             if cfg["a"] == 3:
                 raise ValueError("boom")
@@ -302,3 +304,58 @@ def test_run_jobs_fixed_records_gloo_world2(tmp_path):
         np.random.seed(11 + 7 * (i + 1))
         assert r[1] == 11 + 7 * (i + 1) and r[3] == 0.5 * i and r[4] == i
         assert np.allclose(r[5], np.arange(i + 2, dtype=float) + np.random.rand(), atol=0, rtol=0)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` started as ONE plain process must become N ranks (job_executor.py:136-143 fans out by
+    itself too): the launcher spawns them with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / AQC_COMM_FILE set, relays rank 0's
+    single JSON line and propagates failures.  --rank-echo keeps the ranks off the GPU (a gloo group on the CPU)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rank-echo"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["world_size"] == 3 and out["ranks_seen"] == [0, 1, 2] and out["local_ranks"] == [0, 1, 2] and out["comm_files"] == 1
+    # a rank that fails takes the launch down with a non-zero exit code (the others are terminated, nothing hangs)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-echo"], capture_output=True, text=True,
+                       env=dict(env, AQC_BENCH_ECHO_FAIL_RANK="1"), timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+
+
+def test_run_jobs_fails_instead_of_hanging_when_a_rank_dies(tmp_path):
+    """A rank that dies before the final gather must fail the job list on the survivors (here: the gloo double's collective
+    raises after its time-out), not leave them waiting forever (job_executor.py:149-159 reports failures, it never hangs)."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, datetime
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np, torch.distributed as dist
+        from aqc_research_amd.job_executor import run_jobs
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=8))
+        from tests.gloo_double import install; install(dist)
+        def job(i, cfg):
+            if dist.get_rank() == 1:
+                os._exit(17)          # the rank dies inside its first job
+            return {{"cost": 0.0, "fidelity": 1.0, "num_iters": 1, "num_fun_ev": 1, "num_grad_ev": 1, "thetas": np.zeros(3)}}
+        try:
+            run_jobs([{{"a": i}} for i in range(4)], 3, job, records="fixed")
+        except Exception as ex:
+            open(os.path.join({str(tmp_path)!r}, "failed.txt"), "w").write(type(ex).__name__)
+            os._exit(9)
+        os._exit(0)
+    """))
+    import time as _time
+
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+    t0 = _time.time()
+    codes = [q.wait(timeout=120) for q in procs]
+    assert codes[1] == 17 and codes[0] == 9, codes          # the survivor failed loudly ...
+    assert _time.time() - t0 < 100 and (tmp_path / "failed.txt").exists()   # ... within the collective's time-out

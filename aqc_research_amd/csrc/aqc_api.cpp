@@ -1098,7 +1098,9 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     struct MirrorScope {
         aqc_ws* w;
         MirrorScope(aqc_ws* w_, double* g, double* s) : w(w_) { w->mirror_grads = g; w->mirror_small = s; }
-        ~MirrorScope() { w->mirror_grads = nullptr; w->mirror_small = nullptr; }
+        ~MirrorScope() {   // also on the error paths of enqueue(): no stale pinned thetas / riding gather in the next call
+            w->mirror_grads = nullptr; w->mirror_small = nullptr; w->theta_host = nullptr; w->gather_rides = false;
+        }
     } mirror_scope(ws, zero_copy ? pin_gr : nullptr, zero_copy ? pin_sm : nullptr);
     auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
         if (thetas) {

@@ -13,8 +13,11 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 
 #include "../../include/aqc_hip.h"
 #include "aqc_launch.h"
@@ -30,6 +33,8 @@ typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, NcclComm, hipStream_t);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
 typedef const char* (*GetErrorStringFn)(int);
+typedef int (*GetAsyncErrorFn)(NcclComm, int*);
+typedef int (*CommAbortFn)(NcclComm);
 constexpr int kNcclFloat64 = 8, kNcclSum = 0;
 
 struct Rccl {
@@ -40,6 +45,8 @@ struct Rccl {
     AllGatherFn all_gather = nullptr;
     AllReduceFn all_reduce = nullptr;
     GetErrorStringFn error_string = nullptr;
+    GetAsyncErrorFn get_async_error = nullptr;   // optional: a communicator that lost a peer reports it here
+    CommAbortFn comm_abort = nullptr;            // optional: tears a communicator down without waiting for its peers
     std::string error;
 };
 
@@ -58,6 +65,8 @@ Rccl& rccl() {
     r.all_gather = (AllGatherFn)dlsym(r.handle, "ncclAllGather");
     r.all_reduce = (AllReduceFn)dlsym(r.handle, "ncclAllReduce");
     r.error_string = (GetErrorStringFn)dlsym(r.handle, "ncclGetErrorString");
+    r.get_async_error = (GetAsyncErrorFn)dlsym(r.handle, "ncclCommGetAsyncError");
+    r.comm_abort = (CommAbortFn)dlsym(r.handle, "ncclCommAbort");
     if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce) {
         r.error = "librccl lacks an expected symbol";
         r.handle = nullptr;
@@ -79,6 +88,7 @@ struct aqc_comm {
     hipStream_t stream = nullptr;
     double* d_buf = nullptr;   // [send | recv]
     size_t cap = 0;            // doubles
+    bool broken = false;       // a collective failed or timed out: the communicator was aborted, every later call fails at once
 };
 
 namespace {
@@ -91,6 +101,42 @@ int ensure_cap(aqc_comm* c, size_t doubles) {
     if (hipMalloc((void**)&c->d_buf, doubles * sizeof(double)) != hipSuccess) return comm_fail("hipMalloc of the staging buffer failed");
     c->cap = doubles;
     return 0;
+}
+
+// Waits for the collective enqueued on the communicator's stream WITHOUT blocking in the runtime: the stream is polled,
+// and so is the communicator's asynchronous error state.  A rank that died leaves its peers inside the collective's
+// kernel forever; after AQC_COMM_TIMEOUT_S seconds (default 300) -- or as soon as RCCL reports the failure -- the
+// communicator is aborted (ncclCommAbort), marked broken and the call returns an error, so that a job list fails
+// instead of hanging (the reference's run_jobs reports failed jobs, job_executor.py:149-159; it never waits on the dead).
+double comm_timeout_s() {
+    const char* e = getenv("AQC_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 300.0;
+}
+
+int wait_collective(aqc_comm* c, const char* what) {
+    Rccl& r = rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_s();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return 0;
+        std::string why;
+        if (q != hipErrorNotReady) why = std::string("stream error: ") + hipGetErrorString(q);
+        if (why.empty() && r.get_async_error && (spin & 63u) == 0) {
+            int async = 0;
+            const int rc = r.get_async_error(c->comm, &async);
+            if (rc != 0 || async != 0) why = std::string("RCCL reports an asynchronous error: ") + (r.error_string ? r.error_string(rc != 0 ? rc : async) : "?");
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (why.empty() && waited > limit) why = "no completion after " + std::to_string((int)limit) + " s (AQC_COMM_TIMEOUT_S): a rank has probably died";
+        if (!why.empty()) {
+            c->broken = true;
+            if (r.comm_abort && c->comm) { (void)r.comm_abort(c->comm); c->comm = nullptr; }
+            return comm_fail(std::string(what) + " did not complete -- " + why + "; the communicator was aborted");
+        }
+        if (waited > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(waited > 0.1 ? 1000 : 50));   // spin first: the records are tiny
+    }
 }
 
 }  // namespace
@@ -132,7 +178,7 @@ int aqc_comm_create(const char* id128, int nranks, int rank, int device, aqc_com
 int aqc_comm_destroy(aqc_comm* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->stream) { if (!c->broken) (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_buf) (void)hipFree(c->d_buf);
     if (c->comm) rccl().comm_destroy(c->comm);
     delete c;
@@ -145,6 +191,7 @@ int aqc_comm_size(const aqc_comm* c) { return c ? c->nranks : -1; }
 // recv[r * count + i] = send of rank r; count doubles per rank (host pointers)
 int aqc_comm_allgather(aqc_comm* c, const double* send, double* recv, size_t count) {
     if (!c || !send || !recv || count < 1) return comm_fail("invalid all-gather arguments");
+    if (c->broken) return comm_fail("the communicator was aborted after a failed collective");
     if (hipSetDevice(c->device) != hipSuccess) return comm_fail("hipSetDevice failed");
     if (ensure_cap(c, count * (size_t)(c->nranks + 1))) return 1;
     double* d_send = c->d_buf;
@@ -153,7 +200,7 @@ int aqc_comm_allgather(aqc_comm* c, const double* send, double* recv, size_t cou
     const int rc = rccl().all_gather(d_send, d_recv, count, kNcclFloat64, c->comm, c->stream);
     if (rc != 0) return nccl_fail("ncclAllGather", rc);
     if (hipMemcpyAsync(recv, d_recv, count * c->nranks * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return comm_fail("stream synchronisation failed (collective did not complete)");
+    if (wait_collective(c, "ncclAllGather")) return 1;
     return 0;
 }
 
@@ -161,13 +208,14 @@ int aqc_comm_allgather(aqc_comm* c, const double* send, double* recv, size_t cou
 int aqc_comm_allreduce(aqc_comm* c, double* data, size_t count, int op) {
     if (!c || !data || count < 1) return comm_fail("invalid all-reduce arguments");
     if (op != 0 && op != 2) return comm_fail("op must be 0 (sum) or 2 (max)");
+    if (c->broken) return comm_fail("the communicator was aborted after a failed collective");
     if (hipSetDevice(c->device) != hipSuccess) return comm_fail("hipSetDevice failed");
     if (ensure_cap(c, count)) return 1;
     if (hipMemcpyAsync(c->d_buf, data, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
     const int rc = rccl().all_reduce(c->d_buf, c->d_buf, count, kNcclFloat64, op == 0 ? kNcclSum : 2 /* ncclMax */, c->comm, c->stream);
     if (rc != 0) return nccl_fail("ncclAllReduce", rc);
     if (hipMemcpyAsync(data, c->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return comm_fail("stream synchronisation failed (collective did not complete)");
+    if (wait_collective(c, "ncclAllReduce")) return 1;
     return 0;
 }
 

@@ -159,6 +159,8 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         sweeps = status[0];
     }
     if (sweeps_out) *sweeps_out = sweeps;   // the single-launch paths deliver their count with this synchronisation
+    // every path stops at 60 sweeps; matrices of this engine converge in 6-14, so the cap means "did not converge"
+    if (cols > 1 && sweeps >= 60) return failf("Jacobi SVD: no convergence within 60 sweeps (%d x %d)", rows, cols);
     return 0;
 }
 

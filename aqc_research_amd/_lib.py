@@ -78,6 +78,7 @@ SIGNATURES = {
     "aqc_gate_dot": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int, _D, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),
+    "aqc_ws_mps_to_vec_batch": (c_int, [_P, c_int, POINTER(c_int32), c_int, POINTER(c_int32)]),
     "aqc_ws_mps_dot": (c_int, [_P, c_int, c_int, _D]),
     "aqc_ws_theta_bank": (c_int, [_P, _D, c_int]),
     "aqc_ws_use_theta_set": (c_int, [_P, c_int]),

@@ -154,6 +154,7 @@ class BatchedSurrogateObjective:
         nfev = ctypes.c_int64()
         lo, hi = (-1, -1) if self._block_range is None else self._block_range
         i64 = ctypes.POINTER(ctypes.c_int64)
+        self.ws._touch(_lib.BUF_Z, _lib.BUF_W, _lib.BUF_ZW, _lib.BUF_X2)   # rewritten by the driver
         _lib.check(self.ws._L.aqc_ws_lbfgs(self.ws.handle, _lib.dptr(x), int(maxiter), int(memory), float(gtol), float(ftol),
                                           float(fidelity_thr), int(max_backtracks), int(lo), int(hi), int(self._front),
                                           _lib.dptr(xo), _lib.dptr(f), _lib.dptr(fid), nit.ctypes.data_as(i64), ctypes.byref(nfev),

@@ -173,5 +173,6 @@ def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray, wor
     ws = HipContext.of(circ).workspace(1, target.shape[1])
     ws.upload(BUF_Y, target)
     fobj = np.zeros(1)
+    ws._touch(_lib.BUF_X, _lib.BUF_Z, _lib.BUF_W, _lib.BUF_ZW)   # rewritten by the sweep
     check(_lib.lib().aqc_ws_cd_sweep(ws.handle, dptr(thetas), dptr(fobj)))
     return float(fobj[0])

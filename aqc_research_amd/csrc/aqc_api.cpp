@@ -332,6 +332,8 @@ struct aqc_ws {
     size_t mps_lam_cap = 0;
     double2* d_mps_scratch = nullptr;
     size_t mps_scratch_cap = 0;
+    const void** d_mps_tabs = nullptr;  // device pointer tables of the batched MPS -> dense contraction (grow-only)
+    size_t mps_tabs_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     const double* theta_host = nullptr;      // aqc_ws_eval: pinned thetas the next U build reads directly (and copies to d_thetas)
     bool gather_rides = false;               // aqc_ws_eval: the next gradient walk also performs the registered gather (see there)
@@ -788,6 +790,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
     for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
+    if (ws->d_mps_tabs) (void)hipFree(ws->d_mps_tabs);
     if (ws->d_mps_lam) (void)hipFree(ws->d_mps_lam);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1}) if (ev) (void)hipEventDestroy(ev);
     if (ws->stream) (void)hipStreamDestroy(ws->stream);
@@ -1720,6 +1723,99 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
             const int chi = m.dims[h];
             HIP_OK(launch_zgemm(false, false, 1 << h, 1 << mh, chi, L, chi, Rt, 1 << mh, g, 1 << mh, ws->stream));
             HIP_OK(launch_mps_permute(g, out, h, mh, ws->stream));
+        }
+    }
+    return 0;
+}
+
+// The same contraction for `count` (slot, lane) pairs at once: MPS slots[i] -> lane lanes[i] of `buf`.  When all the slots
+// have the same bond dimensions (the lanes of a batched objective) every step of the chain is ONE launch for all lanes
+// (zgemm over device pointer tables): (n/2 - 1) + (n - n/2) + 2 launches whatever the number of lanes; otherwise the
+// pairs are served one after the other.
+int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf, const int32_t* lanes) {
+    if (!ws || !slots || !lanes || count < 1) return fail("invalid batched MPS arguments");
+    if (check_buf(ws, buf)) return 1;
+    for (int i = 0; i < count; ++i) {
+        if (check_mps_slot(ws, slots[i], true)) return 1;
+        if (lanes[i] < 0 || lanes[i] >= ws->batch) return fail("lane out of range");
+    }
+    bool uniform = true;
+    for (int i = 1; i < count; ++i) uniform = uniform && ws->mps[slots[i]].dims == ws->mps[slots[0]].dims;
+    const int n = ws->ctx->prog.n;
+    const int h = n / 2, mh = n - h;
+    if (!uniform || count == 1 || h == 0) {
+        for (int i = 0; i < count; ++i)
+            if (aqc_ws_mps_to_vec(ws, slots[i], buf, lanes[i])) return 1;
+        return 0;
+    }
+    HIP_OK(hipSetDevice(ws->device));
+    const std::vector<int>& dims = ws->mps[slots[0]].dims;
+    const std::vector<size_t>& off = ws->mps[slots[0]].offset;
+    size_t need_l = 2, need_r = 2;
+    for (int q = 0; q < h; ++q) need_l = std::max(need_l, ((size_t)2 << q) * dims[q + 1]);
+    for (int q = n - 1; q >= h; --q) need_r = std::max(need_r, ((size_t)2 << (n - 1 - q)) * dims[q]);
+    const size_t need_g = (size_t)1 << n, per = 2 * need_l + 2 * need_r + need_g;
+    if (mps_scratch(ws, per * (size_t)count)) return 1;
+    ws->combo_valid[buf] = false;
+    // pointer tables of every launch of the chain, uploaded in one copy
+    struct Step { int kind, q; size_t a, b, c; };   // offsets (in pointers) of the three tables inside the upload
+    std::vector<const void*> tabs;
+    std::vector<Step> steps;
+    auto lb = [&](int i, int k) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + need_l * (size_t)k); };
+    auto rb = [&](int i, int k) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + 2 * need_l + need_r * (size_t)k); };
+    auto gb = [&](int i) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + 2 * need_l + 2 * need_r); };
+    auto site = [&](int i, int q) { return (const void*)(ws->mps[slots[i]].d_t + off[q]); };
+    auto table = [&](auto fn) { const size_t at = tabs.size(); for (int i = 0; i < count; ++i) tabs.push_back(fn(i)); return at; };
+    for (int q = 1; q < h; ++q) {       // left part: L_q = L_{q-1} T_q, both values of the site's bit (inner = 2)
+        Step st{0, q, 0, 0, 0};
+        st.a = q == 1 ? table([&](int i) { return site(i, 0); }) : table([&](int i) { return lb(i, (q - 1) & 1); });
+        st.b = table([&](int i) { return site(i, q); });
+        st.c = table([&](int i) { return lb(i, q & 1); });
+        steps.push_back(st);
+    }
+    for (int q = n - 1; q >= h; --q) {  // right part
+        const int j = n - 1 - q;
+        Step st{j == 0 ? 1 : 2, q, 0, 0, 0};
+        st.a = table([&](int i) { return site(i, q); });
+        st.b = j == 0 ? st.a : table([&](int i) { return rb(i, (j - 1) & 1); });
+        st.c = table([&](int i) { return rb(i, j & 1); });
+        steps.push_back(st);
+    }
+    Step fin{3, 0, 0, 0, 0};
+    fin.a = h == 1 ? table([&](int i) { return site(i, 0); }) : table([&](int i) { return lb(i, (h - 1) & 1); });
+    fin.b = table([&](int i) { return rb(i, (mh - 1) & 1); });
+    fin.c = table([&](int i) { return gb(i); });
+    steps.push_back(fin);
+    Step perm{4, 0, fin.c, 0, 0};
+    perm.c = table([&](int i) { return (const void*)(ws->bufs[buf] + (size_t)lanes[i] * ws->lane_elems); });
+    steps.push_back(perm);
+    if (tabs.size() > ws->mps_tabs_cap) {
+        HIP_OK(hipStreamSynchronize(ws->stream));
+        if (ws->d_mps_tabs) HIP_OK(hipFree(ws->d_mps_tabs));
+        ws->d_mps_tabs = nullptr; ws->mps_tabs_cap = 0;
+        HIP_OK(hipMalloc((void**)&ws->d_mps_tabs, tabs.size() * sizeof(void*)));
+        ws->mps_tabs_cap = tabs.size();
+    }
+    HIP_OK(hipMemcpyAsync(ws->d_mps_tabs, tabs.data(), tabs.size() * sizeof(void*), hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));   // `tabs` goes away
+    const void* const* T = ws->d_mps_tabs;
+    ProfScope ps(ws, AQC_K_MISC);
+    for (const Step& st : steps) {
+        if (st.kind == 0) {
+            const int q = st.q, rows = 1 << q, kk = dims[q], nn = dims[q + 1];
+            HIP_OK(launch_zgemm_tables(rows, nn, kk, T + st.a, kk, T + st.b, nn, (void* const*)(T + st.c), nn, 0, (size_t)kk * nn, (size_t)rows * nn,
+                                       count, 2, ws->stream));
+        } else if (st.kind == 1) {
+            HIP_OK(launch_mps_last_site(T + st.a, (void* const*)(T + st.c), dims[st.q], count, ws->stream));
+        } else if (st.kind == 2) {
+            const int q = st.q, j = n - 1 - q, cols = 1 << j, chil = dims[q], chir = dims[q + 1];
+            HIP_OK(launch_zgemm_tables(chil, cols, chir, T + st.a, chir, T + st.b, cols, (void* const*)(T + st.c), 2 * cols, (size_t)chil * chir, 0,
+                                       (size_t)cols, count, 2, ws->stream));
+        } else if (st.kind == 3) {
+            const int chi = dims[h];
+            HIP_OK(launch_zgemm_tables(1 << h, 1 << mh, chi, T + st.a, chi, T + st.b, 1 << mh, (void* const*)(T + st.c), 1 << mh, 0, 0, 0, count, 1, ws->stream));
+        } else {
+            HIP_OK(launch_mps_permute_tables(T + st.a, (void* const*)(T + st.c), h, mh, count, ws->stream));
         }
     }
     return 0;

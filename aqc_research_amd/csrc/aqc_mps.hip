@@ -49,11 +49,20 @@ __global__ void mps_permute_kernel(const cplx* g, cplx* out, int h, int m) {
 // Workgroup = 4 waves, 64 x 64 outputs; wave w owns rows [16w, 16w+16) and all four 16-column tiles.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int TM = 64, TN = 64, TK = 16;
+// Batching: product z = blockIdx.z uses operand pointers advanced by z * stride; with pointer tables (ZTables, device
+// arrays) product z = outer * inner + i takes its bases from entry `outer` of each table and advances them by i * stride --
+// the lanes of a batched MPS contraction live in unrelated allocations.
+struct ZTables { const cplx* const* a; const cplx* const* b; cplx* const* c; int inner; };
 template <bool CONJ_T, bool ACCUM>
 __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const cplx* __restrict__ A, int lda,
                                                     const cplx* __restrict__ B, int ldb, cplx* __restrict__ C, int ldc,
-                                                    size_t stride_a, size_t stride_b, size_t stride_c, int b_herm) {
-    A += (size_t)blockIdx.z * stride_a; B += (size_t)blockIdx.z * stride_b; C += (size_t)blockIdx.z * stride_c;   // batched
+                                                    size_t stride_a, size_t stride_b, size_t stride_c, int b_herm, ZTables tab) {
+    if (tab.inner > 0) {
+        const int outer = blockIdx.z / tab.inner, i = blockIdx.z % tab.inner;
+        A = tab.a[outer] + (size_t)i * stride_a; B = tab.b[outer] + (size_t)i * stride_b; C = tab.c[outer] + (size_t)i * stride_c;
+    } else {
+        A += (size_t)blockIdx.z * stride_a; B += (size_t)blockIdx.z * stride_b; C += (size_t)blockIdx.z * stride_c;   // batched
+    }
     __shared__ double sar[TK][TM + 4], sai[TK][TM + 4];
     __shared__ double sbr[TK][TN + 4], sbi[TK][TN + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,18 +141,18 @@ hipError_t launch_mps_permute(const void* g, void* out, int h, int m, hipStream_
 
 namespace {
 hipError_t zgemm_launch(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, size_t sa,
-                        size_t sb, size_t sc, int nbatch, int b_herm, hipStream_t s) {
+                        size_t sb, size_t sc, int nbatch, int b_herm, hipStream_t s, ZTables tab = ZTables{nullptr, nullptr, nullptr, 0}) {
     if (M <= 0 || N <= 0 || nbatch <= 0) return hipSuccess;
     const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch);
     const cplx* a = static_cast<const cplx*>(A);
     const cplx* b = static_cast<const cplx*>(B);
     cplx* c = static_cast<cplx*>(C);
     if (conj_t) {
-        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
-        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
+        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
+        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
     } else {
-        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
-        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm);
+        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
+        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
     }
     return hipGetLastError();
 }
@@ -163,6 +172,41 @@ hipError_t launch_zgemm_bh(bool conj_t, bool accum, int M, int N, int K, const v
 hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                 void* C, int ldc, size_t sa, size_t sb, size_t sc, int nbatch, hipStream_t s) {
     return zgemm_launch(conj_t, accum, M, N, K, A, lda, B, ldb, C, ldc, sa, sb, sc, nbatch, 0, s);
+}
+
+// `outer` x `inner` products in one launch: bases from the device pointer tables, advanced by the strides per inner index
+hipError_t launch_zgemm_tables(int M, int N, int K, const void* const* a_tab, int lda, const void* const* b_tab, int ldb, void* const* c_tab, int ldc,
+                               size_t sa, size_t sb, size_t sc, int outer, int inner, hipStream_t s) {
+    const ZTables tab{reinterpret_cast<const cplx* const*>(a_tab), reinterpret_cast<const cplx* const*>(b_tab), reinterpret_cast<cplx* const*>(c_tab), inner};
+    return zgemm_launch(false, false, M, N, K, nullptr, lda, nullptr, ldb, nullptr, ldc, sa, sb, sc, outer * inner, 0, s, tab);
+}
+
+// batched forms of the two data-movement steps of the MPS -> dense contraction (one entry per lane in the tables):
+// last site: rt[chi][b] = t[b][chi][0];   final: out[(rev(i) << h) + lo] = g[lo * 2^m + i]
+__global__ void mps_last_site_kernel(const cplx* const* t_tab, cplx* const* rt_tab, int chil) {
+    const cplx* t = t_tab[blockIdx.y];
+    cplx* rt = rt_tab[blockIdx.y];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 2 * chil) rt[(size_t)(e % chil) * 2 + e / chil] = t[e];
+}
+__global__ void mps_permute_tables_kernel(const cplx* const* g_tab, cplx* const* out_tab, int h, int m) {
+    const cplx* g = g_tab[blockIdx.y];
+    cplx* out = out_tab[blockIdx.y];
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ((size_t)1 << (h + m))) return;
+    const unsigned i = (unsigned)(e & (((size_t)1 << m) - 1)), lo = (unsigned)(e >> m);
+    const unsigned r = m ? (__brev(i) >> (32 - m)) : 0u;
+    out[((size_t)r << h) + lo] = g[e];
+}
+hipError_t launch_mps_last_site(const void* const* t_tab, void* const* rt_tab, int chil, int count, hipStream_t s) {
+    mps_last_site_kernel<<<dim3((2 * chil + 255) / 256, count), 256, 0, s>>>(reinterpret_cast<const cplx* const*>(t_tab), reinterpret_cast<cplx* const*>(rt_tab), chil);
+    return hipGetLastError();
+}
+hipError_t launch_mps_permute_tables(const void* const* g_tab, void* const* out_tab, int h, int m, int count, hipStream_t s) {
+    const size_t total = (size_t)1 << (h + m);
+    mps_permute_tables_kernel<<<dim3((unsigned)((total + 255) / 256), count), 256, 0, s>>>(reinterpret_cast<const cplx* const*>(g_tab),
+                                                                                           reinterpret_cast<cplx* const*>(out_tab), h, m);
+    return hipGetLastError();
 }
 
 // out = sum_i e[i] conj(rc[i]): closes an inner product between a left environment and a (conjugated) right one;

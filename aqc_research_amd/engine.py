@@ -118,6 +118,16 @@ class Workspace:
         check(self._L.aqc_ws_create(ctx.handle, device, batch, ncols, tile_bits_apply, tile_bits_sweep, byref(handle)))
         self.handle = handle
         self._gather_count = 0
+        self._gen = [0] * 6   # per buffer: bumped by every call that (re)writes it
+
+    def _touch(self, *bufs) -> None:
+        for b in bufs:
+            self._gen[b] += 1
+
+    def generation(self, buf: int) -> int:
+        """Changes whenever `buf` is written through this object: lets a caller that left a result there find out later
+        whether it is still the one (mps_operations.DenseBackedMPS)."""
+        return self._gen[buf]
 
     # -- data movement -------------------------------------------------------
     def _shape(self):
@@ -128,6 +138,7 @@ class Workspace:
         check(self._L.aqc_ws_set_thetas(self.handle, dptr(th)))
 
     def upload(self, buf: int, data, lane: Optional[int] = None) -> None:
+        self._touch(buf)
         if lane is None:
             a = _lib.as_c128(data)
             if a.size != self.batch * self.dim * self.ncols:
@@ -140,6 +151,7 @@ class Workspace:
             check(self._L.aqc_ws_upload_lane(self.handle, buf, lane, dptr(a)))
 
     def broadcast(self, buf: int, data) -> None:
+        self._touch(buf)
         a = _lib.as_c128(data)
         if a.size != self.dim * self.ncols:
             raise ValueError("broadcast data has the wrong size")
@@ -161,26 +173,32 @@ class Workspace:
 
     def copy_lane_from(self, src: "Workspace", src_buf: int, src_lane: int, dst_buf: int, dst_lane: int) -> None:
         """this.dst_buf[dst_lane] <- src.src_buf[src_lane], device to device (targets that are already resident)."""
+        self._touch(dst_buf)
         check(self._L.aqc_ws_copy_lane(self.handle, dst_buf, dst_lane, src.handle, src_buf, src_lane))
 
     def set_basis(self, buf: int, index) -> None:
+        self._touch(buf)
         idx = np.ascontiguousarray(np.broadcast_to(np.asarray(index, dtype=np.int64), (self.batch,)))
         check(self._L.aqc_ws_set_basis(self.handle, buf, idx.ctypes.data_as(ctypes.POINTER(c_int64))))
 
     def set_combo(self, buf: int, index, coef) -> None:
         """buffer[lane] = coef[lane][0] |index[lane][0]> + coef[lane][1] |index[lane][1]>  (index[lane][1] < 0: one term)."""
+        self._touch(buf)
         idx = np.ascontiguousarray(np.asarray(index, dtype=np.int64).reshape(self.batch, 2))
         cf = np.ascontiguousarray(np.asarray(coef, dtype=np.complex128).reshape(self.batch, 2))
         check(self._L.aqc_ws_set_combo(self.handle, buf, idx.ctypes.data_as(ctypes.POINTER(c_int64)), dptr(cf)))
 
     def set_identity(self, buf: int) -> None:
+        self._touch(buf)
         check(self._L.aqc_ws_set_identity(self.handle, buf))
 
     # -- compute -------------------------------------------------------------
     def apply(self, inverse: bool, src: int = BUF_Y, dst: int = BUF_Z) -> None:
+        self._touch(dst)
         check(self._L.aqc_ws_apply(self.handle, int(bool(inverse)), src, dst))
 
     def grad(self, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
+        self._touch(BUF_W, BUF_ZW)
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
         check(self._L.aqc_ws_grad(self.handle, lo, hi, int(bool(front_layer))))
 
@@ -188,6 +206,7 @@ class Workspace:
              block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True):
         """One native call, one host synchronisation: [thetas ->] [Z = V^H Y] [gather from Z] [sweep].
         Returns (gathered or None, grads or None)."""
+        self._touch(*(([BUF_Z] if vdag else []) + ([BUF_W, BUF_ZW] if grad else [])))
         th = None if thetas is None else _lib.as_f64(thetas, self.batch * self.T, "thetas")
         hs = np.empty((self.batch, self._gather_count), dtype=np.complex128) if gather else None
         g = np.empty((self.batch, self.T), dtype=np.complex128) if grad else None
@@ -198,6 +217,7 @@ class Workspace:
         return hs, g
 
     def grad_from(self, x_buf: int, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
+        self._touch(BUF_W, BUF_ZW)
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
         check(self._L.aqc_ws_grad_from(self.handle, x_buf, lo, hi, int(bool(front_layer))))
 
@@ -344,6 +364,7 @@ def _ws_mps_upload(self, slot: int, mps) -> None:
 
 
 def _ws_mps_to_vec(self, slot: int, buf: int, lane: int = 0) -> None:
+    self._touch(buf)
     check(self._L.aqc_ws_mps_to_vec(self.handle, slot, buf, lane))
 
 
@@ -353,9 +374,72 @@ def _ws_mps_dot(self, slot_a: int, slot_b: int) -> complex:
     return complex(out[0])
 
 
+_MPS_SLOTS = 64          # AQC_MPS_SLOTS of include/aqc_hip.h
+_MPS_FIRST_CACHED = 4    # slots 0..3 stay with the explicit mps_upload / mps_to_vec / mps_dot calls
+
+
+def _mps_fingerprint(mps) -> tuple:
+    """Cheap content check of a QiskitMPS tuple: shapes and three entries of every tensor.  Guards the resident copy against
+    arrays that were modified in place; identity (id) of the tuple is the primary key."""
+    gam, lam = mps
+    out = []
+    for g0, g1 in gam:
+        a0, a1 = np.asarray(g0), np.asarray(g1)
+        f0, f1 = a0.reshape(-1), a1.reshape(-1)
+        out.append((a0.shape, complex(f0[0]), complex(f0[-1]), complex(f1[f1.size // 2])))
+    for l in lam:
+        fl = np.asarray(l).reshape(-1)
+        out.append((fl.size, float(fl[0]), float(fl[-1])))
+    return tuple(out)
+
+
+def _ws_mps_slot_for(self, mps) -> int:
+    """Slot holding a device-resident copy of `mps`: uploaded on first sight, found again by the tuple's identity plus a
+    cheap fingerprint of its tensors (mps_dot_objective.py:41 receives the same target tuple on every call of an
+    optimisation; the reference re-loads it into the simulator each time, :100-101).  Least recently used slot is recycled."""
+    cache = self.__dict__.setdefault("_mps_cache", {})        # id(mps) -> [slot, fingerprint, tick, keep-alive reference]
+    self._mps_tick = getattr(self, "_mps_tick", 0) + 1
+    fp = _mps_fingerprint(mps)
+    ent = cache.get(id(mps))
+    if ent is not None and ent[1] == fp:
+        ent[2] = self._mps_tick
+        return ent[0]
+    if ent is not None:
+        slot = ent[0]                                           # same object, new contents: re-upload in place
+    elif len(cache) < _MPS_SLOTS - _MPS_FIRST_CACHED:
+        slot = _MPS_FIRST_CACHED + len(cache)
+    else:
+        victim = min(cache, key=lambda k: cache[k][2])
+        slot = cache.pop(victim)[0]
+    self.mps_upload(slot, mps)
+    cache[id(mps)] = [slot, fp, self._mps_tick, mps]
+    return slot
+
+
+def _ws_mps_to_vec_batch(self, mps_list, buf: int, lanes=None) -> None:
+    """Dense states of `mps_list` (QiskitMPS tuples, one per lane) into lanes `lanes` (default 0..len-1) of `buf`: resident
+    copies through the slot cache, lanes that share a tuple share its slot, ONE contraction chain for all lanes."""
+    lanes = np.arange(len(mps_list), dtype=np.int32) if lanes is None else np.ascontiguousarray(lanes, dtype=np.int32)
+    if lanes.size != len(mps_list):
+        raise ValueError("one lane per MPS")
+    if len({id(m) for m in mps_list}) > _MPS_SLOTS - _MPS_FIRST_CACHED:
+        raise ValueError(f"at most {_MPS_SLOTS - _MPS_FIRST_CACHED} distinct MPS per batched contraction")
+    by_id = {}
+    slots = np.empty(len(mps_list), dtype=np.int32)
+    for i, m in enumerate(mps_list):
+        if id(m) not in by_id:
+            by_id[id(m)] = self.mps_slot_for(m)
+        slots[i] = by_id[id(m)]
+    i32 = ctypes.POINTER(c_int32)
+    check(self._L.aqc_ws_mps_to_vec_batch(self.handle, int(slots.size), slots.ctypes.data_as(i32), buf, lanes.ctypes.data_as(i32)))
+    self._touch(buf)
+
+
 Workspace.mps_upload = _ws_mps_upload
 Workspace.mps_to_vec = _ws_mps_to_vec
 Workspace.mps_dot = _ws_mps_dot
+Workspace.mps_slot_for = _ws_mps_slot_for
+Workspace.mps_to_vec_batch = _ws_mps_to_vec_batch
 
 
 def zgemm(a: np.ndarray, b: np.ndarray, conj_trans_a: bool = False, device: int = 0) -> np.ndarray:

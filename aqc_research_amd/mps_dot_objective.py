@@ -48,12 +48,21 @@ def fast_dot_gradient(
                                         and 0 <= block_range[0] < block_range[1] <= circ.num_blocks):
         raise ValueError("block_range must be a tuple (from, to) with 0 <= from < to <= num_blocks")
     if use_dense(circ.num_qubits, trunc_thr):
+        from .mps_operations import DenseBackedMPS
+
         ws = HipContext.of(circ).workspace(1, 1)
         ws.set_thetas(th)
-        ws.mps_upload(0, lvec)
-        ws.mps_upload(1, vh_phi)
-        ws.mps_to_vec(0, BUF_X, 0)
-        ws.mps_to_vec(1, BUF_Z, 0)
+        # vh_phi straight from v_dagger_mul_mps on this workspace: its dense state is still in Z -- no host round trip;
+        # operands that arrive as plain tuples keep a resident device copy (slot cache) and are contracted on the device
+        if not (isinstance(vh_phi, DenseBackedMPS) and vh_phi.dense_on(ws, BUF_Z)):
+            if isinstance(vh_phi, DenseBackedMPS):
+                ws.upload(BUF_Z, vh_phi.dense_state)
+            else:
+                ws.mps_to_vec_batch([vh_phi], BUF_Z)
+        if isinstance(lvec, DenseBackedMPS):
+            ws.upload(BUF_X, lvec.dense_state)
+        else:
+            ws.mps_to_vec_batch([lvec], BUF_X)
         ws.grad(block_range, bool(front_layer))
         return ws.get_grads()[0]
     from .mps_engine import DeviceMPS, fast_dot_gradient_mps   # registers beyond dense reach, or real truncation

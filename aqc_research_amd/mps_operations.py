@@ -4,15 +4,18 @@ MPS helpers with the reference signatures (mps_operations.py:33-371) on the GPU.
 The reference delegates gate application on MPS to qiskit-aer's matrix_product_state
 simulator (third party).  This path works at the level the reference's own tests pin it
 -- exact (no truncation) dense semantics: an MPS is contracted to its 2^n amplitudes on the
-device (chain of zgemm), the state-vector kernels do the work, and results that must be
-MPS again are returned as an *exact* MPS (bond dimension <= 2^(n/2), all lambdas = 1).
-Truncated-SVD MPS gates (trunc_thr > 0, n > ~26) are not provided.
+device (chain of zgemm), the state-vector kernels do the work, and a result that must be an MPS
+again comes back as a ``DenseBackedMPS``: a QiskitMPS tuple whose canonical (Vidal-form, Schmidt
+values sorted, discarded weight <= trunc_thr) tensors are computed when somebody looks at them, and
+which remembers where its dense state still sits on the device, so that ``v_dagger_mul_mps`` ->
+``fast_dot_gradient`` hands the state over without a round trip through the host.  Registers beyond
+dense reach and real truncation go to the native MPS engine (mps_engine.py).
 """
 from typing import List, Optional, Tuple
 
 import numpy as np
 
-from .engine import BUF_Y, BUF_Z, HipContext
+from .engine import BUF_Y, BUF_Z, HipContext  # noqa: F401
 
 _NO_TRUNCATION_THR = 1e-16
 QiskitMPS = Tuple[List[Tuple[np.ndarray, np.ndarray]], List[np.ndarray]]
@@ -26,6 +29,8 @@ def check_mps(qiskit_mps) -> bool:
     """Structural check of a (gammas, lambdas) tuple (mps_operations.py:87-123)."""
     if not (isinstance(qiskit_mps, tuple) and len(qiskit_mps) == 2):
         return False
+    if isinstance(qiskit_mps, DenseBackedMPS):   # canonical by construction; looking inside would run its SVD chain
+        return True
     gam, lam = qiskit_mps
     n = len(gam)
     if len(lam) != n - 1:
@@ -109,6 +114,84 @@ def vector_to_exact_mps(vec: np.ndarray) -> QiskitMPS:
     return gam, lam
 
 
+def vector_to_canonical_mps(vec: np.ndarray, trunc_thr: float = _NO_TRUNCATION_THR) -> QiskitMPS:
+    """Canonical Vidal form (Gamma, lambda) of a dense state by successive SVDs -- the form Aer hands the reference
+    (mps_operations.py:216-243): Schmidt values descending, at every bond the smallest ones dropped while the sum of their
+    squares stays below ``trunc_thr`` (and those below 1e-14 of the largest), kept values renormalised."""
+    vec = np.asarray(vec, dtype=np.complex128).ravel()
+    n = int(round(np.log2(vec.size)))
+    if vec.size != 1 << n or n < 2:
+        raise ValueError("expects a vector of size 2^n, n >= 2")
+    rest = vec.reshape([2] * n).transpose(list(range(n - 1, -1, -1))).reshape(1, -1)   # axes (b_0, ..., b_{n-1})
+    gam, lam, prev = [], [], np.ones(1)
+    for _ in range(n - 1):
+        chi_l = rest.shape[0]
+        u, sv, vh = np.linalg.svd(rest.reshape(chi_l * 2, -1), full_matrices=False)
+        keep = int((sv > 1e-14 * sv[0]).sum())
+        total, dropped = float(np.sum(sv ** 2)), 0.0
+        while keep > 1 and dropped + sv[keep - 1] ** 2 <= trunc_thr * total:   # the rule of the native engine (mps_engine.py)
+            dropped += sv[keep - 1] ** 2
+            keep -= 1
+        u, sv, vh = u[:, :keep], sv[:keep] / np.linalg.norm(sv[:keep]), vh[:keep]
+        a = u.reshape(chi_l, 2, keep)
+        gam.append((np.ascontiguousarray(a[:, 0, :] / prev[:, None]), np.ascontiguousarray(a[:, 1, :] / prev[:, None])))
+        lam.append(sv.copy())
+        prev = sv
+        rest = sv[:, None] * vh
+    a = rest.reshape(rest.shape[0], 2, 1)
+    gam.append((np.ascontiguousarray(a[:, 0, :] / prev[:, None]), np.ascontiguousarray(a[:, 1, :] / prev[:, None])))
+    return gam, lam
+
+
+class DenseBackedMPS(tuple):
+    """A QiskitMPS ``(gammas, lambdas)`` tuple that was produced from a dense state on the device.
+
+    * It IS a tuple of length 2 (``check_mps``, unpacking, indexing and iteration all work); its canonical tensors are
+      computed from the host copy of the state the first time any of them is asked for.
+    * ``dense_on(ws, buf)`` tells a later call on the same workspace whether the dense state is still in that buffer
+      (nothing has overwritten it since): ``fast_dot_gradient`` then sweeps from it directly."""
+
+    def __new__(cls, vec: np.ndarray, trunc_thr: float, ws=None, buf: int = BUF_Z):
+        self = super().__new__(cls, (None, None))
+        self._vec = np.asarray(vec, dtype=np.complex128).ravel()
+        self._thr = float(trunc_thr)
+        self._ws, self._buf = ws, buf
+        self._gen = None if ws is None else ws.generation(buf)
+        self._mps = None
+        return self
+
+    def _materialise(self) -> tuple:
+        if self._mps is None:
+            self._mps = vector_to_canonical_mps(self._vec, self._thr)
+        return self._mps
+
+    def dense_on(self, ws, buf: int) -> bool:
+        return ws is self._ws and buf == self._buf and ws.generation(buf) == self._gen
+
+    @property
+    def dense_state(self) -> np.ndarray:
+        """The 2^n amplitudes this MPS stands for (host copy)."""
+        return self._vec
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return 2
+
+    def __eq__(self, other):
+        return self is other
+
+    def __hash__(self):
+        return id(self)
+
+    def __repr__(self):
+        return f"DenseBackedMPS(n={int(np.log2(self._vec.size))}, materialised={self._mps is not None})"
+
+
 def _apply_to_mps(circ, thetas, mps_vec, inverse: bool, trunc_thr) -> QiskitMPS:
     if not check_mps(mps_vec) or len(mps_vec[0]) != circ.num_qubits:
         raise ValueError("MPS does not match the circuit")
@@ -118,10 +201,14 @@ def _apply_to_mps(circ, thetas, mps_vec, inverse: bool, trunc_thr) -> QiskitMPS:
     if use_dense(circ.num_qubits, thr):   # exact: fused state-vector kernels on the densified state
         ws = HipContext.of(circ).workspace(1, 1)
         ws.set_thetas(thetas)
-        ws.mps_upload(0, mps_vec)
-        ws.mps_to_vec(0, BUF_Y, 0)
+        if isinstance(mps_vec, DenseBackedMPS) and mps_vec.dense_on(ws, BUF_Z):
+            ws.copy_lane_from(ws, BUF_Z, 0, BUF_Y, 0)          # the operand is still on the device
+        elif isinstance(mps_vec, DenseBackedMPS):
+            ws.upload(BUF_Y, mps_vec.dense_state)
+        else:
+            ws.mps_to_vec_batch([mps_vec], BUF_Y)              # resident copy of the operand (slot cache)
         ws.apply(inverse, BUF_Y, BUF_Z)
-        return vector_to_exact_mps(ws.download(BUF_Z, lane=0))
+        return DenseBackedMPS(ws.download(BUF_Z, lane=0), thr, ws, BUF_Z)
     from . import mps_engine                # large registers / real truncation: gate by gate on the MPS
 
     m = mps_engine.DeviceMPS.from_qiskit(mps_vec)

@@ -46,9 +46,9 @@ WORKLOADS = {
     # h), 10 objective+gradient pairs per job -- sharded over the ranks by run_jobs (job j on rank j % world), results
     # gathered as fixed-size records.  One step = the whole mix.
     "cfg4_jobs": dict(n=20, kind="jobs", seeds=64, horizons=8, evals=10, desc="20-qubit ASP job mix: 64 seeds x 8 horizons (2nd-order Trotter ansatz, 2h layers), 10 objective+gradient pairs per job, sharded by run_jobs"),
-    "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=16 uploaded + densified every evaluation"),
-    "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=64 uploaded + densified every evaluation"),
-    "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS target chi=256 uploaded + densified every evaluation"),
+    "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=16 (a different one per lane every step), contracted to dense on the device every evaluation"),
+    "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=64 (a different one per lane every step), contracted to dense on the device every evaluation"),
+    "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
 
 
@@ -505,18 +505,24 @@ def main():
     chi = w.get("chi", 0)
     # lanes per GPU: 256 for state vectors up to 2^16 amplitudes (the persistent sweep walks 16 tiles per workgroup: launch
     # ramp and tail are amortised; 64 lanes give 135.9k evals/s at the headline, 256 give 150k -- DESIGN 6), 64 otherwise
-    B = args.batch if args.batch > 0 else (8 if chi else ((256 if n <= 16 else 64) if ncols == 1 else (32 if ncols >= 256 else 64)))
+    B = args.batch if args.batch > 0 else (64 if chi else ((256 if n <= 16 else 64) if ncols == 1 else (32 if ncols >= 256 else 64)))
     K, W = args.steps, args.warmup
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule
     ws = Workspace(ctx, batch=B, ncols=ncols, device=local_rank)
     flip_idx = orc.flip_state_indices(n, 1)
     mps_targets = None
-    if chi:   # lanes cycle through a few distinct random Vidal-form targets (their normalisation is host SVD work)
-        distinct = [orc.random_mps(n, chi, rng) for _ in range(min(B, 2))]
-        mps_targets = [distinct[b % len(distinct)] for b in range(B)]
+    if chi:   # a few distinct random Vidal-form targets (their normalisation is host SVD work); lane b of step i works on
+        # target (i + b) mod D, so every lane's target CHANGES EVERY STEP.  The tuples keep resident device copies (slot cache
+        # of the workspace, found again by identity + fingerprint); what a step pays is the contraction of all lanes' targets
+        # and lhs states to dense vectors on the device -- one batched launch chain each (aqc_ws_mps_to_vec_batch).
+        distinct = [orc.random_mps(n, chi, rng) for _ in range(min(B, 4))]
+        D = len(distinct)
+        mps_targets = [[distinct[(i + b) % D] for b in range(B)] for i in range(D)]
         zero_mps = ([(np.ones((1, 1), complex), np.zeros((1, 1), complex)) for _ in range(n)], [np.ones(1) for _ in range(n - 1)])
-        targets = np.stack([orc.mps_to_vector(m) for m in distinct])[[b % len(distinct) for b in range(B)]]
+        zero_list = [zero_mps] * B
+        dense = np.stack([orc.mps_to_vector(m) for m in distinct])
+        targets = dense[[(K + W - 1 + b) % D for b in range(B)]]      # the last timed step's assignment (parity check)
         ws.gather_setup(flip_idx)
     elif ncols == 1:
         targets = np.stack([orc.rand_state(n, rng) for _ in range(B)])
@@ -534,12 +540,9 @@ def main():
 
     def step(i):
         ws.use_theta_set(i % nsets)
-        if mps_targets is not None:   # QiskitMPS operands arrive from the host on every evaluation (mps_dot_objective.py:41)
-            for b in range(B):
-                ws.mps_upload(0, zero_mps)
-                ws.mps_to_vec(0, BUF_X, b)
-                ws.mps_upload(1, mps_targets[b])
-                ws.mps_to_vec(1, BUF_Y, b)
+        if mps_targets is not None:   # QiskitMPS operands arrive as host tuples on every evaluation (mps_dot_objective.py:41)
+            ws.mps_to_vec_batch(zero_list, BUF_X)
+            ws.mps_to_vec_batch(mps_targets[i % len(mps_targets)], BUF_Y)
         ws.apply(True, BUF_Y, BUF_Z)
         if ncols == 1:
             ws.gather_launch(BUF_Z)       # hs = <state_i|V^H|target>

@@ -147,11 +147,14 @@ int aqc_ws_results_fetch(aqc_ws* ws, double* small_out /* [batch][count] c128 */
  *   gammas : per site [2][dims[q]][dims[q+1]] complex128, sites concatenated
  *   lambdas: per site [dims[q+1]] float64, sites 0..n-2 concatenated
  * Upload folds lambda into the right bond of Gamma on the device (_preprocess_mps, :126-156). */
-enum { AQC_MPS_SLOTS = 4 };
+enum { AQC_MPS_SLOTS = 64 };   /* 0..3: explicit calls; the rest: resident copies managed by the host side (engine.py slot cache) */
 int aqc_ws_mps_upload(aqc_ws* ws, int slot, const int32_t* dims /* [n+1] */, const double* gammas,
                       const double* lambdas);
 /* buf[lane] <- dense state of the MPS; index bit q <-> site q   (mps_to_vector, :159-189) */
 int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane);
+/* the same for `count` (slot, lane) pairs; slots of equal bond dimensions (the lanes of a batched objective,
+ * mps_dot_objective.py:41 called once per lane in the reference) share every launch of the contraction chain */
+int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf, const int32_t* lanes);
 /* out <- <mps_a|mps_b> by transfer matrices                      (mps_dot, :192-213) */
 int aqc_ws_mps_dot(aqc_ws* ws, int slot_a, int slot_b, double* out /* 1 c128 */);
 

@@ -209,3 +209,87 @@ def test_cfg4_style_run_jobs_replayed_on_the_host():
             _, g, w, mx = _batched_reference(circ, idx, th, target, w, mx)
             th = th - 0.05 * g
         assert maxdiff(r["thetas"], th) < 1e-9      # three chained descent steps
+
+
+def test_mps_batched_contraction_and_slot_cache():
+    """aqc_ws_mps_to_vec_batch: all lanes' MPS -> dense in one launch chain (mps_operations.py:159-189 per lane), lanes that
+    share a tuple share its resident copy, mixed bond dimensions fall back to lane-by-lane, a tuple modified in place is
+    uploaded again (fingerprint), and more distinct tuples than slots recycle the least recently used one."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_Y, HipContext, Workspace
+
+    n, B = 10, 7
+    rng = np.random.default_rng(1010)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", 9))
+    ws = Workspace(HipContext.of(circ), batch=B)
+    a, b, c = orc.random_mps(n, 8, rng), orc.random_mps(n, 8, rng), orc.random_mps(n, 3, rng)
+    lanes = [a, b, a, b, b, a, a]
+    ws.mps_to_vec_batch(lanes, BUF_Y)
+    got = ws.download(BUF_Y)
+    for i, m in enumerate(lanes):
+        assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
+    assert len(ws._mps_cache) == 2
+    mixed = [a, c, b, c, a, c, b]                      # two different sets of bond dimensions
+    ws.mps_to_vec_batch(mixed, BUF_Y)
+    got = ws.download(BUF_Y)
+    for i, m in enumerate(mixed):
+        assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
+    a[0][3][0][0, 0] += 0.25                            # in place: same tuple, new contents
+    ws.mps_to_vec_batch([a] * B, BUF_Y, lanes=np.arange(B)[::-1])
+    assert maxdiff(ws.download(BUF_Y)[0], orc.mps_to_vector(a)) < 1e-12
+    many = [orc.random_mps(n, 2, rng) for _ in range(70)]   # more than the 60 cached slots
+    for k in range(0, 70, B):
+        chunk = (many[k:k + B] + many[:B])[:B]
+        ws.mps_to_vec_batch(chunk, BUF_Y)
+        got = ws.download(BUF_Y)
+        for i, m in enumerate(chunk):
+            assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
+    assert len(ws._mps_cache) <= 60
+    ws.close()
+
+
+def test_mps_front_door_hands_the_state_over_on_the_device():
+    """v_dagger_mul_mps -> fast_dot_gradient (mps_operations.py:349-371, mps_dot_objective.py:41-242): the returned MPS is a
+    QiskitMPS tuple in canonical form (checked by contracting it back), and the gradient call that follows takes its dense
+    state from the device; the same objects keep giving the right answer after the device copy has been overwritten."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_Z, HipContext
+    from aqc_research_amd.mps_dot_objective import fast_dot_gradient
+    from aqc_research_amd.mps_operations import DenseBackedMPS, check_mps, mps_dot, mps_to_vector, v_dagger_mul_mps
+
+    n = 12
+    rng = np.random.default_rng(1212)
+    circ = ParametricCircuit(n, "cz", create_ansatz_structure(n, "spin", "full", 15))
+    target = orc.random_mps(n, 8, rng)
+    lvec = orc.random_mps(n, 2, rng)
+    th = orc.rand_thetas(circ.num_thetas, rng)
+    y, x = orc.mps_to_vector(target), orc.mps_to_vector(lvec)
+    z_ref = cref.v_dagger_mul_vec(circ, th, y)
+    g_ref = cref.grad_of_dot_product(circ, th, x, z_ref, None, True)
+    scale = np.linalg.norm(x) * np.linalg.norm(y)
+    vh = v_dagger_mul_mps(circ, th, target)
+    ws = HipContext.of(circ).workspace(1, 1)
+    assert isinstance(vh, DenseBackedMPS) and isinstance(vh, tuple) and vh.dense_on(ws, BUF_Z) and vh._mps is None
+    g = fast_dot_gradient(circ, th, lvec, vh)
+    assert vh._mps is None                              # nobody looked at the tensors: no SVD chain was run
+    assert maxdiff(g, g_ref) < TOL * max(1.0, scale)
+    assert check_mps(vh) and len(vh) == 2 and vh._mps is None
+    gam, lam = vh
+    assert check_mps((gam, lam))                        # the materialised tensors pass the structural check as a plain tuple
+    assert len(gam) == n and all(np.all(np.diff(l) <= 1e-15) for l in lam) and max(l.size for l in lam) <= 1 << (n // 2)
+    # (contracting it back runs on another workspace; the tensors carry the truncation of trunc_thr = 1e-16 per bond, i.e. an
+    # amplitude error of up to sqrt(n * 1e-16) -- the dense state behind the tuple does not)
+    assert maxdiff(mps_to_vector(vh), z_ref) < 1e-7 and maxdiff(vh.dense_state, z_ref) < TOL
+    other = v_dagger_mul_mps(circ, th + 0.1, target)    # overwrites Z of the circuit's workspace
+    assert not vh.dense_on(ws, BUF_Z) and other.dense_on(ws, BUF_Z)
+    assert maxdiff(fast_dot_gradient(circ, th, lvec, vh), g_ref) < TOL * max(1.0, scale)   # falls back to the host copy
+    assert abs(mps_dot(lvec, vh) - np.vdot(x, z_ref)) < 1e-7 * max(1.0, scale)
+    # a truncated result is a smaller MPS whose infidelity is the discarded weight's order
+    tr = v_dagger_mul_mps(circ, th, target, trunc_thr=1e-12)
+    full = max(l.size for l in vh[1])
+    small = DenseBackedMPS(tr.dense_state, 1e-3)
+    w = orc.mps_to_vector((small[0], small[1]))
+    infid = 1 - abs(np.vdot(w, z_ref)) ** 2 / (np.vdot(w, w).real * np.vdot(z_ref, z_ref).real)
+    assert max(l.size for l in small[1]) < full and 0 <= infid < 2e-2

@@ -107,6 +107,7 @@ SIGNATURES = {
     "aqc_comm_allgather": (c_int, [_P, _D, _D, ctypes.c_size_t]),
     "aqc_comm_allreduce": (c_int, [_P, _D, ctypes.c_size_t, c_int]),
     "aqc_comm_barrier": (c_int, [_P]),
+    "aqc_plan_substages": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int]),
     "aqc_plan_query": (
         c_int,
         [_P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],

@@ -583,6 +583,29 @@ int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bi
     return 0;
 }
 
+// host-only: register bits (local positions inside the stage's tile) and number of gate groups of every sub-stage of stage
+// `stage` as the matrix-core kernels run it (4 register bits, unlimited groups); subs_out receives [num_subs][5] ints
+int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage, int* num_subs, int* subs_out, int max_subs) {
+    if (!ctx || !num_subs) return fail("null argument");
+    if (ncols < 1) return fail("ncols must be positive");
+    const int col_bits = ceil_log2(ncols);
+    if (tile_bits <= 0) tile_bits = 12;
+    if (low_bits < 0) low_bits = 3;
+    Plan plan = make_plan(ctx->prog, col_bits, tile_bits, low_bits, which == 0);
+    split_substages(ctx->prog, plan, 4, 1 << 20);
+    const std::string err = check_plan(ctx->prog, plan);
+    if (!err.empty()) return fail("planner produced an invalid plan: %s", err.c_str());
+    if (stage < 0 || stage >= (int)plan.stages.size()) return fail("stage index out of range");
+    const Stage& st = plan.stages[stage];
+    *num_subs = (int)st.subs.size();
+    if (subs_out)
+        for (int i = 0; i < (int)st.subs.size() && i < max_subs; ++i) {
+            for (int j = 0; j < 4; ++j) subs_out[5 * i + j] = j < (int)st.subs[i].bits.size() ? st.subs[i].bits[j] : -1;
+            subs_out[5 * i + 4] = (int)st.subs[i].ops.size();
+        }
+    return 0;
+}
+
 int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_apply, int tile_bits_sweep, aqc_ws** out) {
     if (!out) return fail("out pointer is null");
     *out = nullptr;

@@ -248,6 +248,11 @@ int aqc_ws_kernel_family(aqc_ws* ws, int which);
 int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage,
                    int* num_stages, int* bits_out, int* num_bits, int* ops_out, int* num_ops);
 
+/* host-only: the sub-stages of stage `stage` as the matrix-core kernels run it: subs_out[i] = {4 register bits as local
+ * positions inside the stage's tile (-1: unused), number of gate groups}; at most max_subs entries are written */
+int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage, int* num_subs,
+                       int* subs_out /* [max_subs][5] */, int max_subs);
+
 /* ---- device-resident multi-start L-BFGS on the lane-batched surrogate objective: one optimisation per lane, thetas /
  * gradients / history stay in HBM (stand-in for the scipy L-BFGS-B behind AqcOptimizer.optimize, optimizer.py:579-590,
  * on objective_lhs_sur_max.py:82-191).  Preconditions: targets in buffer Y, flip-state indices registered with

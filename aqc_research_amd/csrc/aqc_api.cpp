@@ -500,8 +500,36 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
             a.lane_stride = ws->lane_elems;
             a.ntiles = p.ntiles;
             a.batch = ws->batch;
-            ProfScope ps(ws, AQC_K_APPLY);
-            HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the V / V^H workgroups of this launch, on stderr
+            static unsigned long long* d_stamps_a = nullptr;
+            const size_t nwg = (size_t)p.ntiles * ws->batch;
+            if (env_int("AQC_STAMPS", 0) != 0 && nwg <= 65536) {
+                if (!d_stamps_a) HIP_OK(hipMalloc((void**)&d_stamps_a, sizeof(unsigned long long) * 65536 * kStampSlots));
+                HIP_OK(hipMemsetAsync(d_stamps_a, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream));
+                a.stamps = d_stamps_a;
+            }
+#endif
+            {
+                ProfScope ps(ws, AQC_K_APPLY);
+                HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+            }
+#ifdef AQC_TUNING
+            if (a.stamps) {
+                std::vector<unsigned long long> h(nwg * kStampSlots);
+                HIP_OK(hipStreamSynchronize(ws->stream));
+                HIP_OK(hipMemcpy(h.data(), d_stamps_a, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                double load = 0, loop = 0, store = 0, bar = 0;
+                const int ns = p.h_stages[s].nsubs;
+                for (size_t w = 0; w < nwg; ++w) {
+                    const unsigned long long* t = h.data() + w * kStampSlots;
+                    load += (double)(t[1] - t[0]); loop += (double)(t[2] - t[1]); store += (double)(t[3] - t[2]);
+                    for (int i = 0; i < ns && 5 + i < kStampSlots; ++i) bar += (double)(t[5 + i] - t[4 + i]);
+                }
+                fprintf(stderr, "aqc_hip stamps: V/V^H stage %zu (%d sub-stages, %zu workgroups): load %.0f + sub-stage loop %.0f (%.0f per sub-stage, of which "
+                        "waiting at its barrier %.0f) + store %.0f cycles per workgroup\n", s, ns, nwg, load / nwg, loop / nwg, loop / nwg / std::max(ns, 1),
+                        bar / nwg / std::max(ns, 1), store / nwg);
+            }
+#endif
         }
         return 0;
     }

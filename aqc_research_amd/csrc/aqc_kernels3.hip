@@ -191,6 +191,11 @@ __device__ __forceinline__ size_t tile_base3(const DevStage& st, unsigned tile) 
 }
 
 // ---- V / V^H -------------------------------------------------------------------------------------------------
+// 2^12 tiles (AQC_APPLY_PERSIST, the default there): a persistent grid of two workgroups per CU, each walking over its
+// (tile, lane) items with the NEXT item's tile prefetched into registers behind sub-stages 0..3 -- the scheme of the sweep.
+// In-kernel stamps of the one-tile-per-workgroup form showed the sub-stage loop at the matrix pipe's rate, and a fifth to
+// a third of a workgroup's life in the tile load before and the store after it (every workgroup of a wave of tiles loads at
+// the same moment: an HBM burst with idle matrix cores).
 template <int K>
 __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kernel(const Stage3Args a) {
     using TS = TileShape<K>;
@@ -201,22 +206,53 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     if (lds_base & ((16u << K) - 1)) __builtin_trap();   // XOR addressing needs the tile aligned to its own size
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t lane_off = (size_t)blockIdx.y * a.lane_stride + tile_base3(st, blockIdx.x);
-    const double* umat = a.umat + (size_t)blockIdx.y * a.nsubs_total * 12 * 64;
+    constexpr int NL = TS::kLoads, NW = TS::kWaves;
+    constexpr bool kPersist = K >= 12;      // grid < items only there (launch_apply3)
+    const int nwork = a.ntiles * a.batch;   // items = (tile, lane of the batch), item wi on workgroup wi mod gridDim.x
     const unsigned lo = st.dlo[lane];
+    const unsigned lo16 = lo << 4;
     SubRegs cur, nxt;
     SubAddr<TS::kGpw> ad;   // clustered software pipeline, see sweep_mfma_kernel
-    if (st.nsubs > 0) {
-        fetch_sub<TS::kGpw>(cur, a.subs, umat, st.sub_begin, lane, wave, TS::kWaves);
-        fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, TS::kWaves);
+    dbl2_t pw[NL];          // the prefetched tile: accumulation registers, inline-assembly loads (see sweep_mfma_kernel)
+    int wi = blockIdx.x + (kPersist ? 0 : (int)blockIdx.y * a.ntiles);
+    {
+        const int bl = wi / a.ntiles;
+        if (st.nsubs > 0) {
+            fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)bl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+            fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, NW);
+        }
+        AQC_STAMP(0);
+        load_tiles3<K, 1>(tw, nullptr, a.in0 + (size_t)bl * a.lane_stride + tile_base3(st, wi - bl * a.ntiles), nullptr, st, lo, wave);
     }
-    load_tiles3<K, 1>(tw, nullptr, a.in0 + lane_off, nullptr, st, lo, wave);
     // Every load so far has landed before the loop: otherwise the compiler's wait-count analysis, merging the loop
     // entry with the back edge, makes the first use of `cur` inside the loop wait for the prefetch of `nxt` as well.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    AQC_STAMP(1);
+    for (;;) {
+    const int bl = wi / a.ntiles;
+    const size_t lane_off = (size_t)bl * a.lane_stride + tile_base3(st, wi - bl * a.ntiles);
+    const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
+    const int nwi = wi + (int)gridDim.x;
+    const bool more = kPersist && st.nsubs > 0 && nwi < nwork;
+    const int nbl = more ? nwi / a.ntiles : 0;
+    const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
     for (int si = 0; si < st.nsubs; ++si) {
+        AQC_STAMP(4 + si);
         __syncthreads();
-        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, TS::kWaves);
+        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
+        else if (more) fetch_sub<TS::kGpw>(nxt, a.subs, a.umat + (size_t)nbl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+        if (kPersist && more) {   // a quarter of the next item's tile, issued BEHIND the operand fetch (loads retire in order)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (si == (c < st.nsubs ? c : st.nsubs - 1)) {
+#pragma unroll
+                    for (int i = c * (NL / 4); i < (c + 1) * (NL / 4); ++i) {
+                        const size_t ub = next_off + st.dhi[wave + i * NW];
+                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(lo16), "s"(uniform_ptr(a.in0 + ub)) : "memory");
+                    }
+                }
+            }
+        }
         sub_addr(ad, cur, lds_base);
         cplx v[2][4];
         Acc3 acc;
@@ -268,10 +304,27 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (si + 1 < st.nsubs) { cur = nxt; fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin + si + 1, wave, TS::kWaves); }
+        if (si + 1 < st.nsubs || more) {
+            cur = nxt;
+            fetch_k<TS::kGpw>(ad, a.subs, si + 1 < st.nsubs ? st.sub_begin + si + 1 : st.sub_begin, wave, NW);
+        }
     }
+    AQC_STAMP(4 + st.nsubs);
     __syncthreads();
+    AQC_STAMP(2);
     store_tile3<K, false>(tw, a.out0 + lane_off, st, lo, wave);
+    AQC_STAMP(3);
+    if (!more) break;
+    __syncthreads();   // every wave has finished with the LDS tile (the stores' LDS reads included)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the prefetched tile has arrived
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const unsigned slot = swz3((unsigned)((wave + i * NW) << 6) | (threadIdx.x & 63u));
+        asm volatile("ds_write_b128 %0, %1" : : "v"(lds_base + (slot << 4)), "a"(pw[i]) : "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes above are not tracked by the compiler
+    wi = nwi;
+    }
 }
 
 // ---- forward w / z sweep with R = Z W^H per sub-stage ------------------------------------------------------
@@ -912,20 +965,6 @@ int mfma_occupancy(int k, bool sweep) {   // resident workgroups per CU for the 
 #undef AQC_OCC
     return e == hipSuccess ? n : -1;
 }
-hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
-    const dim3 grid(ntiles, batch);
-    const int t = mfma_threads(k, false);
-    const size_t l = apply3_lds_bytes(k);
-    switch (k) {
-        case 8: apply_mfma_kernel<8><<<grid, t, l, s>>>(a); break;
-        case 9: apply_mfma_kernel<9><<<grid, t, l, s>>>(a); break;
-        case 10: apply_mfma_kernel<10><<<grid, t, l, s>>>(a); break;
-        case 11: apply_mfma_kernel<11><<<grid, t, l, s>>>(a); break;
-        case 12: apply_mfma_kernel<12><<<grid, t, l, s>>>(a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
 // workgroups of the persistent 2^12 sweep: one per CU of the current device (the occupancy its 144 KiB of LDS allows)
 static long persistent_sweep_grid() {
     static int cus[64] = {0};
@@ -937,6 +976,27 @@ static long persistent_sweep_grid() {
     }
     if (const char* e = getenv("AQC_SWEEP_GRID")) { const long v = atol(e); if (v > 0) return v; }   // experiments
     return cus[dev];
+}
+hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
+    if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
+    for (int l = 0; l < 64; ++l)   // 32-bit byte offset per lane in the prefetch (see launch_sweep3)
+        if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
+    // 2^12 tiles: persistent workgroups, two per CU, walking over (tile, lane) items; smaller tiles: one item per workgroup
+    const long nwork = (long)ntiles * batch;
+    static const long persist = []() { const char* e = getenv("AQC_APPLY_PERSIST"); return e ? atol(e) : 2L; }();   // workgroups per CU, 0 = off
+    const dim3 grid = (k >= 12 && persist > 0 && a.stage.nsubs > 0) ? dim3((unsigned)std::min<long>(nwork, persist * persistent_sweep_grid()))
+                                                                     : (k >= 12 ? dim3((unsigned)nwork) : dim3(ntiles, batch));
+    const int t = mfma_threads(k, false);
+    const size_t l = apply3_lds_bytes(k);
+    switch (k) {
+        case 8: apply_mfma_kernel<8><<<grid, t, l, s>>>(a); break;
+        case 9: apply_mfma_kernel<9><<<grid, t, l, s>>>(a); break;
+        case 10: apply_mfma_kernel<10><<<grid, t, l, s>>>(a); break;
+        case 11: apply_mfma_kernel<11><<<grid, t, l, s>>>(a); break;
+        case 12: apply_mfma_kernel<12><<<grid, t, l, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;

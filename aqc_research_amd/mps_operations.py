@@ -117,7 +117,8 @@ def vector_to_exact_mps(vec: np.ndarray) -> QiskitMPS:
 def vector_to_canonical_mps(vec: np.ndarray, trunc_thr: float = _NO_TRUNCATION_THR) -> QiskitMPS:
     """Canonical Vidal form (Gamma, lambda) of a dense state by successive SVDs -- the form Aer hands the reference
     (mps_operations.py:216-243): Schmidt values descending, at every bond the smallest ones dropped while the sum of their
-    squares stays below ``trunc_thr`` (and those below 1e-14 of the largest), kept values renormalised."""
+    squares stays below ``trunc_thr`` (none at the reference's no-truncation threshold 1e-16) and those below 1e-14 of the
+    largest, kept values renormalised."""
     vec = np.asarray(vec, dtype=np.complex128).ravel()
     n = int(round(np.log2(vec.size)))
     if vec.size != 1 << n or n < 2:
@@ -129,7 +130,9 @@ def vector_to_canonical_mps(vec: np.ndarray, trunc_thr: float = _NO_TRUNCATION_T
         u, sv, vh = np.linalg.svd(rest.reshape(chi_l * 2, -1), full_matrices=False)
         keep = int((sv > 1e-14 * sv[0]).sum())
         total, dropped = float(np.sum(sv ** 2)), 0.0
-        while keep > 1 and dropped + sv[keep - 1] ** 2 <= trunc_thr * total:   # the rule of the native engine (mps_engine.py)
+        # the rule of the native engine (mps_engine.py); the reference's "no truncation" threshold (1e-16) really means none:
+        # only numerically zero Schmidt values go, so that the tensors reproduce the state to ~1e-14
+        while trunc_thr > _NO_TRUNCATION_THR and keep > 1 and dropped + sv[keep - 1] ** 2 <= trunc_thr * total:
             dropped += sv[keep - 1] ** 2
             keep -= 1
         u, sv, vh = u[:, :keep], sv[:keep] / np.linalg.norm(sv[:keep]), vh[:keep]

@@ -335,6 +335,9 @@ struct aqc_ws {
     const void** d_mps_tabs = nullptr;  // device pointer tables of the batched MPS -> dense contraction (grow-only)
     size_t mps_tabs_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    hipStream_t copy_stream = nullptr;        // aqc_ws_results_async: result copies run beside the next evaluation's kernels
+    hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+    bool copy_pending = false;                // the producers of the next evaluation wait for ev_copied before they overwrite the results
     const double* theta_host = nullptr;      // aqc_ws_eval: pinned thetas the next U build reads directly (and copies to d_thetas)
     bool gather_rides = false;               // aqc_ws_eval: the next gradient walk also performs the registered gather (see there)
     bool profile = false;
@@ -843,7 +846,8 @@ int aqc_ws_destroy(aqc_ws* ws) {
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
     if (ws->d_mps_tabs) (void)hipFree(ws->d_mps_tabs);
     if (ws->d_mps_lam) (void)hipFree(ws->d_mps_lam);
-    for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1, ws->ev_ready, ws->ev_copied}) if (ev) (void)hipEventDestroy(ev);
+    if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
     if (ws->stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
     return 0;
@@ -999,8 +1003,11 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
     return aqc_ws_grad_from(ws, AQC_BUF_X, block_from, block_to, front_layer);
 }
 
+static int results_guard(aqc_ws* ws);
+
 int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer) {
     if (check_buf(ws, x_buf)) return 1;
+    if (results_guard(ws)) return 1;
     if (x_buf == AQC_BUF_W || x_buf == AQC_BUF_ZW || x_buf == AQC_BUF_Z) return fail("lhs buffer must not be Z, W or ZW");
     if (ensure_coef(ws)) return 1;
     const Program& prog = ws->ctx->prog;
@@ -1133,6 +1140,10 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
                 int front_layer, double* grads) {
     if (!ws) return fail("null workspace");
     HIP_OK(hipSetDevice(ws->device));
+    if (ws->copy_pending) {   // result copies of an earlier aqc_ws_results_async: this call reuses the pinned buffer and may replay a graph
+        HIP_OK(hipStreamSynchronize(ws->copy_stream));
+        ws->copy_pending = false;
+    }
     const Program& prog = ws->ctx->prog;
     const size_t nth = (size_t)ws->batch * prog.num_thetas();
     double* pin_th = ws->h_pin;
@@ -1469,6 +1480,7 @@ int aqc_ws_gather_launch(aqc_ws* ws, int buf) {
     if (check_buf(ws, buf)) return 1;
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
     HIP_OK(hipSetDevice(ws->device));
+    if (results_guard(ws)) return 1;
     ProfScope ps(ws, AQC_K_MISC);
     HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream, ws->mirror_small));
     return 0;
@@ -1912,6 +1924,7 @@ int aqc_ws_vdot_launch(aqc_ws* ws, int buf_a, int buf_b) {
     if (check_buf(ws, buf_a) || check_buf(ws, buf_b)) return 1;
     HIP_OK(hipSetDevice(ws->device));
     if (!ws->d_vdot_out) HIP_OK(hipMalloc((void**)&ws->d_vdot_out, sizeof(double2) * ws->batch));
+    if (results_guard(ws)) return 1;
     ProfScope ps(ws, AQC_K_MISC);
     HIP_OK(launch_vdot(ws->bufs[buf_a], ws->bufs[buf_b], ws->lane_elems, ws->lane_elems, ws->batch, ws->d_vdot_part,
                        ws->vdot_parts, ws->d_vdot_out, ws->stream));
@@ -1929,17 +1942,36 @@ int aqc_ws_vdot_fetch(aqc_ws* ws, double* out) {
 
 // Results of the evaluation just enqueued -> pinned host memory, asynchronously on the workspace's stream (what an optimizer
 // on the host consumes every evaluation: gradients, gathered amplitudes, <A|B>); aqc_ws_results_fetch waits and hands them out.
+// The copies run on a second stream: they wait for the producing kernels (event) and overlap with the kernels of the NEXT
+// evaluation; the kernels that overwrite the results (gather, <A|B>, gradient walk) wait for the copies in turn (results_guard).
+static int results_guard(aqc_ws* ws) {
+    if (ws->copy_pending && !ws->capturing) {
+        HIP_OK(hipStreamWaitEvent(ws->stream, ws->ev_copied, 0));
+        ws->copy_pending = false;
+    }
+    return 0;
+}
+
 int aqc_ws_results_async(aqc_ws* ws) {
     if (!ws) return fail("null workspace");
     HIP_OK(hipSetDevice(ws->device));
+    if (!ws->copy_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ws->ev_ready, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ws->ev_copied, hipEventDisableTiming));
+    }
     const size_t nth = (size_t)ws->batch * ws->ctx->prog.num_thetas();
     double* pin_gr = ws->h_pin + ws->pin_thetas;
     double* pin_sm = pin_gr + ws->pin_grads;
-    HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipEventRecord(ws->ev_ready, ws->stream));
+    HIP_OK(hipStreamWaitEvent(ws->copy_stream, ws->ev_ready, 0));
+    HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->copy_stream));
     if (ws->gather_count > 0 && 2 * (size_t)ws->batch * ws->gather_count <= ws->pin_small)
-        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * (size_t)ws->batch * ws->gather_count, hipMemcpyDeviceToHost, ws->stream));
+        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * (size_t)ws->batch * ws->gather_count, hipMemcpyDeviceToHost, ws->copy_stream));
     else if (ws->d_vdot_out && 2 * (size_t)ws->batch <= ws->pin_small)
-        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_vdot_out, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->stream));
+        HIP_OK(hipMemcpyAsync(pin_sm, ws->d_vdot_out, sizeof(double2) * (size_t)ws->batch, hipMemcpyDeviceToHost, ws->copy_stream));
+    HIP_OK(hipEventRecord(ws->ev_copied, ws->copy_stream));
+    ws->copy_pending = true;
     return 0;
 }
 
@@ -1947,6 +1979,8 @@ int aqc_ws_results_fetch(aqc_ws* ws, double* small_out, double* grads_out) {
     if (!ws) return fail("null workspace");
     HIP_OK(hipSetDevice(ws->device));
     HIP_OK(hipStreamSynchronize(ws->stream));
+    if (ws->copy_stream) HIP_OK(hipStreamSynchronize(ws->copy_stream));
+    ws->copy_pending = false;
     const size_t nth = (size_t)ws->batch * ws->ctx->prog.num_thetas();
     const double* pin_gr = ws->h_pin + ws->pin_thetas;
     const double* pin_sm = pin_gr + ws->pin_grads;

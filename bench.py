@@ -786,7 +786,8 @@ def main():
             "sustained_evals_per_s": None if sustained is None else sustained[0],
             "sustained": None if sustained is None else {"seconds": sustained[1], "steps": sustained[2]},
             "results_to_host": "every timed step ends with asynchronous copies of its gradients (batch x T complex128) and amplitudes "
-                               "into pinned host memory on the workspace stream (aqc_ws_results_async); the last step's copies are the checked ones",
+                               "into pinned host memory (aqc_ws_results_async: a second stream, overlapped with the next step's kernels; the "
+                               "kernels that overwrite the results wait for the copies); the last step's copies are the checked ones",
             "objective_object": objective_object,
             "kernel_ms_per_step": {k: v[1] / prof_steps for k, v in prof.items()},
             "device_ms_per_step_events": ev_ms / K,

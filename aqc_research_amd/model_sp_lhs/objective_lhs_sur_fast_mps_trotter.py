@@ -52,7 +52,7 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
             return
         from ..mps_engine import DeviceMPS
 
-        self._target_dev = DeviceMPS.from_qiskit(target, device=self._mps_device())
+        self._target_dev = DeviceMPS.from_qiskit(target, device=self._mps_device(), trunc_thr=self._trunc_thr)
         self._vh = None
         self._basis_dev = {}
 

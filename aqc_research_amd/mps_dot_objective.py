@@ -67,7 +67,7 @@ def fast_dot_gradient(
         return ws.get_grads()[0]
     from .mps_engine import DeviceMPS, fast_dot_gradient_mps   # registers beyond dense reach, or real truncation
 
-    w, z = DeviceMPS.from_qiskit(lvec), DeviceMPS.from_qiskit(vh_phi)
+    w, z = DeviceMPS.from_qiskit(lvec, trunc_thr=float(trunc_thr)), DeviceMPS.from_qiskit(vh_phi, trunc_thr=float(trunc_thr))
     try:
         return fast_dot_gradient_mps(circ, th, w, z, trunc_thr=float(trunc_thr), block_range=block_range, front_layer=bool(front_layer))
     finally:
@@ -135,7 +135,7 @@ def _gate2q_mul_mps(g2x2, ctrl: int, targ: int, mps_vec, trunc_thr: float):
         raise ValueError("not a valid MPS in Qiskit format")
     if not (isinstance(trunc_thr, float) and trunc_thr >= 0):
         raise ValueError("trunc_thr must be a non-negative float")
-    m = DeviceMPS.from_qiskit(mps_vec)
+    m = DeviceMPS.from_qiskit(mps_vec, trunc_thr=float(trunc_thr))
     try:
         return m.gate2(_gates.controlled(g2x2), int(ctrl), int(targ), float(trunc_thr)).to_qiskit()
     finally:

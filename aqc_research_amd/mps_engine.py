@@ -42,6 +42,23 @@ def _pack(qiskit_mps):
     return n, dims, np.ascontiguousarray(g), np.ascontiguousarray(lm)
 
 
+def is_canonical(qiskit_mps, tol: float = 1e-8) -> bool:
+    """Vidal canonical form, checked on the host: with A_q[b] = Gamma_q[b] diag(lambda_q) every site is right-normalised,
+    sum_b A_q[b] A_q[b]^H = 1, and with B_q[b] = diag(lambda_{q-1}) Gamma_q[b] left-normalised, sum_b B_q[b]^H B_q[b] = 1
+    (O(n chi^3) on small matrices; Aer's states pass, hand-made tensors such as the oracle's random_mps do not)."""
+    gam, lam = qiskit_mps
+    n = len(gam)
+    for q in range(n):
+        g0, g1 = np.asarray(gam[q][0], dtype=np.complex128), np.asarray(gam[q][1], dtype=np.complex128)
+        lr = np.asarray(lam[q], dtype=np.float64).ravel() if q < n - 1 else np.ones(1)
+        ll = np.asarray(lam[q - 1], dtype=np.float64).ravel() if q > 0 else np.ones(1)
+        right = sum((g * lr[None, :]) @ (g * lr[None, :]).conj().T for g in (g0, g1))
+        left = sum((ll[:, None] * g).conj().T @ (ll[:, None] * g) for g in (g0, g1))
+        if np.abs(right - np.eye(right.shape[0])).max() > tol or np.abs(left - np.eye(left.shape[0])).max() > tol:
+            return False
+    return True
+
+
 class DeviceMPS:
     """One MPS resident on the GPU."""
 
@@ -50,11 +67,29 @@ class DeviceMPS:
         self._L = _lib.lib()
 
     @classmethod
-    def from_qiskit(cls, qiskit_mps, device: int = 0) -> "DeviceMPS":
+    def from_qiskit(cls, qiskit_mps, device: int = 0, trunc_thr: float = 0.0) -> "DeviceMPS":
+        """Uploads a QiskitMPS tuple.  The engine's truncation rule is stated on Schmidt values, i.e. for states in
+        canonical (Vidal) form -- what Aer hands the reference (mps_operations.py:216-243).  When a real truncation is asked
+        for (``trunc_thr`` > 1e-12) an input that is NOT canonical is brought into that form first (two sweeps of exact
+        SVDs, ``canonicalize``); with exact arithmetic the gauge does not matter and the tensors are taken as they are."""
         n, dims, g, lm = _pack(qiskit_mps)
         h = c_void_p()
         check(_lib.lib().aqc_mps_create(device, n, dims.ctypes.data_as(POINTER(c_int32)), dptr(g), dptr(lm), byref(h)))
-        return cls(h)
+        m = cls(h)
+        if trunc_thr > 1e-12 and not is_canonical(qiskit_mps):
+            m.canonicalize()
+        return m
+
+    def canonicalize(self) -> "DeviceMPS":
+        """Canonical form by exact identity "gates" on every bond: right to left (all sites right-orthonormal), then left to
+        right (the singular values of each bond are now the state's Schmidt values)."""
+        eye4 = np.eye(4, dtype=np.complex128)
+        n = self.num_qubits
+        for q in range(n - 2, -1, -1):
+            self.gate2(eye4, q, q + 1, 0.0)
+        for q in range(n - 1):
+            self.gate2(eye4, q, q + 1, 0.0)
+        return self
 
     @classmethod
     def basis_state(cls, num_qubits: int, index: int = 0, device: int = 0) -> "DeviceMPS":

@@ -214,7 +214,7 @@ def _apply_to_mps(circ, thetas, mps_vec, inverse: bool, trunc_thr) -> QiskitMPS:
         return DenseBackedMPS(ws.download(BUF_Z, lane=0), thr, ws, BUF_Z)
     from . import mps_engine                # large registers / real truncation: gate by gate on the MPS
 
-    m = mps_engine.DeviceMPS.from_qiskit(mps_vec)
+    m = mps_engine.DeviceMPS.from_qiskit(mps_vec, trunc_thr=thr)
     try:
         return mps_engine._apply_circuit(circ, thetas, m, inverse, thr, 0).to_qiskit()
     finally:

@@ -796,7 +796,8 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         }
     }
     if (ws->sweep.v3)
-        WS_HIP(hipMalloc((void**)&ws->sweep.d_rpart, sizeof(double2) * (size_t)batch * std::max<size_t>(ws->sweep.h_subs3.size(), 1) * ws->sweep.ntiles * 256));
+        WS_HIP(hipMalloc((void**)&ws->sweep.d_rpart, sizeof(double2) * (size_t)batch * std::max<size_t>(ws->sweep.h_subs3.size(), 1) *
+                                                        sweep3_nparts(ws->sweep.ntiles, batch, ws->sweep.k) * 256));
     WS_HIP(hipMalloc((void**)&ws->d_grads, sizeof(double2) * (size_t)batch * std::max(T, 1)));
     WS_HIP(hipMalloc((void**)&ws->d_theta_slots, sizeof(int) * theta_slots.size()));
     WS_HIP(hipMalloc((void**)&ws->d_slot_ntiles, sizeof(int) * slot_ntiles.size()));
@@ -1034,6 +1035,8 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
             a.rpart = p.d_rpart;
             a.ntiles = p.ntiles;
             a.batch = ws->batch;
+            a.chunk = sweep3_chunk(p.ntiles, ws->batch, p.k);
+            a.nparts = sweep3_nparts(p.ntiles, ws->batch, p.k);
             a.store_out = s + 1 < p.h_stages.size() ? 1 : 0;
 #ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the sweep workgroups of this launch, on stderr
             static unsigned long long* d_stamps = nullptr;
@@ -1092,7 +1095,8 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                             ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream,
                             ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads, ws->mirror_grads,
                             ws->gather_rides ? GatherJob{ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->d_small, ws->mirror_small}
-                                             : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr}));
+                                             : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},
+                            sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k)));
         if (!ws->grads_direct)   // some theta collects two slots (2nd-order Trotter half-layers, core_operations.py:966-968)
             HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
                                    1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));

@@ -369,7 +369,20 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     dbl2_t pw[NL], pz[NL];
     unsigned parity = 0;   // scratch buffer of the running sub-stage (kDouble)
     AQC_STAMP(0);
-    int wi = blockIdx.x;
+    // Persistent form: workgroup g walks over the CONTIGUOUS items [g chunk, (g + 1) chunk) in lane-major order, i.e. over
+    // consecutive tiles of one lane (a.chunk > 0, launch_sweep3).  The R of a sub-stage is a sum over the tiles of a lane, so
+    // the workgroup accumulates it over its run of tiles of that lane (a "segment") instead of leaving one partial per
+    // tile: the per-(lane, sub-stage) partials in HBM shrink from `ntiles` to at most ntiles / chunk + 2 -- 16x less for the
+    // gradient walk to read at the headline, 40x less memory at 20 qubits -- by a read-modify-write of the segment's own 4 KB
+    // that stays in L2: the old value is requested at the top of the sub-stage (accumulation register, L1 bypassed: the
+    // line was written by this workgroup one item earlier) and added where the sum over the waves is formed.
+    const int chunk = kPersist ? a.chunk : 0;
+    const int wi_first = kPersist ? (int)blockIdx.x * chunk : (int)blockIdx.x;
+    const int wi_end = kPersist ? (wi_first + chunk < nwork ? wi_first + chunk : nwork) : wi_first + 1;
+    int wi = wi_first;
+    if (wi >= nwork) return;   // (a whole workgroup: no barrier has been reached yet)
+    const unsigned e16 = threadIdx.x << 4;
+    dbl2_t racc;               // this thread's entry of the segment's accumulated R (kPersist; 256 threads = 256 entries)
     {
         const size_t off0 = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
         if (st.nsubs > 0) {
@@ -385,9 +398,13 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     const int bl = wi / a.ntiles, tile = wi - bl * a.ntiles;
     const size_t lane_off = (size_t)bl * a.lane_stride + tile_base3(st, tile);
     const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
-    cplx* rpart = a.rpart + (((size_t)bl * a.nsubs_total + st.sub_begin) * a.ntiles + tile) * 256;
-    const int nwi = wi + (int)gridDim.x;
-    const bool more = kPersist && nwi < nwork;
+    // slot of this item's partial: its tile (one partial per tile), or its segment = number of workgroups that hold earlier
+    // tiles of the lane
+    const int part = kPersist ? (int)blockIdx.x - (bl * a.ntiles) / chunk : tile;
+    const bool seg_first = !kPersist || wi == wi_first || tile == 0;   // nothing accumulated yet in this segment
+    cplx* rpart = a.rpart + (((size_t)bl * a.nsubs_total + st.sub_begin) * a.nparts + part) * 256;
+    const int nwi = wi + 1;
+    const bool more = kPersist && nwi < wi_end;
     const int nbl = more ? nwi / a.ntiles : 0;
     const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
     constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
@@ -418,6 +435,8 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 }
             }
         }
+        if (kPersist && !seg_first)
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=a"(racc) : "v"(e16), "s"(uniform_ptr(rpart + (size_t)si * a.nparts * 256)) : "memory");
         double4_t t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
         // Software pipeline over the wave's groups, written as CLUSTERS that the compiler may not interleave
         // (sched_barrier): on gfx950 an fp64 MFMA and vector-ALU instructions of the same SIMD do not overlap, and every
@@ -552,7 +571,11 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             double re = p[0].x, im = p[0].y;
 #pragma unroll
             for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
-            rpart[(size_t)si * a.ntiles * 256 + threadIdx.x] = make_double2(re, im);
+            if (kPersist && !seg_first) {   // + what the earlier tiles of the segment left (requested at the top of the sub-stage)
+                asm volatile("s_waitcnt vmcnt(0)" : "+a"(racc) : : "memory");   // the load is not tracked by the compiler; the
+                re += racc.x; im += racc.y;                                      // operand ties every later read of racc to this wait
+            }
+            rpart[(size_t)si * a.nparts * 256 + threadIdx.x] = make_double2(re, im);
             if (!kDouble) __syncthreads();
         } else {
             for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {
@@ -562,7 +585,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 double re = p[0].x, im = p[0].y;
 #pragma unroll
                 for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
-                rpart[(size_t)si * a.ntiles * 256 + e] = make_double2(re, im);
+                rpart[(size_t)si * a.nparts * 256 + e] = make_double2(re, im);
             }
             if (!kDouble) __syncthreads();
             if (go_on) cur = nxt;
@@ -801,7 +824,7 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                            int from, int to, int front, const int* slot_theta, cplx* grads, cplx* mirror,
-                                                           const GatherJob gj) {
+                                                           const GatherJob gj, int tiles_per_lane, int chunk) {   // ntiles: partial slots per (lane, sub-stage)
     if ((int)blockIdx.x == nsubs_total) {   // the passenger (see GatherJob): one extra workgroup per lane of the batch
         const cplx* src = static_cast<const cplx*>(gj.buf) + (size_t)blockIdx.y * gj.lane_stride;
         for (int i = threadIdx.x; i < gj.count; i += 64 * WAVES) {
@@ -818,7 +841,11 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, si = blockIdx.x, b = blockIdx.y;
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
-    const cplx* rp = rpart + ((size_t)b * nsubs_total + si) * ntiles * 256;
+    // partials of this (lane, sub-stage): one per tile, or one per segment of the persistent sweep (chunk > 0: the workgroups
+    // that hold tiles of lane b are (b ntiles) / chunk .. ((b + 1) ntiles - 1) / chunk; summed in that fixed order)
+    const int nparts_stride = ntiles;
+    if (chunk > 0) ntiles = ((b + 1) * tiles_per_lane - 1) / chunk - (b * tiles_per_lane) / chunk + 1;
+    const cplx* rp = rpart + ((size_t)b * nsubs_total + si) * nparts_stride * 256;
     {   // fixed-order sum over the tiles (wave w: tiles w, w + WAVES, ...), 8 tiles (32 loads per lane) in flight at a time;
         // in the few-lane variant wave 0 decodes the last chunk of groups (the first one the walk needs) while its first batch
         // of loads is in flight
@@ -998,13 +1025,24 @@ hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stag
     }
     return hipGetLastError();
 }
+// persistent sweep: items per workgroup (contiguous, lane-major) and partial slots per (lane, sub-stage); 0 / ntiles otherwise
+int sweep3_chunk(int ntiles, int batch, int k) {
+    if (k < 12) return 0;
+    const long nwork = (long)ntiles * batch, g = std::min<long>(nwork, persistent_sweep_grid());
+    return (int)((nwork + g - 1) / g);
+}
+int sweep3_nparts(int ntiles, int batch, int k) {
+    const int chunk = sweep3_chunk(ntiles, batch, k);
+    return chunk > 0 ? std::min(ntiles, (ntiles + chunk - 1) / chunk + 1) : ntiles;
+}
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
+    if (a.chunk != sweep3_chunk(ntiles, batch, k) || a.nparts != sweep3_nparts(ntiles, batch, k)) return hipErrorInvalidValue;
     for (int l = 0; l < 64; ++l)   // the persistent sweep addresses its prefetch with a 32-bit byte offset per lane
         if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
     // 2^12 tiles: one persistent workgroup per CU walking over its items (see the kernel); smaller tiles: one item each
     const long nwork = (long)ntiles * batch;
-    const dim3 grid((unsigned)(k >= 12 ? std::min<long>(nwork, persistent_sweep_grid()) : nwork));
+    const dim3 grid((unsigned)(k >= 12 ? (nwork + a.chunk - 1) / a.chunk : nwork));
     const int t = mfma_threads(k, true);
     const size_t l = sweep3_lds_bytes(k);
     switch (k) {
@@ -1024,17 +1062,20 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 }
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
-                        const int* slot_theta, void* grads, void* mirror, GatherJob gather) {
+                        const int* slot_theta, void* grads, void* mirror, GatherJob gather, int nparts, int chunk) {
     if (nsubs_total < 1) return hipSuccess;
     const int extra = gather.count > 0 && gather.buf ? 1 : 0;
-    if (ntiles >= 32)
+    const int tiles_per_lane = ntiles;
+    if (nparts <= 0) nparts = ntiles;
+    ntiles = nparts;   // slots per (lane, sub-stage); the kernels derive the number in use from (tiles_per_lane, chunk)
+    if (nparts >= 32)
         rgrad_kernel<4><<<dim3(nsubs_total + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                   nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather);
+                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk);
     else
         rgrad_kernel<1><<<dim3(nsubs_total + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather);
+                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk);
     return hipGetLastError();
 }
 

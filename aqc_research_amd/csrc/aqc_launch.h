@@ -66,6 +66,8 @@ struct Stage3Args {
     double2* rpart;          // sweep: [batch][nsubs_total][ntiles][256] per-tile R = Z W^H of every sub-stage
     int ntiles;
     int batch;               // lanes of the batch (sweep: work items = ntiles x batch)
+    int chunk, nparts;       // sweep: items per persistent workgroup (0: one item per workgroup) and partial-R slots per
+                             // (lane, sub-stage) -- sweep3_chunk / sweep3_nparts
     int store_out;           // sweep: 0 for the last stage (its w and z are never read again)
     int debug;               // tuning builds: work-skipping bits for timing experiments (1 LDS writes, 2 LDS reads, 4 R MFMAs, 8 U MFMAs)
     unsigned long long* stamps;   // tuning builds (-DAQC_TUNING): [workgroup][kStampSlots] s_memtime stamps of wave 0, else null
@@ -76,6 +78,8 @@ int mfma_threads(int k, bool sweep);
 int mfma_occupancy(int k, bool sweep);
 hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
+int sweep3_chunk(int ntiles, int batch, int k);
+int sweep3_nparts(int ntiles, int batch, int k);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
     const DevSub3* sub;
     const DevGrp* grps;      // the plan's gate groups
@@ -90,7 +94,8 @@ struct GatherJob {           // optional passenger of the gradient walk: out[lan
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
                         const int* slot_theta = nullptr, void* grads = nullptr, void* mirror = nullptr,
-                        GatherJob gather = GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr});   // slot_theta: direct mode, see rgrad_kernel
+                        GatherJob gather = GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},   // slot_theta: direct mode, see rgrad_kernel
+                        int nparts = 0, int chunk = 0);   // partial-R slots per (lane, sub-stage) and the persistent sweep's chunk
 
 // aqc_lbfgs.hip (device-resident multi-start L-BFGS on the lane-batched surrogate objective)
 struct LbState {

@@ -191,6 +191,9 @@ class DenseBackedMPS(tuple):
     def __hash__(self):
         return id(self)
 
+    def __reduce__(self):   # pickled (result files of the drivers) as the plain tuple it stands for
+        return (tuple, (self._materialise(),))
+
     def __repr__(self):
         return f"DenseBackedMPS(n={int(np.log2(self._vec.size))}, materialised={self._mps is not None})"
 

@@ -359,3 +359,31 @@ def test_run_jobs_fails_instead_of_hanging_when_a_rank_dies(tmp_path):
     codes = [q.wait(timeout=120) for q in procs]
     assert codes[1] == 17 and codes[0] == 9, codes          # the survivor failed loudly ...
     assert _time.time() - t0 < 100 and (tmp_path / "failed.txt").exists()   # ... within the collective's time-out
+
+
+def test_dense_backed_mps_is_a_lazy_canonical_qiskit_tuple():
+    """What v_dagger_mul_mps hands back on the dense route (mps_operations.py:349-371 returns Aer's canonical MPS): a tuple of
+    length 2 whose Vidal-form tensors are computed on first access, canonical, exact at the no-truncation threshold, smaller
+    under a real one, and pickled as a plain tuple."""
+    import pickle
+
+    from aqc_research_amd.mps_engine import is_canonical
+    from aqc_research_amd.mps_operations import DenseBackedMPS, check_mps, vector_to_canonical_mps
+
+    rng = np.random.default_rng(31)
+    v = orc.rand_state(7, rng)
+    d = DenseBackedMPS(v, 1e-16)
+    assert isinstance(d, tuple) and len(d) == 2 and check_mps(d) and d._mps is None        # nothing computed yet
+    gam, lam = d
+    assert d._mps is not None and len(gam) == 7 and len(lam) == 6 and check_mps((gam, lam)) and is_canonical((gam, lam))
+    assert all(np.all(np.diff(l) <= 1e-15) for l in lam)
+    assert np.abs(orc.mps_to_vector((gam, lam)) - v).max() < 1e-13
+    assert np.abs(orc.mps_to_vector(d) - v).max() < 1e-13 and d[1][0].size == 2
+    back = pickle.loads(pickle.dumps(d))
+    assert type(back) is tuple and np.abs(orc.mps_to_vector(back) - v).max() < 1e-13
+    cut = vector_to_canonical_mps(v, 1e-2)
+    w = orc.mps_to_vector(cut)
+    assert max(l.size for l in cut[1]) < max(l.size for l in lam)
+    assert 0 < 1 - abs(np.vdot(w, v)) ** 2 / np.vdot(w, w).real < 5e-2
+    assert not is_canonical(orc.random_mps(7, 4, rng))        # hand-made Vidal-form tensors are not canonical
+    assert not d.dense_on(object(), 1)                        # no workspace behind this one

@@ -56,6 +56,9 @@ CASES = [
     (12, "cz", 25, 8, 9, 1),
     (13, "cx", 40, 13, 12, 2),
     (14, "cx", 40, 10, 10, 1),
+    (14, "cz", 33, 11, 11, 3),      # 2^11 tiles, 8 tiles per lane: single-buffered scratch + second barrier
+    (15, "cx", 30, 12, 11, 2),
+    (16, "cp", 24, 11, 12, 5),      # persistent sweep next to the one-tile-per-workgroup V^H
 ]
 
 
@@ -285,11 +288,13 @@ def test_full_size_direct_parity_headline_batch():
     ws.close()
 
 
-@pytest.mark.parametrize("n,B", [(13, 150), (14, 70), (12, 300)])
+@pytest.mark.parametrize("n,B", [(13, 150), (14, 70), (12, 300), (14, 150), (15, 80)])
 def test_persistent_sweep_uneven_work(n, B):
     """The 2^12 sweep runs one persistent workgroup per CU over (tile, lane) items with the next tile prefetched into
     registers: item counts that are not a multiple of the grid (300 / 280 / 300 items on 256 CUs: some workgroups take two
-    items, most one) and a per-lane theta, every lane against the compiled CPU restatement."""
+    items, most one; 600 / 640 items: three contiguous items per workgroup, so the segments over which a workgroup
+    accumulates R start and end in the middle of lanes of 4 / 8 tiles) and a per-lane theta, every lane against the
+    compiled CPU restatement."""
     from oracle import aqc_ref as cref
     from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
 

@@ -820,6 +820,12 @@ __device__ __forceinline__ cplx rho_dot(const cplx (&rho)[16], int kind) {
 // WAVES = 4 (many tiles per lane of the batch, i.e. few lanes: the single-evaluation regime): three helper waves share
 // the sum over the tiles -- the dependent-load chain that otherwise dominates this kernel -- and retire; wave 0 adds the
 // four partial sums in a fixed order and walks the groups alone.
+#ifdef AQC_TUNING
+__device__ unsigned long long g_rgrad_stamps[32 * 8];
+#define RG_STAMP(slot) do { if (blockIdx.y == 0 && blockIdx.x < 32 && threadIdx.x == 0) g_rgrad_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RG_STAMP(slot) do { } while (0)
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
@@ -839,6 +845,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     __shared__ cplx rho_s[kGrpChunk][16];
     __shared__ cplx psum[WAVES > 1 ? WAVES - 1 : 1][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, si = blockIdx.x, b = blockIdx.y;
+    RG_STAMP(0);
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
     // partials of this (lane, sub-stage): one per tile, or one per segment of the persistent sweep (chunk > 0: the workgroups
@@ -881,6 +888,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
         for (int r = 0; r < 4; ++r)   // MFMA D layout: entry 64 r + l is R[4 r + l / 16][l % 16]
             R[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[r];
     }
+    RG_STAMP(1);
     cplx* out = partial + (size_t)b * nslots;
     // slot_theta != null: every theta is fed by exactly one slot, so the entry is final here -- it goes straight into the
     // gradient (and its pinned host copy) and finalize_kernel is not launched; entries outside block_range / front_layer
@@ -901,6 +909,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
         __syncthreads();
         if (WAVES == 1 || top != sub.ngrp) stage_groups(gm, grps, sub.grp_begin + base, count, th, ent, lane);   // WAVES > 1: the first chunk was decoded above
         __syncthreads();
+        RG_STAMP(2);
         for (int i = count - 1; i >= 0; --i) {
             const Gm& g = gm[i];
             {   // rho_g[a][b] = sum_o R[(a, o)][(b, o)]: lane = (a, b, o), quad sum over o
@@ -925,6 +934,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
             for (int l = 0; l < 4; ++l) R[idx[l]] = x[l];
             __syncthreads();
         }
+        RG_STAMP(3);
         if (lane < count) {   // one group per lane: walk rho backwards through the group's rotations
             const Gm& g = gm[lane];
             const bool on = g.jblock < 0 ? (front != 0) : (g.jblock >= from && g.jblock < to);
@@ -957,8 +967,19 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
                 for (int k = 0; k < 5; ++k) put(g.slot0 + k, make_double2(0.0, 0.0));
             }
         }
+        RG_STAMP(4);
     }
 }
+#ifdef AQC_TUNING
+void rgrad_print_stamps(int nsubs) {
+    unsigned long long h[32 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rgrad_stamps), sizeof h) != hipSuccess) return;
+    double a = 0, b = 0, c = 0, d = 0;
+    const int n = nsubs < 32 ? nsubs : 32;
+    for (int i = 0; i < n; ++i) { a += h[i * 8 + 1] - h[i * 8]; b += h[i * 8 + 2] - h[i * 8 + 1]; c += h[i * 8 + 3] - h[i * 8 + 2]; d += h[i * 8 + 4] - h[i * 8 + 3]; }
+    fprintf(stderr, "aqc_hip stamps: gradient walk (lane 0, %d sub-stages): tile sum %.0f + group decode %.0f + R walk %.0f + rho walk %.0f cycles\n", n, a / n, b / n, c / n, d / n);
+}
+#endif
 
 // ---- launchers -----------------------------------------------------------------------------------------------
 int mfma_threads(int k, bool sweep) { return (sweep && k == 12) ? 64 * SweepShape<12>::kWaves : 64 * std::min(4, 1 << std::max(0, k - 8)); }

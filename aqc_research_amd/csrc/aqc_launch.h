@@ -78,6 +78,7 @@ int mfma_threads(int k, bool sweep);
 int mfma_occupancy(int k, bool sweep);
 hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a);
+void rgrad_print_stamps(int nsubs);   // tuning builds only
 int sweep3_chunk(int ntiles, int batch, int k);
 int sweep3_nparts(int ntiles, int batch, int k);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages

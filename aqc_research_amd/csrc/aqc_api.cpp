@@ -1038,6 +1038,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
             a.chunk = sweep3_chunk(p.ntiles, ws->batch, p.k);
             a.nparts = sweep3_nparts(p.ntiles, ws->batch, p.k);
             a.store_out = s + 1 < p.h_stages.size() ? 1 : 0;
+            if (a.stage.nsubs > 0) stage3_first_offsets(a, p.h_subs3[a.stage.sub_begin]);
 #ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the sweep workgroups of this launch, on stderr
             static unsigned long long* d_stamps = nullptr;
             const size_t nwg = (size_t)p.ntiles * ws->batch;

@@ -69,8 +69,13 @@ __device__ __forceinline__ void u_combine(const Acc3& t, cplx (&o)[4]) {
 #ifdef AQC_TUNING   // in-kernel stamps (diagnostic builds only): where a workgroup's time goes
 #define AQC_STAMP(slot) do { if (a.stamps && threadIdx.x == 0 && (slot) < kStampSlots) \
     a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef AQC_TUNING_NODBG   // stamps only: the work-skipping switches cost registers (the 2^12 sweep spills with them)
+#define AQC_DBG_AND(x)
+#define AQC_DBG_TEST(x) false
+#else
 #define AQC_DBG_AND(x) && (x)
 #define AQC_DBG_TEST(x) (x)
+#endif
 #else
 #define AQC_STAMP(slot) do { } while (0)
 #define AQC_DBG_AND(x)
@@ -186,7 +191,14 @@ __device__ __forceinline__ void store_tile3(const cplx* tile, cplx* dst, const D
 }
 __device__ __forceinline__ size_t tile_base3(const DevStage& st, unsigned tile) {
     size_t base = 0;
-    for (int i = 0; i < st.nub; ++i) base |= (size_t)((tile >> i) & 1u) << st.ubits[i];
+    for (int i0 = 0; i0 < st.nub; i0 += 4) {   // four bit positions per scalar load (ubits[32], nub <= 32): one load latency per four
+        int ub[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ub[u] = st.ubits[i0 + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u < st.nub) base |= (size_t)((tile >> (i0 + u)) & 1u) << ub[u];
+    }
     return base;
 }
 
@@ -334,6 +346,15 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
 // the barrier of sub-stage s + 1, which every writer has passed -- no second barrier, no counter.  2^10 and 2^11 tiles
 // are the exception (sweep_scratch_double): a second buffer would cost them a resident workgroup per CU (2^11: two
 // workgroups share a CU only if each stays within exactly 80 KiB), so there a second barrier per sub-stage takes its place.
+// vmcnt(0) for loads issued by inline assembly into accumulation registers: the "+a" operands make every later read of the
+// registers depend on the wait (the compiler does not know that the loads are outstanding)
+template <int N>
+__device__ __forceinline__ void wait_prefetched(dbl2_t (&pw)[N], dbl2_t (&pz)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+a"(pw[i]), "+a"(pz[i]));
+}
+__device__ __forceinline__ unsigned tile_offset3(const DevStage& st, unsigned local) { return st.dlo[local & 63u] | st.dhi[local >> 6]; }
 template <int K> struct SweepShape : TileShape<K, true> {};   // (no comma inside the __launch_bounds__ macro arguments)
 template <int K>
 __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void sweep_mfma_kernel(const Stage3Args a) {
@@ -359,7 +380,6 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     constexpr int NL = TS::kLoads, NW = TS::kWaves;
     const int nwork = a.ntiles * a.batch;
     const unsigned lo = st.dlo[lane];
-    const unsigned lo16 = lo << 4;   // byte offset of this lane inside a run of the tile (dlo < 2^28 elements)
     SubRegs cur, nxt;
     SubAddr<TS::kGpw> ad;
     // The prefetched tiles live in ACCUMULATION registers (the sub-stage pipeline fills all 256 architectural VGPRs; left
@@ -383,20 +403,43 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     if (wi >= nwork) return;   // (a whole workgroup: no barrier has been reached yet)
     const unsigned e16 = threadIdx.x << 4;
     dbl2_t racc;               // this thread's entry of the segment's accumulated R (kPersist; 256 threads = 256 entries)
+    // Persistent form: the prefetched registers ARE the operands of an item's first sub-stage -- the loads fetch, for every
+    // lane, exactly the amplitudes that sub-stage's MFMAs take from it (L1 layout: chunk l % 16, amplitude 4 s + l / 16 of
+    // the wave's groups), so a tile never passes through LDS on its way in.  (Moving a prefetched tile from accumulation
+    // registers to LDS between two items cost 4.2-4.7k cycles per item with nothing else running on the CU.)
+    static_assert(!kPersist || NL == 4 * TS::kGpw, "the prefetch registers are the first sub-stage's operands");
+    const bool reg_first = kPersist && st.nsubs > 0;
+    unsigned flo16 = 0;        // first sub-stage: byte offset of this lane's operand position inside a tile (+ a.first_hi[group][K-step])
+    // element offset of the running item's tile; the next item's is worked out once (a chain of dependent scalar loads)
+    // and handed on
+    size_t item_off = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
     {
-        const size_t off0 = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
+        const size_t off0 = item_off;
         if (st.nsubs > 0) {
             fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)(wi / a.ntiles) * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
             fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, NW);
         }
-        load_tiles3<K, 2>(tw, tz, a.in0 + off0, a.in1 + off0, st, lo, wave);
+        if (reg_first) {
+            // slot tables hold swz3(local index); swz3 is an involution and GF(2)-linear, lane part and uniform part use
+            // disjoint bits of the local index, so their tile offsets simply add
+            flo16 = tile_offset3(st, swz3(cur.lane12 & 0xffffu)) << 4;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const size_t ub = off0 + a.first_hi[wave + (i / 4) * NW][i % 4];
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(flo16), "s"(uniform_ptr(a.in0 + ub)) : "memory");
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(flo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
+            }
+        } else {
+            load_tiles3<K, 2>(tw, tz, a.in0 + off0, a.in1 + off0, st, lo, wave);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see apply_mfma_kernel
+    if (reg_first) wait_prefetched<NL>(pw, pz);
     __syncthreads();
     AQC_STAMP(1);
     for (;;) {
     const int bl = wi / a.ntiles, tile = wi - bl * a.ntiles;
-    const size_t lane_off = (size_t)bl * a.lane_stride + tile_base3(st, tile);
+    const size_t lane_off = item_off;
     const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
     // slot of this item's partial: its tile (one partial per tile), or its segment = number of workgroups that hold earlier
     // tiles of the lane
@@ -404,36 +447,44 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     const bool seg_first = !kPersist || wi == wi_first || tile == 0;   // nothing accumulated yet in this segment
     cplx* rpart = a.rpart + (((size_t)bl * a.nsubs_total + st.sub_begin) * a.nparts + part) * 256;
     const int nwi = wi + 1;
-    const bool more = kPersist && nwi < wi_end;
+    const bool more = reg_first && nwi < wi_end;   // (launch_sweep3 refuses a persistent stage without sub-stages)
     const int nbl = more ? nwi / a.ntiles : 0;
     const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
     constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
     cplx vw[2][4], vz[2][4];   // operands of group j (slot j & 1) and j + 1; group 0 of a sub-stage is requested right after the
                                // barrier that ends the previous one, ahead of the R reduction (its latency hides there)
     constexpr bool kEarly = K >= 11;   // (smaller tiles: the ten extra live registers would cost a resident wave per SIMD)
-    if (kEarly && st.nsubs > 0) {
+    if (reg_first) {
+        sub_addr(ad, cur, lds_base);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { vw[0][s] = make_double2(pw[s].x, pw[s].y); vz[0][s] = make_double2(pz[s].x, pz[s].y); }
+    } else if (kEarly && st.nsubs > 0) {
         sub_addr(ad, cur, lds_base);
 #pragma unroll
         for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
     }
+    auto prefetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i / (NL / 4) == c) {   // scalar base + 32-bit lane offset: no vector address arithmetic
+                const size_t ub = next_off + a.first_hi[wave + (i / 4) * NW][i % 4];
+                // (s_nop: the hazard recogniser does not look inside inline assembly -- a scalar base that was written by
+                // v_readfirstlane needs 5 wait states before a vector-memory instruction may read it)
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(flo16), "s"(uniform_ptr(a.in0 + ub)) : "memory");
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(flo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
+            }
+    };
     for (int si = 0; si < st.nsubs; ++si) {
+        const bool from_regs = reg_first && si == 0;
         AQC_STAMP(2 + 4 * si);
         if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
         else if (more) fetch_sub<TS::kGpw>(nxt, a.subs, a.umat + (size_t)nbl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
-        if (kPersist && more) {   // a quarter of the next item's tiles, issued BEHIND the operand fetch (loads retire in order)
+        // a quarter of the next item's operands, issued BEHIND the operand fetch (loads retire in order): chunk c at the top of
+        // sub-stage min(1 + c, nsubs - 1) -- sub-stage 0 still reads the registers (a single sub-stage: below the group loop)
+        if (kPersist && more && si > 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (si == (c < st.nsubs ? c : st.nsubs - 1)) {
-#pragma unroll
-                    for (int i = c * (NL / 4); i < (c + 1) * (NL / 4); ++i) {   // scalar base + 32-bit lane offset: no vector address arithmetic
-                        const size_t ub = next_off + st.dhi[wave + i * NW];
-                        // (s_nop: the hazard recogniser does not look inside inline assembly -- a scalar base that was written by
-                        // v_readfirstlane needs 5 wait states before a vector-memory instruction may read it)
-                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(lo16), "s"(uniform_ptr(a.in0 + ub)) : "memory");
-                        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(lo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
-                    }
-                }
-            }
+            for (int c = 0; c < 4; ++c)
+                if (si == (1 + c < st.nsubs ? 1 + c : st.nsubs - 1)) prefetch(c);
         }
         if (kPersist && !seg_first)
             asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=a"(racc) : "v"(e16), "s"(uniform_ptr(rpart + (size_t)si * a.nparts * 256)) : "memory");
@@ -454,10 +505,18 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
 #pragma unroll
         for (int j = 0; j <= TS::kGpw; ++j) {
             if (j + 1 < TS::kGpw AQC_DBG_AND(!(a.debug & 2))) {
+                if (kPersist && from_regs) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    vw[(j + 1) & 1][s] = lds_get(ad.a1 ^ ad.k1[j + 1][s]);
-                    vz[(j + 1) & 1][s] = lds_get(a1z ^ ad.k1[j + 1][s]);
+                    for (int s = 0; s < 4; ++s) {
+                        vw[(j + 1) & 1][s] = make_double2(pw[4 * (j + 1) + s].x, pw[4 * (j + 1) + s].y);
+                        vz[(j + 1) & 1][s] = make_double2(pz[4 * (j + 1) + s].x, pz[4 * (j + 1) + s].y);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        vw[(j + 1) & 1][s] = lds_get(ad.a1 ^ ad.k1[j + 1][s]);
+                        vz[(j + 1) & 1][s] = lds_get(a1z ^ ad.k1[j + 1][s]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -527,6 +586,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             __builtin_amdgcn_sched_barrier(0);
         }
         AQC_STAMP(3 + 4 * si);
+        if (kPersist && more && st.nsubs == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) prefetch(c);
+        }
         if (si + 1 < st.nsubs || more) fetch_k<TS::kGpw>(ad, a.subs, si + 1 < st.nsubs ? st.sub_begin + si + 1 : st.sub_begin, wave, NW);
         cplx rr[4];
 #pragma unroll
@@ -594,6 +657,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         if (!go_on && more) cur = nxt;
     }
     AQC_STAMP(kStampSlots - 2);
+    // The next item's operands are waited for BEFORE this item's stores are issued: vmcnt counts stores as well, and a wait
+    // placed after them would sit out their whole write latency; the loads went out sub-stages ago.  (The loads are inline
+    // assembly: the register operands tie every later read of the prefetched values to this wait.)
+    if (more) wait_prefetched<NL>(pw, pz);
     if (a.store_out) {   // the last stage's w and z are never read again (only the gradient entries are results)
         store_tile3<K, true>(tw, a.out0 + lane_off, st, lo, wave);
         store_tile3<K, true>(tz, a.out1 + lane_off, st, lo, wave);
@@ -601,18 +668,11 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     AQC_STAMP(kStampSlots - 1);
     if (!more) break;
     AQC_STAMP(kStampSlots - 6);
-    __syncthreads();   // every wave has finished with the LDS tiles (sub-stage reads, scratch, the stores' LDS reads)
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the prefetched tiles have arrived
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const unsigned slot = swz3((unsigned)((wave + i * NW) << 6) | (threadIdx.x & 63u));
-        asm volatile("ds_write_b128 %0, %1" : : "v"(lds_base + (slot << 4)), "a"(pw[i]) : "memory");
-        asm volatile("ds_write_b128 %0, %1" : : "v"(lds_base + ((slot + tsize) << 4)), "a"(pz[i]) : "memory");
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes above are not tracked by the compiler either
-    __syncthreads();
+    __syncthreads();   // every wave has finished with the LDS tiles (sub-stage reads, scratch, the stores' LDS reads) before the
+                       // next item's first sub-stage writes its results there; the stores drain under that sub-stage
     AQC_STAMP(kStampSlots - 5);
     wi = nwi;
+    item_off = next_off;
     }
     AQC_STAMP(kStampSlots - 4);
 }
@@ -982,6 +1042,16 @@ void rgrad_print_stamps(int nsubs) {
 #endif
 
 // ---- launchers -----------------------------------------------------------------------------------------------
+// first_hi[g][s]: tile offset of (amplitude 4 s, chunk 16 g) of the stage's first sub-stage.  The slot tables hold swz3(local
+// index); swz3 is an involution, and the uniform part uses other bits of the local index than a lane's own part.
+void stage3_first_offsets(Stage3Args& a, const DevSub3& first_sub) {
+    for (int g = 0; g < 16; ++g)
+        for (int s = 0; s < 4; ++s) {
+            const unsigned local = swz3(first_sub.kk[g][s] >> 4);
+            a.first_hi[g][s] = a.stage.dlo[local & 63u] | a.stage.dhi[local >> 6];
+        }
+}
+
 int mfma_threads(int k, bool sweep) { return (sweep && k == 12) ? 64 * SweepShape<12>::kWaves : 64 * std::min(4, 1 << std::max(0, k - 8)); }
 size_t apply3_lds_bytes(int k) { return (size_t)16 << k; }
 size_t sweep3_lds_bytes(int k) {   // two tiles + R scratch of up to 4 slots, double-buffered where sweep_scratch_double says so
@@ -1059,6 +1129,7 @@ int sweep3_nparts(int ntiles, int batch, int k) {
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
     if (a.chunk != sweep3_chunk(ntiles, batch, k) || a.nparts != sweep3_nparts(ntiles, batch, k)) return hipErrorInvalidValue;
+    if (k >= 12 && a.stage.nsubs <= 0) return hipErrorInvalidValue;   // the persistent form feeds the first sub-stage from registers
     for (int l = 0; l < 64; ++l)   // the persistent sweep addresses its prefetch with a 32-bit byte offset per lane
         if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
     // 2^12 tiles: one persistent workgroup per CU walking over its items (see the kernel); smaller tiles: one item each

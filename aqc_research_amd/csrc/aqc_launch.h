@@ -69,10 +69,13 @@ struct Stage3Args {
     int chunk, nparts;       // sweep: items per persistent workgroup (0: one item per workgroup) and partial-R slots per
                              // (lane, sub-stage) -- sweep3_chunk / sweep3_nparts
     int store_out;           // sweep: 0 for the last stage (its w and z are never read again)
+    unsigned first_hi[16][4];   // persistent sweep: tile offset (elements) of the FIRST sub-stage's operand of (group, K-step);
+                                // a lane adds the offset of its own (chunk l % 16, amplitude l / 16) position (stage3_first_offsets)
     int debug;               // tuning builds: work-skipping bits for timing experiments (1 LDS writes, 2 LDS reads, 4 R MFMAs, 8 U MFMAs)
     unsigned long long* stamps;   // tuning builds (-DAQC_TUNING): [workgroup][kStampSlots] s_memtime stamps of wave 0, else null
 };
 constexpr int kStampSlots = 40;
+void stage3_first_offsets(Stage3Args& a, const DevSub3& first_sub);   // host: fills first_hi from the stage and its first sub-stage
 hipError_t init_kernels3();
 int mfma_threads(int k, bool sweep);
 int mfma_occupancy(int k, bool sweep);

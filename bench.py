@@ -409,7 +409,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=0, help="independent evaluations resident per GPU (default: 256 state vectors up to 16 qubits, 64 beyond, 32-64 matrices)")
+    ap.add_argument("--batch", type=int, default=0, help="independent evaluations resident per GPU (default: 1024 state vectors up to 16 qubits, 64 beyond, 32-64 matrices)")
     ap.add_argument("--workload", default="sv16_l40", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -503,9 +503,10 @@ def main():
     ncols = w.get("ncols", 1)
     N = (1 << n) * ncols          # complex128 elements per lane
     chi = w.get("chi", 0)
-    # lanes per GPU: 256 for state vectors up to 2^16 amplitudes (the persistent sweep walks 16 tiles per workgroup: launch
-    # ramp and tail are amortised; 64 lanes give 135.9k evals/s at the headline, 256 give 150k -- DESIGN 6), 64 otherwise
-    B = args.batch if args.batch > 0 else (64 if chi else ((256 if n <= 16 else 64) if ncols == 1 else (32 if ncols >= 256 else 64)))
+    # lanes per GPU: 1024 for state vectors up to 2^16 amplitudes (1 GiB per buffer at 16 qubits; a persistent sweep
+    # workgroup then walks 64 tiles, so launch ramp, prologue and tail are amortised: 64 lanes give 156k evals/s at the
+    # headline, 256 give 178k, 1024 give 183k -- DESIGN 6), 64 otherwise
+    B = args.batch if args.batch > 0 else (64 if chi else ((1024 if n <= 16 else 64) if ncols == 1 else (32 if ncols >= 256 else 64)))
     K, W = args.steps, args.warmup
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule
@@ -636,6 +637,14 @@ def main():
     out = None
     if rank == 0:
         # ---- per-kernel durations on this stream (HIP events around every launch) ----------
+        # (the card idled through the CPU check above: half a second of the same steps first, so that the profiled launches run
+        # at the clocks of the timed loop -- measured straight after the idle phase they come out 5-7 % longer than in the
+        # rocprofv3 kernel trace of the same command)
+        t_burst = time.perf_counter()
+        while time.perf_counter() - t_burst < 0.5:
+            for i in range(10):
+                step(W + i)
+            ws.sync()
         ws.profile(True)
         prof_steps = min(K, 10)
         for i in range(W, W + prof_steps):

@@ -147,14 +147,15 @@ def test_batched_surrogate_and_device_lbfgs_with_leading_flip_states():
     bo.close()
 
 
-def test_headline_at_256_lanes_all_lanes():
-    """The bench's default unit of work: 16 qubits, 40 blocks, 256 lanes (16 items per persistent sweep workgroup), every
-    lane against the compiled CPU restatement."""
+@pytest.mark.parametrize("B", [256, 1024])
+def test_headline_all_lanes(B):
+    """The bench's unit of work: 16 qubits, 40 blocks, 1024 lanes by default (64 items per persistent sweep workgroup; 256
+    lanes: 16), every lane against the compiled CPU restatement."""
     from aqc_research_amd import ParametricCircuit
     from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
 
-    n, L, B = 16, 40, 256
-    rng = np.random.default_rng(16256)
+    n, L = 16, 40
+    rng = np.random.default_rng(16000 + B)
     a = orc.Ansatz(n, "cx", orc.spin_blocks(n, L))
     thetas = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(B)])
     y = orc.rand_state(n, rng)

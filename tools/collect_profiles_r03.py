@@ -26,20 +26,20 @@ def copy(src, dst):
 
 for name in os.listdir(SRC):
     if name.startswith("bench_") and name.endswith(".json") and os.path.getsize(os.path.join(SRC, name)) > 0:
-        tag = {"bench_default.json": "r03_sv16_l40_b256_bench.json", "bench_b64.json": "r03_sv16_l40_b64_bench.json",
-               "bench_under_rocprof.json": "r03_sv16_l40_b256_bench_under_rocprof.json",
+        tag = {"bench_default.json": "r03_sv16_l40_b1024_bench.json", "bench_b64.json": "r03_sv16_l40_b64_bench.json", "bench_b256.json": "r03_sv16_l40_b256_bench.json",
+               "bench_under_rocprof.json": "r03_sv16_l40_b1024_bench_under_rocprof.json",
                "bench_cfg4_under_rocprof.json": "r03_cfg4_jobs_bench_under_rocprof.json"}.get(name, "r03_" + name)
         copy(name, tag)
-copy(os.path.join("kt", "kt_kernel_stats.csv"), "r03_sv16_l40_b256_kernel_stats.csv")
+copy(os.path.join("kt", "kt_kernel_stats.csv"), "r03_sv16_l40_b1024_kernel_stats.csv")
 copy(os.path.join("kt_cfg4", "kt_kernel_stats.csv"), "r03_cfg4_jobs_kernel_stats.csv")
 if have("gpu_tests.log"):
     with open(os.path.join(SRC, "gpu_tests.log")) as f, open(os.path.join(DST, "r03_gpu_tests_tail.txt"), "w") as g:
         g.write("".join(f.readlines()[-4:]))
 
 if have("pmc_f", "f_counter_collection.csv") and have("pmc_w", "w_counter_collection.csv"):
-    out = os.path.join(DST, "r03_sv16_l40_b256_pmc_traffic.json")
+    out = os.path.join(DST, "r03_sv16_l40_b1024_pmc_traffic.json")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(SRC, "pmc_f", "f_counter_collection.csv"),
-                    os.path.join(SRC, "pmc_w", "w_counter_collection.csv"), out, "sv16_l40", "256"], check=True, stdout=subprocess.DEVNULL)
+                    os.path.join(SRC, "pmc_w", "w_counter_collection.csv"), out, "sv16_l40", "1024"], check=True, stdout=subprocess.DEVNULL)
     d = json.load(open(out))
     d["date"] = today
     d["source"] = "builder-run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/prof_run3.py, tools/refresh_profiles_r03.sh"
@@ -51,7 +51,7 @@ sq = [os.path.join(SRC, d, "s_counter_collection.csv") for d in ("sq1", "sq2", "
 if sq:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_summary.py")] + sq, check=True, capture_output=True, text=True).stdout
     with open(os.path.join(DST, "r03_sq_counters.txt"), "w") as f:
-        f.write("# rocprofv3 --pmc passes of tools/prof_run3.py (16 qubits, 40 blocks, 256 lanes; mean per launch), " + today + "\n")
+        f.write("# rocprofv3 --pmc passes of tools/prof_run3.py (16 qubits, 40 blocks, 1024 lanes; mean per launch), " + today + "\n")
         f.write("# SIMD-cycles of a launch = duration x clock x 1024 SIMDs; GRBM_GUI_ACTIVE / 8 XCDs / duration = the clock the launch really ran at\n")
         f.write(txt)
     print("wrote sq counters")

@@ -11,7 +11,7 @@ from aqc_research_amd import ParametricCircuit  # noqa: E402
 from aqc_research_amd.circuit_structures import create_ansatz_structure  # noqa: E402
 from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace  # noqa: E402
 
-n, L, B = 16, 40, int(os.environ.get("AQC_PROF_BATCH", "256"))   # bench.py's default lanes per GPU at this size
+n, L, B = 16, 40, int(os.environ.get("AQC_PROF_BATCH", "1024"))   # bench.py's default lanes per GPU at this size
 circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", L))
 ctx = HipContext.of(circ)
 rng = np.random.default_rng(0)

@@ -1,4 +1,4 @@
-# Round-3 evidence run (GPU box): GPU suite, default bench (256 lanes) and 64 lanes, kernel trace, PMC traffic, SQ counters,
+# Round-3 evidence run (GPU box): GPU suite, default bench (1024 lanes), 256 and 64 lanes, kernel trace, PMC traffic, SQ counters,
 # every other workload, the config-4 job mix with its own kernel trace.  Usage: bash tools/refresh_profiles_r03.sh [part ...]
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -11,7 +11,8 @@ tests)
   tail -3 $O/gpu_tests.log ;;
 bench)
   python bench.py > $O/bench_default.json 2> $O/bench_default.err
-  python bench.py --batch 64 --no-cpu-baseline > $O/bench_b64.json 2> $O/bench_b64.err
+  python bench.py --batch 256 --no-cpu-baseline --no-objective-object > $O/bench_b256.json 2> $O/bench_b256.err
+  python bench.py --batch 64 --no-cpu-baseline --no-objective-object > $O/bench_b64.json 2> $O/bench_b64.err
   echo "bench done" ;;
 trace)
   rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-objective-object --sustain-seconds 0 > $O/bench_under_rocprof.json 2> $O/kt.err

@@ -169,6 +169,29 @@ def test_headline_all_lanes(B):
     ws.close()
 
 
+def test_config2_size_at_the_bench_lane_count():
+    """bench.py --workload sv12_trotter2 as it runs by default: 12 qubits, 2nd-order Trotter ansatz of 2 layers, 1024 lanes
+    (one 2^12 tile per lane, four items per persistent workgroup), each lane with its own target; every seventh lane against
+    the compiled CPU restatement."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
+
+    n, B = 12, 1024
+    circ, base, neel = _trotter(n, 2)
+    rng = np.random.default_rng(121024)
+    thetas = base[None, :] + 0.2 * np.pi * (2 * rng.random((B, circ.num_thetas)) - 1)
+    tg = rng.standard_normal((B, 1 << n)) + 1j * rng.standard_normal((B, 1 << n))
+    tg /= np.linalg.norm(tg, axis=1, keepdims=True)
+    ws = Workspace(HipContext.of(circ), batch=B)
+    ws.upload(BUF_Y, tg)
+    ws.set_basis(BUF_X, neel)
+    ws.gather_setup([neel])
+    hs, grads = ws.eval(thetas, gather=True)
+    for b in list(range(0, B, 7)) + [B - 1]:   # (the restatement takes one target per call)
+        h_ref, g_ref = cref.eval_batch(circ, thetas[b][None, :], tg[b], neel, threads=1)
+        assert abs(hs[b, 0] - h_ref[0]) < TOL and maxdiff(grads[b], g_ref[0]) < TOL
+    ws.close()
+
+
 @pytest.mark.parametrize("n,layers,B,T", [(12, 12, 6, 1620), (20, 16, 2, 3708)])
 def test_deepest_horizons_direct_parity(n, layers, B, T):
     """Config 2's last horizon (12 qubits, 12 layers) and config 4's (20 qubits, 16 layers: L = 912 blocks) through the

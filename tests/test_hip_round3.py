@@ -169,6 +169,28 @@ def test_headline_all_lanes(B):
     ws.close()
 
 
+@pytest.mark.parametrize("n,L,B", [(13, 1, 300), (13, 2, 300), (14, 3, 150), (13, 6, 517)])
+def test_shallow_circuits_on_the_persistent_sweep(n, L, B):
+    """Stages with one or two sub-stages on 2^12 tiles, several items per persistent workgroup: the next item's operands are
+    then requested after (single sub-stage) or inside the last sub-stage, not behind sub-stages 1-4 as at the headline depth."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
+
+    rng = np.random.default_rng(1000 * n + 10 * L + B)
+    a = orc.Ansatz(n, "cx", orc.spin_blocks(n, L))
+    thetas = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(B)])
+    y = orc.rand_state(n, rng)
+    ws = Workspace(HipContext.of(ParametricCircuit(n, "cx", a.blocks)), batch=B)
+    assert ws.plan_info(1)[1] == 12
+    ws.broadcast(BUF_Y, y)
+    ws.set_basis(BUF_X, 5)
+    ws.gather_setup([5])
+    hs, grads = ws.eval(thetas, gather=True)
+    hs_ref, g_ref = cref.eval_batch(a, thetas, y, 5, threads=16)
+    assert maxdiff(hs[:, 0], hs_ref) < TOL and maxdiff(grads, g_ref) < TOL
+    ws.close()
+
+
 def test_config2_size_at_the_bench_lane_count():
     """bench.py --workload sv12_trotter2 as it runs by default: 12 qubits, 2nd-order Trotter ansatz of 2 layers, 1024 lanes
     (one 2^12 tile per lane, four items per persistent workgroup), each lane with its own target; every seventh lane against

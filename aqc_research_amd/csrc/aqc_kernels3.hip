@@ -89,7 +89,9 @@ constexpr int kSweepSpread = 2, kApplySpread = 1;   // MFMAs between two LDS wri
 template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
     // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
     // work itself runs at 64 cycles per MFMA either way, and the per-wave cost of a sub-stage (operand prefetch, address
-    // set-up, R hand-over, barriers) doubles: 14.2k vs 13.0k cycles per sub-stage.  kSweepWaves12 = 8 re-enables them.)
+    // set-up, R hand-over, barriers) doubles: 14.2k vs 13.0k cycles per sub-stage.  That was before the prefetch moved into
+    // accumulation registers: two waves per SIMD leave 256 registers per wave for the pipeline AND the prefetch, and the round-3
+    // kernel no longer builds with kSweepWaves12 = 8.)
     static constexpr int kSweepWaves12 = 4;
     static constexpr int kWaves = (SWEEP && K == 12) ? kSweepWaves12 : (K >= 10 ? 4 : (1 << (K - 8)));
     static constexpr int kGroups = 1 << (K - 8);                       // groups of 16 chunks x 16 amplitudes

@@ -93,10 +93,11 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         np.copyto(self._hs2, np.absolute(self._hs) ** 2)
         # hysteresis: the leading state changes only for a 10 % better candidate (:113-117)
         max_proj = self._hs2[self._max_no]
-        for i in range(self._num_states):
-            if 1.1 * max_proj < self._hs2[i]:
-                max_proj = self._hs2[i]
-                self._max_no = i
+        if 1.1 * max_proj < self._hs2.max():   # (otherwise no candidate passes the test below: skip the Python loop)
+            for i in range(self._num_states):
+                if 1.1 * max_proj < self._hs2[i]:
+                    max_proj = self._hs2[i]
+                    self._max_no = i
         wgh = self._weight
         self._fobj = float(1.0 - (1.0 - wgh) * self._hs2[0] - wgh * self._hs2[self._max_no])
         self._fidelity = float(self._hs2[0])

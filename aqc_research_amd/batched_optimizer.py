@@ -21,6 +21,30 @@ from .model_sp_lhs.objective_base import ThinStateHandler
 __all__ = ["BatchedSurrogateObjective", "BatchedSketchingObjective", "batched_lbfgs"]
 
 
+class _RawResults:
+    """(hs, g0, None, max_no) of the last evaluation, as ``commit`` and ``batched_lbfgs`` index it.  g0 -- the raw complex
+    gradient of the sweep from |state_0>, available while |state_0> leads on every lane -- is the device's combined gradient
+    divided by c_0; the division is only done when somebody asks for it."""
+
+    def __init__(self, hs, gc, c0, max_no):
+        self._hs, self._gc, self._c0, self._max_no, self._g0 = hs, gc, c0, max_no.copy(), None
+
+    def __getitem__(self, i):
+        if i == 0:
+            return self._hs
+        if i == 1:
+            if self._c0 is None:
+                return None
+            if self._g0 is None:
+                self._g0 = self._gc / self._c0[:, None]
+            return self._g0
+        if i == 2:
+            return None
+        if i == 3:
+            return self._max_no
+        raise IndexError(i)
+
+
 class BatchedSurrogateObjective:
     """B lanes of the surrogate state-preparation objective on one workspace.  ``targets``: (B, 2^n) complex128;
     ``base_index``: computational-basis preparation (e.g. the Neel pattern) shared by all lanes."""
@@ -68,18 +92,25 @@ class BatchedSurrogateObjective:
         without touching them (line-search trials); ``True`` first applies the hysteresis and the weight smoothing --
         once per accepted step, as an objective()/gradient() pair does -- and evaluates under the new state.
 
-        While every lane leads with |state_0> one native call does V^H, the amplitudes and the sweep from |state_0>.  As soon
-        as some lane leads with a flip state, the sweep waits for the amplitudes: its lhs is then the combination
-        conj(c_0)|state_0> + conj(c_max)|state_max> per lane, whose gradient IS c_0 g_0 + c_max g_max (the gradient of <V x|y>
-        is conjugate-linear in x) -- one sweep where objective_lhs_sur_max.py:147-175 runs two."""
+        One native call (``aqc_ws_surrogate_eval``): V^H, the amplitudes, the state update and the lhs state of every lane on
+        the device, then ONE sweep -- its lhs is the combination conj(c_0)|state_0> + conj(c_max)|state_max> per lane, whose
+        gradient IS c_0 g_0 + c_max g_max (the gradient of <V x|y> is conjugate-linear in x) where
+        objective_lhs_sur_max.py:147-175 runs two sweeps.  (``_update`` / ``_assemble`` below are the same arithmetic on the
+        host: ``commit`` uses them on results that are already known.)"""
         th = np.ascontiguousarray(thetas, dtype=np.float64).reshape(self.batch, self.T)
         self.num_evals += self.batch
-        if not (self.max_no != 0).any():
-            hs, g0 = self.ws.eval(th, vdag=True, gather=True, grad=True, x_buf=BUF_X, block_range=self._block_range,
-                                  front_layer=self._front)
-            return self._assemble(hs, g0, None, update_state)
-        hs, _ = self.ws.eval(th, vdag=True, gather=True, grad=False, x_buf=BUF_X, block_range=self._block_range, front_layer=self._front)
-        return self._assemble(hs, None, None, update_state)
+        w = np.array(self.weight, dtype=np.float64)
+        mx = np.array(self.max_no, dtype=np.int64)
+        f, fid, hs, gc = self.ws.surrogate_eval(th, w, mx, update_state, self._block_range, self._front)
+        if update_state:
+            self.max_no, self.weight, self.fidelity = mx, w, fid
+        c0 = None
+        if not (mx != 0).any():   # |state_0> leads everywhere: the sweep ran from conj(c_0)|state_0>, c_0 = -2 conj(h_0)
+            c0 = -2.0 * np.conj(hs[:, 0])
+            if not (np.abs(c0) > 1e-150).all():
+                c0 = None
+        self.last_raw = _RawResults(hs, gc, c0, mx)
+        return f, gc.real.copy()
 
     def _update(self, hs2: np.ndarray):
         """10 % hysteresis (objective_lhs_sur_max.py:113-117) and weight smoothing (:186), lane-wise; returns (max_no, w)."""

@@ -307,6 +307,10 @@ struct aqc_ws {
     long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
     long long* d_combo_prev[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // set_combo: positions written last time
     bool combo_valid[AQC_NUM_BUFS] = {false, false, false, false, false, false};   // buffer holds exactly that sparse pattern
+    // aqc_ws_surrogate_eval: device block [f B | fidelity B | weight B | hs 2 B S | max_no B ints], its pinned mirror
+    void* d_sur = nullptr;
+    void* h_sur = nullptr;
+    int sur_states = 0;
     long long* d_combo_index = nullptr;   // [batch][2] staging of set_combo
     double2* d_combo_coef = nullptr;      // [batch][2]
     size_t small_cap = 0, index_cap = 0;
@@ -840,6 +844,8 @@ int aqc_ws_destroy(aqc_ws* ws) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->d_combo_prev[b]) (void)hipFree(ws->d_combo_prev[b]);
+    if (ws->d_sur) (void)hipFree(ws->d_sur);
+    if (ws->h_sur) (void)hipHostFree(ws->h_sur);
     if (ws->d_combo_index) (void)hipFree(ws->d_combo_index);
     if (ws->d_combo_coef) (void)hipFree(ws->d_combo_coef);
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
@@ -1382,6 +1388,90 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     cleanup();
 #undef LB_OK
 #undef LB_TRY
+    return 0;
+}
+
+// One evaluation of the lane-batched surrogate objective without the host inside it: V^H, the flip-state amplitudes, the
+// optional state update (hysteresis + weight smoothing, objective_lhs_sur_max.py:113-117,186), the value, the combined lhs
+// state of every lane and ONE sweep from it (see aqc_ws_set_combo) -- the evaluate step of aqc_ws_lbfgs as a call of its own.
+// Same preconditions: targets in Y, flip-state indices registered (state 0 first), X2 is used for the lhs states.
+int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, double* weight_io, int64_t* max_no_io, int block_from,
+                          int block_to, int front_layer, double* f_out, double* fidelity_out, double* hs_out, double* grads_out) {
+    if (!ws || !thetas || !weight_io || !max_no_io || !f_out || !grads_out) return fail("null argument");
+    if (ws->ncols != 1) return fail("the surrogate objective works on state-vector workspaces");
+    if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called (flip-state indices, state 0 first)");
+    HIP_OK(hipSetDevice(ws->device));
+    if (ws->copy_pending) {   // as in aqc_ws_eval: the pinned staging buffer is reused
+        HIP_OK(hipStreamSynchronize(ws->copy_stream));
+        ws->copy_pending = false;
+    }
+    const Program& prog = ws->ctx->prog;
+    const int B = ws->batch, T = prog.num_thetas(), S = ws->gather_count;
+    const size_t nth = (size_t)B * T;
+    for (int b = 0; b < B; ++b)
+        if (max_no_io[b] < 0 || max_no_io[b] >= S) return fail("leading state %lld of lane %d out of range", (long long)max_no_io[b], b);
+    hipStream_t st = ws->stream;
+    const size_t ndbl = (size_t)B * (3 + 2 * (size_t)S), bytes = ndbl * sizeof(double) + (size_t)B * sizeof(int);
+    if (ws->sur_states != S) {
+        HIP_OK(hipStreamSynchronize(st));
+        if (ws->d_sur) { HIP_OK(hipFree(ws->d_sur)); ws->d_sur = nullptr; }
+        if (ws->h_sur) { HIP_OK(hipHostFree(ws->h_sur)); ws->h_sur = nullptr; }
+        ws->sur_states = 0;
+        HIP_OK(hipMalloc(&ws->d_sur, bytes));
+        HIP_OK(hipHostMalloc(&ws->h_sur, bytes, hipHostMallocDefault));
+        ws->sur_states = S;
+    }
+    double* dd = static_cast<double*>(ws->d_sur);
+    double* hd = static_cast<double*>(ws->h_sur);
+    LbState L;
+    memset(&L, 0, sizeof L);
+    L.B = B; L.T = T; L.S = S;
+    double* d_f = dd;
+    L.fidelity = dd + B;
+    L.weight = dd + 2 * (size_t)B;
+    double2* d_hs = reinterpret_cast<double2*>(dd + 3 * (size_t)B);
+    L.max_no = reinterpret_cast<int*>(dd + ndbl);
+    int* h_max = reinterpret_cast<int*>(hd + ndbl);
+    // state in: weight and leading state of every lane
+    memcpy(hd + 2 * (size_t)B, weight_io, sizeof(double) * B);
+    for (int b = 0; b < B; ++b) h_max[b] = (int)max_no_io[b];
+    HIP_OK(hipMemcpyAsync(L.weight, hd + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(L.max_no, h_max, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    double* pin_th = ws->h_pin;
+    double* pin_gr = ws->h_pin + ws->pin_thetas;
+    memcpy(pin_th, thetas, sizeof(double) * nth);
+    ws->d_thetas = ws->d_thetas_own;
+    HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
+    if (run_coef(ws)) return 1;
+    if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+    if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+    if (!ws->d_combo_prev[AQC_BUF_X2]) {
+        HIP_OK(hipMalloc((void**)&ws->d_combo_prev[AQC_BUF_X2], sizeof(long long) * 2 * B));
+        ws->combo_valid[AQC_BUF_X2] = false;
+    }
+    if (!ws->combo_valid[AQC_BUF_X2]) {
+        HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st));
+        HIP_OK(hipMemsetAsync(ws->d_combo_prev[AQC_BUF_X2], 0xff, sizeof(long long) * 2 * B, st));   // -1: nothing to clear
+    }
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(lb_prepare(L, ws->d_small, update_state ? 1 : 0, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
+                          ws->d_combo_prev[AQC_BUF_X2], st));
+    }
+    // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
+    if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
+    ws->combo_valid[AQC_BUF_X2] = true;   // (grad_from does not write its lhs buffer)
+    HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(hd, dd, bytes, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    memcpy(grads_out, pin_gr, sizeof(double2) * nth);
+    memcpy(f_out, hd, sizeof(double) * B);
+    if (update_state) {
+        if (fidelity_out) memcpy(fidelity_out, hd + B, sizeof(double) * B);
+        memcpy(weight_io, hd + 2 * (size_t)B, sizeof(double) * B);
+        for (int b = 0; b < B; ++b) max_no_io[b] = h_max[b];
+    }
+    if (hs_out) memcpy(hs_out, hd + 3 * (size_t)B, sizeof(double2) * (size_t)B * S);
     return 0;
 }
 

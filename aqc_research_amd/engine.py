@@ -216,6 +216,28 @@ class Workspace:
                                   None if g is None else g.ctypes.data))
         return hs, g
 
+    def surrogate_eval(self, thetas, weight: np.ndarray, max_no: np.ndarray, update_state: bool = True,
+                       block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True):
+        """One evaluation of the lane-batched surrogate objective in one native call (``aqc_ws_surrogate_eval``): V^H, the
+        flip-state amplitudes, the optional state update, the value and ONE sweep from every lane's combined lhs state.
+        ``weight`` (float64[batch]) and ``max_no`` (int64[batch]) are the objective state, updated IN PLACE when
+        ``update_state``.  Returns (f[batch], fidelity[batch] or None, hs[batch][states], complex grads[batch][T])."""
+        self._touch(BUF_Z, BUF_W, BUF_ZW, BUF_X2)
+        th = _lib.as_f64(thetas, self.batch * self.T, "thetas")
+        if not (isinstance(weight, np.ndarray) and weight.dtype == np.float64 and weight.flags.c_contiguous and weight.size == self.batch):
+            raise ValueError("weight must be a C-contiguous float64 array of one entry per lane")
+        if not (isinstance(max_no, np.ndarray) and max_no.dtype == np.int64 and max_no.flags.c_contiguous and max_no.size == self.batch):
+            raise ValueError("max_no must be a C-contiguous int64 array of one entry per lane")
+        f = np.empty(self.batch)
+        fid = np.empty(self.batch) if update_state else None
+        hs = np.empty((self.batch, self._gather_count), dtype=np.complex128)
+        g = np.empty((self.batch, self.T), dtype=np.complex128)
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        check(self._L.aqc_ws_surrogate_eval(self.handle, dptr(th), int(bool(update_state)), dptr(weight),
+                                            max_no.ctypes.data_as(ctypes.POINTER(c_int64)), lo, hi, int(bool(front_layer)),
+                                            dptr(f), None if fid is None else dptr(fid), dptr(hs), dptr(g)))
+        return f, fid, hs, g
+
     def grad_from(self, x_buf: int, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
         self._touch(BUF_W, BUF_ZW)
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))

@@ -260,6 +260,16 @@ int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int lo
  * sweep from conj(c_0)|state_0> + conj(c_max)|state_max> (see aqc_ws_set_combo).  block_from / block_to / front_layer as in
  * aqc_ws_grad (block_from < 0: all blocks).  x0 / x_out: [batch][T]; f / fidelity / nit / weight / max_no: [batch]; the
  * last two are the objective's state at exit (smoothed weight, index of the leading state), either may be NULL. */
+/* One evaluation of that objective as a call of its own (the evaluate step of aqc_ws_lbfgs; stand-in for one
+ * objective(theta) + gradient(theta) pair of objective_lhs_sur_max.py:82-191 on every lane, one host synchronisation):
+ * thetas [batch][T]; weight_io / max_no_io [batch]: the objective state of every lane (smoothed weight, index of the leading
+ * state), updated in place when update_state != 0 (hysteresis :113-117 and smoothing :186 FIRST, then value and gradient under
+ * the new state) and left alone otherwise (line-search trials); f_out [batch]; fidelity_out [batch] (|h_0|^2, written on an
+ * update; may be NULL); hs_out [batch][states] complex amplitudes (may be NULL); grads_out [batch][T] COMPLEX gradient of the
+ * lane's one sweep from conj(c_0)|state_0> + conj(c_max)|state_max> -- its real part is the surrogate's gradient. */
+int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, double* weight_io, int64_t* max_no_io,
+                          int block_from, int block_to, int front_layer, double* f_out, double* fidelity_out, double* hs_out,
+                          double* grads_out);
 int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double gtol, double ftol, double fid_thr,
                  int max_backtracks, int block_from, int block_to, int front_layer, double* x_out, double* f_out,
                  double* fidelity_out, int64_t* nit_out, int64_t* nfev_out, double* weight_out, int64_t* max_no_out);

@@ -1435,34 +1435,68 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
     // state in: weight and leading state of every lane
     memcpy(hd + 2 * (size_t)B, weight_io, sizeof(double) * B);
     for (int b = 0; b < B; ++b) h_max[b] = (int)max_no_io[b];
-    HIP_OK(hipMemcpyAsync(L.weight, hd + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(L.max_no, h_max, sizeof(int) * B, hipMemcpyHostToDevice, st));
     double* pin_th = ws->h_pin;
     double* pin_gr = ws->h_pin + ws->pin_thetas;
     memcpy(pin_th, thetas, sizeof(double) * nth);
-    ws->d_thetas = ws->d_thetas_own;
-    HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
-    if (run_coef(ws)) return 1;
-    if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
-    if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
     if (!ws->d_combo_prev[AQC_BUF_X2]) {
         HIP_OK(hipMalloc((void**)&ws->d_combo_prev[AQC_BUF_X2], sizeof(long long) * 2 * B));
         ws->combo_valid[AQC_BUF_X2] = false;
     }
-    if (!ws->combo_valid[AQC_BUF_X2]) {
+    if (!ws->combo_valid[AQC_BUF_X2]) {   // (outside the replayed part: a whole-buffer clear is a one-off)
         HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st));
         HIP_OK(hipMemsetAsync(ws->d_combo_prev[AQC_BUF_X2], 0xff, sizeof(long long) * 2 * B, st));   // -1: nothing to clear
     }
-    {
-        ProfScope ps(ws, AQC_K_MISC);
-        HIP_OK(lb_prepare(L, ws->d_small, update_state ? 1 : 0, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
-                          ws->d_combo_prev[AQC_BUF_X2], st));
+    auto enqueue = [&]() -> int {   // everything between the host copies of the inputs and the final synchronisation
+        HIP_OK(hipMemcpyAsync(L.weight, hd + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(L.max_no, h_max, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        ws->d_thetas = ws->d_thetas_own;
+        HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
+        if (run_coef(ws)) return 1;
+        if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+        {
+            ProfScope ps(ws, AQC_K_MISC);
+            HIP_OK(lb_prepare(L, ws->d_small, update_state ? 1 : 0, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
+                              ws->d_combo_prev[AQC_BUF_X2], st));
+        }
+        // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
+        if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
+        HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(hd, dd, bytes, hipMemcpyDeviceToHost, st));
+        return 0;
+    };
+    static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
+    if (graphs_on && !ws->profile) {   // the launch sequence is replayed as a graph, as in aqc_ws_eval
+        const std::vector<long long> key = {1000 + (update_state ? 1 : 0), block_from, block_to, front_layer, (long long)S,
+                                            (long long)(size_t)ws->d_sur, (long long)(size_t)ws->h_sur, (long long)(size_t)ws->h_pin,
+                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2]};
+        auto it = ws->graphs.find(key);
+        if (it == ws->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_OK(hipStreamSynchronize(st));
+            HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            ws->capturing = true;
+            const int rc = enqueue();
+            ws->capturing = false;
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+            if (e != hipSuccess || !graph) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+            if (ws->graphs.size() >= 16) drop_graphs(ws);
+            it = ws->graphs.emplace(key, exec).first;
+        }
+        ws->d_thetas = ws->d_thetas_own;   // host-side state that enqueue() would have set
+        ws->coef_valid = true;
+        ws->fwd.u_valid = false;
+        ws->inv.u_valid = ws->sweep.u_valid = ws->inv.v3 && ws->sweep.v3;
+        HIP_OK(hipGraphLaunch(it->second, st));
+    } else if (enqueue()) {
+        return 1;
     }
-    // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
-    if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
     ws->combo_valid[AQC_BUF_X2] = true;   // (grad_from does not write its lhs buffer)
-    HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(hd, dd, bytes, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     memcpy(grads_out, pin_gr, sizeof(double2) * nth);
     memcpy(f_out, hd, sizeof(double) * B);

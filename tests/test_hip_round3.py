@@ -147,6 +147,57 @@ def test_batched_surrogate_and_device_lbfgs_with_leading_flip_states():
     bo.close()
 
 
+def test_surrogate_eval_call_between_other_users_of_the_lhs_buffer():
+    """aqc_ws_surrogate_eval (one native call per evaluation, replayed as a graph) keeps its two-hot lhs states in X2 next to
+    set_combo and the device L-BFGS, which write the same buffer: after either of them the next evaluation must still match the
+    host replay of the reference's state machine; trials (update_state=False) leave the state alone; bad states are refused."""
+    from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective
+    from aqc_research_amd.engine import BUF_X2
+
+    n, B = 13, 5
+    circ, base, neel = _trotter(n, 2)
+    rng = np.random.default_rng(1313)
+    targets = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    idx = orc.flip_state_indices(n, 1, neel)
+    bo = BatchedSurrogateObjective(circ, targets, base_index=neel)
+    w, mx = np.ones(B), np.zeros(B, dtype=int)
+
+    def check(th, update):
+        f, g = bo.value_and_grad(th, update_state=update)
+        for b in range(B):
+            if update:
+                fr, gr, w[b], mx[b] = _batched_reference(circ, idx, th[b], targets[b], w[b], mx[b])
+            else:   # the frozen state: value and two-sweep gradient of the reference under (w, mx) as they are
+                z = cref.v_dagger_mul_vec(circ, th[b], targets[b])
+                hs = z[idx]
+                fr = 1.0 - (1.0 - w[b]) * abs(hs[0]) ** 2 - w[b] * abs(hs[mx[b]]) ** 2
+                e0 = np.zeros(1 << n, complex); e0[idx[0]] = 1
+                g0 = cref.grad_of_dot_product(circ, th[b], e0, z, None, True)
+                if mx[b] == 0:
+                    gr = (g0 * (-2 * np.conj(hs[0]))).real
+                else:
+                    em = np.zeros(1 << n, complex); em[idx[mx[b]]] = 1
+                    gm = cref.grad_of_dot_product(circ, th[b], em, z, None, True)
+                    gr = (g0 * (-2 * (1 - w[b]) * np.conj(hs[0]))).real + (gm * (-2 * w[b] * np.conj(hs[mx[b]]))).real
+            assert abs(f[b] - fr) < TOL and maxdiff(g[b], gr) < TOL
+            assert bo.max_no[b] == mx[b] and abs(bo.weight[b] - w[b]) < 1e-13
+        return g
+
+    th = base + 0.1 * np.pi * (2 * rng.random((B, base.size)) - 1)
+    g = check(th, True)
+    g = check(th - 0.05 * g, False)                       # a trial: state untouched
+    bo.ws.set_combo(BUF_X2, np.tile([3, 70], (B, 1)), np.ones((B, 2), dtype=complex))   # somebody else's pattern in X2
+    g = check(th - 0.02 * g, True)
+    res = bo.minimize_on_device(th, maxiter=2)            # the device L-BFGS rewrites X2 and the objective state
+    w[:], mx[:] = bo.weight, bo.max_no
+    check(res["x"], True)
+    check(res["x"] + 0.01, False)
+    bad = np.full(B, idx.size, dtype=np.int64)
+    with pytest.raises(RuntimeError):
+        bo.ws.surrogate_eval(th, np.ones(B), bad, True)
+    bo.close()
+
+
 @pytest.mark.parametrize("B", [256, 1024])
 def test_headline_all_lanes(B):
     """The bench's unit of work: 16 qubits, 40 blocks, 1024 lanes by default (64 items per persistent sweep workgroup; 256

@@ -1400,6 +1400,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
     if (!ws || !thetas || !weight_io || !max_no_io || !f_out || !grads_out) return fail("null argument");
     if (ws->ncols != 1) return fail("the surrogate objective works on state-vector workspaces");
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called (flip-state indices, state 0 first)");
+    if (update_state < 0 || update_state > 2) return fail("update_state is 0 (none), 1 (hysteresis and weight) or 2 (hysteresis only)");
     HIP_OK(hipSetDevice(ws->device));
     if (ws->copy_pending) {   // as in aqc_ws_eval: the pinned staging buffer is reused
         HIP_OK(hipStreamSynchronize(ws->copy_stream));
@@ -1421,8 +1422,17 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         HIP_OK(hipHostMalloc(&ws->h_sur, bytes, hipHostMallocDefault));
         ws->sur_states = S;
     }
-    double* dd = static_cast<double*>(ws->d_sur);
     double* hd = static_cast<double*>(ws->h_sur);
+    // Small problems (single evaluations above all): no copy nodes -- the kernels read the thetas and the objective state from
+    // pinned host memory and write the state block and a second copy of the gradient straight back into it (as aqc_ws_eval does)
+    const bool zero_copy = sizeof(double2) * (nth + (size_t)B * S) <= 65536;
+    const bool direct_thetas = zero_copy && ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef;
+    double* dd = zero_copy ? hd : static_cast<double*>(ws->d_sur);
+    struct Scope {
+        aqc_ws* w;
+        Scope(aqc_ws* w_, double* g) : w(w_) { w->mirror_grads = g; w->mirror_small = nullptr; }
+        ~Scope() { w->mirror_grads = nullptr; w->mirror_small = nullptr; w->theta_host = nullptr; w->gather_rides = false; }
+    } scope(ws, zero_copy ? ws->h_pin + ws->pin_thetas : nullptr);
     LbState L;
     memset(&L, 0, sizeof L);
     L.B = B; L.T = T; L.S = S;
@@ -1447,27 +1457,33 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         HIP_OK(hipMemsetAsync(ws->d_combo_prev[AQC_BUF_X2], 0xff, sizeof(long long) * 2 * B, st));   // -1: nothing to clear
     }
     auto enqueue = [&]() -> int {   // everything between the host copies of the inputs and the final synchronisation
-        HIP_OK(hipMemcpyAsync(L.weight, hd + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(L.max_no, h_max, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        if (!zero_copy) {
+            HIP_OK(hipMemcpyAsync(L.weight, hd + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(L.max_no, h_max, sizeof(int) * B, hipMemcpyHostToDevice, st));
+        }
         ws->d_thetas = ws->d_thetas_own;
-        HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
+        if (!direct_thetas) HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
         if (run_coef(ws)) return 1;
+        ws->theta_host = direct_thetas ? pin_th : nullptr;   // the U builder reads the pinned thetas and stores them to HBM
         if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         {
             ProfScope ps(ws, AQC_K_MISC);
-            HIP_OK(lb_prepare(L, ws->d_small, update_state ? 1 : 0, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
+            HIP_OK(lb_prepare(L, ws->d_small, update_state, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
                               ws->d_combo_prev[AQC_BUF_X2], st));
         }
         // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
         if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
-        HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(hd, dd, bytes, hipMemcpyDeviceToHost, st));
+        ws->theta_host = nullptr;
+        if (!zero_copy) {
+            HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(hd, dd, bytes, hipMemcpyDeviceToHost, st));
+        }
         return 0;
     };
     static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
     if (graphs_on && !ws->profile) {   // the launch sequence is replayed as a graph, as in aqc_ws_eval
-        const std::vector<long long> key = {1000 + (update_state ? 1 : 0), block_from, block_to, front_layer, (long long)S,
+        const std::vector<long long> key = {1000 + update_state + (zero_copy ? 10 : 0), block_from, block_to, front_layer, (long long)S,
                                             (long long)(size_t)ws->d_sur, (long long)(size_t)ws->h_sur, (long long)(size_t)ws->h_pin,
                                             (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2]};
         auto it = ws->graphs.find(key);

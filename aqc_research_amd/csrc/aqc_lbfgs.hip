@@ -43,12 +43,13 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 
 // State update of one lane from its amplitudes: 10 % hysteresis on the leading flip state and the smoothed weight
 // (objective_lhs_sur_max.py:113-117, :186).
-__device__ __forceinline__ void lb_update(const cplx* h, int S, int& max_no, double& w) {
+__device__ __forceinline__ void lb_update(const cplx* h, int S, int& max_no, double& w, bool smooth = true) {
     double best = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
     for (int i = 0; i < S; ++i) {
         const double v = h[i].x * h[i].x + h[i].y * h[i].y;
         if (1.1 * best < v) { best = v; max_no = i; }
     }
+    if (!smooth) return;   // objective() alone: the weight moves when the gradient has been taken (objective_lhs_sur_max.py:186)
     const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
     const double f_old = 1.0 - (1.0 - w) * h0 - w * hm;
     w = w + 0.1 * (sqrt(fabs(f_old)) - w);
@@ -67,7 +68,7 @@ __global__ void lb_prepare_kernel(LbState st, const cplx* hs, int update, double
     const cplx* h = hs + (size_t)b * st.S;
     int max_no = st.max_no[b];
     double w = st.weight[b];
-    if (update) lb_update(h, st.S, max_no, w);
+    if (update) lb_update(h, st.S, max_no, w, update == 1);   // update == 2: hysteresis only
     const double h0 = h[0].x * h[0].x + h[0].y * h[0].y, hm = h[max_no].x * h[max_no].x + h[max_no].y * h[max_no].y;
     const bool lead = max_no != 0;
     f_out[b] = 1.0 - (1.0 - w) * h0 - w * hm;

@@ -221,7 +221,8 @@ class Workspace:
         """One evaluation of the lane-batched surrogate objective in one native call (``aqc_ws_surrogate_eval``): V^H, the
         flip-state amplitudes, the optional state update, the value and ONE sweep from every lane's combined lhs state.
         ``weight`` (float64[batch]) and ``max_no`` (int64[batch]) are the objective state, updated IN PLACE when
-        ``update_state``.  Returns (f[batch], fidelity[batch] or None, hs[batch][states], complex grads[batch][T])."""
+        ``update_state`` (True / 1: hysteresis and weight smoothing; 2: hysteresis only, as objective() does on its own).
+        Returns (f[batch], fidelity[batch] or None, hs[batch][states], complex grads[batch][T])."""
         self._touch(BUF_Z, BUF_W, BUF_ZW, BUF_X2)
         th = _lib.as_f64(thetas, self.batch * self.T, "thetas")
         if not (isinstance(weight, np.ndarray) and weight.dtype == np.float64 and weight.flags.c_contiguous and weight.size == self.batch):
@@ -233,7 +234,7 @@ class Workspace:
         hs = np.empty((self.batch, self._gather_count), dtype=np.complex128)
         g = np.empty((self.batch, self.T), dtype=np.complex128)
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
-        check(self._L.aqc_ws_surrogate_eval(self.handle, dptr(th), int(bool(update_state)), dptr(weight),
+        check(self._L.aqc_ws_surrogate_eval(self.handle, dptr(th), int(update_state), dptr(weight),
                                             max_no.ctypes.data_as(ctypes.POINTER(c_int64)), lo, hi, int(bool(front_layer)),
                                             dptr(f), None if fid is None else dptr(fid), dptr(hs), dptr(g)))
         return f, fid, hs, g

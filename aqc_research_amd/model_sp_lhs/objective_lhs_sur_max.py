@@ -45,6 +45,8 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         # round trip.  Pure caching: values are exactly those of separate calls.
         self._speculative = bool(user_parameters.get("speculative_gradient", True)) and not self._dense
         self._grad0 = None       # cached complex gradient of the |state_0> term at self._last_thetas
+        self._gradc = None       # cached complex gradient of the combined sweep at self._last_thetas (a flip state leads)
+        self._gradc_max_no = -1  # leading state that sweep was taken for
         self._x2_state = -1      # state currently held in BUF_X2
         if not self._dense and self._ws is not None:
             self._ws.set_basis(BUF_X, int(self._state_handler.state_indices[0]))
@@ -71,11 +73,22 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         """Z = V^H|target> and hs[i] = <state_i|Z> on the device (objective_lhs_sur_max.py:96-108)."""
         ws = self._ws
         front = bool(self._front_layer or self._block_range == (0, self._circuit.num_blocks))
+        self._gradc = None
         if self._dense:
             ws.set_thetas(thetas)
             ws.apply(True, BUF_Y, BUF_Z)
             self._hs[:] = self._projections()
             self._grad0 = None
+        elif self._speculative and self._max_no != 0 and hasattr(ws, "surrogate_eval"):   # (not on a lockstep LaneView)
+            # a flip state leads: ONE native call does V^H, the amplitudes, the hysteresis (the weight stays: it moves in
+            # gradient()) and the sweep from the combination of |state_0> and the leading state under that state
+            # (aqc_ws_surrogate_eval, mode 2), so the gradient() call that follows costs no GPU round trip either
+            w = np.array([self._weight], dtype=np.float64)
+            mx = np.array([self._max_no], dtype=np.int64)
+            _, _, hs, gc = ws.surrogate_eval(thetas, w, mx, 2, self._block_range, front)
+            self._hs[:] = hs[0]
+            self._grad0, self._gradc, self._gradc_max_no = None, gc[0], int(mx[0])
+            self._x2_state = -1
         else:
             # the sweep from |state_0> rides along only while |state_0> leads: otherwise gradient() runs ONE sweep from the
             # combination of |state_0> and the leading state (see gradient), and a speculative one would be wasted
@@ -98,6 +111,8 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
                 if 1.1 * max_proj < self._hs2[i]:
                     max_proj = self._hs2[i]
                     self._max_no = i
+        if self._gradc is not None and self._gradc_max_no != self._max_no:
+            self._gradc = None   # (a tie broken differently on the device: gradient() sweeps again)
         wgh = self._weight
         self._fobj = float(1.0 - (1.0 - wgh) * self._hs2[0] - wgh * self._hs2[self._max_no])
         self._fidelity = float(self._hs2[0])
@@ -138,7 +153,11 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
         self._service.on_begin_gradient(self._fobj, thetas, self._fidelity)  # may raise (stoppers)
         self._calc_objective_before_gradient(thetas)
         front = bool(self._front_layer or self._block_range == (0, self._circuit.num_blocks))
-        if self._max_no == 0:
+        if self._gradc is not None:
+            # taken together with the objective: c_0 g_0 + c_max g_max under the weight and the leading state of this pair
+            # (c_max = 0 and c_0 = -2 conj(h_0) when the hysteresis went back to |state_0>)
+            full_grad, self._gradc = self._gradc.real.copy(), None
+        elif self._max_no == 0:
             grad_0 = self._sweep(0, front)
             full_grad = (grad_0 * (-2 * np.conj(self._hs[0]))).real.copy()
         else:

@@ -263,8 +263,9 @@ int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int lo
 /* One evaluation of that objective as a call of its own (the evaluate step of aqc_ws_lbfgs; stand-in for one
  * objective(theta) + gradient(theta) pair of objective_lhs_sur_max.py:82-191 on every lane, one host synchronisation):
  * thetas [batch][T]; weight_io / max_no_io [batch]: the objective state of every lane (smoothed weight, index of the leading
- * state), updated in place when update_state != 0 (hysteresis :113-117 and smoothing :186 FIRST, then value and gradient under
- * the new state) and left alone otherwise (line-search trials); f_out [batch]; fidelity_out [batch] (|h_0|^2, written on an
+ * state), updated in place when update_state != 0 -- 1: hysteresis :113-117 and smoothing :186 FIRST, then value and gradient
+ * under the new state (one accepted optimizer step); 2: hysteresis only, the weight stays (what objective(theta) does before
+ * gradient(theta) moves the weight) -- and left alone when it is 0 (line-search trials); f_out [batch]; fidelity_out [batch] (|h_0|^2, written on an
  * update; may be NULL); hs_out [batch][states] complex amplitudes (may be NULL); grads_out [batch][T] COMPLEX gradient of the
  * lane's one sweep from conj(c_0)|state_0> + conj(c_max)|state_max> -- its real part is the surrogate's gradient. */
 int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, double* weight_io, int64_t* max_no_io,

@@ -1885,64 +1885,22 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
     if (check_mps_slot(ws, slot, true) || check_buf(ws, buf)) return 1;
     if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
     HIP_OK(hipSetDevice(ws->device));
-    const aqc_ws::MpsSlot& m = ws->mps[slot];
     const int n = ws->ctx->prog.n;
-    const int h = n / 2, mh = n - h;     // low bits from sites 0..h-1, high bits from sites h..n-1
-    size_t need_l = 2, need_r = 2;
-    for (int q = 0; q < h; ++q) need_l = std::max(need_l, ((size_t)2 << q) * m.dims[q + 1]);
-    for (int q = n - 1; q >= h; --q) need_r = std::max(need_r, ((size_t)2 << (n - 1 - q)) * m.dims[q]);
-    const size_t need_g = (size_t)1 << n;
-    if (mps_scratch(ws, 2 * need_l + 2 * need_r + need_g)) return 1;
-    double2* lbuf[2] = {ws->d_mps_scratch, ws->d_mps_scratch + need_l};
-    double2* rbuf[2] = {lbuf[1] + need_l, lbuf[1] + need_l + need_r};
-    double2* g = rbuf[1] + need_r;
-    double2* out = ws->bufs[buf] + (size_t)lane * ws->lane_elems;
+    if (n >= 2) {   // one (slot, lane) pair of the batched chain below
+        const int32_t s1 = slot, l1 = lane;
+        return aqc_ws_mps_to_vec_batch(ws, 1, &s1, buf, &l1);
+    }
+    // n == 1: the state is the site tensor itself, [b][1][1]
     ws->combo_valid[buf] = false;
-    // left part: L_q[idx + 2^q b][chi'] = sum_chi L[idx][chi] T_q[b][chi][chi']; site 0 is L_0 = T_0 viewed as (2 x chi_1)
-    const double2* L = m.d_t;
-    for (int q = 1; q < h; ++q) {
-        double2* dst = lbuf[q & 1];
-        const int rows = 1 << q, kk = m.dims[q], nn = m.dims[q + 1];
-        ProfScope ps(ws, AQC_K_MISC);
-        HIP_OK(launch_zgemm_batched(false, false, rows, nn, kk, L, kk, m.d_t + m.offset[q], nn, dst, nn, 0, (size_t)kk * nn,
-                                    (size_t)rows * nn, 2, ws->stream));
-        L = dst;
-    }
-    // right part: Rt_q[chi_l][i + 2^j b] = sum_chi_r T_q[b][chi_l][chi_r] Rt[chi_r][i], j = n - 1 - q; the last site is
-    // Rt = T_{n-1} viewed as (chi x 2): element [chi][b] = T[b][chi][0]  -> built by the same recurrence from Rt = [1]
-    const double2* Rt = nullptr;
-    for (int q = n - 1; q >= h; --q) {
-        const int j = n - 1 - q, cols = 1 << j, chil = m.dims[q], chir = m.dims[q + 1];
-        double2* dst = rbuf[j & 1];
-        ProfScope ps(ws, AQC_K_MISC);
-        if (j == 0) {   // Rt[chi_l][b] = T[b][chi_l][0]: a (chi_l x 1)(1 x 1) product per b with the constant 1
-            HIP_OK(hipMemcpy2DAsync(dst, 2 * sizeof(double2), m.d_t + m.offset[q], sizeof(double2), sizeof(double2), chil,
-                                    hipMemcpyDeviceToDevice, ws->stream));
-            HIP_OK(hipMemcpy2DAsync(dst + 1, 2 * sizeof(double2), m.d_t + m.offset[q] + chil, sizeof(double2), sizeof(double2), chil,
-                                    hipMemcpyDeviceToDevice, ws->stream));
-        } else {
-            HIP_OK(launch_zgemm_batched(false, false, chil, cols, chir, m.d_t + m.offset[q], chir, Rt, cols, dst, 2 * cols,
-                                        (size_t)chil * chir, 0, (size_t)cols, 2, ws->stream));
-        }
-        Rt = dst;
-    }
-    {
-        ProfScope ps(ws, AQC_K_MISC);
-        if (h == 0) {   // n == 1: the state is Rt itself
-            HIP_OK(hipMemcpyAsync(out, Rt, sizeof(double2) * 2, hipMemcpyDeviceToDevice, ws->stream));
-        } else {
-            const int chi = m.dims[h];
-            HIP_OK(launch_zgemm(false, false, 1 << h, 1 << mh, chi, L, chi, Rt, 1 << mh, g, 1 << mh, ws->stream));
-            HIP_OK(launch_mps_permute(g, out, h, mh, ws->stream));
-        }
-    }
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(hipMemcpyAsync(ws->bufs[buf] + (size_t)lane * ws->lane_elems, ws->mps[slot].d_t, sizeof(double2) * 2, hipMemcpyDeviceToDevice, ws->stream));
     return 0;
 }
 
-// The same contraction for `count` (slot, lane) pairs at once: MPS slots[i] -> lane lanes[i] of `buf`.  When all the slots
-// have the same bond dimensions (the lanes of a batched objective) every step of the chain is ONE launch for all lanes
-// (zgemm over device pointer tables): (n/2 - 1) + (n - n/2) + 2 launches whatever the number of lanes; otherwise the
-// pairs are served one after the other.
+// MPS -> dense (mps_operations.py:159-189) for `count` (slot, lane) pairs at once: MPS slots[i] -> lane lanes[i] of `buf`.
+// When all the slots have the same bond dimensions (the lanes of a batched objective) every step of the chain is ONE launch
+// for all lanes (zgemm over device pointer tables): (n/2 - 1) + (n - n/2 - 1) + 1 launches whatever the number of lanes, ONE
+// for product states; otherwise the pairs are served one after the other.
 int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf, const int32_t* lanes) {
     if (!ws || !slots || !lanes || count < 1) return fail("invalid batched MPS arguments");
     if (check_buf(ws, buf)) return 1;
@@ -1954,7 +1912,7 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
     for (int i = 1; i < count; ++i) uniform = uniform && ws->mps[slots[i]].dims == ws->mps[slots[0]].dims;
     const int n = ws->ctx->prog.n;
     const int h = n / 2, mh = n - h;
-    if (!uniform || count == 1 || h == 0) {
+    if (!uniform || h == 0) {
         for (int i = 0; i < count; ++i)
             if (aqc_ws_mps_to_vec(ws, slots[i], buf, lanes[i])) return 1;
         return 0;
@@ -1962,21 +1920,46 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
     HIP_OK(hipSetDevice(ws->device));
     const std::vector<int>& dims = ws->mps[slots[0]].dims;
     const std::vector<size_t>& off = ws->mps[slots[0]].offset;
+    ws->combo_valid[buf] = false;
+    std::vector<const void*> tabs;
+    auto table = [&](auto fn) { const size_t at = tabs.size(); for (int i = 0; i < count; ++i) tabs.push_back(fn(i)); return at; };
+    auto out_lane = [&](int i) { return (const void*)(ws->bufs[buf] + (size_t)lanes[i] * ws->lane_elems); };
+    auto upload_tables = [&]() -> int {   // pointer tables of every launch of the chain, one copy
+        if (tabs.size() > ws->mps_tabs_cap) {
+            HIP_OK(hipStreamSynchronize(ws->stream));
+            if (ws->d_mps_tabs) HIP_OK(hipFree(ws->d_mps_tabs));
+            ws->d_mps_tabs = nullptr; ws->mps_tabs_cap = 0;
+            HIP_OK(hipMalloc((void**)&ws->d_mps_tabs, tabs.size() * sizeof(void*)));
+            ws->mps_tabs_cap = tabs.size();
+        }
+        HIP_OK(hipMemcpyAsync(ws->d_mps_tabs, tabs.data(), tabs.size() * sizeof(void*), hipMemcpyHostToDevice, ws->stream));
+        HIP_OK(hipStreamSynchronize(ws->stream));   // `tabs` goes away
+        return 0;
+    };
+    bool product = true;
+    for (int q = 0; q <= n; ++q) product = product && dims[q] == 1;
+    if (product) {   // product states (|0>, the Neel state, ...: the usual lhs operand): one launch, no chain
+        const size_t ta = table([&](int i) { return (const void*)ws->mps[slots[i]].d_t; });
+        const size_t tc = table(out_lane);
+        if (upload_tables()) return 1;
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_mps_product(ws->d_mps_tabs + ta, (void* const*)(ws->d_mps_tabs + tc), n, count, ws->stream));
+        return 0;
+    }
+    // Left half L[l][chi] (sites 0 .. h-1, site 0 the lowest bit of l), right half transposed Rt[r][chi] (sites n-1 .. h, every
+    // new site becoming the LOWEST bit of r, so that site h ends up there), and out[r 2^h + l] = sum_chi Rt[r][chi] L[l][chi]
+    // written by the last product straight into the lane's buffer in the workspace's bit order (bit q = site q): no
+    // scratch copy of the dense state, no permutation pass.
     size_t need_l = 2, need_r = 2;
     for (int q = 0; q < h; ++q) need_l = std::max(need_l, ((size_t)2 << q) * dims[q + 1]);
     for (int q = n - 1; q >= h; --q) need_r = std::max(need_r, ((size_t)2 << (n - 1 - q)) * dims[q]);
-    const size_t need_g = (size_t)1 << n, per = 2 * need_l + 2 * need_r + need_g;
+    const size_t per = 2 * need_l + 2 * need_r;
     if (mps_scratch(ws, per * (size_t)count)) return 1;
-    ws->combo_valid[buf] = false;
-    // pointer tables of every launch of the chain, uploaded in one copy
     struct Step { int kind, q; size_t a, b, c; };   // offsets (in pointers) of the three tables inside the upload
-    std::vector<const void*> tabs;
     std::vector<Step> steps;
     auto lb = [&](int i, int k) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + need_l * (size_t)k); };
     auto rb = [&](int i, int k) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + 2 * need_l + need_r * (size_t)k); };
-    auto gb = [&](int i) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + 2 * need_l + 2 * need_r); };
     auto site = [&](int i, int q) { return (const void*)(ws->mps[slots[i]].d_t + off[q]); };
-    auto table = [&](auto fn) { const size_t at = tabs.size(); for (int i = 0; i < count; ++i) tabs.push_back(fn(i)); return at; };
     for (int q = 1; q < h; ++q) {       // left part: L_q = L_{q-1} T_q, both values of the site's bit (inner = 2)
         Step st{0, q, 0, 0, 0};
         st.a = q == 1 ? table([&](int i) { return site(i, 0); }) : table([&](int i) { return lb(i, (q - 1) & 1); });
@@ -1984,31 +1967,21 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
         st.c = table([&](int i) { return lb(i, q & 1); });
         steps.push_back(st);
     }
-    for (int q = n - 1; q >= h; --q) {  // right part
+    // right part: Rt_0 = the last site as it is stored ([2][chi][1] = [r][chi]); Rt_j[2 c + b] = Rt_{j-1}[c] T_q[b]^T
+    for (int q = n - 2; q >= h; --q) {
         const int j = n - 1 - q;
-        Step st{j == 0 ? 1 : 2, q, 0, 0, 0};
-        st.a = table([&](int i) { return site(i, q); });
-        st.b = j == 0 ? st.a : table([&](int i) { return rb(i, (j - 1) & 1); });
+        Step st{2, q, 0, 0, 0};
+        st.a = j == 1 ? table([&](int i) { return site(i, n - 1); }) : table([&](int i) { return rb(i, (j - 1) & 1); });
+        st.b = table([&](int i) { return site(i, q); });
         st.c = table([&](int i) { return rb(i, j & 1); });
         steps.push_back(st);
     }
     Step fin{3, 0, 0, 0, 0};
-    fin.a = h == 1 ? table([&](int i) { return site(i, 0); }) : table([&](int i) { return lb(i, (h - 1) & 1); });
-    fin.b = table([&](int i) { return rb(i, (mh - 1) & 1); });
-    fin.c = table([&](int i) { return gb(i); });
+    fin.a = mh == 1 ? table([&](int i) { return site(i, n - 1); }) : table([&](int i) { return rb(i, (mh - 1) & 1); });
+    fin.b = h == 1 ? table([&](int i) { return site(i, 0); }) : table([&](int i) { return lb(i, (h - 1) & 1); });
+    fin.c = table(out_lane);
     steps.push_back(fin);
-    Step perm{4, 0, fin.c, 0, 0};
-    perm.c = table([&](int i) { return (const void*)(ws->bufs[buf] + (size_t)lanes[i] * ws->lane_elems); });
-    steps.push_back(perm);
-    if (tabs.size() > ws->mps_tabs_cap) {
-        HIP_OK(hipStreamSynchronize(ws->stream));
-        if (ws->d_mps_tabs) HIP_OK(hipFree(ws->d_mps_tabs));
-        ws->d_mps_tabs = nullptr; ws->mps_tabs_cap = 0;
-        HIP_OK(hipMalloc((void**)&ws->d_mps_tabs, tabs.size() * sizeof(void*)));
-        ws->mps_tabs_cap = tabs.size();
-    }
-    HIP_OK(hipMemcpyAsync(ws->d_mps_tabs, tabs.data(), tabs.size() * sizeof(void*), hipMemcpyHostToDevice, ws->stream));
-    HIP_OK(hipStreamSynchronize(ws->stream));   // `tabs` goes away
+    if (upload_tables()) return 1;
     const void* const* T = ws->d_mps_tabs;
     ProfScope ps(ws, AQC_K_MISC);
     for (const Step& st : steps) {
@@ -2016,17 +1989,14 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
             const int q = st.q, rows = 1 << q, kk = dims[q], nn = dims[q + 1];
             HIP_OK(launch_zgemm_tables(rows, nn, kk, T + st.a, kk, T + st.b, nn, (void* const*)(T + st.c), nn, 0, (size_t)kk * nn, (size_t)rows * nn,
                                        count, 2, ws->stream));
-        } else if (st.kind == 1) {
-            HIP_OK(launch_mps_last_site(T + st.a, (void* const*)(T + st.c), dims[st.q], count, ws->stream));
-        } else if (st.kind == 2) {
+        } else if (st.kind == 2) {   // C rows 2 c + b: ldc = 2 chil, the bit's block starts chil further; B = T_q[b] stored [chil][chir], used transposed
             const int q = st.q, j = n - 1 - q, cols = 1 << j, chil = dims[q], chir = dims[q + 1];
-            HIP_OK(launch_zgemm_tables(chil, cols, chir, T + st.a, chir, T + st.b, cols, (void* const*)(T + st.c), 2 * cols, (size_t)chil * chir, 0,
-                                       (size_t)cols, count, 2, ws->stream));
-        } else if (st.kind == 3) {
+            HIP_OK(launch_zgemm_tables(cols, chil, chir, T + st.a, chir, T + st.b, chir, (void* const*)(T + st.c), 2 * chil, 0, (size_t)chil * chir,
+                                       (size_t)chil, count, 2, ws->stream, 1));
+        } else {                     // out [2^mh][2^h] = Rt [2^mh][chi] . L^T, L stored [2^h][chi]
             const int chi = dims[h];
-            HIP_OK(launch_zgemm_tables(1 << h, 1 << mh, chi, T + st.a, chi, T + st.b, 1 << mh, (void* const*)(T + st.c), 1 << mh, 0, 0, 0, count, 1, ws->stream));
-        } else {
-            HIP_OK(launch_mps_permute_tables(T + st.a, (void* const*)(T + st.c), h, mh, count, ws->stream));
+            HIP_OK(launch_zgemm_tables(1 << mh, 1 << h, chi, T + st.a, chi, T + st.b, chi, (void* const*)(T + st.c), 1 << h, 0, 0, 0, count, 1,
+                                       ws->stream, 1));
         }
     }
     return 0;

@@ -138,9 +138,8 @@ hipError_t launch_mps_env_dot(const void* e, const void* rc, size_t count, void*
 hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                 void* C, int ldc, size_t stride_a, size_t stride_b, size_t stride_c, int nbatch, hipStream_t s);
 hipError_t launch_zgemm_tables(int M, int N, int K, const void* const* a_tab, int lda, const void* const* b_tab, int ldb, void* const* c_tab, int ldc,
-                               size_t stride_a, size_t stride_b, size_t stride_c, int outer, int inner, hipStream_t s);
-hipError_t launch_mps_last_site(const void* const* t_tab, void* const* rt_tab, int chil, int count, hipStream_t s);
-hipError_t launch_mps_permute_tables(const void* const* g_tab, void* const* out_tab, int h, int m, int count, hipStream_t s);
+                               size_t stride_a, size_t stride_b, size_t stride_c, int outer, int inner, hipStream_t s, int b_transposed = 0);
+hipError_t launch_mps_product(const void* const* t_tab, void* const* out_tab, int n, int count, hipStream_t s);
 struct MpsSites {            // site table of one MPS (by value in the kernel arguments)
     int n;
     size_t total;            // complex elements of all site tensors
@@ -149,7 +148,6 @@ struct MpsSites {            // site table of one MPS (by value in the kernel ar
     int cols[64];            // right bond dimension of site q
 };
 hipError_t launch_mps_scale_all(void* t, const double* lam, const MpsSites& sites, hipStream_t s);
-hipError_t launch_mps_permute(const void* g, void* out, int h, int m, hipStream_t s);
 
 // aqc_cd.hip
 int cd_num_parts(size_t npairs);

@@ -31,15 +31,6 @@ __global__ void mps_scale_all_kernel(cplx* t, const double* lam, MpsSites sites)
     t[i].x *= sc;
     t[i].y *= sc;
 }
-// out[(rev(i) << h) + lo] = g[lo * 2^m + i], rev = bit reversal over m bits (final step of the MPS -> dense contraction)
-__global__ void mps_permute_kernel(const cplx* g, cplx* out, int h, int m) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ((size_t)1 << (h + m))) return;
-    const unsigned i = (unsigned)(e & (((size_t)1 << m) - 1)), lo = (unsigned)(e >> m);
-    const unsigned r = m ? (__brev(i) >> (32 - m)) : 0u;
-    out[((size_t)r << h) + lo] = g[e];
-}
-
 // C[M x N] (+)= op(A) * B, row-major.  CONJ_T: op(A)[m][k] = conj(A[k][m]) with A stored (K x M).
 //
 // fp64 matrix cores: one v_mfma_f64_16x16x4_f64 multiplies a 16x4 by a 4x16 real tile.  Operand layout
@@ -88,7 +79,8 @@ __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const c
             const int gk = k0 + kk, gn = n0 + nn;
             cplx v = make_double2(0.0, 0.0);
             if (gk < K && gn < N) {
-                if (b_herm) { v = B[(size_t)gn * ldb + gk]; v.y = -v.y; } else { v = B[(size_t)gk * ldb + gn]; }   // b_herm: B holds (N x K), used as B^H
+                // b_herm 1: B holds (N x K) and is used as B^H; 2: the same storage used as B^T (no conjugation)
+                if (b_herm) { v = B[(size_t)gn * ldb + gk]; if (b_herm == 1) v.y = -v.y; } else { v = B[(size_t)gk * ldb + gn]; }
             }
             sbr[kk][nn] = v.x;
             sbi[kk][nn] = v.y;
@@ -133,12 +125,6 @@ hipError_t launch_mps_scale_all(void* t, const double* lam, const MpsSites& site
     mps_scale_all_kernel<<<(unsigned)((sites.total + 255) / 256), 256, 0, s>>>(static_cast<cplx*>(t), lam, sites);
     return hipGetLastError();
 }
-hipError_t launch_mps_permute(const void* g, void* out, int h, int m, hipStream_t s) {
-    const size_t total = (size_t)1 << (h + m);
-    mps_permute_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<const cplx*>(g), static_cast<cplx*>(out), h, m);
-    return hipGetLastError();
-}
-
 namespace {
 hipError_t zgemm_launch(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, size_t sa,
                         size_t sb, size_t sc, int nbatch, int b_herm, hipStream_t s, ZTables tab = ZTables{nullptr, nullptr, nullptr, 0}) {
@@ -176,36 +162,29 @@ hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, co
 
 // `outer` x `inner` products in one launch: bases from the device pointer tables, advanced by the strides per inner index
 hipError_t launch_zgemm_tables(int M, int N, int K, const void* const* a_tab, int lda, const void* const* b_tab, int ldb, void* const* c_tab, int ldc,
-                               size_t sa, size_t sb, size_t sc, int outer, int inner, hipStream_t s) {
+                               size_t sa, size_t sb, size_t sc, int outer, int inner, hipStream_t s, int b_transposed) {
     const ZTables tab{reinterpret_cast<const cplx* const*>(a_tab), reinterpret_cast<const cplx* const*>(b_tab), reinterpret_cast<cplx* const*>(c_tab), inner};
-    return zgemm_launch(false, false, M, N, K, nullptr, lda, nullptr, ldb, nullptr, ldc, sa, sb, sc, outer * inner, 0, s, tab);
+    return zgemm_launch(false, false, M, N, K, nullptr, lda, nullptr, ldb, nullptr, ldc, sa, sb, sc, outer * inner, b_transposed ? 2 : 0, s, tab);
 }
 
-// batched forms of the two data-movement steps of the MPS -> dense contraction (one entry per lane in the tables):
-// last site: rt[chi][b] = t[b][chi][0];   final: out[(rev(i) << h) + lo] = g[lo * 2^m + i]
-__global__ void mps_last_site_kernel(const cplx* const* t_tab, cplx* const* rt_tab, int chil) {
+// product states (every bond dimension 1): out[i] = prod_q t_q[bit q of i], t_q = the two numbers of site q (2 q, 2 q + 1 of the
+// lane's packed tensors); one launch per batch instead of the whole contraction chain
+__global__ void mps_product_kernel(const cplx* const* t_tab, cplx* const* out_tab, int n) {
     const cplx* t = t_tab[blockIdx.y];
-    cplx* rt = rt_tab[blockIdx.y];
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 2 * chil) rt[(size_t)(e % chil) * 2 + e / chil] = t[e];
-}
-__global__ void mps_permute_tables_kernel(const cplx* const* g_tab, cplx* const* out_tab, int h, int m) {
-    const cplx* g = g_tab[blockIdx.y];
     cplx* out = out_tab[blockIdx.y];
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ((size_t)1 << (h + m))) return;
-    const unsigned i = (unsigned)(e & (((size_t)1 << m) - 1)), lo = (unsigned)(e >> m);
-    const unsigned r = m ? (__brev(i) >> (32 - m)) : 0u;
-    out[((size_t)r << h) + lo] = g[e];
+    if (e >= ((size_t)1 << n)) return;
+    cplx v = t[e & 1];
+    for (int q = 1; q < n; ++q) {
+        const cplx f = t[2 * q + ((e >> q) & 1)];
+        v = make_double2(v.x * f.x - v.y * f.y, v.x * f.y + v.y * f.x);
+    }
+    out[e] = v;
 }
-hipError_t launch_mps_last_site(const void* const* t_tab, void* const* rt_tab, int chil, int count, hipStream_t s) {
-    mps_last_site_kernel<<<dim3((2 * chil + 255) / 256, count), 256, 0, s>>>(reinterpret_cast<const cplx* const*>(t_tab), reinterpret_cast<cplx* const*>(rt_tab), chil);
-    return hipGetLastError();
-}
-hipError_t launch_mps_permute_tables(const void* const* g_tab, void* const* out_tab, int h, int m, int count, hipStream_t s) {
-    const size_t total = (size_t)1 << (h + m);
-    mps_permute_tables_kernel<<<dim3((unsigned)((total + 255) / 256), count), 256, 0, s>>>(reinterpret_cast<const cplx* const*>(g_tab),
-                                                                                           reinterpret_cast<cplx* const*>(out_tab), h, m);
+hipError_t launch_mps_product(const void* const* t_tab, void* const* out_tab, int n, int count, hipStream_t s) {
+    const size_t total = (size_t)1 << n;
+    mps_product_kernel<<<dim3((unsigned)((total + 255) / 256), count), 256, 0, s>>>(reinterpret_cast<const cplx* const*>(t_tab),
+                                                                                    reinterpret_cast<cplx* const*>(out_tab), n);
     return hipGetLastError();
 }
 

@@ -114,6 +114,17 @@ def vector_to_exact_mps(vec: np.ndarray) -> QiskitMPS:
     return gam, lam
 
 
+def _svd(a: np.ndarray):
+    """Thin SVD.  LAPACK's divide-and-conquer driver (numpy's only one) occasionally gives up on the nearly rank-deficient
+    matrices met here ("SVD did not converge", seen at 16 qubits / bond 16); the QR-iteration driver does not."""
+    try:
+        return np.linalg.svd(a, full_matrices=False)
+    except np.linalg.LinAlgError:
+        import scipy.linalg
+
+        return scipy.linalg.svd(a, full_matrices=False, lapack_driver="gesvd")
+
+
 def vector_to_canonical_mps(vec: np.ndarray, trunc_thr: float = _NO_TRUNCATION_THR) -> QiskitMPS:
     """Canonical Vidal form (Gamma, lambda) of a dense state by successive SVDs -- the form Aer hands the reference
     (mps_operations.py:216-243): Schmidt values descending, at every bond the smallest ones dropped while the sum of their
@@ -127,7 +138,7 @@ def vector_to_canonical_mps(vec: np.ndarray, trunc_thr: float = _NO_TRUNCATION_T
     gam, lam, prev = [], [], np.ones(1)
     for _ in range(n - 1):
         chi_l = rest.shape[0]
-        u, sv, vh = np.linalg.svd(rest.reshape(chi_l * 2, -1), full_matrices=False)
+        u, sv, vh = _svd(rest.reshape(chi_l * 2, -1))
         keep = int((sv > 1e-14 * sv[0]).sum())
         total, dropped = float(np.sum(sv ** 2)), 0.0
         # the rule of the native engine (mps_engine.py); the reference's "no truncation" threshold (1e-16) really means none:

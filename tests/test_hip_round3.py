@@ -346,6 +346,40 @@ def test_mps_batched_contraction_and_slot_cache():
     ws.close()
 
 
+@pytest.mark.parametrize("n,chi", [(2, 2), (3, 2), (5, 4), (9, 7), (13, 16)])
+def test_mps_batched_contraction_shapes(n, chi):
+    """The batched MPS -> dense chain on small and odd registers (left half of one site, right half of one or two), and its
+    product-state shortcut (every bond dimension 1: |0>, a Neel state, random product states) -- each lane against
+    orc.mps_to_vector, i.e. mps_operations.py:159-189."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
+
+    B = 4
+    rng = np.random.default_rng(100 * n + chi)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", max(n - 1, 1)))
+    ws = Workspace(HipContext.of(circ), batch=B)
+    lanes = [orc.random_mps(n, chi, rng) for _ in range(B)]
+    ws.mps_to_vec_batch(lanes, BUF_Y)
+    got = ws.download(BUF_Y)
+    for i, m in enumerate(lanes):
+        assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
+
+    def product(vecs):   # QiskitMPS of a product state: gamma_q = ([[v0]], [[v1]]), lambdas 1
+        return ([(np.array([[v[0]]], complex), np.array([[v[1]]], complex)) for v in vecs], [np.ones(1) for _ in range(n - 1)])
+
+    zero = product([(1.0, 0.0)] * n)
+    neel = product([(1.0, 0.0) if q % 2 == 0 else (0.0, 1.0) for q in range(n)])
+    rnd = [product(rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))) for _ in range(2)]
+    prods = [zero, neel] + rnd
+    ws.mps_to_vec_batch(prods, BUF_X)
+    got = ws.download(BUF_X)
+    for i, m in enumerate(prods):
+        assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
+    assert got[0][0] == 1.0 and np.count_nonzero(got[0]) == 1 and np.count_nonzero(got[1]) == 1
+    ws.close()
+
+
 def test_mps_front_door_hands_the_state_over_on_the_device():
     """v_dagger_mul_mps -> fast_dot_gradient (mps_operations.py:349-371, mps_dot_objective.py:41-242): the returned MPS is a
     QiskitMPS tuple in canonical form (checked by contracting it back), and the gradient call that follows takes its dense

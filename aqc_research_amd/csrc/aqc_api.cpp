@@ -336,8 +336,11 @@ struct aqc_ws {
     size_t mps_lam_cap = 0;
     double2* d_mps_scratch = nullptr;
     size_t mps_scratch_cap = 0;
-    const void** d_mps_tabs = nullptr;  // device pointer tables of the batched MPS -> dense contraction (grow-only)
-    size_t mps_tabs_cap = 0;
+    // device pointer tables of the batched MPS -> dense contraction: a few resident sets, found again by their contents (an
+    // optimisation converts the same operands into the same lanes evaluation after evaluation: no upload, no synchronisation)
+    struct MpsTabs { std::vector<const void*> host; const void** dev = nullptr; size_t cap = 0; unsigned long long tick = 0; };
+    MpsTabs mps_tabs[8];
+    unsigned long long mps_tabs_tick = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     hipStream_t copy_stream = nullptr;        // aqc_ws_results_async: result copies run beside the next evaluation's kernels
     hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
@@ -851,7 +854,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
     if (ws->h_pin) (void)hipHostFree(ws->h_pin);
     for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
-    if (ws->d_mps_tabs) (void)hipFree(ws->d_mps_tabs);
+    for (auto& t : ws->mps_tabs) if (t.dev) (void)hipFree(t.dev);
     if (ws->d_mps_lam) (void)hipFree(ws->d_mps_lam);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1, ws->ev_ready, ws->ev_copied}) if (ev) (void)hipEventDestroy(ev);
     if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
@@ -1924,16 +1927,28 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
     std::vector<const void*> tabs;
     auto table = [&](auto fn) { const size_t at = tabs.size(); for (int i = 0; i < count; ++i) tabs.push_back(fn(i)); return at; };
     auto out_lane = [&](int i) { return (const void*)(ws->bufs[buf] + (size_t)lanes[i] * ws->lane_elems); };
-    auto upload_tables = [&]() -> int {   // pointer tables of every launch of the chain, one copy
-        if (tabs.size() > ws->mps_tabs_cap) {
-            HIP_OK(hipStreamSynchronize(ws->stream));
-            if (ws->d_mps_tabs) HIP_OK(hipFree(ws->d_mps_tabs));
-            ws->d_mps_tabs = nullptr; ws->mps_tabs_cap = 0;
-            HIP_OK(hipMalloc((void**)&ws->d_mps_tabs, tabs.size() * sizeof(void*)));
-            ws->mps_tabs_cap = tabs.size();
+    const void* const* T = nullptr;
+    auto upload_tables = [&]() -> int {   // pointer tables of every launch of the chain: a resident set, or one copy
+        aqc_ws::MpsTabs* hit = nullptr;
+        aqc_ws::MpsTabs* lru = &ws->mps_tabs[0];
+        for (auto& t : ws->mps_tabs) {
+            if (t.dev && t.host == tabs) hit = &t;
+            if (t.tick < lru->tick) lru = &t;
         }
-        HIP_OK(hipMemcpyAsync(ws->d_mps_tabs, tabs.data(), tabs.size() * sizeof(void*), hipMemcpyHostToDevice, ws->stream));
-        HIP_OK(hipStreamSynchronize(ws->stream));   // `tabs` goes away
+        if (!hit) {
+            HIP_OK(hipStreamSynchronize(ws->stream));   // launches in flight may still read the set that is recycled
+            if (tabs.size() > lru->cap) {
+                if (lru->dev) HIP_OK(hipFree(lru->dev));
+                lru->dev = nullptr; lru->cap = 0; lru->host.clear();
+                HIP_OK(hipMalloc((void**)&lru->dev, tabs.size() * sizeof(void*)));
+                lru->cap = tabs.size();
+            }
+            lru->host = tabs;   // (stays alive next to the device copy: nothing to wait for after the upload)
+            HIP_OK(hipMemcpyAsync(lru->dev, lru->host.data(), tabs.size() * sizeof(void*), hipMemcpyHostToDevice, ws->stream));
+            hit = lru;
+        }
+        hit->tick = ++ws->mps_tabs_tick;
+        T = hit->dev;
         return 0;
     };
     bool product = true;
@@ -1943,7 +1958,7 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
         const size_t tc = table(out_lane);
         if (upload_tables()) return 1;
         ProfScope ps(ws, AQC_K_MISC);
-        HIP_OK(launch_mps_product(ws->d_mps_tabs + ta, (void* const*)(ws->d_mps_tabs + tc), n, count, ws->stream));
+        HIP_OK(launch_mps_product(T + ta, (void* const*)(T + tc), n, count, ws->stream));
         return 0;
     }
     // Left half L[l][chi] (sites 0 .. h-1, site 0 the lowest bit of l), right half transposed Rt[r][chi] (sites n-1 .. h, every
@@ -1982,7 +1997,6 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
     fin.c = table(out_lane);
     steps.push_back(fin);
     if (upload_tables()) return 1;
-    const void* const* T = ws->d_mps_tabs;
     ProfScope ps(ws, AQC_K_MISC);
     for (const Step& st : steps) {
         if (st.kind == 0) {

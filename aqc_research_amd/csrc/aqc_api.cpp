@@ -344,6 +344,8 @@ struct aqc_ws {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     hipStream_t copy_stream = nullptr;        // aqc_ws_results_async: result copies run beside the next evaluation's kernels
     hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+    hipStream_t mps_stream = nullptr;         // batched MPS -> dense: the right half's chain runs beside the left half's
+    hipEvent_t ev_mps_fork = nullptr, ev_mps_join = nullptr;
     bool copy_pending = false;                // the producers of the next evaluation wait for ev_copied before they overwrite the results
     const double* theta_host = nullptr;      // aqc_ws_eval: pinned thetas the next U build reads directly (and copies to d_thetas)
     bool gather_rides = false;               // aqc_ws_eval: the next gradient walk also performs the registered gather (see there)
@@ -858,6 +860,8 @@ int aqc_ws_destroy(aqc_ws* ws) {
     if (ws->d_mps_lam) (void)hipFree(ws->d_mps_lam);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1, ws->ev_ready, ws->ev_copied}) if (ev) (void)hipEventDestroy(ev);
     if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
+    if (ws->mps_stream) { (void)hipStreamSynchronize(ws->mps_stream); (void)hipStreamDestroy(ws->mps_stream); }
+    for (hipEvent_t ev : {ws->ev_mps_fork, ws->ev_mps_join}) if (ev) (void)hipEventDestroy(ev);
     if (ws->stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
     return 0;
@@ -1998,19 +2002,36 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
     steps.push_back(fin);
     if (upload_tables()) return 1;
     ProfScope ps(ws, AQC_K_MISC);
+    // the two halves are independent chains of small launches (latency-bound at small bond dimensions): the right half runs
+    // on a second stream, forked after everything queued so far and joined before the last product
+    const bool fork = !ws->profile && !ws->capturing && h > 1 && mh > 1;
+    if (fork) {
+        if (!ws->mps_stream) {
+            HIP_OK(hipStreamCreateWithFlags(&ws->mps_stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&ws->ev_mps_fork, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&ws->ev_mps_join, hipEventDisableTiming));
+        }
+        HIP_OK(hipEventRecord(ws->ev_mps_fork, ws->stream));
+        HIP_OK(hipStreamWaitEvent(ws->mps_stream, ws->ev_mps_fork, 0));
+    }
     for (const Step& st : steps) {
+        hipStream_t sst = (fork && st.kind == 2) ? ws->mps_stream : ws->stream;
+        if (fork && st.kind == 3) {
+            HIP_OK(hipEventRecord(ws->ev_mps_join, ws->mps_stream));
+            HIP_OK(hipStreamWaitEvent(ws->stream, ws->ev_mps_join, 0));
+        }
         if (st.kind == 0) {
             const int q = st.q, rows = 1 << q, kk = dims[q], nn = dims[q + 1];
             HIP_OK(launch_zgemm_tables(rows, nn, kk, T + st.a, kk, T + st.b, nn, (void* const*)(T + st.c), nn, 0, (size_t)kk * nn, (size_t)rows * nn,
-                                       count, 2, ws->stream));
+                                       count, 2, sst));
         } else if (st.kind == 2) {   // C rows 2 c + b: ldc = 2 chil, the bit's block starts chil further; B = T_q[b] stored [chil][chir], used transposed
             const int q = st.q, j = n - 1 - q, cols = 1 << j, chil = dims[q], chir = dims[q + 1];
             HIP_OK(launch_zgemm_tables(cols, chil, chir, T + st.a, chir, T + st.b, chir, (void* const*)(T + st.c), 2 * chil, 0, (size_t)chil * chir,
-                                       (size_t)chil, count, 2, ws->stream, 1));
+                                       (size_t)chil, count, 2, sst, 1));
         } else {                     // out [2^mh][2^h] = Rt [2^mh][chi] . L^T, L stored [2^h][chi]
             const int chi = dims[h];
             HIP_OK(launch_zgemm_tables(1 << mh, 1 << h, chi, T + st.a, chi, T + st.b, chi, (void* const*)(T + st.c), 1 << h, 0, 0, 0, count, 1,
-                                       ws->stream, 1));
+                                       sst, 1));
         }
     }
     return 0;

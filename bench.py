@@ -503,10 +503,10 @@ def main():
     ncols = w.get("ncols", 1)
     N = (1 << n) * ncols          # complex128 elements per lane
     chi = w.get("chi", 0)
-    # lanes per GPU: 1024 for state vectors up to 2^16 amplitudes (1 GiB per buffer at 16 qubits; a persistent sweep
+    # lanes per GPU: 1024 for problems of up to 2^16 amplitudes per lane (1 GiB per buffer at 16 qubits; a persistent sweep
     # workgroup then walks 64 tiles, so launch ramp, prologue and tail are amortised: 64 lanes give 156k evals/s at the
     # headline, 256 give 178k, 1024 give 183k -- DESIGN 6), 64 otherwise
-    B = args.batch if args.batch > 0 else (64 if chi else ((1024 if n <= 16 else 64) if ncols == 1 else (32 if ncols >= 256 else 64)))
+    B = args.batch if args.batch > 0 else (64 if chi else (1024 if (ncols << n) <= (1 << 16) else (64 if ncols < 256 else 32)))
     K, W = args.steps, args.warmup
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule

@@ -242,6 +242,35 @@ def test_shallow_circuits_on_the_persistent_sweep(n, L, B):
     ws.close()
 
 
+def test_config1_size_at_the_bench_lane_count():
+    """bench.py --workload mat5_cyc180 as it runs by default: the docs/aqc.ipynb ansatz (5 qubits, cyclic_spin, 180 blocks,
+    T = 735) on 32-column targets, 1024 lanes (one 2^10 tile per lane): <I|V^H U> and the gradient of every 41st lane against
+    the compiled CPU restatement (core_op_matrix.py:645-762)."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, HipContext, Workspace
+
+    n, d, B = 5, 32, 1024
+    rng = np.random.default_rng(51024)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "cyclic_spin", "full", 180))
+    th = np.pi * (2 * rng.random((B, circ.num_thetas)) - 1)
+    targets = np.stack([np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0] for _ in range(B)])
+    ws = Workspace(HipContext.of(circ), batch=B, ncols=d)
+    ws.upload(BUF_Y, targets)
+    ws.set_identity(BUF_X)
+    ws.set_thetas(th)
+    ws.apply(True, BUF_Y, BUF_Z)
+    tr = ws.vdot(BUF_X, BUF_Z)
+    ws.grad(None, True)
+    g = ws.get_grads()
+    eye = np.eye(d, dtype=complex)
+    for b in list(range(0, B, 41)) + [B - 1]:
+        vhy = cref.v_dagger_mul_mat(circ, th[b], targets[b])
+        assert abs(tr[b] - np.vdot(eye, vhy)) < TOL * d
+        assert maxdiff(g[b], cref.grad_of_matrix_dot_product(circ, th[b], eye, vhy)) < TOL * d
+    ws.close()
+
+
 def test_config2_size_at_the_bench_lane_count():
     """bench.py --workload sv12_trotter2 as it runs by default: 12 qubits, 2nd-order Trotter ansatz of 2 layers, 1024 lanes
     (one 2^12 tile per lane, four items per persistent workgroup), each lane with its own target; every seventh lane against

@@ -1365,15 +1365,15 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
             LB_TRY(evaluate(0, ft, gt, raw_hs_t, raw_g0_t));
             LB_OK(hipMemsetAsync(d_flags + 3, 0, sizeof(int), st_));
             LB_OK(lb_armijo(L, 1e-4, ws->d_thetas_own, ft, raw_hs_t, raw_g0_t, d_flags, st_));
+            // the probe of the state update rides on the same read of the flags (it is only used once no lane backtracks any more)
+            LB_OK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), st_));
+            LB_OK(lb_probe(L, L.acc_hs, d_flags, st_));
             LB_TRY(read_flags());
             if (!h_flags[3]) break;
         }
         // state update at the accepted points: from their raw results when no lane would lead with a flip state,
         // else by a device evaluation at x_new (the second sweep depends on the state chosen now)
-        LB_OK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), st_));
-        LB_OK(lb_probe(L, L.acc_hs, d_flags, st_));
-        LB_TRY(read_flags());
-        if (h_flags[1]) {
+        if (h_flags[1]) {   // (the last round's probe: nothing has touched the accepted points since)
             LB_OK(hipMemcpyAsync(ws->d_thetas_own, L.x_new, sizeof(double) * BT, hipMemcpyDeviceToDevice, st_));
             LB_TRY(evaluate(1, f_acc, g_acc, L.acc_hs, L.acc_g0));
         } else {

@@ -376,8 +376,9 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     // Work items = (tile, lane of the batch), item wi on workgroup wi mod gridDim.x.  2^12 tiles leave room for ONE
     // workgroup per CU, so nothing else would hide its HBM traffic: there the grid is one workgroup per CU, each walks
     // over its items and fetches the NEXT item's w and z tiles into registers (2 x 16 x 16 B per lane, in four chunks
-    // behind the operand fetch of sub-stages 0..3) while the current one computes; the stores of a finished tile drain
-    // under the next one as well.  Smaller tiles run two workgroups per CU, which overlap by themselves (grid = items).
+    // behind the operand fetch of sub-stages 1..4, in the operand layout of the item's FIRST sub-stage) while the current
+    // one computes; the stores of a finished tile drain under the next one as well.  Smaller tiles run two workgroups per
+    // CU, which overlap by themselves (grid = items).
     constexpr bool kPersist = K >= 12;
     constexpr int NL = TS::kLoads, NW = TS::kWaves;
     const int nwork = a.ntiles * a.batch;
@@ -385,9 +386,8 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     SubRegs cur, nxt;
     SubAddr<TS::kGpw> ad;
     // The prefetched tiles live in ACCUMULATION registers (the sub-stage pipeline fills all 256 architectural VGPRs; left
-    // to itself the allocator spills a prefetch array to scratch memory): global_load with an AGPR destination, LDS write
-    // with an AGPR source, both as inline assembly; the compiler does not track these loads, so the wait before the LDS
-    // writes is explicit.
+    // to itself the allocator spills a prefetch array to scratch memory): global_load with an AGPR destination as inline
+    // assembly; the compiler does not track these loads, so the wait before their first use is explicit (wait_prefetched).
     dbl2_t pw[NL], pz[NL];
     unsigned parity = 0;   // scratch buffer of the running sub-stage (kDouble)
     AQC_STAMP(0);

@@ -255,6 +255,40 @@ def test_surrogate_eval_state_machine_on_crafted_amplitudes():
     bo.close()
 
 
+def test_surrogate_object_steered_through_its_state_machine():
+    """SpSurrogateObjectiveMax, objective() + gradient() pairs, on the crafted amplitudes of the test above: |state_0> leads,
+    a flip state takes over, holds against a slightly better one, loses to a much better one, |state_0> returns -- the pairs
+    with a leading flip state are ONE device call (aqc_ws_surrogate_eval, mode 2); every value, gradient, leading state and
+    weight against orc.SurMaxOracle (the reference's two sweeps)."""
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax
+
+    n = 12
+    circ, base, neel = _trotter(n, 2)
+    rng = np.random.default_rng(4048)
+    idx = orc.flip_state_indices(n, 1, neel)
+    th = base + 0.05 * np.pi * (2 * rng.random(base.size) - 1)
+    script = [(0.50, 0.60, 0.10), (0.60, 0.62, 0.64), (0.30, 0.55, 0.70), (0.70, 0.50, 0.60), (0.70, 0.72, 0.10), (0.40, 0.30, 0.60)]
+    expect = [1, 1, 2, 0, 0, 2]
+    user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: neel, enable_optim_stats=False, verbose=0)
+    obj = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+    o = None
+    for step, mods in enumerate(script):
+        c = 0.01 * (rng.standard_normal(idx.size) + 1j * rng.standard_normal(idx.size))
+        c[:3] = np.array(mods) * np.exp(2j * np.pi * rng.random(3))
+        psi = np.zeros(1 << n, complex)
+        psi[idx] = c
+        target = cref.v_mul_vec(circ, th, psi)
+        obj.set_target(target)
+        if o is None:
+            o = orc.SurMaxOracle(circ, target, 1, None, True, base_index=neel)
+        o.target = target
+        f, fo = obj.objective(th), o.objective(th)
+        assert abs(f - fo) < TOL and obj._max_no == o.max_no == expect[step]
+        g, go = obj.gradient(th), o.gradient(th)
+        assert maxdiff(g, go) < TOL and abs(obj._weight - o.weight) < 1e-13
+        th = th + 1e-3 * rng.standard_normal(th.size)    # a new point every pair (the amplitudes are re-crafted for it)
+
+
 @pytest.mark.parametrize("B", [256, 1024])
 def test_headline_all_lanes(B):
     """The bench's unit of work: 16 qubits, 40 blocks, 1024 lanes by default (64 items per persistent sweep workgroup; 256

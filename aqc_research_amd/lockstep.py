@@ -13,6 +13,7 @@ others.  Results are those of the single-lane calls (each lane sees only its own
 lhs state); only the order of floating-point operations inside the kernels may differ, because the
 batched workspace may pick the throughput kernel family.
 """
+import os
 import threading
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -24,10 +25,10 @@ __all__ = ["LockstepBatch", "LaneView", "run_jobs_lockstep"]
 
 
 class _Request:
-    __slots__ = ("sig", "thetas")
+    __slots__ = ("sig", "thetas", "weight", "max_no")
 
-    def __init__(self, sig, thetas):
-        self.sig, self.thetas = sig, thetas
+    def __init__(self, sig, thetas, weight=1.0, max_no=0):
+        self.sig, self.thetas, self.weight, self.max_no = sig, thetas, weight, max_no
 
 
 class LaneView:
@@ -92,6 +93,22 @@ class LaneView:
         sig = (bool(vdag), bool(gather), bool(grad), int(x_buf), br, bool(front_layer))
         return self._owner._submit(self.lane, _Request(sig, th))
 
+    # A lane's objective()/gradient() pair as ONE request (Workspace.surrogate_eval): with it every lane of a round files the
+    # same kind of request whatever state leads, so a round is one native call.
+    prefers_surrogate_eval = os.environ.get("AQC_LOCKSTEP_SURROGATE_EVAL", "1") != "0"   # 0: the per-call requests of round 2 (cross-check)
+
+    def surrogate_eval(self, thetas, weight: np.ndarray, max_no: np.ndarray, update_state=True,
+                       block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True):
+        th = np.array(thetas, dtype=np.float64).ravel()
+        if th.size != self.T:
+            raise ValueError(f"expected {self.T} thetas, got {th.size}")
+        br = None if block_range is None else (int(block_range[0]), int(block_range[1]))
+        sig = ("sur", int(update_state), br, bool(front_layer))
+        f, fid, hs, gc, w_new, mx_new = self._owner._submit(self.lane, _Request(sig, th, float(weight[0]), int(max_no[0])))
+        if update_state:
+            weight[0], max_no[0] = w_new, mx_new
+        return f, (fid if update_state else None), hs, gc
+
     def close(self) -> None:
         pass
 
@@ -154,6 +171,19 @@ class LockstepBatch:
                 groups.setdefault(req.sig, []).append(lane)
             # calls that recompute Z = V^H Y first, so that sweeps of the same round see current data
             for sig in sorted(groups, key=lambda s: (not s[0], repr(s))):
+                if sig[0] == "sur":   # whole evaluations: V^H, amplitudes, state update and one sweep per lane, on the device
+                    _, mode, br, front = sig
+                    w = np.ones(self.nlanes)
+                    mx = np.zeros(self.nlanes, dtype=np.int64)
+                    for lane in groups[sig]:
+                        w[lane], mx[lane] = self._pending[lane].weight, self._pending[lane].max_no
+                    f, fid, hs, gc = self.ws.surrogate_eval(self._thetas, w, mx, mode, br, front)
+                    self._basis_dirty[BUF_X2] = True   # the call wrote every lane's lhs state into X2
+                    self.native_calls += 1
+                    for lane in groups[sig]:
+                        self._results[lane] = (f[lane:lane + 1].copy(), None if fid is None else fid[lane:lane + 1].copy(),
+                                               hs[lane:lane + 1].copy(), gc[lane:lane + 1].copy(), float(w[lane]), int(mx[lane]))
+                    continue
                 vdag, gather, grad, x_buf, br, front = sig
                 if grad and self._basis_dirty.get(x_buf, False):
                     idx, cf = self._combo_idx[x_buf], self._combo_coef[x_buf]

@@ -79,9 +79,10 @@ class SpSurrogateObjectiveMax(SpLHSObjectiveBase):
             ws.apply(True, BUF_Y, BUF_Z)
             self._hs[:] = self._projections()
             self._grad0 = None
-        elif self._speculative and self._max_no != 0 and hasattr(ws, "surrogate_eval"):   # (not on a lockstep LaneView)
-            # a flip state leads: ONE native call does V^H, the amplitudes, the hysteresis (the weight stays: it moves in
-            # gradient()) and the sweep from the combination of |state_0> and the leading state under that state
+        elif self._speculative and (self._max_no != 0 or getattr(ws, "prefers_surrogate_eval", False)):
+            # a flip state leads (or the workspace is a lane of a lockstep batch, where every lane files this one kind of
+            # request): ONE native call does V^H, the amplitudes, the hysteresis (the weight stays: it moves in gradient())
+            # and the sweep from the combination of |state_0> and the leading state under that state
             # (aqc_ws_surrogate_eval, mode 2), so the gradient() call that follows costs no GPU round trip either
             w = np.array([self._weight], dtype=np.float64)
             mx = np.array([self._max_no], dtype=np.int64)

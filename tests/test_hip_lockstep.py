@@ -98,6 +98,51 @@ def test_lockstep_mixed_requests_against_oracle():
         assert e < TOL
 
 
+def test_lockstep_objects_with_leading_flip_states():
+    """Surrogate objects on lanes of a lockstep batch with random targets (a flip state leads from the first evaluation on):
+    every lane's objective()/gradient() pair is one request served by aqc_ws_surrogate_eval for the whole batch; values,
+    gradients, leading states and weights of every lane against orc.SurMaxOracle, lanes of different lengths, one lane mixing
+    in plain eval requests that use the same lhs buffer."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.engine import BUF_X2
+    from aqc_research_amd.lockstep import LockstepBatch
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax
+
+    n, lanes = 9, 4
+    rng = np.random.default_rng(99)
+    a = orc.Ansatz(n, "cx", orc.spin_blocks(n, 11))
+    circ = ParametricCircuit(n, "cx", a.blocks)
+    batch = LockstepBatch(circ, nlanes=lanes)
+    idx = orc.flip_state_indices(n, 1)
+    data = [(orc.rand_state(n, rng), orc.rand_thetas(a.num_thetas, rng)) for _ in range(lanes)]
+
+    def job(view, lane):
+        y, th = data[lane]
+        user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: 0, enable_optim_stats=False, verbose=0, workspace=view)
+        obj = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+        obj.set_target(y)
+        o = orc.SurMaxOracle(a, y, 1, None, True)
+        errs, led = [], 0
+        for step in range(2 + lane):
+            f, fo = obj.objective(th), o.objective(th)
+            g, go = obj.gradient(th), o.gradient(th)
+            errs += [abs(f - fo), maxdiff(g, go), abs(obj._weight - o.weight), float(obj._max_no != o.max_no)]
+            led += obj._max_no != 0
+            if lane == 1:   # somebody else's request on the lhs buffer between two pairs
+                view.set_basis(BUF_X2, int(idx[2]))
+                _, g2 = view.eval(None, vdag=False, gather=False, grad=True, x_buf=BUF_X2, block_range=None, front_layer=True)
+                x2 = np.zeros(1 << n, complex); x2[idx[2]] = 1
+                errs.append(maxdiff(g2[0], orc.grad_of_dot_product(a, th, x2, orc.v_dagger_mul_vec(a, th, y))))
+            th = th - 0.05 * g
+        return max(errs), led
+
+    out = batch.run([(lambda view, lane=lane: job(view, lane)) for lane in range(lanes)])
+    batch.close()
+    for e in out:
+        assert not isinstance(e, BaseException), e
+        assert e[0] < TOL and e[1] >= 1
+
+
 def test_run_jobs_lockstep_records():
     from aqc_research_amd.lockstep import run_jobs_lockstep
 

@@ -248,6 +248,97 @@ def test_lockstep_round_logic_with_stub_workspace(monkeypatch):
     assert isinstance(res[0], KeyError) and isinstance(res[1], complex)
 
 
+def test_lockstep_serves_whole_surrogate_evaluations_with_stub_workspace(monkeypatch):
+    """SpSurrogateObjectiveMax objects on lockstep lanes, on the CPU: the batched workspace is a stub whose surrogate_eval()
+    is the oracle (amplitudes, hysteresis, combined complex gradient c_0 g_0 + c_max g_max).  Every objective()/gradient()
+    pair must be ONE request, a round ONE native call, and every lane must follow orc.SurMaxOracle."""
+    from aqc_research_amd import ParametricCircuit, lockstep
+    from aqc_research_amd.engine import BUF_Y
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax
+
+    n = 4
+    a = orc.Ansatz(n, "cz", orc.spin_blocks(n, 4))
+    circ = ParametricCircuit(n, "cz", a.blocks)
+    idx = orc.flip_state_indices(n, 1)
+    calls = []
+
+    class StubCtx:
+        @staticmethod
+        def of(c):
+            return StubCtx()
+
+    class StubWorkspace:
+        def __init__(self, ctx, batch=1, ncols=1, device=0):
+            self.batch, self.T, self.dim, self.ctx, self.device = batch, a.num_thetas, 1 << n, ctx, device
+            self.y = np.zeros((batch, 1 << n), complex)
+
+        def upload(self, buf, data, lane=None):
+            assert buf == BUF_Y
+            self.y[lane] = data
+
+        def set_basis(self, buf, index):
+            pass
+
+        def gather_setup(self, index):
+            assert np.array_equal(index, idx)
+
+        def surrogate_eval(self, thetas, weight, max_no, update_state, block_range, front_layer):
+            calls.append(int(update_state))
+            B = self.batch
+            f, fid = np.zeros(B), np.zeros(B)
+            hs, gc = np.zeros((B, idx.size), complex), np.zeros((B, self.T), complex)
+            for b in range(B):
+                z = orc.v_dagger_mul_vec(a, thetas[b], self.y[b])
+                h = z[idx]
+                h2 = np.abs(h) ** 2
+                if update_state:
+                    best = h2[max_no[b]]
+                    for i in range(idx.size):
+                        if 1.1 * best < h2[i]:
+                            best, max_no[b] = h2[i], i
+                assert update_state == 2          # the objects ask for the hysteresis only: the weight moves in gradient()
+                w, k = weight[b], int(max_no[b])
+                f[b], fid[b], hs[b] = 1.0 - (1.0 - w) * h2[0] - w * h2[k], h2[0], h
+
+                def sweep(i):
+                    x = np.zeros(1 << n, complex)
+                    x[idx[i]] = 1
+                    return orc.grad_of_dot_product(a, thetas[b], x, z, block_range, front_layer)
+
+                gc[b] = -2 * np.conj(h[0]) * sweep(0) if k == 0 else (-2 * (1 - w) * np.conj(h[0]) * sweep(0) - 2 * w * np.conj(h[k]) * sweep(k))
+            return f, fid, hs, gc
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(lockstep, "Workspace", StubWorkspace)
+    monkeypatch.setattr(lockstep, "HipContext", StubCtx)
+    monkeypatch.setattr(lockstep.LaneView, "prefers_surrogate_eval", True)
+    rng = np.random.default_rng(44)
+    data = [(orc.rand_state(n, rng), orc.rand_thetas(a.num_thetas, rng)) for _ in range(3)]
+    batch = lockstep.LockstepBatch(circ, 3)
+
+    def job(view, lane):
+        y, th = data[lane]
+        user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: 0, enable_optim_stats=False, verbose=0, workspace=view)
+        obj = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+        obj.set_target(y)
+        o = orc.SurMaxOracle(a, y, 1, None, True)
+        err = 0.0
+        for _ in range(2 + lane):
+            f, fo = obj.objective(th), o.objective(th)
+            g, go = obj.gradient(th), o.gradient(th)
+            err = max(err, abs(f - fo), float(np.abs(g - go).max()), abs(obj._weight - o.weight), float(obj._max_no != o.max_no))
+            th = th - 0.1 * g
+        return err
+
+    res = batch.run([(lambda v, lane=lane: job(v, lane)) for lane in range(3)])
+    for r in res:
+        assert not isinstance(r, BaseException), r
+        assert r < 1e-12
+    assert batch.rounds == 4 and len(calls) == 4 and batch.native_calls == 4   # lanes retire after 2, 3 and 4 pairs
+
+
 def test_result_record_roundtrip():
     """Fixed-size record of run_jobs' final gather: {job_index, seed, ok, time, cost, fidelity, counts, thetas[T_max]}."""
     from aqc_research_amd import job_executor as jex

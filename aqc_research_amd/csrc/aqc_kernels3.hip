@@ -85,7 +85,13 @@ __device__ __forceinline__ void u_combine(const Acc3& t, cplx (&o)[4]) {
 // sweep kernels: R scratch double-buffered (one barrier per sub-stage) where the second buffer costs no occupancy: the
 // persistent 2^12 kernel (one workgroup per CU anyway) and tiles up to 2^9 (scratch of a few KiB)
 __host__ __device__ constexpr bool sweep_scratch_double(int k) { return k >= 12 || k <= 9; }
-constexpr int kSweepSpread = 2, kApplySpread = 1;   // MFMAs between two LDS writes inside a matrix run (sweep / V, V^H)
+#ifndef AQC_SWEEP_SPREAD   // (variant builds: make variant NAME=s2 EXTRA=-DAQC_SWEEP_SPREAD=2; sweep pair 1.012 / 1.016 / 1.026 / 1.037 ms at 1 / 2 / 3 / 4)
+#define AQC_SWEEP_SPREAD 1
+#endif
+#ifndef AQC_APPLY_SPREAD
+#define AQC_APPLY_SPREAD 1
+#endif
+constexpr int kSweepSpread = AQC_SWEEP_SPREAD, kApplySpread = AQC_APPLY_SPREAD;   // MFMAs between two LDS writes inside a matrix run (sweep / V, V^H)
 template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
     // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
     // work itself runs at 64 cycles per MFMA either way, and the per-wave cost of a sub-stage (operand prefetch, address

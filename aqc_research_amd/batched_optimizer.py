@@ -87,6 +87,13 @@ class BatchedSurrogateObjective:
         """Lane ``lane``'s target <- lane ``src_lane`` of buffer ``src_buf`` of another workspace, on the device."""
         self.ws.copy_lane_from(src, src_buf, src_lane, BUF_Y, lane)
 
+    def set_mps_targets(self, mps_list) -> None:
+        """Targets given as QiskitMPS tuples, one per lane (mps_dot_objective.py:41 hands them over like that): resident
+        device copies through the workspace's slot cache, all lanes contracted to dense states by one launch chain."""
+        if len(mps_list) != self.batch:
+            raise ValueError("one MPS per lane")
+        self.ws.mps_to_vec_batch(list(mps_list), BUF_Y)
+
     def value_and_grad(self, thetas: np.ndarray, update_state: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         """f[B], g[B][T] at thetas[B][T].  ``update_state=False`` evaluates with the current weights / leading states
         without touching them (line-search trials); ``True`` first applies the hysteresis and the weight smoothing --

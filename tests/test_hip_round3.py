@@ -500,6 +500,30 @@ def test_mps_batched_contraction_shapes(n, chi):
     ws.close()
 
 
+def test_batched_surrogate_objective_with_mps_targets():
+    """Config 3 as a batched objective: the lanes' targets arrive as QiskitMPS tuples (set_mps_targets); values and gradients
+    equal those of the objective built on the densified targets."""
+    from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective
+
+    n, B = 12, 5
+    circ, base, neel = _trotter(n, 2)
+    rng = np.random.default_rng(1205)
+    mps = [orc.random_mps(n, 6, rng) for _ in range(B)]
+    dense = np.stack([orc.mps_to_vector(m) for m in mps])
+    th = base + 0.1 * np.pi * (2 * rng.random((B, base.size)) - 1)
+    a = BatchedSurrogateObjective(circ, dense, base_index=neel)
+    b = BatchedSurrogateObjective(circ, None, lanes=B, base_index=neel)
+    b.set_mps_targets(mps)
+    for _ in range(2):
+        fa, ga = a.value_and_grad(th)
+        fb, gb = b.value_and_grad(th)
+        assert maxdiff(fa, fb) < TOL and maxdiff(ga, gb) < TOL and (a.max_no == b.max_no).all()
+        th = th - 0.05 * ga
+    with pytest.raises(ValueError):
+        b.set_mps_targets(mps[:2])
+    a.close(); b.close()
+
+
 def test_mps_front_door_hands_the_state_over_on_the_device():
     """v_dagger_mul_mps -> fast_dot_gradient (mps_operations.py:349-371, mps_dot_objective.py:41-242): the returned MPS is a
     QiskitMPS tuple in canonical form (checked by contracting it back), and the gradient call that follows takes its dense

@@ -1,7 +1,7 @@
 """One large aqc_zgemm (both op(A) forms) for rocprofv3 --kernel-trace: kernel time -> fp64 MFMA TFLOP/s."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aqc_research_amd.engine import zgemm
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048

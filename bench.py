@@ -358,19 +358,25 @@ def objective_object_rates(circ, targets, rng, device):
     dt = time.perf_counter() - t0
     out["SpSurrogateObjectiveMax_under_AqcOptimizer_lbfgs"] = {"lanes": 1, "evals_per_s": res["num_fun_ev"] / dt, "pairs": int(res["num_fun_ev"]),
                                                               "seconds": dt, "final_fidelity": float(res["fidelity"])}
-    lanes = min(64, targets.shape[0])
-    bo = BatchedSurrogateObjective(circ, targets[:lanes], base_index=0, device=device)
-    th = 0.2 * np.pi * (2 * rng.random((lanes, T)) - 1)
-    f, g = bo.value_and_grad(th)
-    t0 = time.perf_counter()
-    calls = 0
-    while calls < 20 or time.perf_counter() - t0 < 0.5:
-        th = th - 0.05 * g
+    def value_and_grad_rate(lanes):
+        bo = BatchedSurrogateObjective(circ, targets[:lanes], base_index=0, device=device)
+        th = 0.2 * np.pi * (2 * rng.random((lanes, T)) - 1)
         f, g = bo.value_and_grad(th)
-        calls += 1
-    dt = time.perf_counter() - t0
-    out["BatchedSurrogateObjective_value_and_grad"] = {"lanes": lanes, "evals_per_s": calls * lanes / dt, "calls": calls, "seconds": dt,
-                                                     "lanes_led_by_a_flip_state": int((bo.max_no != 0).sum())}
+        t0 = time.perf_counter()
+        calls = 0
+        while calls < 20 or time.perf_counter() - t0 < 0.5:
+            th = th - 0.05 * g
+            f, g = bo.value_and_grad(th)
+            calls += 1
+        dt = time.perf_counter() - t0
+        return bo, th, {"lanes": lanes, "evals_per_s": calls * lanes / dt, "calls": calls, "seconds": dt,
+                        "lanes_led_by_a_flip_state": int((bo.max_no != 0).sum())}
+
+    if targets.shape[0] > 64:   # the same object at the bench's own lane count (the headline's unit of work)
+        bo, _, out["BatchedSurrogateObjective_value_and_grad_bench_lanes"] = value_and_grad_rate(targets.shape[0])
+        bo.close()
+    lanes = min(64, targets.shape[0])
+    bo, th, out["BatchedSurrogateObjective_value_and_grad"] = value_and_grad_rate(lanes)
     bo.reset_state()
     bo.minimize_on_device(th, maxiter=2)   # warm-up
     bo.reset_state()

@@ -99,7 +99,7 @@ SIGNATURES = {
     "aqc_ws_plan_substages": (c_int, [_P, c_int]),
     "aqc_ws_lbfgs": (c_int, [_P, _D, c_int, c_int, c_double, c_double, c_double, c_int, c_int, c_int, c_int, _D, _D, _D, POINTER(c_int64),
                      POINTER(c_int64), _D, POINTER(c_int64)]),
-    "aqc_ws_surrogate_eval": (c_int, [_P, _D, c_int, _D, POINTER(c_int64), c_int, c_int, c_int, _D, _D, _D, _D]),
+    "aqc_ws_surrogate_eval": (c_int, [_P, _D, c_int, _D, POINTER(c_int64), c_int, c_int, c_int, _D, _D, _D, _D, _D]),
     "aqc_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "aqc_comm_create": (c_int, [ctypes.c_char_p, c_int, c_int, c_int, POINTER(_P)]),
     "aqc_comm_destroy": (c_int, [_P]),

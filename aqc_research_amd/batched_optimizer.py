@@ -108,9 +108,15 @@ class BatchedSurrogateObjective:
         self.num_evals += self.batch
         w = np.array(self.weight, dtype=np.float64)
         mx = np.array(self.max_no, dtype=np.int64)
-        f, fid, hs, gc = self.ws.surrogate_eval(th, w, mx, update_state, self._block_range, self._front)
+        # the complex gradient is only of use to commit(), and only while |state_0> leads everywhere: with a flip state in the
+        # lead before the call the real parts alone cross the bus
+        real_only = bool((self.max_no != 0).any())
+        f, fid, hs, gc = self.ws.surrogate_eval(th, w, mx, update_state, self._block_range, self._front, real_only=real_only)
         if update_state:
             self.max_no, self.weight, self.fidelity = mx, w, fid
+        if real_only:
+            self.last_raw = _RawResults(hs, None, None, mx)
+            return f, gc
         c0 = None
         if not (mx != 0).any():   # |state_0> leads everywhere: the sweep ran from conj(c_0)|state_0>, c_0 = -2 conj(h_0)
             c0 = -2.0 * np.conj(hs[:, 0])

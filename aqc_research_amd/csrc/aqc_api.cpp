@@ -311,6 +311,8 @@ struct aqc_ws {
     void* d_sur = nullptr;
     void* h_sur = nullptr;
     int sur_states = 0;
+    double* d_sur_real = nullptr;     // real parts of the gradient when only those are asked for
+    size_t sur_real_cap = 0;
     long long* d_combo_index = nullptr;   // [batch][2] staging of set_combo
     double2* d_combo_coef = nullptr;      // [batch][2]
     size_t small_cap = 0, index_cap = 0;
@@ -850,6 +852,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->d_combo_prev[b]) (void)hipFree(ws->d_combo_prev[b]);
     if (ws->d_sur) (void)hipFree(ws->d_sur);
+    if (ws->d_sur_real) (void)hipFree(ws->d_sur_real);
     if (ws->h_sur) (void)hipHostFree(ws->h_sur);
     if (ws->d_combo_index) (void)hipFree(ws->d_combo_index);
     if (ws->d_combo_coef) (void)hipFree(ws->d_combo_coef);
@@ -1403,8 +1406,9 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
 // state of every lane and ONE sweep from it (see aqc_ws_set_combo) -- the evaluate step of aqc_ws_lbfgs as a call of its own.
 // Same preconditions: targets in Y, flip-state indices registered (state 0 first), X2 is used for the lhs states.
 int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, double* weight_io, int64_t* max_no_io, int block_from,
-                          int block_to, int front_layer, double* f_out, double* fidelity_out, double* hs_out, double* grads_out) {
-    if (!ws || !thetas || !weight_io || !max_no_io || !f_out || !grads_out) return fail("null argument");
+                          int block_to, int front_layer, double* f_out, double* fidelity_out, double* hs_out, double* grads_out,
+                          double* grad_real_out) {
+    if (!ws || !thetas || !weight_io || !max_no_io || !f_out || !(grads_out || grad_real_out)) return fail("null argument");
     if (ws->ncols != 1) return fail("the surrogate objective works on state-vector workspaces");
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called (flip-state indices, state 0 first)");
     if (update_state < 0 || update_state > 2) return fail("update_state is 0 (none), 1 (hysteresis and weight) or 2 (hysteresis only)");
@@ -1463,6 +1467,13 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st));
         HIP_OK(hipMemsetAsync(ws->d_combo_prev[AQC_BUF_X2], 0xff, sizeof(long long) * 2 * B, st));   // -1: nothing to clear
     }
+    const bool real_only = !zero_copy && !grads_out;
+    if (real_only && ws->sur_real_cap < nth) {
+        HIP_OK(hipStreamSynchronize(st));
+        if (ws->d_sur_real) { HIP_OK(hipFree(ws->d_sur_real)); ws->d_sur_real = nullptr; ws->sur_real_cap = 0; }
+        HIP_OK(hipMalloc((void**)&ws->d_sur_real, sizeof(double) * nth));
+        ws->sur_real_cap = nth;
+    }
     auto enqueue = [&]() -> int {   // everything between the host copies of the inputs and the final synchronisation
         if (!zero_copy) {
             HIP_OK(hipMemcpyAsync(L.weight, hd + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, st));
@@ -1483,14 +1494,20 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
         ws->theta_host = nullptr;
         if (!zero_copy) {
-            HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
+            if (real_only) {   // the surrogate's gradient is the real part: half the bytes over the bus, no pass over them on the host
+                HIP_OK(lb_take(L, ws->d_grads, ws->d_sur_real, nullptr, st));
+                HIP_OK(hipMemcpyAsync(pin_gr, ws->d_sur_real, sizeof(double) * nth, hipMemcpyDeviceToHost, st));
+            } else {
+                HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, st));
+            }
             HIP_OK(hipMemcpyAsync(hd, dd, bytes, hipMemcpyDeviceToHost, st));
         }
         return 0;
     };
     static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
     if (graphs_on && !ws->profile) {   // the launch sequence is replayed as a graph, as in aqc_ws_eval
-        const std::vector<long long> key = {1000 + update_state + (zero_copy ? 10 : 0), block_from, block_to, front_layer, (long long)S,
+        const std::vector<long long> key = {1000 + update_state + (zero_copy ? 10 : 0) + (real_only ? 20 : 0), block_from, block_to, front_layer,
+                                            (long long)S, (long long)(size_t)ws->d_sur_real,
                                             (long long)(size_t)ws->d_sur, (long long)(size_t)ws->h_sur, (long long)(size_t)ws->h_pin,
                                             (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2]};
         auto it = ws->graphs.find(key);
@@ -1521,7 +1538,13 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
     }
     ws->combo_valid[AQC_BUF_X2] = true;   // (grad_from does not write its lhs buffer)
     HIP_OK(hipStreamSynchronize(st));
-    memcpy(grads_out, pin_gr, sizeof(double2) * nth);
+    if (real_only) {
+        memcpy(grad_real_out, pin_gr, sizeof(double) * nth);
+    } else {
+        if (grads_out) memcpy(grads_out, pin_gr, sizeof(double2) * nth);
+        if (grad_real_out)
+            for (size_t i = 0; i < nth; ++i) grad_real_out[i] = pin_gr[2 * i];
+    }
     memcpy(f_out, hd, sizeof(double) * B);
     if (update_state) {
         if (fidelity_out) memcpy(fidelity_out, hd + B, sizeof(double) * B);

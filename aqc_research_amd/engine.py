@@ -217,12 +217,13 @@ class Workspace:
         return hs, g
 
     def surrogate_eval(self, thetas, weight: np.ndarray, max_no: np.ndarray, update_state: bool = True,
-                       block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True):
+                       block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, real_only: bool = False):
         """One evaluation of the lane-batched surrogate objective in one native call (``aqc_ws_surrogate_eval``): V^H, the
         flip-state amplitudes, the optional state update, the value and ONE sweep from every lane's combined lhs state.
         ``weight`` (float64[batch]) and ``max_no`` (int64[batch]) are the objective state, updated IN PLACE when
         ``update_state`` (True / 1: hysteresis and weight smoothing; 2: hysteresis only, as objective() does on its own).
-        Returns (f[batch], fidelity[batch] or None, hs[batch][states], complex grads[batch][T])."""
+        Returns (f[batch], fidelity[batch] or None, hs[batch][states], complex grads[batch][T]); with ``real_only`` the last
+        item is the real part alone (float64[batch][T]: the surrogate's gradient, half the bytes over the bus)."""
         self._touch(BUF_Z, BUF_W, BUF_ZW, BUF_X2)
         th = _lib.as_f64(thetas, self.batch * self.T, "thetas")
         if not (isinstance(weight, np.ndarray) and weight.dtype == np.float64 and weight.flags.c_contiguous and weight.size == self.batch):
@@ -232,11 +233,12 @@ class Workspace:
         f = np.empty(self.batch)
         fid = np.empty(self.batch) if update_state else None
         hs = np.empty((self.batch, self._gather_count), dtype=np.complex128)
-        g = np.empty((self.batch, self.T), dtype=np.complex128)
+        g = np.empty((self.batch, self.T), dtype=np.float64 if real_only else np.complex128)
         lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
         check(self._L.aqc_ws_surrogate_eval(self.handle, dptr(th), int(update_state), dptr(weight),
                                             max_no.ctypes.data_as(ctypes.POINTER(c_int64)), lo, hi, int(bool(front_layer)),
-                                            dptr(f), None if fid is None else dptr(fid), dptr(hs), dptr(g)))
+                                            dptr(f), None if fid is None else dptr(fid), dptr(hs),
+                                            None if real_only else dptr(g), dptr(g) if real_only else None))
         return f, fid, hs, g
 
     def grad_from(self, x_buf: int, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:

@@ -267,10 +267,11 @@ int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int lo
  * under the new state (one accepted optimizer step); 2: hysteresis only, the weight stays (what objective(theta) does before
  * gradient(theta) moves the weight) -- and left alone when it is 0 (line-search trials); f_out [batch]; fidelity_out [batch] (|h_0|^2, written on an
  * update; may be NULL); hs_out [batch][states] complex amplitudes (may be NULL); grads_out [batch][T] COMPLEX gradient of the
- * lane's one sweep from conj(c_0)|state_0> + conj(c_max)|state_max> -- its real part is the surrogate's gradient. */
+ * lane's one sweep from conj(c_0)|state_0> + conj(c_max)|state_max> (may be NULL); grad_real_out [batch][T] its real part,
+ * which is the surrogate's gradient (may be NULL; with grads_out NULL only the real parts cross the bus). */
 int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, double* weight_io, int64_t* max_no_io,
                           int block_from, int block_to, int front_layer, double* f_out, double* fidelity_out, double* hs_out,
-                          double* grads_out);
+                          double* grads_out, double* grad_real_out);
 int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double gtol, double ftol, double fid_thr,
                  int max_backtracks, int block_from, int block_to, int front_layer, double* x_out, double* f_out,
                  double* fidelity_out, int64_t* nit_out, int64_t* nfev_out, double* weight_out, int64_t* max_no_out);

@@ -46,9 +46,13 @@ class RcclCommunicator(Communicator):
 
     transport = "rccl (aqc_comm)"
 
-    def __init__(self, rank: int, size: int, device: int, id_file: str, timeout: float = 120.0):
+    def __init__(self, rank: int, size: int, device: int, id_file: str, timeout: float = 120.0, tag: Optional[str] = None):
+        """``tag`` names the launch (default ``launch_tag()``): rank 0 writes it behind the 128 id bytes and the other ranks
+        only accept a file that carries THEIR tag, so an id left behind by a crashed launch that used the same file name
+        is never taken for this launch's (it made ``ncclCommInitRank`` hang instead of fail)."""
         L = _lib.lib()
         self._L, self.rank, self.size, self.device = L, int(rank), int(size), int(device)
+        nonce = (launch_tag() if tag is None else str(tag)).encode()
         if rank == 0:
             try:
                 os.remove(id_file)   # a crashed earlier launch may have left one behind
@@ -58,25 +62,26 @@ class RcclCommunicator(Communicator):
             _lib.check(L.aqc_comm_unique_id(buf))
             tmp = id_file + f".tmp{os.getpid()}"
             with open(tmp, "wb") as f:
-                f.write(buf.raw)
+                f.write(buf.raw + nonce)
             os.replace(tmp, id_file)   # atomic: readers never see a partial id
             uid = buf.raw
         else:
             t0 = time.time()
 
-            def fresh():   # a complete id written during THIS launch (a crashed run may have left one behind)
+            def read_id():   # the id of THIS launch: 128 bytes followed by this launch's tag (files are replaced atomically)
                 try:
-                    st = os.stat(id_file)
+                    with open(id_file, "rb") as f:
+                        raw = f.read()
                 except OSError:
-                    return False
-                return st.st_size == 128 and st.st_mtime >= t0 - 600.0
+                    return None
+                return raw[:128] if len(raw) >= 128 and raw[128:] == nonce else None
 
-            while not fresh():
+            uid = read_id()
+            while uid is None:
                 if time.time() - t0 > timeout:
-                    raise RuntimeError(f"aqc_comm: rank {rank} timed out waiting for the unique id in {id_file}")
+                    raise RuntimeError(f"aqc_comm: rank {rank} timed out waiting for the unique id of launch {nonce.decode()!r} in {id_file}")
                 time.sleep(0.02)
-            with open(id_file, "rb") as f:
-                uid = f.read()
+                uid = read_id()
         handle = ctypes.c_void_p()
         _lib.check(L.aqc_comm_create(uid, size, rank, device, ctypes.byref(handle)))
         self.handle = handle

@@ -341,7 +341,7 @@ struct aqc_ws {
     // device pointer tables of the batched MPS -> dense contraction: a few resident sets, found again by their contents (an
     // optimisation converts the same operands into the same lanes evaluation after evaluation: no upload, no synchronisation)
     struct MpsTabs { std::vector<const void*> host; const void** dev = nullptr; size_t cap = 0; unsigned long long tick = 0; };
-    MpsTabs mps_tabs[8];
+    MpsTabs mps_tabs[32];   // resident pointer-table sets (one per distinct chain: operands x lanes x bond dimensions)
     unsigned long long mps_tabs_tick = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     hipStream_t copy_stream = nullptr;        // aqc_ws_results_async: result copies run beside the next evaluation's kernels
@@ -1931,6 +1931,8 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
 // When all the slots have the same bond dimensions (the lanes of a batched objective) every step of the chain is ONE launch
 // for all lanes (zgemm over device pointer tables): (n/2 - 1) + (n - n/2 - 1) + 1 launches whatever the number of lanes, ONE
 // for product states; otherwise the pairs are served one after the other.
+static int mps_to_vec_batch_uniform(aqc_ws* ws, int count, const int32_t* slots, int buf, const int32_t* lanes);
+
 int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf, const int32_t* lanes) {
     if (!ws || !slots || !lanes || count < 1) return fail("invalid batched MPS arguments");
     if (check_buf(ws, buf)) return 1;
@@ -1938,15 +1940,37 @@ int aqc_ws_mps_to_vec_batch(aqc_ws* ws, int count, const int32_t* slots, int buf
         if (check_mps_slot(ws, slots[i], true)) return 1;
         if (lanes[i] < 0 || lanes[i] >= ws->batch) return fail("lane out of range");
     }
-    bool uniform = true;
-    for (int i = 1; i < count; ++i) uniform = uniform && ws->mps[slots[i]].dims == ws->mps[slots[0]].dims;
-    const int n = ws->ctx->prog.n;
-    const int h = n / 2, mh = n - h;
-    if (!uniform || h == 0) {
+    if (ws->ctx->prog.n / 2 == 0) {
         for (int i = 0; i < count; ++i)
             if (aqc_ws_mps_to_vec(ws, slots[i], buf, lanes[i])) return 1;
         return 0;
     }
+    // lanes whose operands share their bond dimensions share every launch of the contraction chain: one chain per distinct
+    // dimension vector (truncated canonical tensors -- the reference's trunc_thr = 1e-6 -- differ from target to target by a
+    // few bond entries; taking every such lane through a chain of its own made a 64-lane step 14x slower than equal bonds)
+    std::vector<int> group(count, -1);
+    int ngroups = 0;
+    for (int i = 0; i < count; ++i) {
+        if (group[i] >= 0) continue;
+        group[i] = ngroups;
+        for (int j = i + 1; j < count; ++j)
+            if (group[j] < 0 && ws->mps[slots[j]].dims == ws->mps[slots[i]].dims) group[j] = ngroups;
+        ++ngroups;
+    }
+    if (ngroups == 1) return mps_to_vec_batch_uniform(ws, count, slots, buf, lanes);
+    std::vector<int32_t> gs, gl;
+    for (int g = 0; g < ngroups; ++g) {
+        gs.clear(); gl.clear();
+        for (int i = 0; i < count; ++i)
+            if (group[i] == g) { gs.push_back(slots[i]); gl.push_back(lanes[i]); }
+        if (mps_to_vec_batch_uniform(ws, (int)gs.size(), gs.data(), buf, gl.data())) return 1;
+    }
+    return 0;
+}
+
+static int mps_to_vec_batch_uniform(aqc_ws* ws, int count, const int32_t* slots, int buf, const int32_t* lanes) {
+    const int n = ws->ctx->prog.n;
+    const int h = n / 2, mh = n - h;
     HIP_OK(hipSetDevice(ws->device));
     const std::vector<int>& dims = ws->mps[slots[0]].dims;
     const std::vector<size_t>& off = ws->mps[slots[0]].offset;

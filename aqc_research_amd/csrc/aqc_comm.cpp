@@ -13,9 +13,11 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 
@@ -87,6 +89,10 @@ struct aqc_comm {
     int nranks = 1, rank = 0, device = 0;
     hipStream_t stream = nullptr;
     double* d_buf = nullptr;   // [send | recv]
+    double* h_buf = nullptr;   // pinned mirror of d_buf: the ONLY host memory the asynchronous copies touch.  The caller's
+                               // (pageable) arrays are read before anything is enqueued and written after the collective
+                               // has completed, so a copy can neither block the polling loop below (pageable D2H copies
+                               // are host-synchronous) nor land in memory the caller has freed after a time-out
     size_t cap = 0;            // doubles
     bool broken = false;       // a collective failed or timed out: the communicator was aborted, every later call fails at once
 };
@@ -97,8 +103,12 @@ int ensure_cap(aqc_comm* c, size_t doubles) {
     if (doubles <= c->cap) return 0;
     if (c->d_buf && hipFree(c->d_buf) != hipSuccess) return comm_fail("hipFree failed");
     c->d_buf = nullptr;
+    if (c->h_buf && hipHostFree(c->h_buf) != hipSuccess) return comm_fail("hipHostFree failed");
+    c->h_buf = nullptr;
     c->cap = 0;
     if (hipMalloc((void**)&c->d_buf, doubles * sizeof(double)) != hipSuccess) return comm_fail("hipMalloc of the staging buffer failed");
+    if (hipHostMalloc((void**)&c->h_buf, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
+        return comm_fail("hipHostMalloc of the pinned staging buffer failed");
     c->cap = doubles;
     return 0;
 }
@@ -108,11 +118,12 @@ int ensure_cap(aqc_comm* c, size_t doubles) {
 // kernel forever; after AQC_COMM_TIMEOUT_S seconds (default 300) -- or as soon as RCCL reports the failure -- the
 // communicator is aborted (ncclCommAbort), marked broken and the call returns an error, so that a job list fails
 // instead of hanging (the reference's run_jobs reports failed jobs, job_executor.py:149-159; it never waits on the dead).
-double comm_timeout_s() {
-    const char* e = getenv("AQC_COMM_TIMEOUT_S");
+double env_seconds(const char* name, double fallback) {
+    const char* e = getenv(name);
     const double v = e ? atof(e) : 0.0;
-    return v > 0.0 ? v : 300.0;
+    return v > 0.0 ? v : fallback;
 }
+double comm_timeout_s() { return env_seconds("AQC_COMM_TIMEOUT_S", 300.0); }
 
 int wait_collective(aqc_comm* c, const char* what) {
     Rccl& r = rccl();
@@ -168,8 +179,31 @@ int aqc_comm_create(const char* id128, int nranks, int rank, int device, aqc_com
     c->nranks = nranks; c->rank = rank; c->device = device;
     NcclUniqueId id;
     memcpy(id.internal, id128, sizeof id.internal);
-    const int rc = r.comm_init_rank(&c->comm, nranks, id, rank);
-    if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+    // ncclCommInitRank blocks until ALL ranks have joined: a rank that never starts (or that read a stale id) would hang the
+    // others for ever.  It runs in a helper thread; this thread waits AQC_COMM_INIT_TIMEOUT_S (default 180 s) for it.  On
+    // time-out the call fails and the helper is left behind, detached, with its own copy of everything it touches (the
+    // caller is expected to exit: the run has failed).
+    struct Init { std::atomic<int> done{0}; int rc = 0; NcclComm comm = nullptr; };
+    auto st = std::make_shared<Init>();
+    std::thread([st, id, nranks, rank, device, init = r.comm_init_rank]() {
+        if (hipSetDevice(device) != hipSuccess) st->rc = -1;
+        else st->rc = init(&st->comm, nranks, id, rank);
+        st->done.store(1, std::memory_order_release);
+    }).detach();
+    const double limit = env_seconds("AQC_COMM_INIT_TIMEOUT_S", 180.0);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!st->done.load(std::memory_order_acquire)) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            delete c;
+            return comm_fail("ncclCommInitRank did not return within " + std::to_string((int)limit) + " s (AQC_COMM_INIT_TIMEOUT_S): rank " +
+                             std::to_string(rank) + " of " + std::to_string(nranks) + " is still waiting for its peers -- a rank failed to start, or "
+                             "the ranks do not share one unique id");
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    if (st->rc == -1) { delete c; return comm_fail("hipSetDevice failed in the RCCL initialisation thread"); }
+    if (st->rc != 0) { delete c; return nccl_fail("ncclCommInitRank", st->rc); }
+    c->comm = st->comm;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { r.comm_destroy(c->comm); delete c; return comm_fail("hipStreamCreate failed"); }
     *out = c;
     return 0;
@@ -180,6 +214,7 @@ int aqc_comm_destroy(aqc_comm* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { if (!c->broken) (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
     if (c->comm) rccl().comm_destroy(c->comm);
     delete c;
     return 0;
@@ -196,11 +231,15 @@ int aqc_comm_allgather(aqc_comm* c, const double* send, double* recv, size_t cou
     if (ensure_cap(c, count * (size_t)(c->nranks + 1))) return 1;
     double* d_send = c->d_buf;
     double* d_recv = c->d_buf + count;
-    if (hipMemcpyAsync(d_send, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
+    double* h_send = c->h_buf;
+    double* h_recv = c->h_buf + count;
+    memcpy(h_send, send, count * sizeof(double));
+    if (hipMemcpyAsync(d_send, h_send, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
     const int rc = rccl().all_gather(d_send, d_recv, count, kNcclFloat64, c->comm, c->stream);
     if (rc != 0) return nccl_fail("ncclAllGather", rc);
-    if (hipMemcpyAsync(recv, d_recv, count * c->nranks * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
-    if (wait_collective(c, "ncclAllGather")) return 1;
+    if (hipMemcpyAsync(h_recv, d_recv, count * c->nranks * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
+    if (wait_collective(c, "ncclAllGather")) return 1;   // on failure the caller's memory has not been touched
+    memcpy(recv, h_recv, count * c->nranks * sizeof(double));
     return 0;
 }
 
@@ -211,11 +250,13 @@ int aqc_comm_allreduce(aqc_comm* c, double* data, size_t count, int op) {
     if (c->broken) return comm_fail("the communicator was aborted after a failed collective");
     if (hipSetDevice(c->device) != hipSuccess) return comm_fail("hipSetDevice failed");
     if (ensure_cap(c, count)) return 1;
-    if (hipMemcpyAsync(c->d_buf, data, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
+    memcpy(c->h_buf, data, count * sizeof(double));
+    if (hipMemcpyAsync(c->d_buf, c->h_buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail("H2D copy failed");
     const int rc = rccl().all_reduce(c->d_buf, c->d_buf, count, kNcclFloat64, op == 0 ? kNcclSum : 2 /* ncclMax */, c->comm, c->stream);
     if (rc != 0) return nccl_fail("ncclAllReduce", rc);
-    if (hipMemcpyAsync(data, c->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
-    if (wait_collective(c, "ncclAllReduce")) return 1;
+    if (hipMemcpyAsync(c->h_buf, c->d_buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail("D2H copy failed");
+    if (wait_collective(c, "ncclAllReduce")) return 1;   // on failure the caller's memory has not been touched
+    memcpy(data, c->h_buf, count * sizeof(double));
     return 0;
 }
 

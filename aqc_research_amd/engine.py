@@ -404,8 +404,9 @@ _MPS_FIRST_CACHED = 4    # slots 0..3 stay with the explicit mps_upload / mps_to
 
 
 def _mps_fingerprint(mps) -> tuple:
-    """Cheap content check of a QiskitMPS tuple: shapes and three entries of every tensor.  Guards the resident copy against
-    arrays that were modified in place; identity (id) of the tuple is the primary key."""
+    """Cheap content check of a QiskitMPS tuple: shapes and three entries of every tensor; identity (id) of the tuple is the
+    primary key.  It is a tripwire, not a proof: what keeps a resident copy valid is that ``mps_slot_for`` makes the arrays
+    of a cached tuple read-only."""
     gam, lam = mps
     out = []
     for g0, g1 in gam:
@@ -438,6 +439,16 @@ def _ws_mps_slot_for(self, mps) -> int:
         slot = cache.pop(victim)[0]
     self.mps_upload(slot, mps)
     cache[id(mps)] = [slot, fp, self._mps_tick, mps]
+    # the fingerprint only samples the tensors: the resident copy is kept honest by making the cached arrays read-only --
+    # an in-place edit now raises instead of silently evaluating against the stale device copy (pass new arrays to change a
+    # target; arrays that are views of a writable base are the caller's to leave alone)
+    for g0, g1 in mps[0]:
+        for a in (g0, g1):
+            if isinstance(a, np.ndarray):
+                a.flags.writeable = False
+    for l in mps[1]:
+        if isinstance(l, np.ndarray):
+            l.flags.writeable = False
     return slot
 
 
@@ -467,7 +478,7 @@ Workspace.mps_slot_for = _ws_mps_slot_for
 Workspace.mps_to_vec_batch = _ws_mps_to_vec_batch
 
 
-def zgemm(a: np.ndarray, b: np.ndarray, conj_trans_a: bool = False, device: int = 0) -> np.ndarray:
+def zgemm(a: np.ndarray, b: np.ndarray, conj_trans_a: bool = False, device: Optional[int] = None) -> np.ndarray:
     """op(a) @ b on the device (aqc_zgemm); op(a) = a or a^H."""
     a = _lib.as_c128(a)
     b = _lib.as_c128(b)
@@ -477,5 +488,5 @@ def zgemm(a: np.ndarray, b: np.ndarray, conj_trans_a: bool = False, device: int 
     if b.shape[0] != k:
         raise ValueError("inner dimensions differ")
     c = np.empty((m, b.shape[1]), dtype=np.complex128)
-    check(_lib.lib().aqc_zgemm(device, int(conj_trans_a), m, b.shape[1], k, dptr(a), a.shape[1], dptr(b), b.shape[1], dptr(c), c.shape[1]))
+    check(_lib.lib().aqc_zgemm(default_device() if device is None else int(device), int(conj_trans_a), m, b.shape[1], k, dptr(a), a.shape[1], dptr(b), b.shape[1], dptr(c), c.shape[1]))
     return c

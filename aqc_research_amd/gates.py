@@ -4,6 +4,8 @@ single-gate functions of ``core_operations`` and ``core_op_matrix``.  Arrays are
 in host memory (k = 1: a state vector); ``qubit`` is the bit index of the row (Qiskit order).  Only the tiny
 gate matrices are built on the host; every pass over the data runs on the device.
 """
+from typing import Optional
+
 import numpy as np
 
 from . import _lib
@@ -34,11 +36,20 @@ def ry_matrix(angle: float) -> np.ndarray:
     return np.array([[c, -s], [s, c]], dtype=np.complex128)
 
 
+def _dev(device) -> int:
+    """None: this rank's GPU (LOCAL_RANK under a one-process-per-GPU launcher, engine.default_device)."""
+    if device is not None:
+        return int(device)
+    from .engine import default_device
+
+    return default_device()
+
+
 def rz_matrix(angle: float) -> np.ndarray:
     return np.array([[np.exp(-0.5j * angle), 0], [0, np.exp(0.5j * angle)]], dtype=np.complex128)
 
 
-def apply_1q(gate, qubit: int, src: np.ndarray, dst: np.ndarray, device: int = 0) -> np.ndarray:
+def apply_1q(gate, qubit: int, src: np.ndarray, dst: np.ndarray, device: Optional[int] = None) -> np.ndarray:
     """dst <- (I x gate x I) src; dst may be src."""
     n, k = shape_of(src)
     if dst.shape != src.shape or shape_of(dst) != (n, k):
@@ -48,11 +59,11 @@ def apply_1q(gate, qubit: int, src: np.ndarray, dst: np.ndarray, device: int = 0
     g = np.ascontiguousarray(gate, dtype=np.complex128)
     if g.shape != (2, 2):
         raise ValueError("expects a 2x2 gate")
-    check(_lib.lib().aqc_gate_1q(device, n, k, int(qubit), dptr(g), dptr(src), dptr(dst)))
+    check(_lib.lib().aqc_gate_1q(_dev(device), n, k, int(qubit), dptr(g), dptr(src), dptr(dst)))
     return dst
 
 
-def apply_2q(gate4, ctrl: int, targ: int, src: np.ndarray, dst: np.ndarray, device: int = 0) -> np.ndarray:
+def apply_2q(gate4, ctrl: int, targ: int, src: np.ndarray, dst: np.ndarray, device: Optional[int] = None) -> np.ndarray:
     """dst <- (4x4 gate on (ctrl, targ), basis index 2*bit_ctrl + bit_targ) src; dst may be src."""
     n, k = shape_of(src)
     if dst.shape != src.shape or shape_of(dst) != (n, k):
@@ -62,7 +73,7 @@ def apply_2q(gate4, ctrl: int, targ: int, src: np.ndarray, dst: np.ndarray, devi
     g = np.ascontiguousarray(gate4, dtype=np.complex128)
     if g.shape != (4, 4):
         raise ValueError("expects a 4x4 gate")
-    check(_lib.lib().aqc_gate_2q(device, n, k, int(ctrl), int(targ), dptr(g), dptr(src), dptr(dst)))
+    check(_lib.lib().aqc_gate_2q(_dev(device), n, k, int(ctrl), int(targ), dptr(g), dptr(src), dptr(dst)))
     return dst
 
 
@@ -88,7 +99,7 @@ def block_matrix(c_mat, t_mat, g_mat, dagger: bool) -> np.ndarray:
     return np.kron(c_mat @ _P0, t_mat) + np.kron(c_mat @ _P1, t_mat @ g_mat)
 
 
-def dot(kind: int, q0: int, q1: int, w: np.ndarray, z: np.ndarray, device: int = 0) -> np.complex128:
+def dot(kind: int, q0: int, q1: int, w: np.ndarray, z: np.ndarray, device: Optional[int] = None) -> np.complex128:
     """kind 0/1/2: 0.5j <P w|z> with P = X/Y/Z on qubit q0; kind 3: -1j <P11(q0, q1) w|z>."""
     n, k = shape_of(w)
     if z.shape != w.shape or shape_of(z) != (n, k):
@@ -96,5 +107,5 @@ def dot(kind: int, q0: int, q1: int, w: np.ndarray, z: np.ndarray, device: int =
     if not 0 <= q0 < n or (kind == 3 and not (0 <= q1 < n and q1 != q0)):
         raise ValueError("qubit out of range")
     out = np.empty(1, dtype=np.complex128)
-    check(_lib.lib().aqc_gate_dot(device, n, k, int(kind), int(q0), int(q1), dptr(w), dptr(z), dptr(out)))
+    check(_lib.lib().aqc_gate_dot(_dev(device), n, k, int(kind), int(q0), int(q1), dptr(w), dptr(z), dptr(out)))
     return np.complex128(out[0])

@@ -67,6 +67,37 @@ class ThinStateHandler:
         return vec[self._state_idx[state_no]]
 
 
+def basis_mask_of_circuit(qc, num_qubits: int) -> int:
+    """Bit mask of a state-preparation circuit that only flips qubits -- what the reference's ``state_prep_func``s return
+    (``neel_init_state``, ``half_zero_circuit``, ``identity_circuit``, trotter.py:381-410; consumed at
+    objective_base.py:298-303).  Duck-typed walk over ``qc.data``: entries with ``.operation`` / ``.qubits`` (Qiskit's
+    ``CircuitInstruction``) or the older ``(operation, qargs, cargs)`` triples; X toggles a bit, identities / barriers are
+    skipped, anything else raises.  Qiskit is never imported: a real ``QuantumCircuit`` works through the same attributes."""
+    if getattr(qc, "num_qubits", num_qubits) != num_qubits:
+        raise ValueError("state_prep_func returned a circuit on a different number of qubits")
+    mask = 0
+    for ins in qc.data:
+        op = getattr(ins, "operation", None)
+        qubits = getattr(ins, "qubits", None)
+        if op is None:
+            op, qubits = ins[0], ins[1]
+        name = str(getattr(op, "name", "")).lower()
+        if name in ("id", "i", "barrier", "delay"):
+            continue
+        if name != "x" or len(qubits) != 1:
+            raise NotImplementedError(
+                f"state_prep_func returned a circuit with a '{name}' gate: the HIP path prepares computational-basis states "
+                "only (X / identity circuits, a bit mask, or a dense array of states); Qiskit circuits are not simulated")
+        q = qubits[0]
+        if not isinstance(q, (int, np.integer)):
+            find = getattr(qc, "find_bit", None)
+            q = find(q).index if find is not None else getattr(q, "index", getattr(q, "_index", None))
+        if q is None or not 0 <= int(q) < num_qubits:
+            raise ValueError("state_prep_func: cannot resolve a qubit index of the circuit")
+        mask ^= 1 << int(q)
+    return mask
+
+
 class DenseStateHandler:
     """States given explicitly as rows of a (num_states, 2^n) array -- the HIP-side
     counterpart of GenericStateHandler (objective_base.py:258-342), whose Qiskit circuit
@@ -159,8 +190,9 @@ class SpLHSObjectiveBase:
     state_prep_func, enable_optim_stats, verbose, maxiter, device.
 
     ``state_prep_func(num_qubits)`` may return an ``int`` (bit mask of a computational-basis
-    preparation, e.g. the Neel state) or a dense (num_states, 2^n) array of prepared states;
-    Qiskit circuits are outside this path."""
+    preparation, e.g. the Neel state), a circuit that only flips qubits (the reference's ``neel_init_state`` & co.,
+    duck-typed: ``basis_mask_of_circuit``) or a dense (num_states, 2^n) array of prepared states; other Qiskit circuits
+    are outside this path and raise."""
 
     def __init__(self, user_parameters: dict, circuit: ParametricCircuit, use_mps: bool = False, verbose: bool = False):
         if not isinstance(user_parameters, dict):
@@ -181,6 +213,8 @@ class SpLHSObjectiveBase:
             self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=int(prepared))
         elif isinstance(prepared, np.ndarray):
             self._state_handler = DenseStateHandler(prepared)
+        elif hasattr(prepared, "data") and hasattr(prepared, "num_qubits"):   # a (duck-typed) circuit of X gates
+            self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=basis_mask_of_circuit(prepared, n))
         else:
             raise NotImplementedError(
                 "state_prep_func must return a basis-state bit mask (int) or a dense array of states; "

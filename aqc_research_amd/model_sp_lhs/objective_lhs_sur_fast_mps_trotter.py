@@ -8,7 +8,7 @@ semantics the reference's tests pin for trunc_thr -> 0.
 from typing import Optional, Tuple
 
 from ..engine import BUF_Y
-from ..mps_operations import check_mps
+from ..mps_operations import DenseBackedMPS, check_mps, mps_num_qubits
 from ..parametric_circuit import TrotterAnsatz, first_layer_included, layer_to_block_range
 from .objective_lhs_sur_max import SpSurrogateObjectiveMax
 
@@ -43,12 +43,15 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
         self._layer_range = (0, circ.num_layers) if layer_range is None else layer_range
 
     def _set_mps_target(self, target) -> None:
-        if not check_mps(target) or len(target[0]) != self._circuit.num_qubits:
+        if not check_mps(target) or mps_num_qubits(target) != self._circuit.num_qubits:
             raise ValueError("target must be an MPS in Qiskit format matching the circuit")
         self._target = target
         if not self._native_mps:
-            self._ws.mps_upload(0, target)
-            self._ws.mps_to_vec(0, BUF_Y, 0)
+            if isinstance(target, DenseBackedMPS):      # its dense state is at hand: no tensors, no contraction
+                self._ws.upload(BUF_Y, target.dense_state)
+            else:
+                self._ws.mps_upload(0, target)
+                self._ws.mps_to_vec(0, BUF_Y, 0)
             return
         from ..mps_engine import DeviceMPS
 

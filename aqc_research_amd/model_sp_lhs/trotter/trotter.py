@@ -37,6 +37,64 @@ def neel_state_index(num_qubits: int) -> int:
     return sum(1 << q for q in range(0, num_qubits, 2))
 
 
+class _Op:
+    def __init__(self, name):
+        self.name, self.params = name, []
+
+
+class _Instruction:
+    """One entry of ``BasisPrepCircuit.data``: ``operation.name`` and ``qubits`` (integers), the attribute names of
+    Qiskit's ``CircuitInstruction``."""
+
+    def __init__(self, name, qubit):
+        self.operation, self.qubits, self.clbits = _Op(name), (int(qubit),), ()
+
+
+class BasisPrepCircuit:
+    """Stand-in for the ``QuantumCircuit`` a reference ``state_prep_func`` returns (trotter.py:381-410) when the
+    circuit only flips qubits: ``num_qubits``, ``x(q)`` and ``data`` with Qiskit's attribute names -- what
+    ``objective_base.basis_mask_of_circuit`` walks.  Qiskit itself is not needed (and not imported)."""
+
+    def __init__(self, num_qubits: int):
+        if not (isinstance(num_qubits, (int, np.integer)) and num_qubits >= 2):
+            raise ValueError("num_qubits must be an integer >= 2")
+        self.num_qubits, self.data = int(num_qubits), []
+
+    def x(self, qubit: int):
+        if not 0 <= int(qubit) < self.num_qubits:
+            raise ValueError("qubit out of range")
+        self.data.append(_Instruction("x", qubit))
+        return self
+
+    @property
+    def basis_index(self) -> int:
+        mask = 0
+        for ins in self.data:
+            mask ^= 1 << ins.qubits[0]
+        return mask
+
+
+def identity_circuit(num_qubits: int) -> BasisPrepCircuit:
+    """The empty preparation circuit (trotter.py:381-386)."""
+    return BasisPrepCircuit(num_qubits)
+
+
+def neel_init_state(num_qubits: int) -> BasisPrepCircuit:
+    """|0> -> the Neel state: X on every even qubit (trotter.py:389-398)."""
+    qc = BasisPrepCircuit(num_qubits)
+    for k in range(0, num_qubits, 2):
+        qc.x(k)
+    return qc
+
+
+def half_zero_circuit(num_qubits: int) -> BasisPrepCircuit:
+    """|0> -> half zero / half unit bits: X on the upper half of the qubits (trotter.py:401-410)."""
+    qc = BasisPrepCircuit(num_qubits)
+    for k in range(num_qubits // 2, num_qubits):
+        qc.x(k)
+    return qc
+
+
 def slice2q(circ, vec: np.ndarray, *, layer_range: Optional[Tuple[int, int]] = None):
     """View of the block parameters as (layers, triplets, 12) (trotter.py:431-475)."""
     if not hasattr(circ, "is_second_order"):

@@ -59,6 +59,32 @@ def is_canonical(qiskit_mps, tol: float = 1e-8) -> bool:
     return True
 
 
+def _default_device() -> int:
+    from .engine import default_device
+
+    return default_device()
+
+
+_CANONICAL_CACHE: dict = {}   # id(tuple) -> (weak liveness token, verdict); a few entries (targets of running optimisations)
+
+
+def _canonical_verdict(qiskit_mps) -> bool:
+    """``is_canonical`` once per tuple object: the same target tuple arrives on every evaluation of an optimisation
+    (mps_dot_objective.py:41).  Keyed by identity plus the shapes and a corner of every tensor (an in-place edit that keeps
+    those is the caller's to announce by passing a new tuple)."""
+    key = id(qiskit_mps)
+    gam, lam = qiskit_mps
+    mark = tuple((np.shape(g0), complex(np.asarray(g0).flat[0]), complex(np.asarray(g1).flat[-1])) for g0, g1 in gam)
+    hit = _CANONICAL_CACHE.get(key)
+    if hit is not None and hit[0] == mark:
+        return hit[1]
+    verdict = is_canonical(qiskit_mps)
+    if len(_CANONICAL_CACHE) > 64:
+        _CANONICAL_CACHE.clear()
+    _CANONICAL_CACHE[key] = (mark, verdict)
+    return verdict
+
+
 class DeviceMPS:
     """One MPS resident on the GPU."""
 
@@ -67,16 +93,20 @@ class DeviceMPS:
         self._L = _lib.lib()
 
     @classmethod
-    def from_qiskit(cls, qiskit_mps, device: int = 0, trunc_thr: float = 0.0) -> "DeviceMPS":
+    def from_qiskit(cls, qiskit_mps, device: Optional[int] = None, trunc_thr: float = 0.0, assume_canonical: bool = False) -> "DeviceMPS":
         """Uploads a QiskitMPS tuple.  The engine's truncation rule is stated on Schmidt values, i.e. for states in
         canonical (Vidal) form -- what Aer hands the reference (mps_operations.py:216-243).  When a real truncation is asked
         for (``trunc_thr`` > 1e-12) an input that is NOT canonical is brought into that form first (two sweeps of exact
-        SVDs, ``canonicalize``); with exact arithmetic the gauge does not matter and the tensors are taken as they are."""
+        SVDs, ``canonicalize``); with exact arithmetic the gauge does not matter and the tensors are taken as they are.
+        ``device`` None: this rank's GPU (``engine.default_device()``: LOCAL_RANK under a one-process-per-GPU launcher).
+        The O(n chi^3) host check is made once per tuple (the verdict is remembered by the tuple's identity, the target of an
+        optimisation arrives on every evaluation); ``assume_canonical`` skips it (states that come from Aer or this engine)."""
         n, dims, g, lm = _pack(qiskit_mps)
         h = c_void_p()
-        check(_lib.lib().aqc_mps_create(device, n, dims.ctypes.data_as(POINTER(c_int32)), dptr(g), dptr(lm), byref(h)))
+        dev = _default_device() if device is None else int(device)
+        check(_lib.lib().aqc_mps_create(dev, n, dims.ctypes.data_as(POINTER(c_int32)), dptr(g), dptr(lm), byref(h)))
         m = cls(h)
-        if trunc_thr > 1e-12 and not is_canonical(qiskit_mps):
+        if trunc_thr > 1e-12 and not assume_canonical and not _canonical_verdict(qiskit_mps):
             m.canonicalize()
         return m
 
@@ -92,7 +122,7 @@ class DeviceMPS:
         return self
 
     @classmethod
-    def basis_state(cls, num_qubits: int, index: int = 0, device: int = 0) -> "DeviceMPS":
+    def basis_state(cls, num_qubits: int, index: int = 0, device: Optional[int] = None) -> "DeviceMPS":
         """Product state |index> (bit q of ``index`` = qubit q)."""
         index = int(index)   # Python integer: registers beyond 63 qubits
         gam = [((np.array([[1.0 - ((index >> q) & 1)]], dtype=np.complex128)), np.array([[float((index >> q) & 1)]], dtype=np.complex128))
@@ -177,7 +207,7 @@ class DeviceMPS:
             pass
 
 
-def svd(a: np.ndarray, device: int = 0):
+def svd(a: np.ndarray, device: Optional[int] = None):
     """(U, S, Vh, sweeps) of a complex matrix by the engine's one-sided Jacobi kernel."""
     a = np.ascontiguousarray(a, dtype=np.complex128)
     if a.ndim != 2:
@@ -186,7 +216,7 @@ def svd(a: np.ndarray, device: int = 0):
     k = min(m, n)
     u, s, vh = np.empty((m, k), dtype=np.complex128), np.empty(k), np.empty((k, n), dtype=np.complex128)
     sweeps = c_int(0)
-    check(_lib.lib().aqc_svd(device, m, n, dptr(a), dptr(u), dptr(s), dptr(vh), byref(sweeps)))
+    check(_lib.lib().aqc_svd(_default_device() if device is None else int(device), m, n, dptr(a), dptr(u), dptr(s), dptr(vh), byref(sweeps)))
     return u, s, vh, sweeps.value
 
 

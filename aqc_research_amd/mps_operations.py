@@ -49,6 +49,11 @@ def check_mps(qiskit_mps) -> bool:
     return True
 
 
+def mps_num_qubits(qiskit_mps) -> int:
+    """Number of sites, without looking inside a ``DenseBackedMPS`` (that would run its SVD chain)."""
+    return qiskit_mps.num_qubits if isinstance(qiskit_mps, DenseBackedMPS) else len(qiskit_mps[0])
+
+
 class _Circ:
     """Gate-free n-qubit descriptor: MPS helpers only need a device workspace of size 2^n."""
 
@@ -66,6 +71,8 @@ def mps_to_vector(qiskit_mps) -> np.ndarray:
     """Dense state of an MPS; index bit q <-> site q (mps_operations.py:159-189)."""
     if not check_mps(qiskit_mps):
         raise ValueError("not a valid MPS in Qiskit format")
+    if isinstance(qiskit_mps, DenseBackedMPS) and qiskit_mps.exact:
+        return qiskit_mps.dense_state.copy()
     ws = _workspace(len(qiskit_mps[0]))
     ws.mps_upload(0, qiskit_mps)
     ws.mps_to_vec(0, BUF_Y, 0)
@@ -179,8 +186,17 @@ class DenseBackedMPS(tuple):
             self._mps = vector_to_canonical_mps(self._vec, self._thr)
         return self._mps
 
+    @property
+    def exact(self) -> bool:
+        """No truncation asked for: the tensors stand for the dense state itself (to rounding)."""
+        return self._thr <= 1e-12
+
     def dense_on(self, ws, buf: int) -> bool:
         return ws is self._ws and buf == self._buf and ws.generation(buf) == self._gen
+
+    @property
+    def num_qubits(self) -> int:
+        return int(self._vec.size).bit_length() - 1
 
     @property
     def dense_state(self) -> np.ndarray:
@@ -210,7 +226,7 @@ class DenseBackedMPS(tuple):
 
 
 def _apply_to_mps(circ, thetas, mps_vec, inverse: bool, trunc_thr) -> QiskitMPS:
-    if not check_mps(mps_vec) or len(mps_vec[0]) != circ.num_qubits:
+    if not check_mps(mps_vec) or mps_num_qubits(mps_vec) != circ.num_qubits:
         raise ValueError("MPS does not match the circuit")
     thr = _NO_TRUNCATION_THR if trunc_thr is None else float(trunc_thr)
     from .mps_dot_objective import use_dense

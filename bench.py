@@ -48,6 +48,10 @@ WORKLOADS = {
     "cfg4_jobs": dict(n=20, kind="jobs", seeds=64, horizons=8, evals=10, desc="20-qubit ASP job mix: 64 seeds x 8 horizons (2nd-order Trotter ansatz, 2h layers), 10 objective+gradient pairs per job, sharded by run_jobs"),
     "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=16 (a different one per lane every step), contracted to dense on the device every evaluation"),
     "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=64 (a different one per lane every step), contracted to dense on the device every evaluation"),
+    # the same front door at the threshold the reference's own driver hands over (user_options.py:55: trunc_thr = 1e-6): the targets
+    # are canonical tensors truncated at 1e-6 and the calls take the dense route whatever the threshold (mps_dot_objective.use_dense)
+    "mps16_l40_chi64_thr1e-6": dict(n=16, blocks=40, kind="generic", chi=64, trunc_thr=1e-6, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient at the reference's default trunc_thr = 1e-6: canonical QiskitMPS targets chi<=64 truncated at 1e-6 (a different one per lane every step), dense route"),
+    "sv12_trotter12": dict(n=12, layers=12, kind="trotter2", desc="12-qubit ASP, 2nd-order Trotter ansatz (12 layers: the last horizon of run_time_evol.py's defaults), state-vector objective+gradient"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
 
@@ -163,6 +167,21 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
     }
 
 
+def reference_numpy_record(workload):
+    """The reference's own NumPy path on this workload, as tools/ref_baseline.py measured it in the BUILD container (the
+    reference never travels to the GPU box): read from the committed profiles/ref_baseline.json, labelled with its host."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "ref_baseline.json")))
+        row = rec["configs"][workload]
+    except Exception:
+        return None
+    return {"evals_per_s_1_process": row["single_process"]["rate"], "median_ms_1_process": row["single_process"]["median_ms"],
+            "p10_ms": row["single_process"]["p10_ms"], "p90_ms": row["single_process"]["p90_ms"], "reps": row["single_process"]["reps"],
+            "evals_per_s_parallel_processes": row["parallel_processes"]["rate"], "processes": row["parallel_processes"]["processes"],
+            "measured": f"in the build container on {rec['host']['cpu_model']} ({rec['host']['os_cpu_count']} vCPU), {rec['date']}, "
+                        "tools/ref_baseline.py; NOT on this GPU box"}
+
+
 # ---- config 4: the ASP job mix ---------------------------------------------------------------------------------------
 # What a horizon's jobs share stays resident between them (time_evol_best_init.py:337-382 builds everything per job): the
 # ansatz context and its plans (HipContext cache), ONE batched objective per (horizon, lanes) whose lanes are the seeds of a
@@ -237,7 +256,7 @@ def _mix_release():
         _MIX[kind].clear()
 
 
-def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note):
+def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=None):
     """--workload cfg4_jobs: the whole mix through run_jobs (rank-sharded, fixed-size record gather)."""
     from aqc_research_amd.job_executor import run_jobs
 
@@ -250,7 +269,7 @@ def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note):
     configs = [{"n": w["n"], "horizon": h, "evals": w["evals"], "device": local_rank,
                 "seeds": [0x696969 + 7 * (c * chunk + s + 1) + 1000 * h for s in range(chunk)]}
                for h in range(1, w["horizons"] + 1) for c in range(nchunks)]
-    K, W = max(1, min(args.steps, 3)), min(args.warmup, 1)
+    K, W = max(1, min(args.steps if steps is None else steps, 3)), min(args.warmup, 1)
     for _ in range(W):   # warm-up: contexts, plans, objectives and first launches of every horizon (2 evaluation pairs each)
         run_jobs([dict(c, evals=2) for c in configs], 1, _mix_job, records="fixed")
     comm.barrier()
@@ -299,7 +318,7 @@ def launch_ranks(n_ranks, argv):
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AQC_COMM_FILE=os.path.join(tmp, "rccl_unique_id"),
-                   AQC_BENCH_LAUNCHER="self")
+                   AQC_COMM_TAG=os.path.basename(tmp), AQC_BENCH_LAUNCHER="self")   # the tag names THIS launch inside the id file
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -422,6 +441,8 @@ def main():
     ap.add_argument("--rank-echo", action="store_true", help=argparse.SUPPRESS)   # launcher self-test: no GPU work, see tests/
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained-rate loop after the timed one (0 = off)")
     ap.add_argument("--no-objective-object", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="default workload only: skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each short configuration run")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -486,22 +507,76 @@ def main():
     if ranks_seen != list(range(world)):
         print(f"bench.py: rank {rank}: the process group holds ranks {ranks_seen}, expected 0..{world - 1}", file=sys.stderr)
         os._exit(6)
+    import types
 
+    env = types.SimpleNamespace(comm=comm, comm_note=comm_note, rank=rank, world=world, local_rank=local_rank, n_gpus=n_gpus,
+                                ranks_seen=ranks_seen)
+    t_start = time.perf_counter()
+    out = measure(args.workload, args, env, full=True)
+    # ---- every other BASELINE configuration in the SAME driver-run line: a few timed steps each, parity-checked against the
+    # C oracle like the headline (single GPU, default workload only; --no-configs skips them) ---------------------------------
+    if args.workload == "sv16_l40" and world == 1 and not args.no_configs:
+        configs = {}
+        for name in CONFIG_RUNS:
+            t_cfg = time.perf_counter()
+            try:
+                configs[name] = brief(measure(name, args, env, full=False))
+            except SystemExit as exc:   # a failed short run must not take the headline with it: it is reported as failed
+                configs[name] = {"error": str(exc)}
+            configs[name]["wall_s_incl_setup"] = time.perf_counter() - t_cfg
+            print(f"bench.py: config {name}: {json.dumps(configs[name])}", file=sys.stderr, flush=True)
+        out["configs"] = configs
+        out["configs_note"] = ("short runs of the other BASELINE.json configurations in this same process: --config-steps timed steps "
+                               "after 3 warm-up steps each, inputs resident in HBM, thetas changing every step, the last step checked "
+                               "against the C oracle (parity_maxerr); roofline_frac = executed MFMA flops of a sweep launch / its HIP-event "
+                               "duration / 78.6 TFLOP/s")
+        out["total_bench_wall_s"] = time.perf_counter() - t_start
+    if rank == 0 and out is not None:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    comm.barrier()
+    comm.close()
+
+
+# the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
+# MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
+CONFIG_RUNS = ["mat5_cyc180", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
+               "sv20_trotter2", "cfg4_jobs", "mat10_l40"]
+
+
+def brief(o):
+    """What a configs entry of the default line carries (the full record of a workload: --workload NAME)."""
+    if o is None:
+        return {"error": "no result"}
+    r = o.get("roofline") or {}
+    b = {"evals_per_s": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes": o["config"].get("batch_per_gpu", o["config"].get("lanes_per_entry")),
+         "workload": o["config"]["workload"], "roofline_frac": r.get("frac"), "roofline_kernel": r.get("kernel"),
+         "sweep_avg_launch_ms": r.get("avg_launch_ms"), "parity_maxerr": o.get("parity_maxerr"),
+         "parity_lanes_checked": o.get("parity_lanes_checked")}
+    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity"):
+        if k in o:
+            b[k] = o[k]
+        elif k in o["config"]:
+            b[k] = o["config"][k]
+    return b
+
+
+def measure(workload, args, env, full):
+    """One workload: set-up, warm-up, K timed steps between barriers, parity check of the last timed step, kernel profile.
+    ``full`` adds the sustained loop, single-evaluation latency, objective objects and the CPU baseline (the headline run);
+    the short configuration runs of the default line leave them out and use --config-steps steps."""
+    comm, comm_note, rank, world, local_rank, n_gpus, ranks_seen = (env.comm, env.comm_note, env.rank, env.world, env.local_rank,
+                                                                     env.n_gpus, env.ranks_seen)
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, HipContext, Workspace
     from oracle import aqc_oracle as orc
 
-    w = WORKLOADS[args.workload]
+    w = WORKLOADS[workload]
     if w["kind"] == "jobs":
-        out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note)
+        out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=(args.steps if full else 1))
         out["config"]["ranks_seen"] = ranks_seen
-        if rank == 0:
-            sys.stdout.flush()
-            os.dup2(real_stdout, 1)
-            print(json.dumps(out), flush=True)
-            os.dup2(2, 1)
-        comm.barrier()
-        comm.close()
-        return
+        return out
     circ = build_circuit(w)
     n, T = circ.num_qubits, circ.num_thetas
     ctx = HipContext.of(circ)
@@ -512,8 +587,9 @@ def main():
     # lanes per GPU: 1024 for problems of up to 2^16 amplitudes per lane (1 GiB per buffer at 16 qubits; a persistent sweep
     # workgroup then walks 64 tiles, so launch ramp, prologue and tail are amortised: 64 lanes give 156k evals/s at the
     # headline, 256 give 178k, 1024 give 183k -- DESIGN 6), 64 otherwise
-    B = args.batch if args.batch > 0 else (64 if chi else (1024 if (ncols << n) <= (1 << 16) else (64 if ncols < 256 else 32)))
-    K, W = args.steps, args.warmup
+    B = args.batch if args.batch > 0 and full else (64 if chi else (1024 if (ncols << n) <= (1 << 16) else (64 if ncols < 256 else 32)))
+    K, W = (args.steps, args.warmup) if full else (max(1, min(args.steps, args.config_steps)), 3)
+    thr = float(w.get("trunc_thr", 1e-16))
 
     rng = np.random.default_rng(1234 + 7 * (rank + 1))  # job_executor.py:64 seeding rule
     ws = Workspace(ctx, batch=B, ncols=ncols, device=local_rank)
@@ -525,6 +601,13 @@ def main():
         # and lhs states to dense vectors on the device -- one batched launch chain each (aqc_ws_mps_to_vec_batch).
         distinct = [orc.random_mps(n, chi, rng) for _ in range(min(B, 4))]
         D = len(distinct)
+        if thr > 1e-12:   # the reference's default threshold: canonical tensors truncated at `thr`, as Aer hands them over
+            from aqc_research_amd import mps_dot_objective as mdo
+            from aqc_research_amd.mps_operations import vector_to_canonical_mps
+
+            if not mdo.use_dense(n, thr):
+                raise SystemExit(f"bench.py: {workload}: the MPS front door does not take the dense route at trunc_thr = {thr:g}")
+            distinct = [vector_to_canonical_mps(orc.mps_to_vector(m) / np.linalg.norm(orc.mps_to_vector(m)), thr) for m in distinct]
         mps_targets = [[distinct[(i + b) % D] for b in range(B)] for i in range(D)]
         zero_mps = ([(np.ones((1, 1), complex), np.zeros((1, 1), complex)) for _ in range(n)], [np.ones(1) for _ in range(n - 1)])
         zero_list = [zero_mps] * B
@@ -568,7 +651,7 @@ def main():
     for i in range(min(50, max(W, 1))):
         step(i)
     ws.sync()
-    time.sleep(1.0)
+    time.sleep(1.0 if full else 0.2)
     for i in range(W):
         step(i)
     barrier()
@@ -582,13 +665,17 @@ def main():
     if comm.size > 1:
         wall = float(comm.allreduce(np.array([wall]), "max")[0])
 
+    # per-rank rates from each rank's own device clock (HIP events around its K timed steps): a SCALE record can be read
+    # without a rerun (one more all-gather of a double per rank, outside the timed region)
+    my_rate = K * B / (ev_ms * 1e-3) if ev_ms > 0 else 0.0
+    rank_rates = [float(v) for v in comm.allgather(np.array([my_rate]))[:, 0]] if comm.size > 1 else [my_rate]
     # result record of the last step (checked + gathered: the only inter-GPU traffic)
     hs, grads = ws.results_fetch()   # the host copies the last timed step delivered
     hs = hs.reshape(B, -1)
 
     # sustained rate: the same step for >= --sustain-seconds of wall clock after the driver-sized loop (power / clock settling)
     sustained = None
-    if args.sustain_seconds > 0:
+    if full and args.sustain_seconds > 0:
         barrier()
         t1 = time.perf_counter()
         done_steps = 0
@@ -622,7 +709,10 @@ def main():
     # ---- the timed work is checked, not assumed: the last step's (hs, gradient) of a few lanes against the C
     # restatement of the reference algorithm (oracle/aqc_ref.c) on the same (theta, target) --------------------
     last_th = bank[(W + K - 1) % nsets]
-    check_lanes = sorted(set([0, B // 3, (2 * B) // 3, B - 1]))[: (4 if N <= (1 << 17) else 2)]
+    # headline-sized problems: 32 lanes spread over the batch (the GPU suite checks all 1024 lanes of this exact workload,
+    # tests/test_hip_round3.py::test_headline_all_lanes); 2^20-amplitude lanes: 2 (0.7 s of C oracle each)
+    n_check = (32 if full else 8) if N <= (1 << 17) else 2
+    check_lanes = sorted(set(int(round(v)) for v in np.linspace(0, B - 1, min(B, n_check))))
     parity = 0.0
     from oracle import aqc_ref as cref
 
@@ -683,7 +773,7 @@ def main():
         # ---- single-evaluation latency (batch 1, host-visible result each call) ---------------
         latency = None
         latency_rounds = None
-        if not args.no_latency and ncols == 1 and not chi:
+        if full and not args.no_latency and ncols == 1 and not chi:
             ws1 = Workspace(ctx, batch=1, device=local_rank)
             ws1.upload(BUF_Y, targets[0])
             ws1.set_basis(BUF_X, 0)
@@ -704,7 +794,7 @@ def main():
 
         # ---- the metric as SURVEY 8(d) words it: objective(theta) + gradient(theta) on the objective OBJECT ----------------
         objective_object = None
-        if not args.no_objective_object and ncols == 1 and not chi:
+        if full and not args.no_objective_object and ncols == 1 and not chi:
             objective_object = objective_object_rates(circ, targets, rng, local_rank)
 
         # measured HBM traffic of the dominant kernel (rocprofv3 --pmc passes, tools/pmc_summary.py), if the
@@ -712,7 +802,7 @@ def main():
         traffic, traffic_source = None, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("workload") == args.workload and pj.get("batch_per_gpu") == B:
+            if pj.get("workload") == workload and pj.get("batch_per_gpu") == B:
                 for kname, kv in pj["kernels"].items():
                     if "sweep_stage_kernel" in kname or "sweep_mfma_kernel" in kname:
                         traffic = kv["hbm_bytes_per_launch"]
@@ -720,6 +810,27 @@ def main():
                                           f"committed as profiles/pmc_traffic.json ({pj.get('date', 'undated')}, {pj.get('source', 'builder-run')})")
         except Exception:
             traffic, traffic_source = None, None
+        # ---- the literal reference-signature calls, one lane: v_dagger_mul_mps + fast_dot_gradient with the workload's trunc_thr
+        front_door = None
+        if chi:
+            from aqc_research_amd import mps_dot_objective as mdo
+            from aqc_research_amd import mps_operations as mpo
+
+            th1 = np.pi * (2 * rng.random((40, T)) - 1)
+            for i in range(5):
+                mdo.fast_dot_gradient(circ, th1[i], zero_mps, mpo.v_dagger_mul_mps(circ, th1[i], distinct[i % D], trunc_thr=thr), trunc_thr=thr)
+            t1 = time.perf_counter()
+            for i in range(5, 40):
+                vh1 = mpo.v_dagger_mul_mps(circ, th1[i], distinct[i % D], trunc_thr=thr)
+                g1 = mdo.fast_dot_gradient(circ, th1[i], zero_mps, vh1, trunc_thr=thr)
+            dt1 = time.perf_counter() - t1
+            a1 = orc.as_ansatz(circ)
+            x1 = np.zeros(1 << n, complex)
+            x1[0] = 1
+            g_ref = orc.grad_of_dot_product(a1, th1[39], x1, orc.v_dagger_mul_vec(a1, th1[39], orc.mps_to_vector(distinct[39 % D])))
+            front_door = {"calls": "mps_operations.v_dagger_mul_mps + mps_dot_objective.fast_dot_gradient, trunc_thr = %g" % thr,
+                          "evals_per_s": 35 / dt1, "ms_per_eval": dt1 / 35 * 1e3, "route": "dense" if mdo.use_dense(n, thr) else "mps engine",
+                          "parity_maxerr": float(np.abs(g1 - g_ref).max())}
         evals = K * B * n_gpus
         value = evals / wall
         out = {
@@ -744,10 +855,13 @@ def main():
                 "batch_per_gpu": B,
                 "path": ("MPS front door (mps_dot_objective), dense route" if chi else "state-vector (core_operations)") if ncols == 1 else "matrix (core_op_matrix)",
                 "mps_bond_dimension": chi or None,
+                "mps_trunc_thr": thr if chi else None,
                 "columns": ncols,
                 "transport": comm.transport if comm_note is None else comm_note,
                 "records_gathered": len(gathered),
                 "ranks_seen": ranks_seen,
+                "per_rank_evals_per_s": {"min": min(rank_rates), "max": max(rank_rates), "mean": float(np.mean(rank_rates)),
+                                         "all": rank_rates, "clock": "HIP events on each rank's own stream over its timed steps"},
                 "launcher": os.environ.get("AQC_BENCH_LAUNCHER", "external" if world > 1 else "none"),
                 "tile_bits": {"vdag": k_inv, "sweep": k_sw},
                 "launches_per_eval_step": {"vdag": stages_inv, "sweep": stages_sw},
@@ -810,15 +924,14 @@ def main():
             "latency_batch1_rounds_ms": latency_rounds,
             "algorithmic_GBps_whole_eval": (sweep_bytes_per_step + apply_bytes_per_step) * K / wall / 1e9,
         }
-        if not args.no_cpu_baseline:
+        if front_door is not None:
+            out["front_door_single_lane"] = front_door
+        if full and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(circ, ncols)
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+            out["cpu_baseline"]["reference_numpy"] = reference_numpy_record(workload)
     ws.close()
     comm.barrier()
-    comm.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -430,8 +430,8 @@ def test_cfg4_style_run_jobs_replayed_on_the_host():
 
 def test_mps_batched_contraction_and_slot_cache():
     """aqc_ws_mps_to_vec_batch: all lanes' MPS -> dense in one launch chain (mps_operations.py:159-189 per lane), lanes that
-    share a tuple share its resident copy, mixed bond dimensions fall back to lane-by-lane, a tuple modified in place is
-    uploaded again (fingerprint), and more distinct tuples than slots recycle the least recently used one."""
+    share a tuple share its resident copy, mixed bond dimensions run one chain per distinct dimension vector, the arrays of a
+    cached tuple are read-only (a tuple whose owner modifies it all the same is uploaded again: fingerprint), and more distinct tuples than slots recycle the least recently used one."""
     from aqc_research_amd import ParametricCircuit
     from aqc_research_amd.circuit_structures import create_ansatz_structure
     from aqc_research_amd.engine import BUF_Y, HipContext, Workspace
@@ -452,7 +452,10 @@ def test_mps_batched_contraction_and_slot_cache():
     got = ws.download(BUF_Y)
     for i, m in enumerate(mixed):
         assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
-    a[0][3][0][0, 0] += 0.25                            # in place: same tuple, new contents
+    with pytest.raises(ValueError):                     # arrays of a cached tuple are read-only: an in-place edit raises
+        a[0][3][0][0, 1] += 0.25                        # instead of evaluating against the stale resident copy
+    a[0][3][0].flags.writeable = True                   # the owner insists: same tuple, new contents (a sampled entry)
+    a[0][3][0][0, 0] += 0.25
     ws.mps_to_vec_batch([a] * B, BUF_Y, lanes=np.arange(B)[::-1])
     assert maxdiff(ws.download(BUF_Y)[0], orc.mps_to_vector(a)) < 1e-12
     many = [orc.random_mps(n, 2, rng) for _ in range(70)]   # more than the 60 cached slots

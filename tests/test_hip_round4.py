@@ -1,0 +1,217 @@
+"""GPU: round-4 additions -- the MPS objective at the reference's OWN default truncation threshold (1e-6), on both routes."""
+import numpy as np
+import pytest
+
+from oracle import aqc_oracle as orc
+from tests.helpers import TOL, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _trotter_problem(n, layers, seed):
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index, trotter_state
+    from aqc_research_amd.mps_operations import vector_to_canonical_mps
+
+    rng = np.random.default_rng(seed)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, layers), second_order=True)
+    neel = neel_state_index(n)
+    evol_time = 0.6 * layers
+    th = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=evol_time, delta=1.0)
+    th = th + 0.05 * rng.standard_normal(th.size)
+    dense = trotter_state(n, evol_time=evol_time, num_steps=6 * layers, delta=1.0, second_order=True)
+    target = vector_to_canonical_mps(dense, 1e-6)     # what Aer hands the reference at its default threshold
+    return circ, th, neel, target
+
+
+def test_mps_objective_at_the_reference_default_threshold_takes_the_dense_route():
+    """user_options.py:55 -> time_evol_best_init.py:80 -> objective_lhs_sur_fast_mps_trotter.py:99: the reference's driver
+    hands trunc_thr = 1e-6 to the MPS objective.  At n = 16 that call must run on the fused dense kernels (exact: the
+    north-star tolerance against the dense oracle on the SAME target tensors), not on the truncated-SVD engine."""
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_fast_mps_trotter import SpSurrogateObjectiveFastMpsTrotter
+    from aqc_research_amd import mps_dot_objective as mdo
+
+    n = 16
+    circ, th, neel, target = _trotter_problem(n, 2, 160)
+    assert mdo.use_dense(n, 1e-6) and mdo.use_dense(24, 1e-3) and not mdo.use_dense(25, 1e-16)
+    user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: neel, enable_optim_stats=False, verbose=0, maxiter=5,
+                trunc_thr=1e-6)
+    o = SpSurrogateObjectiveFastMpsTrotter(user_parameters=user, circ=circ)
+    o.set_target(target)
+    assert not o._native_mps
+    ref = orc.SurMaxOracle(circ, orc.mps_to_vector(target), 1, None, True, base_index=neel)
+    for step in range(3):
+        t = th + 0.03 * step
+        f, g = o.objective(t), o.gradient(t)
+        fr, gr = ref.objective(t), ref.gradient(t)
+        assert abs(f - fr) < TOL and maxdiff(g, gr) < TOL
+
+
+def test_mps_objective_truncated_engine_stays_within_the_discarded_weight_bound(monkeypatch):
+    """The opt-in engine route (AQC_MPS_METHOD=mps) at trunc_thr = 1e-6, n = 16, against the dense oracle.  Bound: a state
+    that went through K truncations discarding weights d_k differs from the exact one by eps <= sum_k sqrt(2 d_k) <=
+    sqrt(2 K D), D = sum d_k (aqc_mps_discarded_weight).  |h| changes by <= eps_vh, f = 1 - |h0|^2 by <= 2 eps + eps^2; a
+    gradient entry 0.5j <P w|z> by <= (eps_w + eps_z + eps_w eps_z) / 2, times |c| <= 2 of the surrogate's combination."""
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_fast_mps_trotter import SpSurrogateObjectiveFastMpsTrotter
+    from aqc_research_amd.mps_engine import DeviceMPS, v_dagger_mul_mps, v_mul_mps
+
+    n, thr = 16, 1e-6
+    circ, th, neel, target = _trotter_problem(n, 2, 161)
+    monkeypatch.setenv("AQC_MPS_METHOD", "mps")
+    user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: neel, enable_optim_stats=False, verbose=0, maxiter=5,
+                trunc_thr=thr)
+    o = SpSurrogateObjectiveFastMpsTrotter(user_parameters=user, circ=circ)
+    o.set_target(target)
+    assert o._native_mps
+    f, g = o.objective(th), o.gradient(th)
+    ref = orc.SurMaxOracle(circ, orc.mps_to_vector(target), 1, None, True, base_index=neel)
+    fr, gr = ref.objective(th), ref.gradient(th)
+    # discarded weights of the three walks the evaluation makes: V^H|target>, then V on both sweep operands
+    K = int(circ.num_blocks + circ.half_layer_num_blocks)   # 2-qubit gates = truncation events of one walk
+    tgt = DeviceMPS.from_qiskit(target, trunc_thr=thr)
+    vh = v_dagger_mul_mps(circ, th, tgt, trunc_thr=thr)
+    z = v_mul_mps(circ, th, vh, trunc_thr=thr)
+    w = v_mul_mps(circ, th, DeviceMPS.basis_state(n, neel), trunc_thr=thr)
+    d_vh, d_z, d_w = vh.discarded_weight, z.discarded_weight, w.discarded_weight
+    for m in (tgt, vh, z, w):
+        m.close()
+    eps_vh, eps_z, eps_w = (float(np.sqrt(2 * K * d)) for d in (d_vh, d_z, d_w))
+    bound_f = 2 * eps_vh + eps_vh ** 2
+    bound_g = eps_w + eps_z + eps_w * eps_z
+    assert d_vh <= K * thr * 1.01 and d_z <= 2 * K * thr * 1.01
+    assert abs(f - fr) <= bound_f + TOL and maxdiff(g, gr) <= bound_g + TOL
+    # and what is observed is first order in the discarded weight itself (infidelity ~ D), far inside the bound
+    assert abs(f - fr) <= 50 * max(d_vh, 1e-12) + 1e-9, (abs(f - fr), d_vh)
+
+
+def test_mps_to_vec_batch_with_mixed_bond_dimensions():
+    """Lanes whose MPS operands differ in their bond dimensions (truncated canonical tensors do) go through one launch chain
+    per distinct dimension vector; every lane must still receive ITS state (mps_operations.py:159-189 per lane)."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+    from aqc_research_amd.engine import BUF_Y, HipContext, Workspace
+
+    n = 9
+    rng = np.random.default_rng(94)
+    circ = ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", 4))
+    a, b, c = orc.random_mps(n, 4, rng), orc.random_mps(n, 7, rng), orc.random_mps(n, 7, rng)
+    zero = ([(np.ones((1, 1), complex), np.zeros((1, 1), complex)) for _ in range(n)], [np.ones(1) for _ in range(n - 1)])
+    lanes = [b, a, zero, c, a, b, c]
+    ws = Workspace(HipContext.of(circ), batch=len(lanes))
+    for _ in range(2):                 # second round: resident copies and pointer tables are found again
+        ws.mps_to_vec_batch(lanes, BUF_Y)
+        out = ws.download(BUF_Y)
+        for i, m in enumerate(lanes):
+            assert maxdiff(out[i], orc.mps_to_vector(m)) < TOL
+    ws.close()
+
+
+@pytest.mark.parametrize("objective", ["sur_max", "sur_fast_mps_trotter"])
+def test_horizon_driver_follows_the_reference_logic(objective):
+    """time_evol_best_init.py:118-140,221-334 replayed with the oracle: ground-truth (10x steps) and reference targets, the
+    threshold rule, the three fidelity figures of the record at the returned thetas, and the expansion loop."""
+    from aqc_research_amd.model_sp_lhs import time_evol as te
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index, trotter_ansatz
+
+    n = 8
+    opts = te.UserOptions(num_qubits=n, num_horizons=2, num_layers_inc=1, maxiter=15, objective=objective, fidelity_thr=0.97)
+    assert list(opts.trotter_steps) == [3, 6] and list(opts.evol_times) == [1.2, 2.4] and opts.trunc_thr == 1e-6
+    assert opts.use_mps == (objective != "sur_max") and opts.ini_state_index() == neel_state_index(n)
+    res = te.run_simulation(opts)
+    ini = np.zeros(1 << n, complex)
+    ini[neel_state_index(n)] = 1
+
+    def trotter_vec(steps, t):
+        c = trotter_ansatz(n, steps, True)
+        th = init_ansatz_to_trotter(c, np.zeros(c.num_thetas), evol_time=t, delta=1.0)
+        return orc.v_mul_vec(c, th, ini)
+
+    for i, r in enumerate(res):
+        steps, t = int(opts.trotter_steps[i]), float(opts.evol_times[i])
+        t1_gt, t1 = trotter_vec(10 * steps, t), trotter_vec(steps, t)
+        f_t1 = abs(np.vdot(t1, t1_gt)) ** 2
+        assert r["status"] == "ok" and r["num_trotter_steps"] == steps and r["evol_time1"] == t and r["block_reps"] == 3
+        assert abs(r["fid_t1_vs_gt"] - f_t1) < TOL
+        assert abs(r["fidelity_thr"] - max(f_t1, 0.97)) < TOL                      # _calc_fidelity_threshold
+        a1 = orc.v_mul_vec(trotter_ansatz(n, r["num_layers"], True), r["thetas"], ini)
+        assert abs(r["fid_a1_vs_gt"] - abs(np.vdot(a1, t1_gt)) ** 2) < TOL
+        assert abs(r["fid_a1_vs_t1"] - abs(np.vdot(a1, t1)) ** 2) < TOL
+        assert r["use_mps"] == opts.use_mps and r["entangler"] == "cx" and r["second_order_trotter"]
+        assert r["fid_a1_vs_gt"] >= r["fidelity_trotter_init"] - 1e-9
+        assert r["num_layers"] == i + 1 and r["expansions"] == 0
+    # automatic threshold: 1.03 x fidelity(|t1>, |t1_gt>)
+    tgt = te.generate_target(opts, 1)
+    thr, f = te._calc_fidelity_threshold(tgt, None)
+    assert abs(thr - 1.03 * f) < 1e-15 and abs(f - res[1]["fid_t1_vs_gt"]) < TOL
+    # expansion loop: an unreachable threshold makes every allowed expansion happen, one more layer each
+    hard = te.UserOptions(num_qubits=n, num_horizons=1, num_layers_inc=1, maxiter=3, objective=objective, fidelity_thr=1.0,
+                          num_expansions=2)
+    r = te.run_simulation(hard)[0]
+    assert r["expansions"] == 2 and r["num_layers"] == 3 and r["thetas"].size == trotter_ansatz(n, 3, True).num_thetas
+
+
+def test_state_prep_func_returning_a_circuit():
+    """objective_base.py:298-303: a reference caller hands ``neel_init_state`` (a circuit of X gates) as ``state_prep_func``;
+    the objective must behave exactly as with the equivalent bit mask, and refuse circuits that are not basis preparations."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax
+    from aqc_research_amd.model_sp_lhs.trotter import neel_init_state, neel_state_index
+
+    n = 7
+    rng = np.random.default_rng(7)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 1), second_order=True)
+    target, th = orc.rand_state(n, rng), orc.rand_thetas(circ.num_thetas, rng)
+    vals = []
+    for prep in (neel_init_state, lambda k: neel_state_index(k)):
+        user = dict(num_qubits=n, max_flips=1, state_prep_func=prep, enable_optim_stats=False, verbose=0, maxiter=5)
+        o = SpSurrogateObjectiveMax(user_parameters=user, circ=circ, front_layer=True)
+        o.set_target(target)
+        vals.append((o.objective(th), o.gradient(th)))
+    assert vals[0][0] == vals[1][0] and maxdiff(vals[0][1], vals[1][1]) == 0.0
+    ref = orc.SurMaxOracle(circ, target, 1, None, True, base_index=neel_state_index(n))
+    assert abs(vals[0][0] - ref.objective(th)) < TOL and maxdiff(vals[0][1], ref.gradient(th)) < TOL
+
+    class Had:   # a circuit with a gate that is not a basis preparation
+        num_qubits = n
+
+        class _I:
+            class operation:
+                name = "h"
+            qubits = (0,)
+        data = [_I()]
+
+    with pytest.raises(NotImplementedError):
+        SpSurrogateObjectiveMax(user_parameters=dict(num_qubits=n, max_flips=1, state_prep_func=lambda k: Had()), circ=circ)
+
+
+def test_rccl_init_is_bounded_when_a_rank_never_joins():
+    """ncclCommInitRank blocks until every rank has joined; aqc_comm_create runs it in a helper thread and gives up after
+    AQC_COMM_INIT_TIMEOUT_S with an error naming the cause (a launch whose rank died before the rendezvous must
+    fail, not hang).  Rank 0 of a 2-rank communicator whose rank 1 never starts; in a child process, which exits hard
+    afterwards (the helper thread is still inside RCCL)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import ctypes, os, sys, time
+        os.environ["AQC_COMM_INIT_TIMEOUT_S"] = "3"
+        from aqc_research_amd import _lib
+        L = _lib.lib()
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(L.aqc_comm_unique_id(buf))
+        h = ctypes.c_void_p()
+        t0 = time.time()
+        rc = L.aqc_comm_create(buf.raw, 2, 0, 0, ctypes.byref(h))
+        dt = time.time() - t0
+        msg = L.aqc_last_error().decode()
+        print(rc, round(dt, 2), msg, flush=True)
+        ok = rc != 0 and 2.5 < dt < 30 and "AQC_COMM_INIT_TIMEOUT_S" in msg and not h.value
+        os._exit(0 if ok else 1)
+    """)
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr

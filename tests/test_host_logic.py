@@ -3,6 +3,7 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
 
 import numpy as np
 import pytest
@@ -478,3 +479,86 @@ def test_dense_backed_mps_is_a_lazy_canonical_qiskit_tuple():
     assert 0 < 1 - abs(np.vdot(w, v)) ** 2 / np.vdot(w, w).real < 5e-2
     assert not is_canonical(orc.random_mps(7, 4, rng))        # hand-made Vidal-form tensors are not canonical
     assert not d.dense_on(object(), 1)                        # no workspace behind this one
+
+
+def test_basis_mask_of_duck_typed_preparation_circuits():
+    """state_prep_func may return a circuit (trotter.py:381-410, consumed at objective_base.py:298-303): X-only circuits are
+    turned into the bit mask of the basis state they prepare -- Qiskit-style instruction objects and old-style triples alike --
+    anything else raises."""
+    from aqc_research_amd.model_sp_lhs.objective_base import basis_mask_of_circuit
+    from aqc_research_amd.model_sp_lhs.trotter import (half_zero_circuit, identity_circuit, neel_init_state,
+                                                        neel_state_index)
+
+    assert basis_mask_of_circuit(neel_init_state(7), 7) == neel_state_index(7) == 0b1010101
+    assert basis_mask_of_circuit(identity_circuit(5), 5) == 0
+    assert basis_mask_of_circuit(half_zero_circuit(6), 6) == 0b111000
+    assert neel_init_state(6).basis_index == 0b010101
+
+    class Bit:          # a Qiskit-like qubit object: resolved through circuit.find_bit(q).index
+        def __init__(self, i):
+            self._i = i
+
+    class Loc:
+        def __init__(self, i):
+            self.index = i
+
+    class Op:
+        def __init__(self, name):
+            self.name = name
+
+    class Circ:
+        num_qubits = 4
+
+        def __init__(self, data):
+            self.data = data
+
+        def find_bit(self, q):
+            return Loc(q._i)
+
+    qs = [Bit(i) for i in range(4)]
+    old_style = Circ([(Op("x"), [qs[1]], []), (Op("barrier"), qs, []), (Op("id"), [qs[0]], []), (Op("x"), [qs[3]], []), (Op("x"), [qs[3]], [])])
+    assert basis_mask_of_circuit(old_style, 4) == 0b0010
+    with pytest.raises(NotImplementedError):
+        basis_mask_of_circuit(Circ([(Op("h"), [qs[0]], [])]), 4)
+    with pytest.raises(NotImplementedError):
+        basis_mask_of_circuit(Circ([(Op("cx"), [qs[0], qs[1]], [])]), 4)
+    with pytest.raises(ValueError):
+        basis_mask_of_circuit(Circ([]), 5)
+
+
+def test_horizon_driver_options_follow_the_reference_defaults():
+    """user_options.py:25-129: 6 horizons of 1.2 with 3 Trotter steps each, trunc_thr 1e-6, fidelity_thr 0.995, maxiter 40,
+    2 layers per horizon, the Neel preparation; the threshold rule of time_evol_best_init.py:118-140."""
+    from aqc_research_amd.model_sp_lhs import time_evol as te
+
+    o = te.UserOptions()
+    assert list(o.trotter_steps) == [3, 6, 9, 12, 15, 18] and list(o.evol_times) == [1.2, 2.4, 3.6, 4.8, 6.0, 7.2]
+    assert (o.trunc_thr, o.fidelity_thr, o.maxiter, o.num_layers_inc, o.delta) == (1e-6, 0.995, 40, 2, 1.0)
+    assert o.second_order_trotter and o.enable_grad_scaling and o.num_expansions == 0 and te.precise_multiplier() == 10
+    assert not o.use_mps and te.UserOptions(objective="sur_fast_mps_trotter").use_mps
+    assert te._initial_layers(o, 2) == 6 and te._initial_layers(te.UserOptions(manual_num_layers=[2, 4, 5]), 2) == 5
+    v = np.zeros(4, complex); v[0] = 1
+    w = np.array([np.sqrt(0.9), np.sqrt(0.1), 0, 0], complex)
+    t = te.TargetState(num_qubits=2, num_trot_steps=3, evol_time=1.2, my_id=0, delta=1.0, second_order=True, t1_gt=v, t1=w)
+    assert te._calc_fidelity_threshold(t, 0.995) == (0.995, pytest.approx(0.9))
+    assert te._calc_fidelity_threshold(t, 0.5)[0] == pytest.approx(0.9)
+    assert te._calc_fidelity_threshold(t, None)[0] == pytest.approx(1.03 * 0.9)
+    with pytest.raises(ValueError):
+        te.UserOptions(trotter_steps=[3, 6], evol_times=[1.2])
+
+
+def test_rccl_id_file_of_another_launch_is_not_accepted(tmp_path):
+    """A rank other than 0 must only take a unique id that carries ITS launch's tag: an id file left behind by a crashed
+    launch with the same name (it used to be accepted when younger than 600 s and made ncclCommInitRank hang) times out
+    with a clear error instead -- before any RCCL or HIP call is made."""
+    from aqc_research_amd import comm
+
+    f = tmp_path / "rccl_unique_id"
+    f.write_bytes(b"\x01" * 128 + b"tag_of_a_crashed_launch")
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="timed out waiting for the unique id of launch 'this_launch'"):
+        comm.RcclCommunicator(1, 2, 0, str(f), timeout=0.4, tag="this_launch")
+    assert 0.3 < time.time() - t0 < 5
+    f.write_bytes(b"\x01" * 128)                       # the tag-less format of earlier rounds is not accepted either
+    with pytest.raises(RuntimeError, match="timed out"):
+        comm.RcclCommunicator(1, 2, 0, str(f), timeout=0.2, tag="this_launch")

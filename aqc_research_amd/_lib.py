@@ -58,6 +58,8 @@ SIGNATURES = {
     "aqc_ws_eval": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "aqc_ws_grad_from": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "aqc_ws_cd_sweep": (c_int, [_P, _D, _D]),
+    "aqc_ws_cd_sweeps": (c_int, [_P, _D, _D, c_int, c_int]),
+    "aqc_ws_cd_fits_one_launch": (c_int, [_P]),
     "aqc_zgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, _D, c_int, _D, c_int, _D, c_int]),
     "aqc_gate_1q": (c_int, [c_int, c_int, c_int64, c_int, _D, _D, _D]),
     "aqc_gate_2q": (c_int, [c_int, c_int, c_int64, c_int, c_int, _D, _D, _D]),

@@ -157,7 +157,8 @@ def grad_of_matrix_dot_product(
 def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray, workspace: Optional[np.ndarray] = None) -> float:
     """One Gauss-Seidel sweep over all parameters of ``1 - |<V,U>|^2 / d^2``
     (core_op_matrix.py:765-917).  ``thetas`` is updated in place; returns the objective at the
-    end of the sweep.  The whole sweep (2 launches per parameter) runs on the device."""
+    end of the sweep.  The whole sweep runs on the device: ONE persistent launch while the two d x d operands fit a
+    workgroup's LDS (up to 6 qubits; ``aqc_ws_cd_sweeps``), a chain of 2 launches per parameter beyond."""
     from . import _lib
     from ._lib import check, dptr
 
@@ -176,3 +177,38 @@ def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray, wor
     ws._touch(_lib.BUF_X, _lib.BUF_Z, _lib.BUF_W, _lib.BUF_ZW)   # rewritten by the sweep
     check(_lib.lib().aqc_ws_cd_sweep(ws.handle, dptr(thetas), dptr(fobj)))
     return float(fobj[0])
+
+
+def coord_descent_sweeps(circ, thetas: np.ndarray, targets: np.ndarray, num_sweeps: int = 1, *, device: Optional[int] = None,
+                         max_steps: int = -1) -> np.ndarray:
+    """``num_sweeps`` consecutive ``coord_descent_single_sweep``s for every lane of a batch in ONE launch
+    (core_op_matrix.py:765-917 called in a loop, docs/aqc.ipynb: 1000 sweeps): ``thetas`` (lanes, T) -- random restarts of one
+    ansatz, updated in place -- and ``targets`` (lanes, d, d) or one (d, d) target shared by all lanes.  Returns the objective
+    at the end of every sweep, shape (lanes, num_sweeps).  Up to 6 qubits (the operands live in LDS for the whole walk)."""
+    from . import _lib
+    from ._lib import check, dptr
+    from .engine import Workspace
+
+    if circ.entangler == "cp":
+        raise NotImplementedError("CPhase entangler is not supported yet")
+    th = thetas.reshape(1, -1) if thetas.ndim == 1 else thetas
+    if not (isinstance(thetas, np.ndarray) and thetas.dtype == np.float64 and thetas.flags.c_contiguous and th.ndim == 2
+            and th.shape[1] == circ.num_thetas):
+        raise ValueError("thetas: expects a contiguous float64 array (lanes, circ.num_thetas), updated in place")
+    d = circ.dimension
+    tg = np.asarray(targets)
+    if tg.dtype != np.complex128 or tg.shape[-2:] != (d, d) or tg.ndim not in (2, 3):
+        raise ValueError("targets: expects complex128 (d, d) or (lanes, d, d)")
+    lanes = th.shape[0]
+    if tg.ndim == 3 and tg.shape[0] != lanes:
+        raise ValueError("one target per lane (or one for all)")
+    if int(num_sweeps) < 1:
+        raise ValueError("num_sweeps must be positive")
+    ws = Workspace(HipContext.of(circ), batch=lanes, ncols=d, device=device)
+    try:
+        ws.upload(BUF_Y, np.ascontiguousarray(np.broadcast_to(tg, (lanes, d, d))))
+        fobj = np.zeros((lanes, int(num_sweeps)))
+        check(_lib.lib().aqc_ws_cd_sweeps(ws.handle, dptr(th), dptr(fobj), int(num_sweeps), int(max_steps)))
+    finally:
+        ws.close()
+    return fobj

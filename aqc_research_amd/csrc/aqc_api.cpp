@@ -341,6 +341,12 @@ struct aqc_ws {
     // device pointer tables of the batched MPS -> dense contraction: a few resident sets, found again by their contents (an
     // optimisation converts the same operands into the same lanes evaluation after evaluation: no upload, no synchronisation)
     struct MpsTabs { std::vector<const void*> host; const void** dev = nullptr; size_t cap = 0; unsigned long long tick = 0; };
+    // coordinate descent as one persistent launch: the walk's step list, thetas [batch][T] and objective values on the device
+    void* d_cd_prog = nullptr;
+    int cd_nsteps = 0;
+    double* d_cd_thetas = nullptr;
+    double* d_cd_fobj = nullptr;
+    size_t cd_fobj_cap = 0;
     MpsTabs mps_tabs[32];   // resident pointer-table sets (one per distinct chain: operands x lanes x bond dimensions)
     unsigned long long mps_tabs_tick = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
@@ -860,6 +866,9 @@ int aqc_ws_destroy(aqc_ws* ws) {
     for (auto& m : ws->mps) if (m.d_t) (void)hipFree(m.d_t);
     if (ws->d_mps_scratch) (void)hipFree(ws->d_mps_scratch);
     for (auto& t : ws->mps_tabs) if (t.dev) (void)hipFree(t.dev);
+    if (ws->d_cd_prog) (void)hipFree(ws->d_cd_prog);
+    if (ws->d_cd_thetas) (void)hipFree(ws->d_cd_thetas);
+    if (ws->d_cd_fobj) (void)hipFree(ws->d_cd_fobj);
     if (ws->d_mps_lam) (void)hipFree(ws->d_mps_lam);
     for (hipEvent_t ev : {ws->ev0, ws->ev1, ws->pev0, ws->pev1, ws->ev_ready, ws->ev_copied}) if (ev) (void)hipEventDestroy(ev);
     if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
@@ -1777,13 +1786,80 @@ int aqc_gate_dot(int device, int n, int64_t ncols, int kind, int q0, int q1, con
 
 // ---- coordinate descent ------------------------------------------------------------------------
 
-int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io, double* fobj) {
-    if (!ws || !thetas_io || !fobj) return fail("null argument");
+namespace aqc {
+struct CdStepHost { int32_t kind, hbit, hbit2, tindex; };   // = CdStep of aqc_cd.hip
+size_t cd_persistent_lds_bytes(int nbits, int T);
+hipError_t launch_cd_persistent(const void* prog, int nsteps, int nbits, int col_bits, const void* target, size_t lane_stride, double* thetas,
+                                int T, double* fobj, int nsweeps, int max_steps, int batch, hipStream_t s);
+}
+
+static int cd_checks(const aqc_ws* ws) {
     const Program& prog = ws->ctx->prog;
-    const int dim = 1 << prog.n;
-    if (ws->ncols != dim || ws->batch != 1) return fail("coordinate descent needs a square, single-lane workspace");
+    if (ws->ncols != (1 << prog.n)) return fail("coordinate descent needs a square workspace (ncols == 2^n)");
     if (prog.entangler == AQC_CP) return fail("CPhase entangler is not supported yet");
     if (prog.trotter) return fail("matrix path does not support the Trotter ansatz");
+    return 0;
+}
+
+int aqc_ws_cd_fits_one_launch(const aqc_ws* ws) {
+    if (!ws) return 0;
+    return aqc::cd_persistent_lds_bytes(ws->nbits, ws->ctx->prog.num_thetas()) <= (size_t)160 * 1024 ? 1 : 0;
+}
+
+int aqc_ws_cd_sweeps(aqc_ws* ws, double* thetas_io, double* fobj, int nsweeps, int max_steps) {
+    if (!ws || !thetas_io || !fobj) return fail("null argument");
+    if (nsweeps < 1) return fail("nsweeps must be positive");
+    if (cd_checks(ws)) return 1;
+    if (!aqc_ws_cd_fits_one_launch(ws))
+        return fail("the operands of this coordinate descent (2 x %zu KiB) do not fit one workgroup's LDS: use aqc_ws_cd_sweep (launch chain, one lane)",
+                    (ws->lane_elems * sizeof(double2)) >> 10);
+    const Program& prog = ws->ctx->prog;
+    const int T = prog.num_thetas();
+    HIP_OK(hipSetDevice(ws->device));
+    if (!ws->d_cd_prog) {   // the walk of core_op_matrix.py:852-912 as a flat list of steps (address bits of this workspace)
+        std::vector<aqc::CdStepHost> steps;
+        auto rot = [&](int qubit, int kind, int tindex) { steps.push_back({kind, ws->col_bits + qubit, 0, tindex}); };
+        for (const GateGroup& g : prog.groups) {
+            if (g.type == GROUP_FRONT) {
+                rot(g.q0, 1, g.theta0 + 2); rot(g.q0, 0, g.theta0 + 1); rot(g.q0, 1, g.theta0 + 0);
+            } else {
+                steps.push_back({prog.entangler == AQC_CX ? 3 : 4, ws->col_bits + g.q0, ws->col_bits + g.q1, -1});
+                rot(g.q0, 0, g.theta0); rot(g.q0, 1, g.theta0 + 1); rot(g.q1, 0, g.theta0 + 2);
+                rot(g.q1, prog.entangler == AQC_CX ? 2 : 1, g.theta0 + 3);
+            }
+        }
+        HIP_OK(hipMalloc(&ws->d_cd_prog, steps.size() * sizeof(aqc::CdStepHost)));
+        HIP_OK(hipMemcpy(ws->d_cd_prog, steps.data(), steps.size() * sizeof(aqc::CdStepHost), hipMemcpyHostToDevice));
+        ws->cd_nsteps = (int)steps.size();
+        HIP_OK(hipMalloc((void**)&ws->d_cd_thetas, sizeof(double) * (size_t)ws->batch * T));
+    }
+    const size_t nf = (size_t)ws->batch * nsweeps;
+    if (nf > ws->cd_fobj_cap) {
+        if (ws->d_cd_fobj) HIP_OK(hipFree(ws->d_cd_fobj));
+        ws->d_cd_fobj = nullptr;
+        HIP_OK(hipMalloc((void**)&ws->d_cd_fobj, sizeof(double) * nf));
+        ws->cd_fobj_cap = nf;
+    }
+    HIP_OK(hipMemcpyAsync(ws->d_cd_thetas, thetas_io, sizeof(double) * (size_t)ws->batch * T, hipMemcpyHostToDevice, ws->stream));
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(aqc::launch_cd_persistent(ws->d_cd_prog, ws->cd_nsteps, ws->nbits, ws->col_bits, ws->bufs[AQC_BUF_Y], ws->lane_elems, ws->d_cd_thetas,
+                                         T, ws->d_cd_fobj, nsweeps, max_steps, ws->batch, ws->stream));
+    }
+    HIP_OK(hipMemcpyAsync(thetas_io, ws->d_cd_thetas, sizeof(double) * (size_t)ws->batch * T, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipMemcpyAsync(fobj, ws->d_cd_fobj, sizeof(double) * nf, hipMemcpyDeviceToHost, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io, double* fobj) {
+    if (!ws || !thetas_io || !fobj) return fail("null argument");
+    if (cd_checks(ws)) return 1;
+    const char* chain = getenv("AQC_CD_CHAIN");   // "1": the launch chain below even where one launch would do (cross-check, timing)
+    if (aqc_ws_cd_fits_one_launch(ws) && !(chain && chain[0] == '1')) return aqc_ws_cd_sweeps(ws, thetas_io, fobj, 1, -1);
+    const Program& prog = ws->ctx->prog;
+    const int dim = 1 << prog.n;
+    if (ws->batch != 1) return fail("the launch-chain coordinate descent (operands beyond one workgroup's LDS) runs one lane");
     HIP_OK(hipSetDevice(ws->device));
     const int T = prog.num_thetas();
     if (aqc_ws_set_thetas(ws, thetas_io)) return 1;                  // theta_in = d_thetas_own

@@ -228,6 +228,14 @@ int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, dou
  * Gauss-Seidel sweep over all parameters of 1 - |<V,U>|^2/d^2; thetas are updated in place and
  * the objective at the end of the sweep is returned.  cx / cz entanglers only (:818-827). */
 int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io /* [T] */, double* fobj);
+/* The same walk for EVERY lane of the workspace (lane = an independent problem: a random restart of the ansatz and / or its
+ * own target in AQC_BUF_Y) and for `nsweeps` consecutive sweeps, as ONE persistent launch: a workgroup per lane keeps the two
+ * d x d operands in LDS, re-derives z = V(theta)^H U at the start of every sweep (:806-810) and walks all parameters (:852-912)
+ * without leaving the kernel.  Needs 2 d^2 16 B + 24 T B <= 160 KiB (up to 6 qubits; aqc_ws_cd_fits_one_launch); larger
+ * problems keep the launch chain of aqc_ws_cd_sweep (one lane).  fobj[lane][s] = the objective at the end of sweep s (:917).
+ * max_steps >= 0 stops every sweep's walk after that many parameters (tests pin single steps with it); -1 = all. */
+int aqc_ws_cd_sweeps(aqc_ws* ws, double* thetas_io /* [batch][T] */, double* fobj /* [batch][nsweeps] */, int nsweeps, int max_steps);
+int aqc_ws_cd_fits_one_launch(const aqc_ws* ws);
 
 /* ---- measurement hooks (bench.py): HIP events on the workspace's own stream */
 int aqc_ws_timer_start(aqc_ws* ws);

@@ -404,9 +404,11 @@ def grad_of_matrix_dot_product(circ, thetas: np.ndarray, x_mat: np.ndarray, vh_y
     return _sweep(a, np.asarray(thetas, float), w.reshape(-1), z.reshape(-1), w.shape[1], (0, a.num_blocks), True)
 
 
-def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray) -> Tuple[np.ndarray, float]:
+def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray, max_steps: int = -1) -> Tuple[np.ndarray, float]:
     """One Gauss-Seidel sweep for 1 - |<V,U>|^2/d^2 (core_op_matrix.py:765-917).
-    Returns (updated thetas, fobj); the input ``thetas`` is not modified."""
+    Returns (updated thetas, fobj); the input ``thetas`` is not modified.  ``max_steps`` >= 0 stops the walk after that
+    many parameter updates (the entangler of a block is applied before the block's first update): single steps of the walk
+    can then be pinned without the amplification of rounding by the ~T sequential Newton steps that follow."""
     a = _no_trotter(as_ansatz(circ))
     if a.entangler == "cp":
         raise NotImplementedError("CPhase entangler is not supported yet")
@@ -432,7 +434,12 @@ def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray) -> 
         r = abs(dt / max_dt)
         return dt if r <= 1 else dt / r
 
+    done = [0]
+
     def step(tht: np.ndarray, slot: int, rot, dot, h: int) -> None:
+        if 0 <= max_steps <= done[0]:
+            return
+        done[0] += 1
         grad = dot(w, z, h)
         prod = np.vdot(w, z)
         rot(z, h, tht[slot])
@@ -446,6 +453,8 @@ def coord_descent_single_sweep(circ, thetas: np.ndarray, target: np.ndarray) -> 
         step(t1[q], 0, rz, dot_z, h)
     for _, j, c, t in _block_list(a):
         hc, ht = d << c, d << t
+        if 0 <= max_steps <= done[0]:
+            break
         _entangle(z, hc, ht, a.entangler, 0.0)
         _entangle(w, hc, ht, a.entangler, 0.0)
         step(t2[j], 0, ry, dot_y, hc)

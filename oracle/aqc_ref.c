@@ -216,3 +216,72 @@ int aqc_ref_eval_batch(int n, int ent, const int32_t* blocks, int L, int trotter
     }
     return rc;
 }
+
+/* ---- coordinate descent (core_op_matrix.py:765-917) --------------------------------------------------------------- */
+static double cd_delta(c128 prod, c128 grad, double d) {   /* _delta_theta, :833-850 */
+    const double tol = 1.4901161193847656e-08, lr = M_PI / 16, maxdt = M_PI / 4;
+    double d1 = (-2.0 * creal(conj(prod) * grad)) / (d * d);
+    const double d2 = (-2.0 * (creal(grad) * creal(grad) + cimag(grad) * cimag(grad)) +
+                       0.5 * (creal(prod) * creal(prod) + cimag(prod) * cimag(prod))) / (d * d);
+    double dt;
+    if (d2 < tol) { d1 /= fmax(fabs(d1), 1.0); dt = -lr * d1; } else dt = -d1 / d2;
+    const double r = fabs(dt / maxdt);
+    return r <= 1.0 ? dt : dt / r;
+}
+static c128 vdot_all(const ref_t* a, const c128* w, const c128* z) {
+    c128 s = 0;
+    for (long i = 0; i < a->total; ++i) s += conj(w[i]) * z[i];
+    return s;
+}
+/* one parameter: grad and prod with the current operands, z rotated by the OLD angle, w by the NEW one (:855-912) */
+static void cd_step(const ref_t* a, c128* w, c128* z, int q, int kind /* 0 y, 1 z, 2 x */, double* theta, double d) {
+    const c128 grad = kind == 0 ? dot_y(a, w, z, q) : kind == 1 ? dot_z(a, w, z, q) : dot_x(a, w, z, q);
+    const c128 prod = vdot_all(a, w, z);
+    void (*rot)(const ref_t*, c128*, int, double) = kind == 0 ? ry : kind == 1 ? rz : rx;
+    rot(a, z, q, *theta);
+    *theta += cd_delta(prod, grad, d);
+    rot(a, w, q, *theta);
+}
+static double cd_sweep(const ref_t* a, double* th, const c128* target, c128* w, c128* z) {
+    const long d = (long)1 << a->n;
+    memset(w, 0, sizeof(c128) * a->total);
+    for (long i = 0; i < d; ++i) w[i * d + i] = 1.0;
+    memcpy(z, target, sizeof(c128) * a->total);
+    apply_vh(a, th, z);
+    double* t2 = th + 3 * a->n;
+    for (int q = 0; q < a->n; ++q) {
+        cd_step(a, w, z, q, 1, th + 3 * q + 2, (double)d);
+        cd_step(a, w, z, q, 0, th + 3 * q + 1, (double)d);
+        cd_step(a, w, z, q, 1, th + 3 * q + 0, (double)d);
+    }
+    for (int j = 0; j < a->L; ++j) {
+        const int c = a->blocks[j], t = a->blocks[a->L + j];
+        double* b = t2 + 4L * j;
+        entangle(a, z, c, t, 0.0); entangle(a, w, c, t, 0.0);
+        cd_step(a, w, z, c, 0, b + 0, (double)d);
+        cd_step(a, w, z, c, 1, b + 1, (double)d);
+        cd_step(a, w, z, t, 0, b + 2, (double)d);
+        cd_step(a, w, z, t, a->ent == 0 ? 2 : 1, b + 3, (double)d);
+    }
+    const c128 p = vdot_all(a, w, z) / (double)d;
+    return 1.0 - (creal(p) * creal(p) + cimag(p) * cimag(p));
+}
+/* `nsweeps` consecutive sweeps for each of B lanes (thetas [B][T] updated in place, targets [B][d][d] or one shared [d][d]),
+ * lanes spread over `threads` OpenMP threads; fobj [B][nsweeps].  cx / cz only, no Trotter decorations (matrix path). */
+int aqc_ref_cd_sweeps(int n, int ent, const int32_t* blocks, int L, int B, double* thetas, const double* targets, int shared_target,
+                      int nsweeps, int threads, double* fobj) {
+    ref_t a;
+    if (ent == 2 || ref_init(&a, n, ent, blocks, L, 0, 0, (long)1 << n)) return 1;
+    const int T = 3 * n + 4 * L;
+    int rc = 0;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        c128* w = (c128*)malloc(sizeof(c128) * a.total);
+        c128* z = (c128*)malloc(sizeof(c128) * a.total);
+        if (!w || !z) { rc = 2; free(w); free(z); continue; }
+        const c128* u = (const c128*)targets + (shared_target ? 0 : (long)b * a.total);
+        for (int s = 0; s < nsweeps; ++s) fobj[(long)b * nsweeps + s] = cd_sweep(&a, thetas + (long)b * T, u, w, z);
+        free(w); free(z);
+    }
+    return rc;
+}

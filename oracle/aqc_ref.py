@@ -149,3 +149,24 @@ def eval_batch(circ, thetas, target, x_index: int = 0, threads: int = 1) -> Tupl
     if lib().aqc_ref_eval_batch(*head, t.shape[0], _p(t), _p(y), int(x_index), int(threads), _p(hs), _p(grads)):
         raise ValueError("aqc_ref_eval_batch failed")
     return hs, grads
+
+
+def coord_descent_sweeps(circ, thetas, targets, nsweeps: int = 1, threads: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """``nsweeps`` consecutive coordinate-descent sweeps (core_op_matrix.py:765-917) per lane: thetas (B, T) or (T,), targets
+    (B, d, d) or one shared (d, d).  Returns (updated thetas copy, fobj[B][nsweeps]); the inputs are not modified."""
+    a, blocks, head = _head(circ, True)
+    if a.entangler == "cp":
+        raise NotImplementedError("CPhase entangler is not supported yet")
+    t = np.array(thetas, dtype=np.float64, order="C", copy=True).reshape(-1, a.num_thetas)
+    u = np.ascontiguousarray(targets, dtype=np.complex128)
+    shared = u.ndim == 2
+    if u.shape[-2:] != (a.dim, a.dim) or (not shared and u.shape[0] != t.shape[0]):
+        raise ValueError("wrong target shape")
+    fobj = np.zeros((t.shape[0], int(nsweeps)))
+    lb = lib()
+    i32, ptr = ctypes.c_int, ctypes.c_void_p
+    lb.aqc_ref_cd_sweeps.argtypes = [i32, i32, ptr, i32, i32, ptr, ptr, i32, i32, i32, ptr]
+    if lb.aqc_ref_cd_sweeps(a.n, _ENT[a.entangler], _p(blocks), a.num_blocks, t.shape[0], _p(t), _p(u), int(shared), int(nsweeps),
+                            int(threads), _p(fobj)):
+        raise ValueError("aqc_ref_cd_sweeps failed")
+    return t, fobj

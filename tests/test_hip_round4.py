@@ -215,3 +215,70 @@ def test_rccl_init_is_bounded_when_a_rank_never_joins():
     """)
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def _cd_problem(n, layout, depth, seed, ent="cx"):
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+
+    rng = np.random.default_rng(seed)
+    circ = ParametricCircuit(n, ent, create_ansatz_structure(n, layout, "full", depth))
+    d = 1 << n
+    u = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0]
+    return circ, orc.rand_thetas(circ.num_thetas, rng), np.ascontiguousarray(u), rng
+
+
+@pytest.mark.parametrize("n,ent,steps", [(5, "cx", 1), (5, "cx", 2), (5, "cx", 5), (5, "cx", 17), (5, "cz", 19), (3, "cx", 12), (6, "cx", 3), (2, "cz", 7)])
+def test_coordinate_descent_single_steps_at_the_north_star_tolerance(n, ent, steps):
+    """core_op_matrix.py:833-850 (_delta_theta) and :852-912: the walk stopped after a few parameter updates agrees with the
+    oracle to 1e-10 on every theta -- the per-step arithmetic is exact; only the chain of ~T sequential Newton steps of a
+    whole sweep amplifies rounding (tests/test_hip_parity_mat_obj.py checks full sweeps at 1e-9 / 1e-8)."""
+    from aqc_research_amd.core_op_matrix import coord_descent_sweeps
+
+    circ, th, u, _ = _cd_problem(n, "spin", 12, 500 + 10 * n + steps, ent)
+    ref, f_ref = orc.coord_descent_single_sweep(circ, th, u, max_steps=steps)
+    got = th.copy()
+    f = coord_descent_sweeps(circ, got, u, 1, max_steps=steps)
+    assert f.shape == (1, 1)
+    assert int((np.abs(ref - th) > 0).sum()) == steps               # exactly `steps` parameters moved ...
+    assert maxdiff(got, ref) < TOL and abs(f[0, 0] - f_ref) < TOL   # ... to the oracle's values
+
+
+def test_coordinate_descent_one_launch_lanes_and_sweeps(monkeypatch):
+    """aqc_ws_cd_sweeps: lanes = random restarts and their own targets, several sweeps in one launch (z = V^H U re-derived in
+    the kernel at the start of each, core_op_matrix.py:806-810).  Every lane follows the oracle's consecutive single sweeps
+    (full sweeps: rounding is amplified along ~T sequential steps, hence 1e-8 after the first and 1e-7 after the second),
+    the reference-signature single-lane call gives the same numbers, and so does the launch chain it replaced."""
+    from aqc_research_amd.core_op_matrix import coord_descent_single_sweep, coord_descent_sweeps
+
+    n, lanes = 5, 5
+    circ, th0, u0, rng = _cd_problem(n, "cyclic_spin", 30, 77)
+    d = 1 << n
+    ths = np.stack([th0] + [orc.rand_thetas(circ.num_thetas, rng) for _ in range(lanes - 1)])
+    us = np.stack([u0] + [np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0] for _ in range(lanes - 1)])
+    got = ths.copy()
+    f = coord_descent_sweeps(circ, got, us, 2)
+    assert f.shape == (lanes, 2)
+    for b in range(lanes):
+        t1, f1 = orc.coord_descent_single_sweep(circ, ths[b], us[b])
+        t2, f2 = orc.coord_descent_single_sweep(circ, t1, us[b])
+        assert abs(f[b, 0] - f1) < 1e-8 and abs(f[b, 1] - f2) < 1e-7 and maxdiff(got[b], t2) < 1e-7
+        assert f2 < f1 < 1.0
+    one = ths[1].copy()                                  # reference signature, one lane, one sweep at a time
+    g1 = coord_descent_single_sweep(circ, one, us[1], None)
+    g2 = coord_descent_single_sweep(circ, one, us[1], None)
+    assert abs(g1 - f[1, 0]) < 1e-12 and abs(g2 - f[1, 1]) < 1e-10 and maxdiff(one, got[1]) < 1e-10
+    monkeypatch.setenv("AQC_CD_CHAIN", "1")              # the launch chain (what problems beyond 6 qubits still use)
+    chain = ths[1].copy()
+    c1 = coord_descent_single_sweep(circ, chain, us[1], None)
+    assert abs(c1 - f[1, 0]) < 1e-8
+    monkeypatch.delenv("AQC_CD_CHAIN")
+    # one target shared by all lanes; a 7-qubit problem does not fit one workgroup's LDS and says so
+    shared = ths.copy()
+    fs = coord_descent_sweeps(circ, shared, u0, 1)
+    assert abs(fs[0, 0] - f[0, 0]) < 1e-12
+    big, thb, ub, _ = _cd_problem(7, "spin", 8, 78)
+    with pytest.raises(RuntimeError, match="do not fit"):
+        coord_descent_sweeps(big, thb.copy(), ub, 1)
+    fb = coord_descent_single_sweep(big, thb, ub, None)   # ... while the reference-signature call runs it on the chain
+    assert 0.0 < fb < 1.0

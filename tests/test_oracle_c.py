@@ -70,3 +70,24 @@ def test_rejects_bad_arguments():
         ref.v_mul_vec(a, np.zeros(3), np.zeros(8))
     with pytest.raises(ValueError):
         ref.v_mul_vec(a, np.zeros(a.num_thetas), np.zeros(4))
+
+
+def test_c_coordinate_descent_matches_the_golden_sweeps_and_the_numpy_restatement():
+    """aqc_ref_cd_sweeps (the CPU baseline of bench.py --workload cd5_cyc180) against the NumPy restatement, which the golden
+    fixture of the reference's two consecutive sweeps pins (tests/test_oracle_golden.py)."""
+    import numpy as np
+
+    from oracle import aqc_oracle as orc
+    from oracle import aqc_ref as cref
+
+    rng = np.random.default_rng(5)
+    for ent, n, depth in (("cx", 4, 9), ("cz", 3, 7)):
+        a = orc.Ansatz(n, ent, orc.spin_blocks(n, depth), False, False)
+        d = 1 << n
+        th = np.stack([orc.rand_thetas(a.num_thetas, rng) for _ in range(3)])
+        us = np.stack([np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0] for _ in range(3)])
+        got, f = cref.coord_descent_sweeps(a, th, us, 2, threads=2)
+        for b in range(3):
+            t1, f1 = orc.coord_descent_single_sweep(a, th[b], us[b])
+            t2, f2 = orc.coord_descent_single_sweep(a, t1, us[b])
+            assert abs(f[b, 0] - f1) < 1e-9 and abs(f[b, 1] - f2) < 1e-8 and np.abs(got[b] - t2).max() < 1e-8

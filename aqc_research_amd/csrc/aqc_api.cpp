@@ -1786,13 +1786,6 @@ int aqc_gate_dot(int device, int n, int64_t ncols, int kind, int q0, int q1, con
 
 // ---- coordinate descent ------------------------------------------------------------------------
 
-namespace aqc {
-struct CdStepHost { int32_t kind, hbit, hbit2, tindex; };   // = CdStep of aqc_cd.hip
-size_t cd_persistent_lds_bytes(int nbits, int T);
-hipError_t launch_cd_persistent(const void* prog, int nsteps, int nbits, int col_bits, const void* target, size_t lane_stride, double* thetas,
-                                int T, double* fobj, int nsweeps, int max_steps, int batch, hipStream_t s);
-}
-
 static int cd_checks(const aqc_ws* ws) {
     const Program& prog = ws->ctx->prog;
     if (ws->ncols != (1 << prog.n)) return fail("coordinate descent needs a square workspace (ncols == 2^n)");
@@ -1816,21 +1809,24 @@ int aqc_ws_cd_sweeps(aqc_ws* ws, double* thetas_io, double* fobj, int nsweeps, i
     const Program& prog = ws->ctx->prog;
     const int T = prog.num_thetas();
     HIP_OK(hipSetDevice(ws->device));
-    if (!ws->d_cd_prog) {   // the walk of core_op_matrix.py:852-912 as a flat list of steps (address bits of this workspace)
-        std::vector<aqc::CdStepHost> steps;
-        auto rot = [&](int qubit, int kind, int tindex) { steps.push_back({kind, ws->col_bits + qubit, 0, tindex}); };
+    if (!ws->d_cd_prog) {   // the walk of core_op_matrix.py:852-912 cut into segments (address bits of this workspace)
+        std::vector<aqc::CdSegHost> segs;
         for (const GateGroup& g : prog.groups) {
-            if (g.type == GROUP_FRONT) {
-                rot(g.q0, 1, g.theta0 + 2); rot(g.q0, 0, g.theta0 + 1); rot(g.q0, 1, g.theta0 + 0);
-            } else {
-                steps.push_back({prog.entangler == AQC_CX ? 3 : 4, ws->col_bits + g.q0, ws->col_bits + g.q1, -1});
-                rot(g.q0, 0, g.theta0); rot(g.q0, 1, g.theta0 + 1); rot(g.q1, 0, g.theta0 + 2);
-                rot(g.q1, prog.entangler == AQC_CX ? 2 : 1, g.theta0 + 3);
+            aqc::CdSegHost sg{};
+            if (g.type == GROUP_FRONT) {   // Rz(t2), Ry(t1), Rz(t0) on one qubit; the second bit of the 4-element groups: any other qubit
+                sg.ha = ws->col_bits + g.q0; sg.hb = ws->col_bits + (g.q0 + 1) % prog.n; sg.ent = 0; sg.nrot = 3;
+                const int kinds[3] = {1, 0, 1}, tix[3] = {g.theta0 + 2, g.theta0 + 1, g.theta0};
+                for (int r = 0; r < 3; ++r) { sg.kind[r] = kinds[r]; sg.on_b[r] = 0; sg.tindex[r] = tix[r]; }
+            } else {                       // entangler, Ry(t0) Rz(t1) on the control, Ry(t2) Rs(t3) on the target
+                sg.ha = ws->col_bits + g.q0; sg.hb = ws->col_bits + g.q1; sg.ent = prog.entangler == AQC_CX ? 1 : 2; sg.nrot = 4;
+                const int kinds[4] = {0, 1, 0, prog.entangler == AQC_CX ? 2 : 1};
+                for (int r = 0; r < 4; ++r) { sg.kind[r] = kinds[r]; sg.on_b[r] = r >= 2; sg.tindex[r] = g.theta0 + r; }
             }
+            segs.push_back(sg);
         }
-        HIP_OK(hipMalloc(&ws->d_cd_prog, steps.size() * sizeof(aqc::CdStepHost)));
-        HIP_OK(hipMemcpy(ws->d_cd_prog, steps.data(), steps.size() * sizeof(aqc::CdStepHost), hipMemcpyHostToDevice));
-        ws->cd_nsteps = (int)steps.size();
+        HIP_OK(hipMalloc(&ws->d_cd_prog, segs.size() * sizeof(aqc::CdSegHost)));
+        HIP_OK(hipMemcpy(ws->d_cd_prog, segs.data(), segs.size() * sizeof(aqc::CdSegHost), hipMemcpyHostToDevice));
+        ws->cd_nsteps = (int)segs.size();
         HIP_OK(hipMalloc((void**)&ws->d_cd_thetas, sizeof(double) * (size_t)ws->batch * T));
     }
     const size_t nf = (size_t)ws->batch * nsweeps;

@@ -132,57 +132,179 @@ __global__ __launch_bounds__(256) void cd_entangle_kernel(cplx* __restrict__ w, 
 // workgroup per lane holds w and z for the whole walk: no launch per parameter, no HBM round trip between parameters.  Lanes
 // are independent problems (random restarts of one ansatz, different targets).  Per sweep and lane:
 //   theta -> (cos, sin) of every half angle (all threads in parallel);
-//   z <- target (HBM -> LDS), z <- V(theta)^H z gate by gate in LDS (v_dagger_mul_mat, core_op_matrix.py:562-642), w <- I;
-//   the Gauss-Seidel walk of core_op_matrix.py:852-912: per parameter the two inner products in one pass over the pairs
-//   (fixed-order reduction: lanes by butterfly, waves in order), the Newton / gradient step worked out by EVERY thread from
-//   the same four wave partials (identical arithmetic, no broadcast), z rotated by the old angle, w by the new one;
+//   z <- target (HBM -> LDS), z <- V(theta)^H z in LDS (v_dagger_mul_mat, core_op_matrix.py:562-642), w <- I;
+//   the Gauss-Seidel walk of core_op_matrix.py:852-912;
 //   fobj = 1 - |<w|z>|^2 / d^2 (:917).
-// Consecutive parameters on the same qubit touch the same pairs of the same threads: the barrier between them is skipped.
-struct CdStep {
-    int32_t kind;     // 0 Ry, 1 Rz, 2 Rx: one parameter; 3 CX, 4 CZ: the block's entangler on both operands
-    int32_t hbit;     // address bit of the rotated qubit / of the control
-    int32_t hbit2;    // address bit of the target (entanglers)
-    int32_t tindex;   // index of the parameter
+// The walk is cut into SEGMENTS: a front-layer qubit (3 parameters) or a unit block (entangler + 4 parameters).  All gates of a
+// segment act on two address bits (a, b), so a thread takes the 4 elements of w and of z that differ in exactly those bits into
+// registers ONCE per segment: the entangler is a register permutation, each parameter is
+//   partial inner products on the thread's two pairs -> wave reduction (4 sums in 7 exchange steps: the butterfly transposes
+//   while it adds) -> the waves' partials through LDS, one barrier -> the Newton / gradient step worked out by EVERY thread from
+//   the same numbers in the same order (identical arithmetic, nothing to broadcast) -> z rotated by the old angle, w by the new
+//   one, in registers;
+// and the group goes back to LDS when the segment ends (first version: every parameter read both operands from LDS twice and
+// wrote them once -- 96 KiB of LDS traffic per parameter and lane at d = 32; now 64 KiB per SEGMENT).
+struct CdSeg {
+    int32_t ha, hb;       // address bits of the segment's two qubits: a = control / the front-layer qubit, b = target / any other qubit
+    int32_t ent;          // 0 none (front layer), 1 CX, 2 CZ -- applied to both operands before the rotations
+    int32_t nrot;         // parameters of the segment (3 or 4)
+    int32_t kind[4];      // 0 Ry, 1 Rz, 2 Rx
+    int32_t on_b[4];      // rotated qubit: 0 = a, 1 = b
+    int32_t tindex[4];    // index of the parameter
 };
 
-__device__ __forceinline__ void cd_delta(int kind, double gr, double gi, double pr, double pi, double dim, double t_old, double& t_new) {
+__device__ __forceinline__ void cd_delta(int kind, double gr, double gi, double pr, double pi, double inv_d2n, double& dt_out) {
     // grad = f * S with f = 0.5 (Y) or 0.5j (Z, X)   (core_op_matrix.py:284-389)
     double g_re, g_im;
     if (kind == 0) { g_re = 0.5 * gr; g_im = 0.5 * gi; } else { g_re = -0.5 * gi; g_im = 0.5 * gr; }
-    // _delta_theta (core_op_matrix.py:833-850)
-    const double d2n = dim * dim;
-    double d1 = (-2.0 * (pr * g_re + pi * g_im)) / d2n;
-    const double d2 = (-2.0 * (g_re * g_re + g_im * g_im) + 0.5 * (pr * pr + pi * pi)) / d2n;
+    // _delta_theta (core_op_matrix.py:833-850); d^2 is a power of two: multiplying by its reciprocal IS the division
+    double d1 = (-2.0 * (pr * g_re + pi * g_im)) * inv_d2n;
+    const double d2 = (-2.0 * (g_re * g_re + g_im * g_im) + 0.5 * (pr * pr + pi * pi)) * inv_d2n;
     const double tol = 1.4901161193847656e-08, lr = 0.19634954084936207, maxdt = 0.78539816339744831;
     double dt;
     if (d2 < tol) { d1 /= fmax(fabs(d1), 1.0); dt = -lr * d1; } else { dt = -d1 / d2; }
-    const double r = fabs(dt / maxdt);
-    if (!(r <= 1.0)) dt = dt / r;
-    t_new = t_old + dt;
+    // |dt| <= max_delta_theta: dt / |dt / maxdt| is maxdt with the sign of dt (:849-850); NaN steps are left alone like there
+    if (fabs(dt) > maxdt) dt = copysign(maxdt, dt);
+    dt_out = dt;
 }
 
-__device__ __forceinline__ void cd_entangle_lds(cplx* a, int npairs_half, int cbit, int tbit, int cz, int tid, int nthreads) {
-    const int lo = min(cbit, tbit), hi = max(cbit, tbit);
-    const int ic = 1 << cbit, it = 1 << tbit;
-    for (int g = tid; g < npairs_half; g += nthreads) {
-        const int i0 = (int)pair_index(pair_index((size_t)g, lo), hi);
-        if (!cz) { const cplx t = a[i0 + ic]; a[i0 + ic] = a[i0 + ic + it]; a[i0 + ic + it] = t; }
-        else { const cplx t = a[i0 + ic + it]; a[i0 + ic + it] = make_double2(-t.x, -t.y); }
+// cos / sin of x for |x| <= pi / 8 (half of a step that is clamped to pi / 4): Taylor polynomials in x^2, remainders < 1e-20
+__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+    const double x2 = x * x;
+    double ps = -7.6471637318198164759e-13;           // -1/15!
+    double pc = -1.1470745597729724714e-11;           // -1/14!
+    ps = fma(ps, x2, 1.6059043836821614599e-10);      //  1/13!
+    pc = fma(pc, x2, 2.0876756987868098979e-09);      //  1/12!
+    ps = fma(ps, x2, -2.5052108385441718775e-08);     // -1/11!
+    pc = fma(pc, x2, -2.7557319223985890653e-07);     // -1/10!
+    ps = fma(ps, x2, 2.7557319223985890653e-06);      //  1/9!
+    pc = fma(pc, x2, 2.4801587301587301587e-05);      //  1/8!
+    ps = fma(ps, x2, -1.9841269841269841270e-04);     // -1/7!
+    pc = fma(pc, x2, -1.3888888888888888889e-03);     // -1/6!
+    ps = fma(ps, x2, 8.3333333333333333333e-03);      //  1/5!
+    pc = fma(pc, x2, 4.1666666666666666667e-02);      //  1/4!
+    ps = fma(ps, x2, -1.6666666666666666667e-01);     // -1/3!
+    pc = fma(pc, x2, -0.5);                           // -1/2!
+    s = fma(ps * x2, x, x);
+    c = fma(pc, x2, 1.0);
+}
+
+// lane exchanges of the wave reduction on the vector ALU (no LDS crossbar, no lgkmcnt waits on the critical path of a step):
+// data-parallel-primitive moves inside a row of 16 lanes, gfx950's row / half swaps across rows
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v_permlane16_swap (v, v): first result = rows (0, 0, 2, 2) of v, second = rows (1, 1, 3, 3): their sum is v[l] + v[l ^ 16];
+// v_permlane32_swap (v, v): first = halves (0, 0), second = halves (1, 1): sum = v[l] + v[l ^ 32]
+__device__ __forceinline__ double add_xor16(double v) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double add_xor32(double v) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// Sums of four per-lane values over the wave in 7 exchange steps instead of 24: the first two steps hand half of the values to
+// the partner lane while adding the other half (lane bit 0 ends up with the {g, p} choice, bit 1 with {re, im}), the other four
+// add within the lanes of equal low bits.  Afterwards lane l holds the wave's total of value (l & 3): 0 gr, 1 pr, 2 gi, 3 pi.
+__device__ __forceinline__ double wave_sum4(double gr, double gi, double pr, double pi, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    // step xor 1: even lanes keep (gr, gi), odd lanes keep (pr, pi)
+    const double s0 = b0 ? gr : pr, s1 = b0 ? gi : pi;            // what goes to the partner
+    double k0 = b0 ? pr : gr, k1 = b0 ? pi : gi;                 // what stays
+    k0 += dpp<0xB1>(s0);                       // quad_perm [1, 0, 3, 2]: lane ^ 1
+    k1 += dpp<0xB1>(s1);
+    // step xor 2: bit 1 clear keeps the real part, set keeps the imaginary part
+    double v = (b1 ? k1 : k0) + dpp<0x4E>(b1 ? k0 : k1);   // quad_perm [2, 3, 0, 1]: lane ^ 2
+    v += dpp<0x124>(v);                        // row_ror:4 and row_ror:8: the four lanes of equal (lane & 3) in a row of 16
+    v += dpp<0x128>(v);
+    v = add_xor16(v);
+    v = add_xor32(v);
+    return v;
+}
+
+// rotation of the thread's two pairs: (0,1),(2,3) for a gate on bit a, (0,2),(1,3) on bit b
+template <int KIND, bool ON_B>
+__device__ __forceinline__ void rot_group(cplx (&e)[4], double c, double s) {
+    if (ON_B) { rot_pair(KIND, e[0], e[2], c, s); rot_pair(KIND, e[1], e[3], c, s); }
+    else      { rot_pair(KIND, e[0], e[1], c, s); rot_pair(KIND, e[2], e[3], c, s); }
+}
+
+struct CdShared {          // what a parameter step needs besides the thread's registers
+    double* th;            // LDS: thetas of the lane
+    const double2* cs;     // LDS: (cos, sin) of every half angle at the start of the sweep
+    double* red;           // LDS: [2 parities][4 waves][4] partial sums
+    double inv_d2n;
+    int tid, wave, wl;
+    unsigned parity;
+};
+
+// One parameter of the walk (core_op_matrix.py:855-912) with the gate kind and the rotated bit known at compile time.
+template <int KIND, bool ON_B, int G>
+__device__ __forceinline__ void cd_param(cplx (&ww)[G][4], cplx (&zz)[G][4], const bool (&live)[G], int tix, CdShared& sh) {
+    double gr = 0, gi = 0, pr = 0, pi = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        if (!live[j]) continue;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i0 = ON_B ? p : 2 * p, i1 = ON_B ? p + 2 : 2 * p + 1;
+            const cplx w0 = ww[j][i0], w1 = ww[j][i1], z0 = zz[j][i0], z1 = zz[j][i1];
+            const double c00r = w0.x * z0.x + w0.y * z0.y, c00i = w0.x * z0.y - w0.y * z0.x;
+            const double c11r = w1.x * z1.x + w1.y * z1.y, c11i = w1.x * z1.y - w1.y * z1.x;
+            pr += c00r + c11r;
+            pi += c00i + c11i;
+            if (KIND == 1) {
+                gr += c00r - c11r;
+                gi += c00i - c11i;
+            } else {
+                const double c01r = w0.x * z1.x + w0.y * z1.y, c01i = w0.x * z1.y - w0.y * z1.x;
+                const double c10r = w1.x * z0.x + w1.y * z0.y, c10i = w1.x * z0.y - w1.y * z0.x;
+                if (KIND == 0) { gr += c01r - c10r; gi += c01i - c10i; } else { gr += c01r + c10r; gi += c01i + c10i; }
+            }
+        }
     }
+    const double v = wave_sum4(gr, gi, pr, pi, sh.wl);
+    double* rd = sh.red + 16 * (sh.parity & 1);   // double-buffered: the next parameter's partials never overtake a reader
+    ++sh.parity;
+    if (sh.wl < 4) rd[4 * sh.wave + sh.wl] = v;   // [wave][0 gr, 1 pr, 2 gi, 3 pi]
+    const double2 co = sh.cs[tix];
+#pragma unroll
+    for (int j = 0; j < G; ++j) rot_group<KIND, ON_B>(zz[j], co.x, co.y);   // z <- R(theta_old) z: does not wait for the sums
+    __syncthreads();
+    gr = (rd[0] + rd[4]) + (rd[8] + rd[12]);
+    pr = (rd[1] + rd[5]) + (rd[9] + rd[13]);
+    gi = (rd[2] + rd[6]) + (rd[10] + rd[14]);
+    pi = (rd[3] + rd[7]) + (rd[11] + rd[15]);
+    double dt;
+    cd_delta(KIND, gr, gi, pr, pi, sh.inv_d2n, dt);
+    double sd, cd;
+    sincos_small(0.5 * dt, sd, cd);
+    const double cn = co.x * cd - co.y * sd, sn = co.y * cd + co.x * sd;   // half angle of theta_old + dt
+#pragma unroll
+    for (int j = 0; j < G; ++j) rot_group<KIND, ON_B>(ww[j], cn, sn);       // w <- R(theta_new) w
+    if (sh.tid == 0) sh.th[tix] += dt;   // (read again at the start of the next sweep only)
 }
 
-__global__ __launch_bounds__(256) void cd_persistent_kernel(const CdStep* __restrict__ prog, int nsteps, int nbits, int col_bits,
-                                                            const cplx* __restrict__ target, size_t lane_stride, double* thetas, int T,
-                                                            double* fobj, int nsweeps, int max_steps) {
+template <int G>
+__device__ __forceinline__ void cd_persistent_body(const CdSeg* __restrict__ prog, int nsegs, int nbits, int col_bits,
+                                                   const cplx* __restrict__ target, size_t lane_stride, double* thetas, int T,
+                                                   double* fobj, int nsweeps, int max_steps) {
     extern __shared__ double cd_lds[];
-    const int N = 1 << nbits, npairs = N >> 1;
+    const int N = 1 << nbits, ngroups = N >> 2;
     cplx* w = reinterpret_cast<cplx*>(cd_lds);
     cplx* z = w + N;
     double* th = reinterpret_cast<double*>(z + N);
     double2* cs = reinterpret_cast<double2*>(th + ((T + 1) & ~1));
-    double* red = reinterpret_cast<double*>(cs + T);            // [4 waves][4]
-    const int tid = threadIdx.x, lane = blockIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = blockIdx.x;
     const double dim = (double)(1 << (nbits - col_bits));
+    CdShared sh{th, cs, reinterpret_cast<double*>(cs + T), 1.0 / (dim * dim), tid, tid >> 6, tid & 63, 0u};
     const int cmask = (1 << col_bits) - 1;
     double* my_thetas = thetas + (size_t)lane * T;
     const cplx* y = target + (size_t)lane * lane_stride;
@@ -195,80 +317,90 @@ __global__ __launch_bounds__(256) void cd_persistent_kernel(const CdStep* __rest
             w[e] = make_double2(((e >> col_bits) == (e & cmask)) ? 1.0 : 0.0, 0.0);
         }
         __syncthreads();
-        // z <- V^H z: the gates of the walk in reverse order, every rotation inverted
-        for (int i = nsteps - 1; i >= 0; --i) {
-            const CdStep st = prog[i];
-            if (st.kind >= 3) {
-                cd_entangle_lds(z, N >> 2, st.hbit, st.hbit2, st.kind == 4, tid, 256);
-            } else {
-                const double2 c = cs[st.tindex];
-                const int h = 1 << st.hbit;
-                for (int g = tid; g < npairs; g += 256) {
-                    const int i0 = (int)pair_index((size_t)g, st.hbit);
-                    cplx a0 = z[i0], a1 = z[i0 + h];
-                    rot_pair(st.kind, a0, a1, c.x, -c.y);
-                    z[i0] = a0; z[i0 + h] = a1;
-                }
+        // ---- z <- V^H z: the segments in reverse order, inside a segment the rotations in reverse order with inverted angles,
+        // then the (self-inverse) entangler; one LDS round trip and one barrier per segment
+        for (int sg = nsegs - 1; sg >= 0; --sg) {
+            const CdSeg& seg = prog[sg];
+            const int ha = __builtin_amdgcn_readfirstlane(seg.ha), hb = __builtin_amdgcn_readfirstlane(seg.hb);
+            const int ent = __builtin_amdgcn_readfirstlane(seg.ent);
+            const int t0 = __builtin_amdgcn_readfirstlane(seg.tindex[0]), t1 = __builtin_amdgcn_readfirstlane(seg.tindex[1]);
+            const int t2 = __builtin_amdgcn_readfirstlane(seg.tindex[2]), t3 = __builtin_amdgcn_readfirstlane(seg.tindex[3]);
+            const int lo = min(ha, hb), hi = max(ha, hb), ia = 1 << ha, ib = 1 << hb;
+            cplx zz[G][4];
+            int base[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int g = tid + 256 * j;
+                base[j] = (int)pair_index(pair_index((size_t)(g < ngroups ? g : 0), lo), hi);
+                zz[j][0] = z[base[j]]; zz[j][1] = z[base[j] + ia]; zz[j][2] = z[base[j] + ib]; zz[j][3] = z[base[j] + ia + ib];
             }
-            // the next (earlier) gate pairs the same elements in the same threads when it acts on the same qubit
-            if (!(i > 0 && st.kind < 3 && prog[i - 1].kind < 3 && prog[i - 1].hbit == st.hbit)) __syncthreads();
-        }
-        // the walk
-        int done = 0;
-        for (int i = 0; i < nsteps; ++i) {
-            const CdStep st = prog[i];
-            if (st.kind >= 3) {
-                cd_entangle_lds(z, N >> 2, st.hbit, st.hbit2, st.kind == 4, tid, 256);
-                cd_entangle_lds(w, N >> 2, st.hbit, st.hbit2, st.kind == 4, tid, 256);
-                __syncthreads();
-                continue;
-            }
-            if (max_steps >= 0 && done >= max_steps) break;    // (tests: stop after a given number of parameter steps)
-            ++done;
-            const int h = 1 << st.hbit, kind = st.kind;
-            double gr = 0, gi = 0, pr = 0, pi = 0;
-            for (int g = tid; g < npairs; g += 256) {
-                const int i0 = (int)pair_index((size_t)g, st.hbit);
-                const cplx w0 = w[i0], w1 = w[i0 + h], z0 = z[i0], z1 = z[i0 + h];
-                const double c00r = w0.x * z0.x + w0.y * z0.y, c00i = w0.x * z0.y - w0.y * z0.x;
-                const double c11r = w1.x * z1.x + w1.y * z1.y, c11i = w1.x * z1.y - w1.y * z1.x;
-                pr += c00r + c11r;
-                pi += c00i + c11i;
-                if (kind == 1) {
-                    gr += c00r - c11r;
-                    gi += c00i - c11i;
+            const double2 c0 = cs[t0], c1 = cs[t1], c2 = cs[t2], c3 = cs[ent ? t3 : t0];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (ent == 0) {          // front layer: Rz(t0)^-1 ... after Ry(t1)^-1 after Rz(t2)^-1 in reverse order of the walk
+                    rot_group<1, false>(zz[j], c2.x, -c2.y); rot_group<0, false>(zz[j], c1.x, -c1.y); rot_group<1, false>(zz[j], c0.x, -c0.y);
                 } else {
-                    const double c01r = w0.x * z1.x + w0.y * z1.y, c01i = w0.x * z1.y - w0.y * z1.x;
-                    const double c10r = w1.x * z0.x + w1.y * z0.y, c10i = w1.x * z0.y - w1.y * z0.x;
-                    if (kind == 0) { gr += c01r - c10r; gi += c01i - c10i; } else { gr += c01r + c10r; gi += c01i + c10i; }
+                    if (ent == 1) rot_group<2, true>(zz[j], c3.x, -c3.y); else rot_group<1, true>(zz[j], c3.x, -c3.y);
+                    rot_group<0, true>(zz[j], c2.x, -c2.y); rot_group<1, false>(zz[j], c1.x, -c1.y); rot_group<0, false>(zz[j], c0.x, -c0.y);
+                    if (ent == 1) { const cplx t = zz[j][1]; zz[j][1] = zz[j][3]; zz[j][3] = t; }
+                    else zz[j][3] = make_double2(-zz[j][3].x, -zz[j][3].y);
+                }
+                if (tid + 256 * j < ngroups) {
+                    z[base[j]] = zz[j][0]; z[base[j] + ia] = zz[j][1]; z[base[j] + ib] = zz[j][2]; z[base[j] + ia + ib] = zz[j][3];
                 }
             }
-            gr = wsum(gr); gi = wsum(gi); pr = wsum(pr); pi = wsum(pi);
-            if ((tid & 63) == 0) { red[4 * wave] = gr; red[4 * wave + 1] = gi; red[4 * wave + 2] = pr; red[4 * wave + 3] = pi; }
             __syncthreads();
-            gr = (red[0] + red[4]) + (red[8] + red[12]);
-            gi = (red[1] + red[5]) + (red[9] + red[13]);
-            pr = (red[2] + red[6]) + (red[10] + red[14]);
-            pi = (red[3] + red[7]) + (red[11] + red[15]);
-            const double t_old = th[st.tindex];
-            double t_new;
-            cd_delta(kind, gr, gi, pr, pi, dim, t_old, t_new);
-            const double2 co = cs[st.tindex];
-            double sn, cn;
-            sincos(0.5 * t_new, &sn, &cn);
-            for (int g = tid; g < npairs; g += 256) {
-                const int i0 = (int)pair_index((size_t)g, st.hbit);
-                cplx z0 = z[i0], z1 = z[i0 + h], w0 = w[i0], w1 = w[i0 + h];
-                rot_pair(kind, z0, z1, co.x, co.y);     // z <- R(theta_old) z
-                rot_pair(kind, w0, w1, cn, sn);         // w <- R(theta_new) w
-                z[i0] = z0; z[i0 + h] = z1; w[i0] = w0; w[i0 + h] = w1;
-            }
-            // red / th are read by everybody before this point of the NEXT step's first barrier, so one barrier here orders
-            // both the scratch and -- when the next step pairs other elements -- the operands
-            __syncthreads();
-            if (tid == 0) th[st.tindex] = t_new;   // (this step's entry is not read again before the next sweep's barriers)
         }
-        // fobj = 1 - |<w|z> / d|^2
+        // ---- the walk
+        int left = max_steps >= 0 ? max_steps : 0x7fffffff;   // (tests: stop after a given number of parameter steps)
+        for (int sg = 0; sg < nsegs && left > 0; ++sg) {
+            const CdSeg& seg = prog[sg];
+            const int ha = __builtin_amdgcn_readfirstlane(seg.ha), hb = __builtin_amdgcn_readfirstlane(seg.hb);
+            const int ent = __builtin_amdgcn_readfirstlane(seg.ent);
+            const int t0 = __builtin_amdgcn_readfirstlane(seg.tindex[0]), t1 = __builtin_amdgcn_readfirstlane(seg.tindex[1]);
+            const int t2 = __builtin_amdgcn_readfirstlane(seg.tindex[2]), t3 = __builtin_amdgcn_readfirstlane(seg.tindex[3]);
+            const int lo = min(ha, hb), hi = max(ha, hb), ia = 1 << ha, ib = 1 << hb;
+            cplx ww[G][4], zz[G][4];
+            int base[G];
+            bool live[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int g = tid + 256 * j;
+                live[j] = g < ngroups;
+                base[j] = (int)pair_index(pair_index((size_t)(live[j] ? g : 0), lo), hi);
+                ww[j][0] = w[base[j]]; ww[j][1] = w[base[j] + ia]; ww[j][2] = w[base[j] + ib]; ww[j][3] = w[base[j] + ia + ib];
+                zz[j][0] = z[base[j]]; zz[j][1] = z[base[j] + ia]; zz[j][2] = z[base[j] + ib]; zz[j][3] = z[base[j] + ia + ib];
+            }
+            if (ent == 0) {                       // front layer of one qubit: Rz(t2), Ry(t1), Rz(t0)  (tindex = t2, t1, t0 in walk order)
+                cd_param<1, false, G>(ww, zz, live, t0, sh);
+                if (--left > 0) { cd_param<0, false, G>(ww, zz, live, t1, sh);
+                if (--left > 0) { cd_param<1, false, G>(ww, zz, live, t2, sh); --left; } }
+            } else {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (ent == 1) {
+                        cplx t = zz[j][1]; zz[j][1] = zz[j][3]; zz[j][3] = t;
+                        t = ww[j][1]; ww[j][1] = ww[j][3]; ww[j][3] = t;
+                    } else {
+                        zz[j][3] = make_double2(-zz[j][3].x, -zz[j][3].y);
+                        ww[j][3] = make_double2(-ww[j][3].x, -ww[j][3].y);
+                    }
+                }
+                cd_param<0, false, G>(ww, zz, live, t0, sh);
+                if (--left > 0) { cd_param<1, false, G>(ww, zz, live, t1, sh);
+                if (--left > 0) { cd_param<0, true, G>(ww, zz, live, t2, sh);
+                if (--left > 0) { if (ent == 1) cd_param<2, true, G>(ww, zz, live, t3, sh); else cd_param<1, true, G>(ww, zz, live, t3, sh); --left; } } }
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (live[j]) {
+                    w[base[j]] = ww[j][0]; w[base[j] + ia] = ww[j][1]; w[base[j] + ib] = ww[j][2]; w[base[j] + ia + ib] = ww[j][3];
+                    z[base[j]] = zz[j][0]; z[base[j] + ia] = zz[j][1]; z[base[j] + ib] = zz[j][2]; z[base[j] + ia + ib] = zz[j][3];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- fobj = 1 - |<w|z> / d|^2
         double pr = 0, pi = 0;
         for (int e = tid; e < N; e += 256) {
             const cplx a = w[e], b = z[e];
@@ -276,32 +408,54 @@ __global__ __launch_bounds__(256) void cd_persistent_kernel(const CdStep* __rest
             pi += a.x * b.y - a.y * b.x;
         }
         pr = wsum(pr); pi = wsum(pi);
-        if ((tid & 63) == 0) { red[4 * wave] = pr; red[4 * wave + 1] = pi; }
+        double* rd = sh.red + 16 * (sh.parity & 1);
+        ++sh.parity;
+        if (sh.wl == 0) { rd[4 * sh.wave] = pr; rd[4 * sh.wave + 1] = pi; }
         __syncthreads();
         if (tid == 0) {
-            const double a = (red[0] + red[4]) + (red[8] + red[12]), b = (red[1] + red[5]) + (red[9] + red[13]);
-            fobj[(size_t)lane * nsweeps + sweep] = 1.0 - (a * a + b * b) / (dim * dim);
+            const double a = (rd[0] + rd[4]) + (rd[8] + rd[12]), b = (rd[1] + rd[5]) + (rd[9] + rd[13]);
+            fobj[(size_t)lane * nsweeps + sweep] = 1.0 - (a * a + b * b) * sh.inv_d2n;
         }
         __syncthreads();
     }
     for (int t = tid; t < T; t += 256) my_thetas[t] = th[t];
 }
 
-size_t cd_persistent_lds_bytes(int nbits, int T) {
-    return ((size_t)2 << nbits) * sizeof(cplx) + (size_t)((T + 1) & ~1) * sizeof(double) + (size_t)T * sizeof(double2) + 16 * sizeof(double);
+// up to 5 qubits: one 4-element group per thread; three workgroups per CU (50 KiB of LDS each at 5 qubits and 735 parameters),
+// i.e. three waves per SIMD: the register budget is set accordingly
+__global__ __launch_bounds__(256, 3) void cd_persistent_kernel_g1(const CdSeg* __restrict__ prog, int nsegs, int nbits, int col_bits,
+                                                                  const cplx* __restrict__ target, size_t lane_stride, double* thetas, int T,
+                                                                  double* fobj, int nsweeps, int max_steps) {
+    cd_persistent_body<1>(prog, nsegs, nbits, col_bits, target, lane_stride, thetas, T, fobj, nsweeps, max_steps);
+}
+// 6 qubits: four groups per thread, one workgroup per CU (128 KiB of LDS)
+__global__ __launch_bounds__(256) void cd_persistent_kernel_g4(const CdSeg* __restrict__ prog, int nsegs, int nbits, int col_bits,
+                                                               const cplx* __restrict__ target, size_t lane_stride, double* thetas, int T,
+                                                               double* fobj, int nsweeps, int max_steps) {
+    cd_persistent_body<4>(prog, nsegs, nbits, col_bits, target, lane_stride, thetas, T, fobj, nsweeps, max_steps);
 }
 
-hipError_t launch_cd_persistent(const void* prog, int nsteps, int nbits, int col_bits, const void* target, size_t lane_stride, double* thetas,
+size_t cd_persistent_lds_bytes(int nbits, int T) {
+    return ((size_t)2 << nbits) * sizeof(cplx) + (size_t)((T + 1) & ~1) * sizeof(double) + (size_t)T * sizeof(double2) + 32 * sizeof(double);
+}
+
+hipError_t launch_cd_persistent(const void* prog, int nsegs, int nbits, int col_bits, const void* target, size_t lane_stride, double* thetas,
                                 int T, double* fobj, int nsweeps, int max_steps, int batch, hipStream_t s) {
     const size_t lds = cd_persistent_lds_bytes(nbits, T);
-    static size_t granted = 0;
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cd_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool big = ((size_t)1 << nbits) / 4 > 256;    // more than one 4-element group per thread (6 qubits: 4)
+    static size_t granted[2] = {0, 0};
+    if (lds > granted[big]) {
+        hipError_t e = big ? hipFuncSetAttribute(reinterpret_cast<const void*>(cd_persistent_kernel_g4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(cd_persistent_kernel_g1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        granted = lds;
+        granted[big] = lds;
     }
-    cd_persistent_kernel<<<batch, 256, lds, s>>>(static_cast<const CdStep*>(prog), nsteps, nbits, col_bits, static_cast<const cplx*>(target),
-                                                 lane_stride, thetas, T, fobj, nsweeps, max_steps);
+    if (big)
+        cd_persistent_kernel_g4<<<batch, 256, lds, s>>>(static_cast<const CdSeg*>(prog), nsegs, nbits, col_bits, static_cast<const cplx*>(target),
+                                                        lane_stride, thetas, T, fobj, nsweeps, max_steps);
+    else
+        cd_persistent_kernel_g1<<<batch, 256, lds, s>>>(static_cast<const CdSeg*>(prog), nsegs, nbits, col_bits, static_cast<const cplx*>(target),
+                                                        lane_stride, thetas, T, fobj, nsweeps, max_steps);
     return hipGetLastError();
 }
 

@@ -155,6 +155,11 @@ hipError_t launch_cd_dot(const void* w, const void* z, size_t npairs, int hbit, 
 hipError_t launch_cd_update(void* w, void* z, size_t npairs, int hbit, int kind, const void* part, int nparts,
                             const double* theta_in, double* theta_out, int tindex, double dim, hipStream_t s);
 hipError_t launch_cd_entangle(void* w, void* z, size_t ngroups, int cbit, int tbit, int ent, hipStream_t s);
+// the whole walk as one persistent launch (a workgroup per lane, operands in LDS): segment list entry = CdSeg of aqc_cd.hip
+struct CdSegHost { int32_t ha, hb, ent, nrot, kind[4], on_b[4], tindex[4]; };
+size_t cd_persistent_lds_bytes(int nbits, int T);
+hipError_t launch_cd_persistent(const void* prog, int nsegs, int nbits, int col_bits, const void* target, size_t lane_stride, double* thetas,
+                                int T, double* fobj, int nsweeps, int max_steps, int batch, hipStream_t s);
 
 
 // aqc_gate.hip (gate-level building blocks, one pass per call)

@@ -52,6 +52,9 @@ WORKLOADS = {
     # are canonical tensors truncated at 1e-6 and the calls take the dense route whatever the threshold (mps_dot_objective.use_dense)
     "mps16_l40_chi64_thr1e-6": dict(n=16, blocks=40, kind="generic", chi=64, trunc_thr=1e-6, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient at the reference's default trunc_thr = 1e-6: canonical QiskitMPS targets chi<=64 truncated at 1e-6 (a different one per lane every step), dense route"),
     "sv12_trotter12": dict(n=12, layers=12, kind="trotter2", desc="12-qubit ASP, 2nd-order Trotter ansatz (12 layers: the last horizon of run_time_evol.py's defaults), state-vector objective+gradient"),
+    # coordinate descent (core_op_matrix.coord_descent_single_sweep, docs/aqc.ipynb: 1000 sweeps of the 5-qubit cyclic_spin ansatz):
+    # one step = one Gauss-Seidel sweep over all 735 parameters for every lane (lane = random restart with its own target)
+    "cd5_cyc180": dict(n=5, blocks=180, kind="cd", ncols=32, desc="5-qubit coordinate descent (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks, 735 parameters): one coord_descent_single_sweep per lane and step, lanes = random restarts with their own target unitary"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
 
@@ -299,6 +302,135 @@ def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=None):
     }
 
 
+def run_cd(args, w, env, full):
+    """--workload cd5_cyc180: coordinate-descent sweeps (core_op_matrix.py:765-917).  One step = aqc_ws_cd_sweeps(nsweeps = 1)
+    over all lanes: thetas host -> device, ONE persistent launch (a workgroup per lane keeps w and z in LDS for the whole walk,
+    z = V^H U re-derived inside), thetas and objective values back to the host.  Metric: sweeps per second."""
+    import ctypes
+
+    from aqc_research_amd import _lib as L
+    from aqc_research_amd.core_op_matrix import coord_descent_single_sweep
+    from aqc_research_amd.engine import BUF_Y, HipContext, Workspace
+    from oracle import aqc_ref as cref
+
+    ent = ParametricCircuit_for(w)
+    circ = ent
+    n, T, d = circ.num_qubits, circ.num_thetas, circ.dimension
+    B = args.batch if args.batch > 0 and full else 1536   # 3 workgroups of 50 KiB LDS per CU x 256 CUs = 768 lanes in flight: two full rounds
+    K, W = (args.steps, args.warmup) if full else (max(1, min(args.steps, args.config_steps)), 2)
+    rng = np.random.default_rng(4321 + 7 * (env.rank + 1))
+    distinct = [np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0] for _ in range(16)]
+    targets = np.stack([distinct[b % 16] for b in range(B)])
+    th0 = np.pi * (2 * rng.random((B, T)) - 1)
+    ws = Workspace(HipContext.of(circ), batch=B, ncols=d, device=env.local_rank)
+    ws.upload(BUF_Y, targets)
+    lib = L.lib()
+    fobj = np.zeros((B, 1))
+
+    def sweep(th):
+        L.check(lib.aqc_ws_cd_sweeps(ws.handle, L.dptr(th), L.dptr(fobj), 1, -1))
+
+    # the work is checked, not assumed: the first sweep of 8 lanes against the C restatement of the reference algorithm
+    # (whole sweeps: ~T sequential Newton steps amplify rounding, hence 1e-8; single steps are pinned at 1e-10 in tests/)
+    th = th0.copy()
+    sweep(th)
+    lanes = sorted(set(int(round(v)) for v in np.linspace(0, B - 1, min(B, 8))))
+    t_ref, f_ref = cref.coord_descent_sweeps(circ, th0[lanes], targets[lanes], 1, threads=host_cores())
+    parity = max(float(np.abs(th[lanes] - t_ref).max()), float(np.abs(fobj[lanes, 0] - f_ref[:, 0]).max()))
+    if not parity < 1e-8:
+        raise SystemExit(f"bench.py: cd sweep deviates from the oracle by {parity:g} (> 1e-8)")
+    f_first = float(fobj[:, 0].mean())
+    for _ in range(W):
+        sweep(th)
+    env.comm.barrier()
+    t0 = time.perf_counter()
+    ws.timer_start()
+    for _ in range(K):
+        sweep(th)
+    ev_ms = ws.timer_stop()
+    env.comm.barrier()
+    wall = time.perf_counter() - t0
+    if env.comm.size > 1:
+        wall = float(env.comm.allreduce(np.array([wall]), "max")[0])
+    f_last = float(fobj[:, 0].mean())
+    ws.profile(True)
+    for _ in range(3):
+        sweep(th)
+    from aqc_research_amd.engine import K_MISC
+
+    launches, kern_ms = ws.profile_get(K_MISC)
+    ws.profile(False)
+    ws.close()
+    # one lane: the persistent launch and the launch chain it replaced (2 launches per parameter + 1 per block)
+    one, chain = None, None
+    if env.rank == 0:
+        th1 = th0[0].copy()
+        coord_descent_single_sweep(circ, th1, targets[0], None)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            coord_descent_single_sweep(circ, th1, targets[0], None)
+        one = (time.perf_counter() - t1) / 20
+        os.environ["AQC_CD_CHAIN"] = "1"
+        th1 = th0[0].copy()
+        coord_descent_single_sweep(circ, th1, targets[0], None)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            coord_descent_single_sweep(circ, th1, targets[0], None)
+        chain = (time.perf_counter() - t1) / 5
+        del os.environ["AQC_CD_CHAIN"]
+    if env.rank != 0:
+        return None
+    value = K * B * env.n_gpus / wall
+    avg_launch_ms = kern_ms / max(launches, 1)
+    # bytes the reference's algorithm moves per sweep and lane: per parameter one pass over w, z for the two inner products and
+    # one read-modify-write pass for the two rotations, per block the entangler on both, plus the T gate passes of V^H on z
+    N = d * d
+    alg_bytes = 16.0 * N * (6 * T + 4 * circ.num_blocks + 2 * T)
+    lds_peak = 256 * 128 * 2.4e9 / 1e9      # GB/s: 128 B per clock and CU
+    achieved = alg_bytes * B / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    out = {
+        "metric": "coordinate-descent sweeps/sec", "value": value, "unit": "sweeps/s", "n_gpus": env.n_gpus, "steps": K, "warmup": W,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": w["desc"], "n_qubits": n, "num_thetas": T, "batch_per_gpu": B, "path": "matrix (core_op_matrix.coord_descent_single_sweep)",
+                   "ranks_seen": env.ranks_seen, "transport": env.comm.transport,
+                   "mean_fobj_after_first_sweep": f_first, "mean_fobj_after_last_sweep": f_last, "sweeps_per_lane": 1 + W + K},
+        # the persistent kernel never goes to HBM between parameters: what it moves is LDS traffic
+        "roofline": {"bound": "lds", "kernel": "cd_persistent_kernel", "achieved": achieved, "peak": lds_peak, "unit": "GB/s",
+                     "frac": achieved / lds_peak, "traffic": None, "avg_launch_ms": avg_launch_ms,
+                     "algorithmic_bytes_per_sweep_and_lane": alg_bytes,
+                     "note": "algorithmic bytes = 16 B x d^2 x (8 T + 4 L) per sweep and lane (what the reference's pass-per-gate algorithm moves), "
+                             "served from LDS: one workgroup per lane holds both operands for the whole walk; HBM sees the target once per sweep. "
+                             "The walk is a chain of T dependent steps (two barriers and one fixed-order reduction each): latency-bound, not "
+                             "bandwidth-bound",
+                     "hbm_equivalent_frac_of_8TBps": achieved / HBM_PEAK_GBS},
+        "parity_maxerr": parity, "parity_lanes_checked": len(lanes), "parity_tolerance": 1e-8,
+        "single_lane": {"ms_per_sweep_one_launch": None if one is None else one * 1e3, "ms_per_sweep_launch_chain": None if chain is None else chain * 1e3,
+                        "speedup_one_lane": None if not one else chain / one,
+                        "speedup_all_lanes_vs_chain": None if not chain else value / env.n_gpus * chain},
+        "device_ms_per_step_events": ev_ms / K,
+    }
+    if full and not args.no_cpu_baseline:
+        cores = host_cores()
+        nb = max(cores, 16)
+        t1 = time.perf_counter()
+        cref.coord_descent_sweeps(circ, th0[:nb], targets[:nb], 1, threads=cores)
+        one_round = time.perf_counter() - t1
+        rounds = max(1, int(8.0 / max(one_round, 1e-3)))
+        t1 = time.perf_counter()
+        cref.coord_descent_sweeps(circ, th0[:nb], targets[:nb], rounds, threads=cores)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": nb * rounds / dt, "unit": "sweeps/s", "cores": cores, "kind": "port",
+                               "sample": f"{nb} lanes x {rounds} sweeps of the same ansatz in {dt:.1f} s: C restatement of coord_descent_single_sweep "
+                                         f"(oracle/aqc_ref.c), {cores} thread(s), one lane per thread",
+                               "host": {"cpu_model": cpu_model(), "os_cpu_count": os.cpu_count()},
+                               "reference_numpy": reference_numpy_record("cd5_cyc180")}
+    return out
+
+
+def ParametricCircuit_for(w):
+    return build_circuit(dict(w, kind="cyclic"))
+
+
 def launch_ranks(n_ranks, argv):
     """`bench.py --gpus N` started as ONE plain process: it becomes the launcher -- N fresh child processes of this script,
     one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / AQC_COMM_FILE in their environment, exactly what
@@ -542,7 +674,7 @@ def main():
 
 # the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
 # MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
-CONFIG_RUNS = ["mat5_cyc180", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
+CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
                "sv20_trotter2", "cfg4_jobs", "mat10_l40"]
 
 
@@ -551,11 +683,11 @@ def brief(o):
     if o is None:
         return {"error": "no result"}
     r = o.get("roofline") or {}
-    b = {"evals_per_s": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes": o["config"].get("batch_per_gpu", o["config"].get("lanes_per_entry")),
+    b = {("sweeps_per_s" if o.get("unit") == "sweeps/s" else "evals_per_s"): o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "lanes": o["config"].get("batch_per_gpu", o["config"].get("lanes_per_entry")),
          "workload": o["config"]["workload"], "roofline_frac": r.get("frac"), "roofline_kernel": r.get("kernel"),
          "sweep_avg_launch_ms": r.get("avg_launch_ms"), "parity_maxerr": o.get("parity_maxerr"),
          "parity_lanes_checked": o.get("parity_lanes_checked")}
-    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity"):
+    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane"):
         if k in o:
             b[k] = o[k]
         elif k in o["config"]:
@@ -573,6 +705,8 @@ def measure(workload, args, env, full):
     from oracle import aqc_oracle as orc
 
     w = WORKLOADS[workload]
+    if w["kind"] == "cd":
+        return run_cd(args, w, env, full)
     if w["kind"] == "jobs":
         out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=(args.steps if full else 1))
         out["config"]["ranks_seen"] = ranks_seen

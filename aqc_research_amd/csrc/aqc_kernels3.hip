@@ -91,6 +91,14 @@ __host__ __device__ constexpr bool sweep_scratch_double(int k) { return k >= 12 
 #ifndef AQC_APPLY_SPREAD
 #define AQC_APPLY_SPREAD 1
 #endif
+// Attribution experiments (variant builds only, `make variant NAME=.. EXTRA=-DAQC_EXP_APPLY_SKIP=<bits>`, tools/apply_budget.sh): parts of
+// the V / V^H sub-stage loop compiled OUT -- 1 LDS writes, 2 LDS reads, 8 MFMAs, 16 fp64 adds, 32 address XORs, 64 the tiles' HBM traffic, 128 the operand sums only, 256 the combining adds only
+// (beware: the compiler then drops the third real product as dead code), 512 the barrier of every sub-stage.  Results are garbage by
+// construction, only the launch times matter; the shipped library is built with 0.
+#ifndef AQC_EXP_APPLY_SKIP
+#define AQC_EXP_APPLY_SKIP 0
+#endif
+constexpr int kApplySkip = AQC_EXP_APPLY_SKIP;
 constexpr int kSweepSpread = AQC_SWEEP_SPREAD, kApplySpread = AQC_APPLY_SPREAD;   // MFMAs between two LDS writes inside a matrix run (sweep / V, V^H)
 template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
     // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
             fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, NW);
         }
         AQC_STAMP(0);
-        load_tiles3<K, 1>(tw, nullptr, a.in0 + (size_t)bl * a.lane_stride + tile_base3(st, wi - bl * a.ntiles), nullptr, st, lo, wave);
+        if (!(kApplySkip & 64)) load_tiles3<K, 1>(tw, nullptr, a.in0 + (size_t)bl * a.lane_stride + tile_base3(st, wi - bl * a.ntiles), nullptr, st, lo, wave);
     }
     // Every load so far has landed before the loop: otherwise the compiler's wait-count analysis, merging the loop
     // entry with the back edge, makes the first use of `cur` inside the loop wait for the prefetch of `nxt` as well.
@@ -258,10 +266,10 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
     for (int si = 0; si < st.nsubs; ++si) {
         AQC_STAMP(4 + si);
-        __syncthreads();
+        if (!(kApplySkip & 512)) __syncthreads();
         if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
         else if (more) fetch_sub<TS::kGpw>(nxt, a.subs, a.umat + (size_t)nbl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
-        if (kPersist && more) {   // a quarter of the next item's tile, issued BEHIND the operand fetch (loads retire in order)
+        if (kPersist && more && !(kApplySkip & 64)) {   // a quarter of the next item's tile, issued BEHIND the operand fetch (loads retire in order)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (si == (c < st.nsubs ? c : st.nsubs - 1)) {
@@ -280,18 +288,23 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
         for (int s = 0; s < 4; ++s) v[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]);
 #pragma unroll
         for (int j = 0; j <= TS::kGpw; ++j) {
-            if (j + 1 < TS::kGpw) {
+            if (j + 1 < TS::kGpw && !(kApplySkip & 2)) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) v[(j + 1) & 1][s] = lds_get(ad.a1 ^ ad.k1[j + 1][s]);
+                for (int s = 0; s < 4; ++s) v[(j + 1) & 1][s] = lds_get((kApplySkip & 32) ? ad.a1 : (ad.a1 ^ ad.k1[j + 1][s]));
             }
             __builtin_amdgcn_sched_barrier(0);
             double sv[4];
             cplx o[4];
             if (j < TS::kGpw) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) sv[s] = v[j & 1][s].x + v[j & 1][s].y;
+                for (int s = 0; s < 4; ++s) sv[s] = (kApplySkip & (16 | 128)) ? v[j & 1][s].x : v[j & 1][s].x + v[j & 1][s].y;
             }
-            if (j > 0) u_combine(acc, o);
+            if (j > 0) {
+                if (kApplySkip & (16 | 256)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = make_double2(acc.k1[r], acc.k2[r]);
+                } else u_combine(acc, o);
+            }
             unsigned wa[4];   // LDS write addresses of group j - 1, taken here in the vector-ALU bunch
             if (j < TS::kGpw) {   // (pinned: IR-level sinking otherwise moves the sums in between the MFMAs below)
 #pragma unroll
@@ -299,19 +312,20 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
             }
             if (j > 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { wa[r] = ad.a2 ^ ad.k2[j - 1][r]; asm volatile("" : "+v"(wa[r])); }
+                for (int r = 0; r < 4; ++r) { wa[r] = (kApplySkip & 32) ? ad.a2 : (ad.a2 ^ ad.k2[j - 1][r]); asm volatile("" : "+v"(wa[r])); }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (j < TS::kGpw) {
                 acc.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; acc.k2 = acc.k1; acc.k3 = acc.k1;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
+                    if (kApplySkip & 8) continue;
                     acc.k1 = mfma(sv[s], cur.u0[s], acc.k1);
                     acc.k2 = mfma(v[j & 1][s].x, cur.u1[s], acc.k2);
                     acc.k3 = mfma(v[j & 1][s].y, cur.u2[s], acc.k3);
                 }
             }
-            if (j > 0) {   // the LDS writes of group j - 1 ride inside the MFMA run (see sweep_mfma_kernel)
+            if (j > 0 && !(kApplySkip & 1)) {   // the LDS writes of group j - 1 ride inside the MFMA run (see sweep_mfma_kernel)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) lds_put(wa[r], o[r]);
                 if (j < TS::kGpw) {
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     AQC_STAMP(4 + st.nsubs);
     __syncthreads();
     AQC_STAMP(2);
-    store_tile3<K, false>(tw, a.out0 + lane_off, st, lo, wave);
+    if (!(kApplySkip & 64)) store_tile3<K, false>(tw, a.out0 + lane_off, st, lo, wave);
     AQC_STAMP(3);
     if (!more) break;
     __syncthreads();   // every wave has finished with the LDS tile (the stores' LDS reads included)

@@ -175,7 +175,9 @@ int set_error(const std::string& msg);
 
 // aqc_svd.hip (one-sided Jacobi SVD + the pieces of a truncated 2-qubit MPS gate)
 hipError_t launch_svd_identity(void* V, int cols, hipStream_t s);
-hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, int* rotations, hipStream_t s);
+hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, const double* fro2, int* rotations,
+                               hipStream_t s);
+hipError_t launch_svd_fro2(const void* W, size_t n, double* out, hipStream_t s);   // out[0] = Frobenius norm squared (fixed-order sum)
 hipError_t launch_svd_load(const void* a, int m, int n, int mode, void* work, hipStream_t s);
 hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, const double* sigma, int m, int n, int k, int mode, void* u, void* vh,
                                double* s_sorted, hipStream_t s);
@@ -185,7 +187,7 @@ hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void*
 bool svd_fits_block(int rows, int cols);
 int svd_block_size();
 hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void* bpairs, int rounds, int per_round, double tol, int max_sweeps,
-                               int* rot, unsigned* bar, int* status, hipStream_t s);
+                               const double* fro2, int* rot, unsigned* bar, int* status, hipStream_t s);
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
 hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,

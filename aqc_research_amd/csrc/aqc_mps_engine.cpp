@@ -125,7 +125,8 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         sw.cached_blocked = (int)blocked;
     }
     constexpr int kFlagInts = 64 + 4;   // [0..63] rotations per sweep | [64] barrier | [65] sweeps used | [66] barrier timeout
-    if (sw.flag.reserve(sizeof(int) * kFlagInts) || sw.sigma.reserve(sizeof(double) * std::max(cols, 1))) return 1;
+    if (sw.flag.reserve(sizeof(int) * kFlagInts) || sw.sigma.reserve(sizeof(double) * (std::max(cols, 1) + 1))) return 1;
+    double* fro2 = static_cast<double*>(sw.sigma.p) + std::max(cols, 1);   // scale of the negligible-column rule (aqc_svd.hip: kNegligible2)
     int* flag = static_cast<int*>(sw.flag.p);
     const double tol = 1e-15;
     int sweeps = 0;
@@ -135,16 +136,18 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         HIP_OK(hipMemcpyAsync(&sweeps, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     } else if (blocked) {   // one cooperative launch: persistent workgroups, 16 columns at a time in LDS
         HIP_OK(launch_svd_identity(V, cols, st));
+        HIP_OK(launch_svd_fro2(W, (size_t)rows * cols, fro2, st));
         HIP_OK(hipMemsetAsync(flag, 0, sizeof(int) * kFlagInts, st));
-        HIP_OK(launch_jacobi_block(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, reinterpret_cast<unsigned*>(flag + 64), flag + 65, st));
+        HIP_OK(launch_jacobi_block(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, fro2, flag, reinterpret_cast<unsigned*>(flag + 64), flag + 65, st));
         HIP_OK(hipMemcpyAsync(status, flag + 65, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     } else {
         HIP_OK(launch_svd_identity(V, cols, st));
+        HIP_OK(launch_svd_fro2(W, (size_t)rows * cols, fro2, st));
     }
     for (; !small && !blocked && sweeps < 60 && cols > 1; ++sweeps) {
         HIP_OK(hipMemsetAsync(flag, 0, sizeof(int), st));
         for (int r = 0; r < sw.rounds; ++r)
-            HIP_OK(launch_jacobi_round(W, rows, V, cols, static_cast<int*>(sw.pairs.p) + (size_t)r * sw.per_round * 2, sw.per_round, tol, flag, st));
+            HIP_OK(launch_jacobi_round(W, rows, V, cols, static_cast<int*>(sw.pairs.p) + (size_t)r * sw.per_round * 2, sw.per_round, tol, fro2, flag, st));
         int rotations = 0;
         HIP_OK(hipMemcpyAsync(&rotations, flag, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));

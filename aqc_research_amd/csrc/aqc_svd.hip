@@ -28,10 +28,33 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return r;
 }
 
+// A column whose norm is below 1e-15 of the matrix's Frobenius norm is a numerically zero singular direction (the engine
+// drops singular values below 1e-14 of the largest as rank deficiency anyway) and is left alone: rotating such a column
+// again and again shrinks it geometrically until its norm SQUARED underflows (1e-153 seen on a two-site tensor of a 32-qubit
+// Trotter state with singular values from 0.86 down to 1e-22), where the rotation formulas lose all accuracy, the pair never
+// becomes orthogonal to the relative tolerance and the sweeps never end ("no convergence within 60 sweeps").
+constexpr double kNegligible2 = 1e-30;
+
+// Frobenius norm squared of W (fixed-order sum): the scale of kNegligible2 for the multi-launch / multi-workgroup kernels
+__global__ __launch_bounds__(1024) void svd_fro2_kernel(const cplx* __restrict__ W, size_t n, double* __restrict__ out) {
+    __shared__ double red[16];
+    double a = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) a += W[i].x * W[i].x + W[i].y * W[i].y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[0] = t;
+    }
+}
+
 // One wave per column pair (4 pairs per workgroup): no barriers, the four sums go through one shuffle butterfly.
 __global__ __launch_bounds__(kSvdThreads) void jacobi_round_kernel(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
                                                                    const int2* __restrict__ pairs, int npairs, double tol,
-                                                                   int* __restrict__ rotations) {
+                                                                   const double* __restrict__ fro2, int* __restrict__ rotations) {
     const int lane = threadIdx.x & 63, pair = blockIdx.x * (kSvdThreads / 64) + (threadIdx.x >> 6);
     if (pair >= npairs) return;
     const int2 pq = pairs[pair];
@@ -53,6 +76,7 @@ __global__ __launch_bounds__(kSvdThreads) void jacobi_round_kernel(cplx* __restr
     }
     const double g2 = gr * gr + gi * gi;
     if (g2 <= tol * tol * a * b || g2 == 0.0) return;                    // already orthogonal (or a zero column)
+    if (fmin(a, b) <= kNegligible2 * fro2[0]) return;                    // a numerically zero column: see kNegligible2
     if (lane == 0) atomicAdd(rotations, 1);
     const double g = sqrt(g2);
     const double zeta = (b - a) / (2.0 * g);
@@ -97,10 +121,22 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
     cplx* sw = reinterpret_cast<cplx*>(smem);            // [cols][rows]
     cplx* sv = sw + (size_t)cols * rows;                  // [cols][cols]
     __shared__ int rotated;
+    __shared__ double fro_part[16], fro2;
     const int tid = threadIdx.x, grp = tid >> 5, lane = tid & 31;
-    for (int i = tid; i < rows * cols; i += blockDim.x) sw[i] = W[i];
+    double fr = 0.0;
+    for (int i = tid; i < rows * cols; i += blockDim.x) { const cplx v = W[i]; sw[i] = v; fr += v.x * v.x + v.y * v.y; }
     for (int i = tid; i < cols * cols; i += blockDim.x) sv[i] = make_double2((i / cols) == (i % cols) ? 1.0 : 0.0, 0.0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fr += __shfl_xor(fr, off, 64);
+    if ((tid & 63) == 0) fro_part[tid >> 6] = fr;
     __syncthreads();
+    if (tid == 0) {   // fixed order
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += fro_part[i];
+        fro2 = t;
+    }
+    __syncthreads();
+    const double negligible = kNegligible2 * fro2;
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         if (tid == 0) rotated = 0;
@@ -124,7 +160,7 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
                     gr += __shfl_xor(gr, off, 32); gi += __shfl_xor(gi, off, 32);
                 }
                 const double g2 = gr * gr + gi * gi;
-                if (g2 > tol * tol * a * b && g2 != 0.0) {
+                if (g2 > tol * tol * a * b && g2 != 0.0 && fmin(a, b) > negligible) {
                     if (lane == 0) atomicAdd(&rotated, 1);
                     const double g = sqrt(g2);
                     const double zeta = (b - a) / (2.0 * g);
@@ -171,6 +207,7 @@ struct BlockJacobi {
     const int2* bpairs;   // [rounds][per_round] block pairs; .y = -1: the block plays alone (odd number of blocks)
     int rows, cols, rounds, per_round, max_sweeps;
     double tol;
+    const double* fro2;   // Frobenius norm squared of the matrix (svd_fro2_kernel): scale of kNegligible2
     int* rot;             // [kBlockMaxSweeps] rotations per sweep, zeroed by the host
     unsigned* bar;        // grid barrier counter, zeroed by the host
     int* status;          // [0] sweeps used, [1] != 0: a barrier timed out
@@ -271,7 +308,7 @@ __device__ void block_round(const BlockJacobi& a, int2 bp, bool full, cplx* sw, 
                 gr += __shfl_xor(gr, off, 64); gi += __shfl_xor(gi, off, 64);
             }
             const double g2 = gr * gr + gi * gi;
-            if (g2 > a.tol * a.tol * sa * sb && g2 != 0.0) {
+            if (g2 > a.tol * a.tol * sa * sb && g2 != 0.0 && fmin(sa, sb) > kNegligible2 * a.fro2[0]) {
                 if (lane == 0) atomicAdd(s_rot, 1);
                 const double inv_g = rsqrt(g2);
                 const double zeta = 0.5 * (sb - sa) * inv_g;
@@ -386,8 +423,13 @@ __global__ __launch_bounds__(kBlockThreads) void jacobi_block_kernel(const Block
 
 bool svd_fits_block(int rows, int cols) { return rows <= kBlockMaxRows && cols <= rows && cols >= 2; }
 int svd_block_size() { return kBlk; }
+hipError_t launch_svd_fro2(const void* W, size_t n, double* out, hipStream_t s) {
+    svd_fro2_kernel<<<1, 1024, 0, s>>>(static_cast<const cplx*>(W), n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void* bpairs, int rounds, int per_round, double tol, int max_sweeps,
-                               int* rot, unsigned* bar, int* status, hipStream_t s) {
+                               const double* fro2, int* rot, unsigned* bar, int* status, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -396,7 +438,7 @@ hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void*
         attr_set = true;
     }
     if (max_sweeps > kBlockMaxSweeps) max_sweeps = kBlockMaxSweeps;
-    BlockJacobi a{static_cast<cplx*>(W), static_cast<cplx*>(V), static_cast<const int2*>(bpairs), rows, cols, rounds, per_round, max_sweeps, tol, rot, bar, status, 0};
+    BlockJacobi a{static_cast<cplx*>(W), static_cast<cplx*>(V), static_cast<const int2*>(bpairs), rows, cols, rounds, per_round, max_sweeps, tol, fro2, rot, bar, status, 0};
 #ifdef AQC_TUNING
     if (const char* e = getenv("AQC_SVD_DEBUG")) a.debug = atoi(e);
 #endif
@@ -473,9 +515,10 @@ hipError_t launch_svd_identity(void* V, int cols, hipStream_t s) {
     svd_identity_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<cplx*>(V), cols);
     return hipGetLastError();
 }
-hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, int* rotations, hipStream_t s) {
+hipError_t launch_jacobi_round(void* W, int rows, void* V, int cols, const void* pairs, int npairs, double tol, const double* fro2, int* rotations,
+                               hipStream_t s) {
     jacobi_round_kernel<<<(npairs + kSvdThreads / 64 - 1) / (kSvdThreads / 64), kSvdThreads, 0, s>>>(
-        static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols, static_cast<const int2*>(pairs), npairs, tol, rotations);
+        static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols, static_cast<const int2*>(pairs), npairs, tol, fro2, rotations);
     return hipGetLastError();
 }
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s) {

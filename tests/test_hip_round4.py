@@ -282,3 +282,44 @@ def test_coordinate_descent_one_launch_lanes_and_sweeps(monkeypatch):
         coord_descent_sweeps(big, thb.copy(), ub, 1)
     fb = coord_descent_single_sweep(big, thb, ub, None)   # ... while the reference-signature call runs it on the chain
     assert 0.0 < fb < 1.0
+
+
+def test_jacobi_svd_on_a_graded_two_site_tensor_that_did_not_converge():
+    """tests/golden/svd_graded_26.npz: the 26 x 26 two-site matrix of a 32-qubit Trotter state (singular values from 0.86 down
+    to 1e-22) on which the engine's SVD gave up after 60 sweeps -- rotating a numerically zero column over and over shrank it
+    until its squared norm underflowed.  Columns below 1e-15 of the Frobenius norm are now left alone (all three kernels)."""
+    import os
+
+    from aqc_research_amd.mps_engine import svd
+    from tests.helpers import GOLDEN
+
+    m = np.load(os.path.join(GOLDEN, "svd_graded_26.npz"))["m"]
+    ref = np.linalg.svd(m, compute_uv=False)
+    for a in (m, m.conj().T, np.vstack([m, 1e-3 * m]), np.kron(np.diag([1.0, 1e-9, 1e-18]), m)):   # small / small / small / blocked kernel
+        u, s, vh, sweeps = svd(a)
+        assert 0 < sweeps < 30
+        assert maxdiff((u * s) @ vh, a) < 1e-14
+        good = s > 1e-13 * s[0]
+        assert maxdiff(u[:, good].conj().T @ u[:, good], np.eye(int(good.sum()))) < 1e-11
+    u, s, vh, _ = svd(m)
+    assert maxdiff(s, ref) < 1e-15
+
+
+def test_mps_engine_builds_a_32_qubit_trotter_target_without_truncation():
+    """The walk that hit the non-converging SVD: V|neel> for a 32-qubit 2nd-order Trotter circuit of 6 layers at trunc_thr =
+    1e-12, C-side loop and gate-by-gate calls; norm 1 and equal tensors' bonds on both routes."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd import mps_engine as me
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index
+
+    n = 32
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 6), second_order=True)
+    th = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=1.2, delta=1.0)
+    basis = me.DeviceMPS.basis_state(n, neel_state_index(n))
+    a = me.v_mul_mps(circ, th, basis, trunc_thr=1e-12)
+    b = me._apply_circuit_gatewise(circ, th, basis.clone(), False, 1e-12, 0)
+    assert abs(a.dot(a) - 1.0) < 1e-9 and abs(abs(a.dot(b)) - 1.0) < 1e-9
+    assert a.bond_dims.max() <= 32 and list(a.bond_dims) == list(b.bond_dims)
+    for m in (a, b, basis):
+        m.close()

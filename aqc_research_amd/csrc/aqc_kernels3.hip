@@ -99,6 +99,10 @@ __host__ __device__ constexpr bool sweep_scratch_double(int k) { return k >= 12 
 #define AQC_EXP_APPLY_SKIP 0
 #endif
 constexpr int kApplySkip = AQC_EXP_APPLY_SKIP;
+#ifndef AQC_EXP_SWEEP_SKIP   // the same for the sweep: 64 = no HBM traffic of the w / z tiles (loads, prefetch, stores)
+#define AQC_EXP_SWEEP_SKIP 0
+#endif
+constexpr int kSweepSkip = AQC_EXP_SWEEP_SKIP;
 constexpr int kSweepSpread = AQC_SWEEP_SPREAD, kApplySpread = AQC_APPLY_SPREAD;   // MFMAs between two LDS writes inside a matrix run (sweep / V, V^H)
 template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
     // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             // disjoint bits of the local index, so their tile offsets simply add
             flo16 = tile_offset3(st, swz3(cur.lane12 & 0xffffu)) << 4;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
+            for (int i = 0; i < ((kSweepSkip & 64) ? 0 : NL); ++i) {
                 const size_t ub = off0 + a.first_hi[wave + (i / 4) * NW][i % 4];
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pw[i]) : "v"(flo16), "s"(uniform_ptr(a.in0 + ub)) : "memory");
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(flo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     }
     auto prefetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
+        for (int i = 0; i < ((kSweepSkip & 64) ? 0 : NL); ++i)
             if (i / (NL / 4) == c) {   // scalar base + 32-bit lane offset: no vector address arithmetic
                 const size_t ub = next_off + a.first_hi[wave + (i / 4) * NW][i % 4];
                 // (s_nop: the hazard recogniser does not look inside inline assembly -- a scalar base that was written by
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     // placed after them would sit out their whole write latency; the loads went out sub-stages ago.  (The loads are inline
     // assembly: the register operands tie every later read of the prefetched values to this wait.)
     if (more) wait_prefetched<NL>(pw, pz);
-    if (a.store_out) {   // the last stage's w and z are never read again (only the gradient entries are results)
+    if (a.store_out && !(kSweepSkip & 64)) {   // the last stage's w and z are never read again (only the gradient entries are results)
         store_tile3<K, true>(tw, a.out0 + lane_off, st, lo, wave);
         store_tile3<K, true>(tz, a.out1 + lane_off, st, lo, wave);
     }

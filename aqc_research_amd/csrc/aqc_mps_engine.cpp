@@ -179,6 +179,12 @@ struct aqc_mps {
     std::vector<std::vector<double>> lam;     // n - 1 Schmidt vectors (host copy)
     std::vector<double*> d_lam;               // the same on the device
     Scratch theta, work, vmat, ord, tmp;
+    // Pinned staging of what the host decides per 2-qubit gate (column order, new Schmidt values): two buffers used in turn.
+    // A gate's uploads are asynchronous; the NEXT gate synchronises the stream to read its singular values, so by the time a
+    // buffer is written again (two gates later) the copy out of it has completed -- no synchronisation of its own.
+    void* stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    unsigned stage_turn = 0;
     SvdWork svd;
     double discarded = 0.0;                   // accumulated discarded weight (sum of squared singular values)
     int last_sweeps = 0;
@@ -188,17 +194,37 @@ namespace {
 
 size_t site_elems(const aqc_mps* m, int q) { return (size_t)2 * m->dims[q] * m->dims[q + 1]; }
 
-int set_lambda(aqc_mps* m, int bond, const std::vector<double>& v) {
-    m->lam[bond] = v;
-    if (v.size() > m->lam_cap[bond]) {
+int reserve_lambda(aqc_mps* m, int bond, size_t count) {
+    if (count > m->lam_cap[bond]) {
         HIP_OK(hipStreamSynchronize(m->stream));
         if (m->d_lam[bond]) HIP_OK(hipFree(m->d_lam[bond]));
         m->d_lam[bond] = nullptr;
-        HIP_OK(hipMalloc((void**)&m->d_lam[bond], sizeof(double) * v.size()));
-        m->lam_cap[bond] = v.size();
+        HIP_OK(hipMalloc((void**)&m->d_lam[bond], sizeof(double) * count));
+        m->lam_cap[bond] = count;
     }
+    return 0;
+}
+
+int set_lambda(aqc_mps* m, int bond, const std::vector<double>& v) {
+    m->lam[bond] = v;
+    if (reserve_lambda(m, bond, v.size())) return 1;
     HIP_OK(hipMemcpyAsync(m->d_lam[bond], m->lam[bond].data(), sizeof(double) * v.size(), hipMemcpyHostToDevice, m->stream));
     HIP_OK(hipStreamSynchronize(m->stream));   // the host vector may be replaced by the next gate
+    return 0;
+}
+
+// pinned staging buffer of this gate (see aqc_mps::stage)
+int stage_buffer(aqc_mps* m, size_t bytes, void** out) {
+    const unsigned i = m->stage_turn++ & 1u;
+    if (bytes > m->stage_cap[i]) {
+        HIP_OK(hipStreamSynchronize(m->stream));
+        if (m->stage[i]) HIP_OK(hipHostFree(m->stage[i]));
+        m->stage[i] = nullptr; m->stage_cap[i] = 0;
+        const size_t cap = std::max<size_t>(bytes * 2, 4096);
+        HIP_OK(hipHostMalloc(&m->stage[i], cap, hipHostMallocDefault));
+        m->stage_cap[i] = cap;
+    }
+    *out = m->stage[i];
     return 0;
 }
 
@@ -218,6 +244,7 @@ void destroy(aqc_mps* m) {
     for (double2* p : m->t) if (p) (void)hipFree(p);
     for (double* p : m->d_lam) if (p) (void)hipFree(p);
     m->theta.release(); m->work.release(); m->vmat.release(); m->ord.release(); m->tmp.release(); m->svd.release();
+    for (void* p : m->stage) if (p) (void)hipHostFree(p);
     if (m->stream && m->owns_stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -283,15 +310,23 @@ int gate_adjacent(aqc_mps* m, int q, const double* g16, double trunc_thr, int ma
     // new tensors
     // theta has consumed the old site tensors: the new ones go into the same (grow-only) buffers
     if (reserve_site(m, q, (size_t)rows * k) || reserve_site(m, q + 1, (size_t)k * cols)) return 1;
-    if (m->ord.reserve(sizeof(int) * wcols)) return 1;
-    HIP_OK(hipMemcpyAsync(m->ord.p, ord.data(), sizeof(int) * wcols, hipMemcpyHostToDevice, st));
+    if (m->ord.reserve(sizeof(int) * wcols) || reserve_lambda(m, q, (size_t)k)) return 1;
+    // column order and new Schmidt values go up through the pinned staging buffer of this gate: asynchronous, no wait (the
+    // one synchronisation of a gate is the read-back of its singular values in jacobi_svd)
+    void* stage = nullptr;
+    const size_t lam_off = (sizeof(int) * (size_t)wcols + 15) & ~(size_t)15;
+    if (stage_buffer(m, lam_off + sizeof(double) * (size_t)k, &stage)) return 1;
+    memcpy(stage, ord.data(), sizeof(int) * wcols);
+    double* h_lam = reinterpret_cast<double*>(static_cast<char*>(stage) + lam_off);
+    std::vector<double>& lam = m->lam[q];
+    lam.resize(k);
+    for (int j = 0; j < k; ++j) h_lam[j] = lam[j] = sigma[ord[j]] * rescale;
+    HIP_OK(hipMemcpyAsync(m->ord.p, stage, sizeof(int) * wcols, hipMemcpyHostToDevice, st));
     HIP_OK(launch_mps_split(m->work.p, m->vmat.p, static_cast<int*>(m->ord.p), static_cast<double*>(m->svd.sigma.p), lam_left, chil, chir, k,
                             mode, rescale, m->t[q], m->t[q + 1], st));
-    HIP_OK(hipStreamSynchronize(st));           // `ord` (host vector) goes out of scope
+    HIP_OK(hipMemcpyAsync(m->d_lam[q], h_lam, sizeof(double) * (size_t)k, hipMemcpyHostToDevice, st));
     m->dims[q + 1] = k;
-    std::vector<double> lam(k);
-    for (int j = 0; j < k; ++j) lam[j] = sigma[ord[j]] * rescale;
-    return set_lambda(m, q, lam);
+    return 0;
 }
 
 void permute_gate(const double* g, bool flip, double* out) {   // flip: swap the roles of the two qubits (index 2a+b -> 2b+a)

@@ -386,3 +386,53 @@ def fast_dot_gradient_mps_gatewise(circ, thetas, lvec: DeviceMPS, vh_phi: Device
     w.close()
     z.close()
     return grad
+
+
+# ---- lanes beyond dense reach ---------------------------------------------------------------------------------------
+# Every DeviceMPS owns its stream and every circuit / gradient walk is ONE native call that releases the GIL, so independent
+# problems (the seeds / restarts of a horizon, mps_dot_objective.py:41 called once per job in the reference, job_executor.py:141)
+# run as lanes on host threads: the walks are chains of small dependent launches with one host decision (the truncation rank) per
+# 2-qubit gate, i.e. latency-bound -- concurrent lanes fill the device while one lane waits.
+
+_POOL = None
+
+
+def _pool(workers: int):
+    global _POOL
+    from concurrent.futures import ThreadPoolExecutor
+
+    if _POOL is None or _POOL._max_workers < workers:
+        if _POOL is not None:
+            _POOL.shutdown(wait=True)
+        _POOL = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="aqc-mps-lane")
+    return _POOL
+
+
+def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float = 0.0, max_bond: int = 0,
+                   block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, workers: int = 0):
+    """One objective+gradient evaluation per lane on the native engine: lane b computes vh_b = V(thetas[b])^H |targets[b]>
+    (v_dagger_mul_mps), h_b = <lhs[b]|vh_b> and the complex gradient of <V lhs[b]|targets[b]> (fast_dot_gradient_mps), all lanes
+    concurrently on ``workers`` host threads (default: one per lane, at most 16).  ``targets`` / ``lhs``: one DeviceMPS per lane, or a
+    single one shared by all lanes (operands are only read).  Returns (h[B] complex, grads[B][T] complex)."""
+    th = np.ascontiguousarray(thetas, dtype=np.float64)
+    if th.ndim != 2 or th.shape[1] != circ.num_thetas:
+        raise ValueError("thetas: expects shape (lanes, circ.num_thetas)")
+    lanes = th.shape[0]
+    tg = list(targets) if isinstance(targets, (list, tuple)) else [targets] * lanes
+    lh = list(lhs) if isinstance(lhs, (list, tuple)) else [lhs] * lanes
+    if len(tg) != lanes or len(lh) != lanes:
+        raise ValueError("one target and one lhs state per lane (or one for all)")
+
+    def one(b: int):
+        vh = v_dagger_mul_mps(circ, th[b], tg[b], trunc_thr=trunc_thr, max_bond=max_bond)
+        try:
+            h = lh[b].dot(vh)
+            g = fast_dot_gradient_mps(circ, th[b], lh[b], vh, trunc_thr=trunc_thr, max_bond=max_bond, block_range=block_range,
+                                      front_layer=front_layer)
+        finally:
+            vh.close()
+        return h, g
+
+    nw = min(lanes, workers if workers > 0 else 16)
+    res = [one(0)] if lanes == 1 else list(_pool(nw).map(one, range(lanes)))
+    return np.array([r[0] for r in res], dtype=np.complex128), np.stack([r[1] for r in res])

@@ -55,6 +55,8 @@ WORKLOADS = {
     # coordinate descent (core_op_matrix.coord_descent_single_sweep, docs/aqc.ipynb: 1000 sweeps of the 5-qubit cyclic_spin ansatz):
     # one step = one Gauss-Seidel sweep over all 735 parameters for every lane (lane = random restart with its own target)
     "cd5_cyc180": dict(n=5, blocks=180, kind="cd", ncols=32, desc="5-qubit coordinate descent (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks, 735 parameters): one coord_descent_single_sweep per lane and step, lanes = random restarts with their own target unitary"),
+    # beyond dense reach: the native MPS engine (truncated two-site SVDs on the device, no 2^n buffer anywhere), lanes on host threads
+    "mps32_trotter2_engine": dict(n=32, layers=2, kind="mps_engine", trunc_thr=1e-6, lanes=8, desc="32-qubit ASP, 2nd-order Trotter ansatz (2 layers, 840 parameters), MPS-dot objective+gradient on the native MPS engine at the reference's default trunc_thr = 1e-6 (V^H by truncated two-site SVDs, gate-by-gate gradient), targets = 6-layer Trotter states (bond <= 16)"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
 
@@ -427,6 +429,80 @@ def run_cd(args, w, env, full):
     return out
 
 
+def run_mps_engine(args, w, env, full):
+    """--workload mps32_trotter2_engine: registers beyond dense reach.  One step = one objective+gradient evaluation per lane on the
+    native MPS engine (mps_engine.evaluate_lanes: V^H|target>, <neel|.>, gate-by-gate gradient; mps_dot_objective.py:41-242 with
+    the arithmetic the reference hands to qiskit-aer), thetas changing every step.  Truncated arithmetic: parity-unpinned (qiskit-aer
+    is absent); the check below is the engine against itself at trunc_thr -> 0 through a central difference of the objective."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd import mps_engine as me
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index
+
+    n, layers, thr = w["n"], w["layers"], float(w["trunc_thr"])
+    B = args.batch if args.batch > 0 and full else w["lanes"]
+    K, W = (max(1, min(args.steps, 10)), 1) if full else (2, 1)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, layers), second_order=True)
+    T = circ.num_thetas
+    neel = neel_state_index(n)
+    evol = 0.6 * layers
+    th0 = init_ansatz_to_trotter(circ, np.zeros(T), evol_time=evol, delta=1.0)
+    tcirc = TrotterAnsatz(n, make_trotter_like_circuit(n, 3 * layers), second_order=True)
+    tth = init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=evol, delta=1.0)
+    rng = np.random.default_rng(99 + env.rank)
+    basis = me.DeviceMPS.basis_state(n, neel, device=env.local_rank)
+    targets = []
+    for b in range(B):   # a different target per lane: the Trotter state of slightly different evolution parameters
+        tb = init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=evol * (1.0 + 0.01 * b), delta=1.0)
+        targets.append(me.v_mul_mps(tcirc, tb, basis, trunc_thr=1e-12))
+    bonds = int(max(t.bond_dims.max() for t in targets))
+
+    def thetas(i):
+        return th0[None, :] + 0.02 * np.random.default_rng(1000 * i + env.rank).standard_normal((B, T))
+
+    h, g = me.evaluate_lanes(circ, thetas(0), targets, basis, trunc_thr=thr)
+    # consistency of value and gradient (engine against itself): d|h|^2/dtheta_k by a central difference on lane 0
+    k, eps = 3 * n + 7, 1e-5
+    tp, tm = thetas(0)[0].copy(), thetas(0)[0].copy()
+    tp[k] += eps
+    tm[k] -= eps
+    hp, _ = me.evaluate_lanes(circ, tp[None, :], targets[:1], basis, trunc_thr=thr)
+    hm, _ = me.evaluate_lanes(circ, tm[None, :], targets[:1], basis, trunc_thr=thr)
+    fd = (abs(hp[0]) ** 2 - abs(hm[0]) ** 2) / (2 * eps)
+    an = 2.0 * float(np.real(np.conj(h[0]) * g[0, k]))
+    consistency = abs(fd - an)
+    for i in range(W):
+        me.evaluate_lanes(circ, thetas(1 + i), targets, basis, trunc_thr=thr)
+    env.comm.barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        h, g = me.evaluate_lanes(circ, thetas(10 + i), targets, basis, trunc_thr=thr)
+    env.comm.barrier()
+    wall = time.perf_counter() - t0
+    if env.comm.size > 1:
+        wall = float(env.comm.allreduce(np.array([wall]), "max")[0])
+    t1 = time.perf_counter()
+    me.evaluate_lanes(circ, thetas(50)[:1], targets[:1], basis, trunc_thr=thr)
+    one = time.perf_counter() - t1
+    for m in targets + [basis]:
+        m.close()
+    if env.rank != 0:
+        return None
+    return {
+        "metric": "objective+gradient evals/sec", "value": K * B * env.n_gpus / wall, "unit": "evals/s", "n_gpus": env.n_gpus, "steps": K, "warmup": W,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": w["desc"], "n_qubits": n, "num_thetas": T, "batch_per_gpu": B, "path": "MPS front door (mps_dot_objective), native MPS engine",
+                   "mps_trunc_thr": thr, "target_max_bond": bonds, "mean_fidelity_term": float(np.mean(np.abs(h) ** 2)), "ranks_seen": env.ranks_seen,
+                   "lanes": "host threads, one stream per lane (mps_engine.evaluate_lanes)"},
+        "roofline": None,
+        "parity_maxerr": None, "parity_lanes_checked": 0,
+        "parity_note": "truncated MPS arithmetic is parity-unpinned (qiskit-aer absent); value / gradient consistency of the engine: "
+                       f"|central difference - analytic| = {consistency:.2e} on one parameter",
+        "value_gradient_consistency": consistency,
+        "single_lane": {"ms_per_eval": one * 1e3, "evals_per_s": 1.0 / one},
+    }
+
+
 def ParametricCircuit_for(w):
     return build_circuit(dict(w, kind="cyclic"))
 
@@ -675,7 +751,7 @@ def main():
 # the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
 # MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
 CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
-               "sv20_trotter2", "cfg4_jobs", "mat10_l40"]
+               "sv20_trotter2", "cfg4_jobs", "mat10_l40", "mps32_trotter2_engine"]
 
 
 def brief(o):
@@ -687,7 +763,7 @@ def brief(o):
          "workload": o["config"]["workload"], "roofline_frac": r.get("frac"), "roofline_kernel": r.get("kernel"),
          "sweep_avg_launch_ms": r.get("avg_launch_ms"), "parity_maxerr": o.get("parity_maxerr"),
          "parity_lanes_checked": o.get("parity_lanes_checked")}
-    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane"):
+    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane", "value_gradient_consistency", "parity_note"):
         if k in o:
             b[k] = o[k]
         elif k in o["config"]:
@@ -707,6 +783,8 @@ def measure(workload, args, env, full):
     w = WORKLOADS[workload]
     if w["kind"] == "cd":
         return run_cd(args, w, env, full)
+    if w["kind"] == "mps_engine":
+        return run_mps_engine(args, w, env, full)
     if w["kind"] == "jobs":
         out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=(args.steps if full else 1))
         out["config"]["ranks_seen"] = ranks_seen

@@ -39,6 +39,9 @@ WORKLOADS = {
     "sv20_l40": dict(n=20, blocks=40, kind="generic", desc="20-qubit, 40-block cx spin ansatz, state-vector objective+gradient"),
     "sv20_trotter2": dict(n=20, layers=2, kind="trotter2", desc="20-qubit ASP, 2nd-order Trotter ansatz (2 layers), state-vector objective+gradient"),
     "mat10_l40": dict(n=10, blocks=40, kind="generic", ncols=1024, desc="10-qubit full-unitary AQC (1024x1024 target), cx spin ansatz L=40, matrix objective+gradient"),
+    # sketched AQC (aqc_sketching, docs/aqc.ipynb: 16 sketching vectors): the matrix path on k < d columns -- X = the sketching vectors,
+    # Y = U X (sk_core.py:167-194), here random orthonormal d x 16 blocks
+    "mat10_l40_k16": dict(n=10, blocks=40, kind="generic", ncols=16, desc="10-qubit sketched AQC (16 sketching vectors: 1024x16 matrices), cx spin ansatz L=40, matrix objective+gradient"),
     "mat5_cyc180": dict(n=5, blocks=180, kind="cyclic", ncols=32, desc="5-qubit full AQC (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks), matrix objective+gradient"),
     # config 3 through the MPS front door: every step re-uploads each lane's target as a QiskitMPS (host tensors),
     # contracts it to the dense state on the device (mps_to_vector chain) and runs V^H + gather + sweep on it
@@ -750,7 +753,7 @@ def main():
 
 # the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
 # MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
-CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
+CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "mat10_l40_k16", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
                "sv20_trotter2", "cfg4_jobs", "mat10_l40", "mps32_trotter2_engine"]
 
 
@@ -831,9 +834,9 @@ def measure(workload, args, env, full):
         ws.upload(BUF_Y, targets)
         ws.set_basis(BUF_X, 0)  # x = |0>
         ws.gather_setup(flip_idx)
-    else:  # X = I, Y = random unitary per lane (FullRangeSketchingVectors, sk_core.py:317-326)
-        targets = np.stack([np.linalg.qr(rng.standard_normal((1 << n, ncols)) + 1j * rng.standard_normal((1 << n, ncols)))[0]
-                            for _ in range(B)])
+    else:  # X = I, Y = random unitary per lane (FullRangeSketchingVectors, sk_core.py:317-326); k < d: X = the first k columns of I
+        distinct = [np.linalg.qr(rng.standard_normal((1 << n, ncols)) + 1j * rng.standard_normal((1 << n, ncols)))[0] for _ in range(min(B, 8))]
+        targets = np.stack([distinct[b % len(distinct)] * np.exp(2j * np.pi * b / max(B, 1)) for b in range(B)])   # (a lane's own phase)
         ws.upload(BUF_Y, targets)
         ws.set_identity(BUF_X)
     nsets = min(K + W, 64)       # thetas change every step (nothing is served from a cache); the bank is cycled

@@ -17,41 +17,77 @@ class StagnantOptimizationWarning(UserWarning):
     """No progress of the objective for too many iterations (optimizer.py:30-33)."""
 
 
+class _Deadline:
+    """Wall-clock limit shared by the two timeout classes: whole seconds, rounded up, counted from ``arm()``; a limit <= 0
+    never expires (the reference's convention for "no limit", optimizer.py:52-60,177-186)."""
+
+    def __init__(self, seconds: int):
+        self._seconds, self._at = int(seconds), None
+
+    def arm(self) -> None:
+        self._at = None if self._seconds <= 0 else int(round(perf_counter() + 0.5)) + self._seconds
+
+    def expired(self) -> bool:
+        return self._at is not None and perf_counter() > self._at
+
+
+class _BestSoFar:
+    """Smallest objective seen and the iteration it was seen at: the "no improvement for N iterations" rule of
+    NotImproveStopper (optimizer.py:95-116) and EarlyStopper (:305-318)."""
+
+    def __init__(self, window: int):
+        self.window = int(window)
+        self.clear()
+
+    def clear(self) -> None:
+        self.fobj, self.iteration = np.inf, 0
+
+    def stale(self, fobj: float, iter_no: int) -> bool:
+        """Records ``fobj``; True when nothing better has come for more than ``window`` iterations."""
+        if fobj < self.fobj:
+            self.fobj, self.iteration = fobj, iter_no
+            return False
+        return iter_no - self.iteration > self.window
+
+
 class TimeoutStopper:
+    """Raises TimeoutError once ``time_limit`` seconds have passed since construction (optimizer.py:36-65)."""
+
     def __init__(self, *, time_limit: int):
-        self._end_time = int(round(perf_counter() + time_limit + 0.5)) if time_limit > 0 else -1
+        self._deadline = _Deadline(time_limit)
+        self._deadline.arm()
 
     def check(self):
-        if 0 < self._end_time < perf_counter():
+        if self._deadline.expired():
             raise TimeoutError("Early termination: timeout")
 
 
 class NotImproveStopper:
+    """Flags (or raises StagnantOptimizationWarning on) ``num_iters`` iterations without a new minimum (optimizer.py:68-118)."""
+
     def __init__(self, *, num_iters: int, raise_ex: bool = True):
         if not num_iters > 1:
             raise ValueError("num_iters must be > 1")
-        self._num_iters, self._raise_ex = int(num_iters), bool(raise_ex)
-        self.reset()
+        self._best, self._raise_ex, self._enabled = _BestSoFar(num_iters), bool(raise_ex), True
 
     def reset(self):
-        self._min_fobj, self._min_iteration, self._enabled = np.inf, 0, True
+        self._best.clear()
+        self._enabled = True
 
     def disable(self):
         self._enabled = False
 
     def check(self, fobj: float, iter_no: int) -> bool:
-        if not self._enabled:
+        if not (self._enabled and self._best.stale(fobj, iter_no)):
             return False
-        if fobj < self._min_fobj:
-            self._min_fobj, self._min_iteration = fobj, iter_no
-        elif iter_no - self._min_iteration > self._num_iters:
-            if self._raise_ex:
-                raise StagnantOptimizationWarning("Early termination, no improvement")
-            return True
-        return False
+        if self._raise_ex:
+            raise StagnantOptimizationWarning("Early termination, no improvement")
+        return True
 
 
 class SmallObjectiveStopper:
+    """Raises StopIteration when the objective falls below ``fobj_thr`` (optimizer.py:121-155)."""
+
     def __init__(self, *, fobj_thr: float):
         self._fobj_thr = float(fobj_thr)
 
@@ -61,54 +97,55 @@ class SmallObjectiveStopper:
 
 
 class TimeoutChecker:
-    """Timeout that stores the best result through ``on_stop`` before raising (optimizer.py:158-225)."""
+    """Timeout that stores the best result through ``on_stop`` before raising (optimizer.py:158-225); ``time_limit`` may be
+    the user-parameter dictionary with a "timeout" entry."""
 
     def __init__(self, *, time_limit: Union[int, dict], start_immediately: bool = True):
-        if isinstance(time_limit, dict):
-            time_limit = time_limit.get("timeout", -1)
-        self._time_limit, self._end_time, self._results = int(time_limit), -1, {}
+        seconds = time_limit.get("timeout", -1) if isinstance(time_limit, dict) else time_limit
+        self._deadline, self._results = _Deadline(seconds), {}
         if start_immediately:
             self.start()
 
     def start(self):
-        now = int(round(perf_counter() + 0.5))
-        self._end_time = -1 if self._time_limit <= 0 else now + self._time_limit
+        self._deadline.arm()
 
     def check(self, fobj: float, thetas: np.ndarray, on_stop: Optional[Callable] = None):
-        if 0 < self._end_time < perf_counter():
-            if on_stop is not None:
-                self._results = on_stop(fobj, thetas)
-            raise TimeoutError("early termination: timeout")
+        if not self._deadline.expired():
+            return
+        if on_stop is not None:
+            self._results = on_stop(fobj, thetas)
+        raise TimeoutError("early termination: timeout")
 
     optim_results = property(lambda self: self._results)
 
 
 class EarlyStopper:
-    """Objective / fidelity thresholds and no-improvement window (optimizer.py:228-336)."""
+    """Objective / fidelity thresholds and no-improvement window (optimizer.py:228-336).  The three rules are tried in the
+    reference's order: objective threshold, stagnation (reports the BEST point seen, not the current one), fidelity threshold."""
 
     def __init__(self, fobj_thr: Optional[float] = None, fidelity_thr: Optional[float] = None, num_iters: Optional[int] = None):
         if fidelity_thr is not None and not 0 < fidelity_thr <= 1:
             raise ValueError("fidelity_thr must be in (0, 1]")
         self._fobj_thr, self._fidelity_thr = fobj_thr, fidelity_thr
-        self._early_stop_iters = num_iters if num_iters else -1
-        self._min_fobj, self._min_thetas, self._min_iteration, self._results = np.inf, np.empty(0), 0, {}
+        self._best = _BestSoFar(num_iters) if num_iters else None
+        self._best_thetas, self._results = None, {}
+
+    def _stop(self, on_stop: Callable, fobj, thetas, why: str):
+        self._results = on_stop(fobj, thetas)
+        raise StopIteration(why)
 
     def check(self, fobj, fidelity, thetas: np.ndarray, iter_no: int, on_stop: Callable):
-        if self._min_thetas.size == 0:
-            self._min_thetas = thetas.copy()
         if fobj is not None and self._fobj_thr is not None and fobj < self._fobj_thr:
-            self._results = on_stop(fobj, thetas)
-            raise StopIteration(f"early termination, objective fobj={fobj:0.5f} fell below the threshold={self._fobj_thr:0.5f}")
-        if fobj is not None and self._early_stop_iters > 0:
-            if fobj < self._min_fobj:
-                self._min_fobj, self._min_iteration = fobj, iter_no
-                np.copyto(self._min_thetas, thetas)
-            elif iter_no - self._min_iteration > self._early_stop_iters:
-                self._results = on_stop(self._min_fobj, self._min_thetas)
-                raise StopIteration("Early termination, no improvement")
+            self._stop(on_stop, fobj, thetas, f"early termination, objective fobj={fobj:0.5f} fell below the threshold={self._fobj_thr:0.5f}")
+        if fobj is not None and self._best is not None:
+            improved_before = self._best.fobj
+            if self._best.stale(fobj, iter_no):
+                self._stop(on_stop, self._best.fobj, thetas if self._best_thetas is None else self._best_thetas,
+                           "Early termination, no improvement")
+            if self._best.fobj < improved_before or self._best_thetas is None:
+                self._best_thetas = thetas.copy()
         if fidelity is not None and self._fidelity_thr is not None and fidelity >= self._fidelity_thr:
-            self._results = on_stop(fobj, thetas)
-            raise StopIteration(f"early termination, fidelity={fidelity:0.3f} exceeded the threshold={self._fidelity_thr:0.3f}")
+            self._stop(on_stop, fobj, thetas, f"early termination, fidelity={fidelity:0.3f} exceeded the threshold={self._fidelity_thr:0.3f}")
 
     optim_results = property(lambda self: self._results)
 

@@ -562,3 +562,37 @@ def test_rccl_id_file_of_another_launch_is_not_accepted(tmp_path):
     f.write_bytes(b"\x01" * 128)                       # the tag-less format of earlier rounds is not accepted either
     with pytest.raises(RuntimeError, match="timed out"):
         comm.RcclCommunicator(1, 2, 0, str(f), timeout=0.2, tag="this_launch")
+
+
+def test_early_stopper_rules_in_the_reference_order():
+    """optimizer.py:228-336: objective threshold first, then stagnation -- which reports the BEST point seen, not the current
+    one -- then the fidelity threshold; optimizer.py:36-65,158-225: limits <= 0 never expire, a passed limit raises TimeoutError
+    after handing the current point to ``on_stop``."""
+    from aqc_research_amd import optimizer as opt
+
+    seen = []
+
+    def on_stop(f, t):
+        seen.append((f, t.copy()))
+        return {"cost": f, "thetas": t.copy()}
+
+    es = opt.EarlyStopper(num_iters=2)
+    es.check(0.5, None, np.array([1.0, 1.0]), 0, on_stop)
+    es.check(0.3, None, np.array([2.0, 2.0]), 1, on_stop)       # the best point
+    es.check(0.4, None, np.array([3.0, 3.0]), 2, on_stop)
+    es.check(0.35, None, np.array([4.0, 4.0]), 3, on_stop)
+    with pytest.raises(StopIteration, match="no improvement"):
+        es.check(0.45, None, np.array([5.0, 5.0]), 4, on_stop)
+    assert es.optim_results["cost"] == 0.3 and np.all(es.optim_results["thetas"] == 2.0)
+    es = opt.EarlyStopper(fobj_thr=0.1, fidelity_thr=0.5)
+    with pytest.raises(StopIteration, match="fell below"):      # both rules fire: the objective threshold is tried first
+        es.check(0.05, 0.9, np.zeros(2), 0, on_stop)
+    with pytest.raises(ValueError):
+        opt.EarlyStopper(fidelity_thr=1.5)
+    opt.TimeoutStopper(time_limit=-1).check()
+    tc = opt.TimeoutChecker(time_limit={"timeout": 1}, start_immediately=False)
+    tc.check(1.0, np.zeros(1))                                   # not started: never expires
+    tc._deadline._at = 0                                         # (a deadline in the past)
+    with pytest.raises(TimeoutError):
+        tc.check(0.7, np.ones(1), on_stop)
+    assert tc.optim_results["cost"] == 0.7

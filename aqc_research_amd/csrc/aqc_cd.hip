@@ -6,6 +6,7 @@
 // with no host round trip in between.
 #include <hip/hip_runtime.h>
 
+#include "aqc_lanes.h"
 #include "aqc_launch.h"
 
 namespace aqc {
@@ -187,46 +188,6 @@ __device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
     pc = fma(pc, x2, -0.5);                           // -1/2!
     s = fma(ps * x2, x, x);
     c = fma(pc, x2, 1.0);
-}
-
-// lane exchanges of the wave reduction on the vector ALU (no LDS crossbar, no lgkmcnt waits on the critical path of a step):
-// data-parallel-primitive moves inside a row of 16 lanes, gfx950's row / half swaps across rows
-template <int CTRL>
-__device__ __forceinline__ double dpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// v_permlane16_swap (v, v): first result = rows (0, 0, 2, 2) of v, second = rows (1, 1, 3, 3): their sum is v[l] + v[l ^ 16];
-// v_permlane32_swap (v, v): first = halves (0, 0), second = halves (1, 1): sum = v[l] + v[l ^ 32]
-__device__ __forceinline__ double add_xor16(double v) {
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double add_xor32(double v) {
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-// Sums of four per-lane values over the wave in 7 exchange steps instead of 24: the first two steps hand half of the values to
-// the partner lane while adding the other half (lane bit 0 ends up with the {g, p} choice, bit 1 with {re, im}), the other four
-// add within the lanes of equal low bits.  Afterwards lane l holds the wave's total of value (l & 3): 0 gr, 1 pr, 2 gi, 3 pi.
-__device__ __forceinline__ double wave_sum4(double gr, double gi, double pr, double pi, int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    // step xor 1: even lanes keep (gr, gi), odd lanes keep (pr, pi)
-    const double s0 = b0 ? gr : pr, s1 = b0 ? gi : pi;            // what goes to the partner
-    double k0 = b0 ? pr : gr, k1 = b0 ? pi : gi;                 // what stays
-    k0 += dpp<0xB1>(s0);                       // quad_perm [1, 0, 3, 2]: lane ^ 1
-    k1 += dpp<0xB1>(s1);
-    // step xor 2: bit 1 clear keeps the real part, set keeps the imaginary part
-    double v = (b1 ? k1 : k0) + dpp<0x4E>(b1 ? k0 : k1);   // quad_perm [2, 3, 0, 1]: lane ^ 2
-    v += dpp<0x124>(v);                        // row_ror:4 and row_ror:8: the four lanes of equal (lane & 3) in a row of 16
-    v += dpp<0x128>(v);
-    v = add_xor16(v);
-    v = add_xor32(v);
-    return v;
 }
 
 // rotation of the thread's two pairs: (0,1),(2,3) for a gate on bit a, (0,2),(1,3) on bit b

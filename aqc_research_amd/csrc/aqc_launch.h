@@ -183,13 +183,19 @@ hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, con
                                double* s_sorted, hipStream_t s);
 bool svd_fits_small(int rows, int cols);
 hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
-                               int* sweeps_out, hipStream_t s);
+                               int* sweeps_out, double* sigma_out, hipStream_t s);   // sigma_out (may be null): the column norms at the end
 bool svd_fits_block(int rows, int cols);
 int svd_block_size();
 hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void* bpairs, int rounds, int per_round, double tol, int max_sweeps,
                                const double* fro2, int* rot, unsigned* bar, int* status, hipStream_t s);
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
 hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
+// environment steps of <(ops) w|z> for small bonds, one launch per site (aqc_svd.hip); gh8: 2x2 (row-major, 4 c128) applied to z's site or null
+bool mps_env_fits_small(int xa, int ua, int yb, int vb);
+hipError_t launch_mps_env_left(const void* in, const void* A, const void* B, int xa, int ua, int yb, int vb, const double* gh8, void* out, hipStream_t s);
+hipError_t launch_mps_env_right(const void* rc, const void* A, const void* B, int xa, int ua, int yb, int vb, void* out, hipStream_t s);
+hipError_t launch_mps_theta_fused(const void* tq, const void* tq1, const double* lam_left, int chil, int chim, int chir, const double* g16, int mode,
+                                  void* work, hipStream_t s);   // the same from the two site tensors (small bonds: no zgemm launches)
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,
                             int k, int mode, double rescale, void* tq, void* tq1, hipStream_t s);
 hipError_t launch_mps_colscale(void* t, const double* lam, size_t rows, int cols, int mul, hipStream_t s);

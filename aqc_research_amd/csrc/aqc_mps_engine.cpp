@@ -132,7 +132,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
     int sweeps = 0;
     int status[2] = {0, 0};
     if (small) {   // one launch: matrix and V live in the LDS of one workgroup
-        HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, st));
+        HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, static_cast<double*>(sw.sigma.p), st));
         HIP_OK(hipMemcpyAsync(&sweeps, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     } else if (blocked) {   // one cooperative launch: persistent workgroups, 16 columns at a time in LDS
         HIP_OK(launch_svd_identity(V, cols, st));
@@ -154,7 +154,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         if (rotations == 0) { ++sweeps; break; }
     }
     h_sigma.resize(cols);
-    HIP_OK(launch_svd_norms(W, rows, cols, static_cast<double*>(sw.sigma.p), st));
+    if (!small) HIP_OK(launch_svd_norms(W, rows, cols, static_cast<double*>(sw.sigma.p), st));   // (the one-launch kernel delivers them itself)
     HIP_OK(hipMemcpyAsync(h_sigma.data(), sw.sigma.p, sizeof(double) * cols, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     if (blocked) {
@@ -273,17 +273,21 @@ int gate_adjacent(aqc_mps* m, int q, const double* g16, double trunc_thr, int ma
     const int chil = m->dims[q], chim = m->dims[q + 1], chir = m->dims[q + 2];
     const int rows = 2 * chil, cols = 2 * chir;
     hipStream_t st = m->stream;
-    if (m->theta.reserve(sizeof(double2) * (size_t)rows * cols)) return 1;
-    // theta0[(a,l), (b,r)] = sum_m T_q[(a,l), m] T_{q+1}[b][m][r]
-    for (int b = 0; b < 2; ++b)
-        HIP_OK(launch_zgemm(false, false, rows, chir, chim, m->t[q], chim, m->t[q + 1] + (size_t)b * chim * chir, chir,
-                            static_cast<double2*>(m->theta.p) + (size_t)b * chir, cols, st));
     // Jacobi runs on the side with fewer columns
     const int mode = cols <= rows ? 0 : 1;
     const int wrows = mode == 0 ? rows : cols, wcols = mode == 0 ? cols : rows;
     if (m->work.reserve(sizeof(double2) * (size_t)wrows * wcols) || m->vmat.reserve(sizeof(double2) * (size_t)wcols * wcols)) return 1;
     const double* lam_left = q > 0 ? m->d_lam[q - 1] : nullptr;
-    HIP_OK(launch_mps_theta(m->theta.p, lam_left, chil, chir, g16, mode, m->work.p, st));
+    if (chim <= 64 && (size_t)chil * chir <= 4096) {   // small bonds: product, scaling and gate in one launch
+        HIP_OK(launch_mps_theta_fused(m->t[q], m->t[q + 1], lam_left, chil, chim, chir, g16, mode, m->work.p, st));
+    } else {
+        if (m->theta.reserve(sizeof(double2) * (size_t)rows * cols)) return 1;
+        // theta0[(a,l), (b,r)] = sum_m T_q[(a,l), m] T_{q+1}[b][m][r]
+        for (int b = 0; b < 2; ++b)
+            HIP_OK(launch_zgemm(false, false, rows, chir, chim, m->t[q], chim, m->t[q + 1] + (size_t)b * chim * chir, chir,
+                                static_cast<double2*>(m->theta.p) + (size_t)b * chir, cols, st));
+        HIP_OK(launch_mps_theta(m->theta.p, lam_left, chil, chir, g16, mode, m->work.p, st));
+    }
     std::vector<double> sigma;
     if (jacobi_svd(m->svd, m->work.p, wrows, m->vmat.p, wcols, st, sigma, &m->last_sweeps)) return 1;
     // order, rank and truncation (host: wcols numbers)
@@ -474,6 +478,13 @@ struct Environments {
     // out[u][v] = sum_bit sum_xy conj(A_p[bit][x][u]) in[x][y] B_p[bit][y][v]
     int step_left(int p, const void* in, const M2* op, Scratch& out) {
         const int xa = w->dims[p], ua = w->dims[p + 1], yb = z->dims[p], vb = z->dims[p + 1];
+        if (mps_env_fits_small(xa, ua, yb, vb)) {   // small bonds: one launch, the operator folded in
+            if (out.reserve(sizeof(double2) * (size_t)ua * vb)) return 1;
+            double g8[8];
+            if (op) { const M2 gh = {{std::conj(op->m[0]), std::conj(op->m[2]), std::conj(op->m[1]), std::conj(op->m[3])}}; pack(gh, g8); }
+            HIP_OK(launch_mps_env_left(in, w->t[p], z->t[p], xa, ua, yb, vb, op ? g8 : nullptr, out.p, st));
+            return 0;
+        }
         const double2* bq = nullptr;
         if (z_site(p, op, &bq)) return 1;
         if (t.reserve(sizeof(double2) * (size_t)xa * vb) || out.reserve(sizeof(double2) * (size_t)ua * vb)) return 1;
@@ -486,6 +497,11 @@ struct Environments {
     // Rc[p-1][x][y] = sum_bit A_p[bit][x][u] (Rc[p] B_p[bit]^H)[u][y]
     int step_right(int p) {
         const int xa = w->dims[p], ua = w->dims[p + 1], yb = z->dims[p], vb = z->dims[p + 1];
+        if (mps_env_fits_small(xa, ua, yb, vb)) {
+            if (R[p - 1].reserve(sizeof(double2) * (size_t)xa * yb)) return 1;
+            HIP_OK(launch_mps_env_right(R[p].p, w->t[p], z->t[p], xa, ua, yb, vb, R[p - 1].p, st));
+            return 0;
+        }
         if (t.reserve(sizeof(double2) * (size_t)ua * yb) || R[p - 1].reserve(sizeof(double2) * (size_t)xa * yb)) return 1;
         for (int bit = 0; bit < 2; ++bit) {
             HIP_OK(launch_zgemm_bh(false, false, ua, yb, vb, R[p].p, vb, z->t[p] + (size_t)bit * yb * vb, vb, t.p, yb, st));

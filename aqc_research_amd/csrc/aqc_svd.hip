@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 
+#include "aqc_lanes.h"
 #include "aqc_launch.h"
 #include "aqc_math.h"
 
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(kSvdThreads) void svd_norms_kernel(const cplx* __re
 constexpr int kSmallMax = 64;
 __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
                                                             const int2* __restrict__ pairs, int rounds, int per_round, double tol,
-                                                            int max_sweeps, int* __restrict__ sweeps_out) {
+                                                            int max_sweeps, int* __restrict__ sweeps_out, double* __restrict__ sigma_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* sw = reinterpret_cast<cplx*>(smem);            // [cols][rows]
     cplx* sv = sw + (size_t)cols * rows;                  // [cols][cols]
     __shared__ int rotated;
     __shared__ double fro_part[16], fro2;
-    const int tid = threadIdx.x, grp = tid >> 5, lane = tid & 31;
+    const int tid = threadIdx.x, grp = tid >> 5, lane = tid & 31;   // (blockDim = 32 per_round rounded up to whole waves)
     double fr = 0.0;
     for (int i = tid; i < rows * cols; i += blockDim.x) { const cplx v = W[i]; sw[i] = v; fr += v.x * v.x + v.y * v.y; }
     for (int i = tid; i < cols * cols; i += blockDim.x) sv[i] = make_double2((i / cols) == (i % cols) ? 1.0 : 0.0, 0.0);
@@ -154,10 +155,10 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
                     gr += x.x * y.x + x.y * y.y;
                     gi += x.x * y.y - x.y * y.x;
                 }
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {   // butterfly inside the half-wave: every lane gets the totals
-                    a += __shfl_xor(a, off, 32); b += __shfl_xor(b, off, 32);
-                    gr += __shfl_xor(gr, off, 32); gi += __shfl_xor(gi, off, 32);
+                {   // the four sums over the half-wave in 6 exchange steps on the vector ALU (aqc_lanes.h; it was a 5-step
+                    // butterfly of four values through the LDS crossbar: 40 ds_bpermute per round), then every lane takes all four
+                    const double v = halfwave_sum4(a, b, gr, gi, lane);   // slots of a quad: 0 a, 1 gr, 2 b, 3 gi
+                    a = quad_bcast<0>(v); gr = quad_bcast<1>(v); b = quad_bcast<2>(v); gi = quad_bcast<3>(v);
                 }
                 const double g2 = gr * gr + gi * gi;
                 if (g2 > tol * tol * a * b && g2 != 0.0 && fmin(a, b) > negligible) {
@@ -187,6 +188,12 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
     }
     for (int i = tid; i < rows * cols; i += blockDim.x) W[i] = sw[i];
     for (int i = tid; i < cols * cols; i += blockDim.x) V[i] = sv[i];
+    if (sigma_out)   // the column norms = singular values, while the columns are still in LDS (it was a launch of its own); fixed order
+        for (int c = tid; c < cols; c += blockDim.x) {
+            double a = 0.0;
+            for (int i = 0; i < rows; ++i) { const cplx x = sw[(size_t)c * rows + i]; a += x.x * x.x + x.y * x.y; }
+            sigma_out[c] = sqrt(a);
+        }
     if (tid == 0) *sweeps_out = sweep;
 }
 
@@ -496,7 +503,7 @@ hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, con
 
 bool svd_fits_small(int rows, int cols) { return rows <= kSmallMax && cols <= kSmallMax && cols >= 2; }
 hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
-                               int* sweeps_out, hipStream_t s) {
+                               int* sweeps_out, double* sigma_out, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -505,8 +512,9 @@ hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void*
         attr_set = true;
     }
     const size_t lds = sizeof(cplx) * ((size_t)cols * rows + (size_t)cols * cols);
-    jacobi_small_kernel<<<1, 1024, lds, s>>>(static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols, static_cast<const int2*>(pairs), rounds,
-                                             per_round, tol, max_sweeps, sweeps_out);
+    const int threads = std::min(1024, std::max(64, (32 * per_round + 63) & ~63));   // a half-wave per column pair of a round: no idle waves at the barrier
+    jacobi_small_kernel<<<1, threads, lds, s>>>(static_cast<cplx*>(W), rows, static_cast<cplx*>(V), cols, static_cast<const int2*>(pairs), rounds,
+                                             per_round, tol, max_sweeps, sweeps_out, sigma_out);
     return hipGetLastError();
 }
 
@@ -572,6 +580,53 @@ __global__ void mps_theta_kernel(const cplx* __restrict__ theta0, const double* 
         }
 }
 
+// The same with the product T_q . [T_{q+1}[0] | T_{q+1}[1]] formed on the fly (small bonds: the two zgemm launches that produced theta0
+// cost more than the arithmetic): one thread per (l, r) takes its four length-chi_m dot products, scales, applies the gate and writes the
+// Jacobi work matrix.  tq: [2][chi_l][chi_m], tq1: [2][chi_m][chi_r].
+__global__ void mps_theta_fused_kernel(const cplx* __restrict__ tq, const cplx* __restrict__ tq1, const double* __restrict__ lam_left, int chil,
+                                       int chim, int chir, Gate16 g, int mode, cplx* __restrict__ work) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= chil * chir) return;
+    const int l = idx / chir, r = idx - l * chir;
+    const int m = 2 * chil, n = 2 * chir;
+    const double sc = lam_left ? lam_left[l] : 1.0;
+    cplx in[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const cplx* x = tq + ((size_t)a * chil + l) * chim;
+            const cplx* y = tq1 + (size_t)b * chim * chir + r;
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < chim; ++k) {
+                const cplx u = x[k], v = y[(size_t)k * chir];
+                re += u.x * v.x - u.y * v.y;
+                im += u.x * v.y + u.y * v.x;
+            }
+            in[2 * a + b] = make_double2(sc * re, sc * im);
+        }
+    cplx out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            re += g.m[4 * i + j].x * in[j].x - g.m[4 * i + j].y * in[j].y;
+            im += g.m[4 * i + j].x * in[j].y + g.m[4 * i + j].y * in[j].x;
+        }
+        out[i] = make_double2(re, im);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const size_t row = a * chil + l, col = b * chir + r;
+            const cplx v = out[2 * a + b];
+            if (mode == 0) work[col * m + row] = v;
+            else work[row * n + col] = make_double2(v.x, -v.y);
+        }
+}
+
 // New site tensors from the converged Jacobi pair (W, V), keeping columns ord[0..k):
 // mode 0: W = theta' Vj  =>  U S = W, V^H = Vj^H;   mode 1: W = theta'^H Vj  =>  U = Vj, S V^H = W^H.
 // T_q'[a][l][j] = (U S)[(a,l), j] / lam_left[l];  T_{q+1}'[b][j][r] = V^H[j, (b,r)]  (lambda_{q+1} is already inside).
@@ -614,6 +669,101 @@ hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil
     for (int i = 0; i < 16; ++i) g.m[i] = make_double2(g16[2 * i], g16[2 * i + 1]);
     const int total = chil * chir;
     mps_theta_kernel<<<(total + 255) / 256, 256, 0, s>>>(static_cast<const cplx*>(theta0), lam_left, chil, chir, g, mode, static_cast<cplx*>(work));
+    return hipGetLastError();
+}
+// ---- environment steps of <(ops) w|z> for small bonds (every dimension <= 64): ONE launch per site instead of four zgemms (+ one
+// gate1q when an operator sits on the site).  One workgroup; the intermediate of a bit lives in LDS.
+struct Gate4c { cplx m[4]; };
+// out[u][v] = sum_bit sum_x conj(A[bit][x][u]) (sum_y in[x][y] B'[bit][y][v]),  B'[bit] = B[bit], or gh[bit][0] B[0] + gh[bit][1] B[1]
+__global__ __launch_bounds__(256) void mps_env_left_kernel(const cplx* __restrict__ in, const cplx* __restrict__ A, const cplx* __restrict__ B,
+                                                           int xa, int ua, int yb, int vb, int has_op, Gate4c gh, cplx* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char env_smem[];
+    cplx* t = reinterpret_cast<cplx*>(env_smem);   // [xa][vb]
+    const int tid = threadIdx.x;
+    for (int bit = 0; bit < 2; ++bit) {
+        for (int e = tid; e < xa * vb; e += 256) {
+            const int x = e / vb, v = e - x * vb;
+            double re = 0.0, im = 0.0;
+            for (int y = 0; y < yb; ++y) {
+                const cplx a = in[(size_t)x * yb + y];
+                cplx b = B[((size_t)bit * yb + y) * vb + v];
+                if (has_op) {
+                    const cplx b0 = B[(size_t)y * vb + v], b1 = B[((size_t)yb + y) * vb + v], g0 = gh.m[2 * bit], g1 = gh.m[2 * bit + 1];
+                    b = make_double2(g0.x * b0.x - g0.y * b0.y + g1.x * b1.x - g1.y * b1.y, g0.x * b0.y + g0.y * b0.x + g1.x * b1.y + g1.y * b1.x);
+                }
+                re += a.x * b.x - a.y * b.y;
+                im += a.x * b.y + a.y * b.x;
+            }
+            t[e] = make_double2(re, im);
+        }
+        __syncthreads();
+        for (int e = tid; e < ua * vb; e += 256) {
+            const int u = e / vb, v = e - u * vb;
+            double re = 0.0, im = 0.0;
+            if (bit) { const cplx o = out[e]; re = o.x; im = o.y; }   // (written by this very thread in the first pass)
+            for (int x = 0; x < xa; ++x) {
+                const cplx a = A[((size_t)bit * xa + x) * ua + u], b = t[x * vb + v];
+                re += a.x * b.x + a.y * b.y;      // conj(a) b
+                im += a.x * b.y - a.y * b.x;
+            }
+            out[e] = make_double2(re, im);
+        }
+        __syncthreads();
+    }
+}
+// out[x][y] = sum_bit sum_u A[bit][x][u] (sum_v Rc[u][v] conj(B[bit][y][v]))
+__global__ __launch_bounds__(256) void mps_env_right_kernel(const cplx* __restrict__ rc, const cplx* __restrict__ A, const cplx* __restrict__ B,
+                                                            int xa, int ua, int yb, int vb, cplx* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char env_smem[];
+    cplx* t = reinterpret_cast<cplx*>(env_smem);   // [ua][yb]
+    const int tid = threadIdx.x;
+    for (int bit = 0; bit < 2; ++bit) {
+        for (int e = tid; e < ua * yb; e += 256) {
+            const int u = e / yb, y = e - u * yb;
+            double re = 0.0, im = 0.0;
+            for (int v = 0; v < vb; ++v) {
+                const cplx a = rc[(size_t)u * vb + v], b = B[((size_t)bit * yb + y) * vb + v];
+                re += a.x * b.x + a.y * b.y;      // a conj(b)
+                im += a.y * b.x - a.x * b.y;
+            }
+            t[e] = make_double2(re, im);
+        }
+        __syncthreads();
+        for (int e = tid; e < xa * yb; e += 256) {
+            const int x = e / yb, y = e - x * yb;
+            double re = 0.0, im = 0.0;
+            if (bit) { const cplx o = out[e]; re = o.x; im = o.y; }
+            for (int u = 0; u < ua; ++u) {
+                const cplx a = A[((size_t)bit * xa + x) * ua + u], b = t[u * yb + y];
+                re += a.x * b.x - a.y * b.y;
+                im += a.x * b.y + a.y * b.x;
+            }
+            out[e] = make_double2(re, im);
+        }
+        __syncthreads();
+    }
+}
+bool mps_env_fits_small(int xa, int ua, int yb, int vb) { return xa <= 64 && ua <= 64 && yb <= 64 && vb <= 64; }
+hipError_t launch_mps_env_left(const void* in, const void* A, const void* B, int xa, int ua, int yb, int vb, const double* gh8, void* out, hipStream_t s) {
+    Gate4c g;
+    for (int i = 0; i < 4; ++i) g.m[i] = gh8 ? make_double2(gh8[2 * i], gh8[2 * i + 1]) : make_double2(0.0, 0.0);
+    mps_env_left_kernel<<<1, 256, sizeof(cplx) * (size_t)xa * vb, s>>>(static_cast<const cplx*>(in), static_cast<const cplx*>(A), static_cast<const cplx*>(B),
+                                                                       xa, ua, yb, vb, gh8 ? 1 : 0, g, static_cast<cplx*>(out));
+    return hipGetLastError();
+}
+hipError_t launch_mps_env_right(const void* rc, const void* A, const void* B, int xa, int ua, int yb, int vb, void* out, hipStream_t s) {
+    mps_env_right_kernel<<<1, 256, sizeof(cplx) * (size_t)ua * yb, s>>>(static_cast<const cplx*>(rc), static_cast<const cplx*>(A), static_cast<const cplx*>(B),
+                                                                        xa, ua, yb, vb, static_cast<cplx*>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_mps_theta_fused(const void* tq, const void* tq1, const double* lam_left, int chil, int chim, int chir, const double* g16, int mode,
+                                  void* work, hipStream_t s) {
+    Gate16 g;
+    for (int i = 0; i < 16; ++i) g.m[i] = make_double2(g16[2 * i], g16[2 * i + 1]);
+    const int total = chil * chir;
+    mps_theta_fused_kernel<<<(total + 127) / 128, 128, 0, s>>>(static_cast<const cplx*>(tq), static_cast<const cplx*>(tq1), lam_left, chil, chim, chir, g,
+                                                               mode, static_cast<cplx*>(work));
     return hipGetLastError();
 }
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,

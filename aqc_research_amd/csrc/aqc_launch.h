@@ -197,7 +197,7 @@ hipError_t launch_mps_env_right(const void* rc, const void* A, const void* B, in
 hipError_t launch_mps_theta_fused(const void* tq, const void* tq1, const double* lam_left, int chil, int chim, int chir, const double* g16, int mode,
                                   void* work, hipStream_t s);   // the same from the two site tensors (small bonds: no zgemm launches)
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,
-                            int k, int mode, double rescale, void* tq, void* tq1, hipStream_t s);
+                            int k, int mode, double rescale, void* tq, void* tq1, const double* lam_new, double* lam_dst, hipStream_t s);   // lam_new (device, may be null) -> lam_dst[0..k)
 hipError_t launch_mps_colscale(void* t, const double* lam, size_t rows, int cols, int mul, hipStream_t s);
 
 }  // namespace aqc

@@ -125,7 +125,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         sw.cached_blocked = (int)blocked;
     }
     constexpr int kFlagInts = 64 + 4;   // [0..63] rotations per sweep | [64] barrier | [65] sweeps used | [66] barrier timeout
-    if (sw.flag.reserve(sizeof(int) * kFlagInts) || sw.sigma.reserve(sizeof(double) * (std::max(cols, 1) + 1))) return 1;
+    if (sw.flag.reserve(sizeof(int) * kFlagInts) || sw.sigma.reserve(sizeof(double) * (std::max(cols, 1) + 2))) return 1;   // sigma | fro2 | sweeps
     double* fro2 = static_cast<double*>(sw.sigma.p) + std::max(cols, 1);   // scale of the negligible-column rule (aqc_svd.hip: kNegligible2)
     int* flag = static_cast<int*>(sw.flag.p);
     const double tol = 1e-15;
@@ -133,7 +133,6 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
     int status[2] = {0, 0};
     if (small) {   // one launch: matrix and V live in the LDS of one workgroup
         HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, static_cast<double*>(sw.sigma.p), st));
-        HIP_OK(hipMemcpyAsync(&sweeps, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     } else if (blocked) {   // one cooperative launch: persistent workgroups, 16 columns at a time in LDS
         HIP_OK(launch_svd_identity(V, cols, st));
         HIP_OK(launch_svd_fro2(W, (size_t)rows * cols, fro2, st));
@@ -153,10 +152,12 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
         HIP_OK(hipStreamSynchronize(st));
         if (rotations == 0) { ++sweeps; break; }
     }
-    h_sigma.resize(cols);
+    h_sigma.resize(cols + 2);
     if (!small) HIP_OK(launch_svd_norms(W, rows, cols, static_cast<double*>(sw.sigma.p), st));   // (the one-launch kernel delivers them itself)
-    HIP_OK(hipMemcpyAsync(h_sigma.data(), sw.sigma.p, sizeof(double) * cols, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_sigma.data(), sw.sigma.p, sizeof(double) * (small ? cols + 2 : cols), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    if (small) sweeps = (int)h_sigma[cols + 1];   // the sweep count came with the singular values
+    h_sigma.resize(cols);
     if (blocked) {
         if (status[1] != 0) return failf("Jacobi SVD: a grid barrier of the persistent kernel timed out (%d x %d)", rows, cols);
         sweeps = status[0];
@@ -314,21 +315,22 @@ int gate_adjacent(aqc_mps* m, int q, const double* g16, double trunc_thr, int ma
     // new tensors
     // theta has consumed the old site tensors: the new ones go into the same (grow-only) buffers
     if (reserve_site(m, q, (size_t)rows * k) || reserve_site(m, q + 1, (size_t)k * cols)) return 1;
-    if (m->ord.reserve(sizeof(int) * wcols) || reserve_lambda(m, q, (size_t)k)) return 1;
+    const size_t lam_off = (sizeof(int) * (size_t)wcols + 15) & ~(size_t)15;
+    if (m->ord.reserve(lam_off + sizeof(double) * (size_t)wcols) || reserve_lambda(m, q, (size_t)k)) return 1;
     // column order and new Schmidt values go up through the pinned staging buffer of this gate: asynchronous, no wait (the
     // one synchronisation of a gate is the read-back of its singular values in jacobi_svd)
     void* stage = nullptr;
-    const size_t lam_off = (sizeof(int) * (size_t)wcols + 15) & ~(size_t)15;
     if (stage_buffer(m, lam_off + sizeof(double) * (size_t)k, &stage)) return 1;
     memcpy(stage, ord.data(), sizeof(int) * wcols);
     double* h_lam = reinterpret_cast<double*>(static_cast<char*>(stage) + lam_off);
     std::vector<double>& lam = m->lam[q];
     lam.resize(k);
     for (int j = 0; j < k; ++j) h_lam[j] = lam[j] = sigma[ord[j]] * rescale;
-    HIP_OK(hipMemcpyAsync(m->ord.p, stage, sizeof(int) * wcols, hipMemcpyHostToDevice, st));
+    // ONE upload (column order | new Schmidt values); the split kernel copies the latter into the bond's vector
+    HIP_OK(hipMemcpyAsync(m->ord.p, stage, lam_off + sizeof(double) * (size_t)k, hipMemcpyHostToDevice, st));
     HIP_OK(launch_mps_split(m->work.p, m->vmat.p, static_cast<int*>(m->ord.p), static_cast<double*>(m->svd.sigma.p), lam_left, chil, chir, k,
-                            mode, rescale, m->t[q], m->t[q + 1], st));
-    HIP_OK(hipMemcpyAsync(m->d_lam[q], h_lam, sizeof(double) * (size_t)k, hipMemcpyHostToDevice, st));
+                            mode, rescale, m->t[q], m->t[q + 1], reinterpret_cast<const double*>(static_cast<const char*>(m->ord.p) + lam_off),
+                            m->d_lam[q], st));
     m->dims[q + 1] = k;
     return 0;
 }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
             for (int i = 0; i < rows; ++i) { const cplx x = sw[(size_t)c * rows + i]; a += x.x * x.x + x.y * x.y; }
             sigma_out[c] = sqrt(a);
         }
-    if (tid == 0) *sweeps_out = sweep;
+    if (tid == 0) { *sweeps_out = sweep; if (sigma_out) sigma_out[cols + 1] = (double)sweep; }   // (behind sigma and fro2: one read-back for the host)
 }
 
 // Two-level (block) Jacobi for work matrices beyond one workgroup's LDS (64 < columns, rows <= 512: bond dimensions
@@ -632,9 +632,11 @@ __global__ void mps_theta_fused_kernel(const cplx* __restrict__ tq, const cplx* 
 // T_q'[a][l][j] = (U S)[(a,l), j] / lam_left[l];  T_{q+1}'[b][j][r] = V^H[j, (b,r)]  (lambda_{q+1} is already inside).
 __global__ void mps_split_kernel(const cplx* __restrict__ W, const cplx* __restrict__ V, const int* __restrict__ ord,
                                  const double* __restrict__ sigma, const double* __restrict__ lam_left, int chil, int chir, int k,
-                                 int mode, double rescale, cplx* __restrict__ tq, cplx* __restrict__ tq1) {
+                                 int mode, double rescale, cplx* __restrict__ tq, cplx* __restrict__ tq1,
+                                 const double* __restrict__ lam_new, double* __restrict__ lam_dst) {
     const int m = 2 * chil, n = 2 * chir;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lam_new && idx < (size_t)k) lam_dst[idx] = lam_new[idx];   // the bond's new Schmidt values ride along (they were an upload of their own)
     const size_t n_left = (size_t)m * k, n_right = (size_t)k * n;
     if (idx < n_left) {
         const int row = (int)(idx / k), j = (int)(idx - (size_t)row * k);
@@ -767,10 +769,11 @@ hipError_t launch_mps_theta_fused(const void* tq, const void* tq1, const double*
     return hipGetLastError();
 }
 hipError_t launch_mps_split(const void* W, const void* V, const int* ord, const double* sigma, const double* lam_left, int chil, int chir,
-                            int k, int mode, double rescale, void* tq, void* tq1, hipStream_t s) {
+                            int k, int mode, double rescale, void* tq, void* tq1, const double* lam_new, double* lam_dst, hipStream_t s) {
     const size_t total = (size_t)2 * chil * k + (size_t)k * 2 * chir;
     mps_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(static_cast<const cplx*>(W), static_cast<const cplx*>(V), ord, sigma, lam_left,
-                                                                     chil, chir, k, mode, rescale, static_cast<cplx*>(tq), static_cast<cplx*>(tq1));
+                                                                     chil, chir, k, mode, rescale, static_cast<cplx*>(tq), static_cast<cplx*>(tq1),
+                                                                     lam_new, lam_dst);
     return hipGetLastError();
 }
 hipError_t launch_mps_colscale(void* t, const double* lam, size_t rows, int cols, int mul, hipStream_t s) {

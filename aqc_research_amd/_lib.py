@@ -77,6 +77,11 @@ SIGNATURES = {
     "aqc_svd": (c_int, [c_int, c_int, c_int, _D, _D, _D, _D, POINTER(c_int)]),
     "aqc_mps_apply_circuit": (c_int, [_P, _P, _D, c_int, c_double, c_int]),
     "aqc_mps_fast_dot_gradient": (c_int, [_P, _P, _P, _D, c_double, c_int, c_int, c_int, c_int, _D]),
+    "aqc_mpsb_create": (c_int, [c_int, c_int, c_int, POINTER(_P)]),
+    "aqc_mpsb_destroy": (c_int, [_P]),
+    "aqc_mpsb_set_targets": (c_int, [_P, POINTER(_P), c_int]),
+    "aqc_mpsb_set_lhs": (c_int, [_P, POINTER(_P), c_int]),
+    "aqc_mpsb_eval": (c_int, [_P, _P, _D, c_double, c_int, c_int, c_int, c_int, _D, _D, _D, POINTER(c_int32)]),
     "aqc_gate_dot": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int, _D, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),

@@ -190,6 +190,22 @@ hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void*
                                const double* fro2, int* rot, unsigned* bar, int* status, hipStream_t s);
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
 hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
+// ---- lockstep MPS lanes (aqc_mps_batch.cpp): per-lane descriptors of the batched small-bond kernels.  One launch serves every lane of a
+// batch (grid dimension = lane); a lane's operands and its bond dimensions come from its descriptor.
+struct BGate1 { void* t; int ne; int pad; double g[8]; };                                   // T[2][ne] <- g T
+struct BTheta { const void* tq; const void* tq1; const double* lam_left; void* work; int chil, chim, chir, mode; double2 m[16]; };
+struct BJacobi { void* W; void* V; double* sigma; int rows, cols, rounds, per_round, pairs_off, pad; };   // sigma: [cols] norms | fro2 | sweeps
+struct BSplit { const void* W; const void* V; const int* ord; const double* sigma; const double* lam_left; void* tq; void* tq1;
+                const double* lam_new; double* lam_dst; double rescale; int chil, chir, k, mode; };
+struct BEnv { const void* in; const void* A; const void* B; void* out; int xa, ua, yb, vb, has_op, pad; double2 m[4]; };
+struct BDot { const void* e; const void* rc; void* out; int count, pad; };
+hipError_t launch_mpsb_gate1(const BGate1* tab, int lanes, int max_ne, hipStream_t s);
+hipError_t launch_mpsb_theta(const BTheta* tab, int lanes, int max_lr, hipStream_t s);
+hipError_t launch_mpsb_jacobi(const BJacobi* tab, const void* pairs_all, int lanes, int max_per_round, size_t lds_bytes, double tol, int max_sweeps, hipStream_t s);
+hipError_t launch_mpsb_split(const BSplit* tab, int lanes, size_t max_total, hipStream_t s);
+hipError_t launch_mpsb_env_left(const BEnv* tab, int lanes, size_t lds_bytes, hipStream_t s);
+hipError_t launch_mpsb_env_right(const BEnv* tab, int lanes, size_t lds_bytes, hipStream_t s);
+hipError_t launch_mpsb_env_dot(const BDot* tab, int lanes, hipStream_t s);
 // environment steps of <(ops) w|z> for small bonds, one launch per site (aqc_svd.hip); gh8: 2x2 (row-major, 4 c128) applied to z's site or null
 bool mps_env_fits_small(int xa, int ua, int yb, int vb);
 hipError_t launch_mps_env_left(const void* in, const void* A, const void* B, int xa, int ua, int yb, int vb, const double* gh8, void* out, hipStream_t s);

@@ -115,9 +115,9 @@ __global__ __launch_bounds__(kSvdThreads) void svd_norms_kernel(const cplx* __re
 // dimensions up to 32): 32 half-waves, one column pair each per round, __syncthreads between rounds, the sweep
 // loop and the convergence test inside the kernel.  Replaces ~500 launches of jacobi_round_kernel.
 constexpr int kSmallMax = 64;
-__global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
-                                                            const int2* __restrict__ pairs, int rounds, int per_round, double tol,
-                                                            int max_sweeps, int* __restrict__ sweeps_out, double* __restrict__ sigma_out) {
+__device__ __forceinline__ void jacobi_small_body(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
+                                                  const int2* __restrict__ pairs, int rounds, int per_round, double tol,
+                                                  int max_sweeps, int* __restrict__ sweeps_out, double* __restrict__ sigma_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* sw = reinterpret_cast<cplx*>(smem);            // [cols][rows]
     cplx* sv = sw + (size_t)cols * rows;                  // [cols][cols]
@@ -194,7 +194,27 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W
             for (int i = 0; i < rows; ++i) { const cplx x = sw[(size_t)c * rows + i]; a += x.x * x.x + x.y * x.y; }
             sigma_out[c] = sqrt(a);
         }
-    if (tid == 0) { *sweeps_out = sweep; if (sigma_out) sigma_out[cols + 1] = (double)sweep; }   // (behind sigma and fro2: one read-back for the host)
+    if (tid == 0) { if (sweeps_out) *sweeps_out = sweep; if (sigma_out) sigma_out[cols + 1] = (double)sweep; }   // (behind sigma and fro2: one read-back for the host)
+}
+__global__ __launch_bounds__(1024) void jacobi_small_kernel(cplx* __restrict__ W, int rows, cplx* __restrict__ V, int cols,
+                                                            const int2* __restrict__ pairs, int rounds, int per_round, double tol,
+                                                            int max_sweeps, int* __restrict__ sweeps_out, double* __restrict__ sigma_out) {
+    jacobi_small_body(W, rows, V, cols, pairs, rounds, per_round, tol, max_sweeps, sweeps_out, sigma_out);
+}
+// the same for every lane of a lockstep batch (aqc_mps_batch.cpp): blockIdx.x = lane, descriptors in (pinned) host memory
+__global__ __launch_bounds__(1024) void jacobi_small_batch_kernel(const BJacobi* __restrict__ tab, const int2* __restrict__ pairs_all, double tol, int max_sweeps) {
+    const BJacobi d = tab[blockIdx.x];
+    if (d.cols < 2) {   // a 1-column work matrix needs no rotation: V = 1, sigma = its norm (uniform branch)
+        if (threadIdx.x == 0 && d.cols == 1) {
+            double a = 0.0;
+            for (int i = 0; i < d.rows; ++i) { const cplx x = static_cast<const cplx*>(d.W)[i]; a += x.x * x.x + x.y * x.y; }
+            static_cast<cplx*>(d.V)[0] = make_double2(1.0, 0.0);
+            d.sigma[0] = sqrt(a); d.sigma[2] = 0.0;
+        }
+        return;
+    }
+    jacobi_small_body(static_cast<cplx*>(d.W), d.rows, static_cast<cplx*>(d.V), d.cols, pairs_all + d.pairs_off, d.rounds, d.per_round, tol, max_sweeps,
+                      nullptr, d.sigma);
 }
 
 // Two-level (block) Jacobi for work matrices beyond one workgroup's LDS (64 < columns, rows <= 512: bond dimensions
@@ -583,9 +603,9 @@ __global__ void mps_theta_kernel(const cplx* __restrict__ theta0, const double* 
 // The same with the product T_q . [T_{q+1}[0] | T_{q+1}[1]] formed on the fly (small bonds: the two zgemm launches that produced theta0
 // cost more than the arithmetic): one thread per (l, r) takes its four length-chi_m dot products, scales, applies the gate and writes the
 // Jacobi work matrix.  tq: [2][chi_l][chi_m], tq1: [2][chi_m][chi_r].
-__global__ void mps_theta_fused_kernel(const cplx* __restrict__ tq, const cplx* __restrict__ tq1, const double* __restrict__ lam_left, int chil,
-                                       int chim, int chir, Gate16 g, int mode, cplx* __restrict__ work) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+template <typename G>
+__device__ __forceinline__ void mps_theta_fused_body(const cplx* __restrict__ tq, const cplx* __restrict__ tq1, const double* __restrict__ lam_left, int chil,
+                                                     int chim, int chir, const G& g, int mode, cplx* __restrict__ work, int idx) {
     if (idx >= chil * chir) return;
     const int l = idx / chir, r = idx - l * chir;
     const int m = 2 * chil, n = 2 * chir;
@@ -626,16 +646,24 @@ __global__ void mps_theta_fused_kernel(const cplx* __restrict__ tq, const cplx* 
             else work[row * n + col] = make_double2(v.x, -v.y);
         }
 }
+__global__ void mps_theta_fused_kernel(const cplx* __restrict__ tq, const cplx* __restrict__ tq1, const double* __restrict__ lam_left, int chil,
+                                       int chim, int chir, Gate16 g, int mode, cplx* __restrict__ work) {
+    mps_theta_fused_body(tq, tq1, lam_left, chil, chim, chir, g, mode, work, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+__global__ void mps_theta_batch_kernel(const BTheta* __restrict__ tab) {   // blockIdx.y = lane
+    const BTheta d = tab[blockIdx.y];
+    mps_theta_fused_body(static_cast<const cplx*>(d.tq), static_cast<const cplx*>(d.tq1), d.lam_left, d.chil, d.chim, d.chir, d, d.mode,
+                         static_cast<cplx*>(d.work), (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
 
 // New site tensors from the converged Jacobi pair (W, V), keeping columns ord[0..k):
 // mode 0: W = theta' Vj  =>  U S = W, V^H = Vj^H;   mode 1: W = theta'^H Vj  =>  U = Vj, S V^H = W^H.
 // T_q'[a][l][j] = (U S)[(a,l), j] / lam_left[l];  T_{q+1}'[b][j][r] = V^H[j, (b,r)]  (lambda_{q+1} is already inside).
-__global__ void mps_split_kernel(const cplx* __restrict__ W, const cplx* __restrict__ V, const int* __restrict__ ord,
-                                 const double* __restrict__ sigma, const double* __restrict__ lam_left, int chil, int chir, int k,
-                                 int mode, double rescale, cplx* __restrict__ tq, cplx* __restrict__ tq1,
-                                 const double* __restrict__ lam_new, double* __restrict__ lam_dst) {
+__device__ __forceinline__ void mps_split_body(const cplx* __restrict__ W, const cplx* __restrict__ V, const int* __restrict__ ord,
+                                               const double* __restrict__ sigma, const double* __restrict__ lam_left, int chil, int chir, int k,
+                                               int mode, double rescale, cplx* __restrict__ tq, cplx* __restrict__ tq1,
+                                               const double* __restrict__ lam_new, double* __restrict__ lam_dst, size_t idx) {
     const int m = 2 * chil, n = 2 * chir;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lam_new && idx < (size_t)k) lam_dst[idx] = lam_new[idx];   // the bond's new Schmidt values ride along (they were an upload of their own)
     const size_t n_left = (size_t)m * k, n_right = (size_t)k * n;
     if (idx < n_left) {
@@ -655,6 +683,17 @@ __global__ void mps_split_kernel(const cplx* __restrict__ W, const cplx* __restr
         else { v = W[(size_t)c * n + col]; const double f = 1.0 / sigma[c]; v.x *= f; v.y *= -f; }
         tq1[e] = v;
     }
+}
+__global__ void mps_split_kernel(const cplx* __restrict__ W, const cplx* __restrict__ V, const int* __restrict__ ord,
+                                 const double* __restrict__ sigma, const double* __restrict__ lam_left, int chil, int chir, int k,
+                                 int mode, double rescale, cplx* __restrict__ tq, cplx* __restrict__ tq1,
+                                 const double* __restrict__ lam_new, double* __restrict__ lam_dst) {
+    mps_split_body(W, V, ord, sigma, lam_left, chil, chir, k, mode, rescale, tq, tq1, lam_new, lam_dst, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void mps_split_batch_kernel(const BSplit* __restrict__ tab) {   // blockIdx.y = lane
+    const BSplit d = tab[blockIdx.y];
+    mps_split_body(static_cast<const cplx*>(d.W), static_cast<const cplx*>(d.V), d.ord, d.sigma, d.lam_left, d.chil, d.chir, d.k, d.mode, d.rescale,
+                   static_cast<cplx*>(d.tq), static_cast<cplx*>(d.tq1), d.lam_new, d.lam_dst, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // t[row][col] *= (mul ? lam[col] : 1 / lam[col])   -- import (Gamma -> Gamma lambda) and export of MPS tensors
@@ -677,8 +716,9 @@ hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil
 // gate1q when an operator sits on the site).  One workgroup; the intermediate of a bit lives in LDS.
 struct Gate4c { cplx m[4]; };
 // out[u][v] = sum_bit sum_x conj(A[bit][x][u]) (sum_y in[x][y] B'[bit][y][v]),  B'[bit] = B[bit], or gh[bit][0] B[0] + gh[bit][1] B[1]
-__global__ __launch_bounds__(256) void mps_env_left_kernel(const cplx* __restrict__ in, const cplx* __restrict__ A, const cplx* __restrict__ B,
-                                                           int xa, int ua, int yb, int vb, int has_op, Gate4c gh, cplx* __restrict__ out) {
+template <typename G>
+__device__ __forceinline__ void mps_env_left_body(const cplx* __restrict__ in, const cplx* __restrict__ A, const cplx* __restrict__ B,
+                                                  int xa, int ua, int yb, int vb, int has_op, const G& gh, cplx* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char env_smem[];
     cplx* t = reinterpret_cast<cplx*>(env_smem);   // [xa][vb]
     const int tid = threadIdx.x;
@@ -713,9 +753,18 @@ __global__ __launch_bounds__(256) void mps_env_left_kernel(const cplx* __restric
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void mps_env_left_kernel(const cplx* __restrict__ in, const cplx* __restrict__ A, const cplx* __restrict__ B,
+                                                           int xa, int ua, int yb, int vb, int has_op, Gate4c gh, cplx* __restrict__ out) {
+    mps_env_left_body(in, A, B, xa, ua, yb, vb, has_op, gh, out);
+}
+__global__ __launch_bounds__(256) void mps_env_left_batch_kernel(const BEnv* __restrict__ tab) {   // blockIdx.x = lane
+    const BEnv d = tab[blockIdx.x];
+    mps_env_left_body(static_cast<const cplx*>(d.in), static_cast<const cplx*>(d.A), static_cast<const cplx*>(d.B), d.xa, d.ua, d.yb, d.vb, d.has_op, d,
+                      static_cast<cplx*>(d.out));
+}
 // out[x][y] = sum_bit sum_u A[bit][x][u] (sum_v Rc[u][v] conj(B[bit][y][v]))
-__global__ __launch_bounds__(256) void mps_env_right_kernel(const cplx* __restrict__ rc, const cplx* __restrict__ A, const cplx* __restrict__ B,
-                                                            int xa, int ua, int yb, int vb, cplx* __restrict__ out) {
+__device__ __forceinline__ void mps_env_right_body(const cplx* __restrict__ rc, const cplx* __restrict__ A, const cplx* __restrict__ B,
+                                                   int xa, int ua, int yb, int vb, cplx* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char env_smem[];
     cplx* t = reinterpret_cast<cplx*>(env_smem);   // [ua][yb]
     const int tid = threadIdx.x;
@@ -745,6 +794,43 @@ __global__ __launch_bounds__(256) void mps_env_right_kernel(const cplx* __restri
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void mps_env_right_kernel(const cplx* __restrict__ rc, const cplx* __restrict__ A, const cplx* __restrict__ B,
+                                                            int xa, int ua, int yb, int vb, cplx* __restrict__ out) {
+    mps_env_right_body(rc, A, B, xa, ua, yb, vb, out);
+}
+__global__ __launch_bounds__(256) void mps_env_right_batch_kernel(const BEnv* __restrict__ tab) {   // blockIdx.x = lane
+    const BEnv d = tab[blockIdx.x];
+    mps_env_right_body(static_cast<const cplx*>(d.in), static_cast<const cplx*>(d.A), static_cast<const cplx*>(d.B), d.xa, d.ua, d.yb, d.vb,
+                       static_cast<cplx*>(d.out));
+}
+// closes inner products: out[lane][slot] = sum_i e[i] conj(rc[i]); and the 1-qubit gate of a lane on its site tensor [2][ne]
+__global__ __launch_bounds__(256) void mps_env_dot_batch_kernel(const BDot* __restrict__ tab) {
+    const BDot d = tab[blockIdx.x];
+    __shared__ double sr[256], si[256];
+    double re = 0.0, im = 0.0;
+    for (int i = threadIdx.x; i < d.count; i += 256) {
+        const cplx a = static_cast<const cplx*>(d.e)[i], b = static_cast<const cplx*>(d.rc)[i];
+        re += a.x * b.x + a.y * b.y;
+        im += a.y * b.x - a.x * b.y;
+    }
+    sr[threadIdx.x] = re; si[threadIdx.x] = im;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sr[threadIdx.x] += sr[threadIdx.x + s]; si[threadIdx.x] += si[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *static_cast<cplx*>(d.out) = make_double2(sr[0], si[0]);
+}
+__global__ void mps_gate1_batch_kernel(const BGate1* __restrict__ tab) {   // blockIdx.y = lane
+    const BGate1 d = tab[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.ne) return;
+    cplx* t = static_cast<cplx*>(d.t);
+    const cplx a0 = t[i], a1 = t[d.ne + i];
+    const cplx g0 = make_double2(d.g[0], d.g[1]), g1 = make_double2(d.g[2], d.g[3]), g2 = make_double2(d.g[4], d.g[5]), g3 = make_double2(d.g[6], d.g[7]);
+    t[i] = make_double2(g0.x * a0.x - g0.y * a0.y + g1.x * a1.x - g1.y * a1.y, g0.x * a0.y + g0.y * a0.x + g1.x * a1.y + g1.y * a1.x);
+    t[d.ne + i] = make_double2(g2.x * a0.x - g2.y * a0.y + g3.x * a1.x - g3.y * a1.y, g2.x * a0.y + g2.y * a0.x + g3.x * a1.y + g3.y * a1.x);
+}
 bool mps_env_fits_small(int xa, int ua, int yb, int vb) { return xa <= 64 && ua <= 64 && yb <= 64 && vb <= 64; }
 hipError_t launch_mps_env_left(const void* in, const void* A, const void* B, int xa, int ua, int yb, int vb, const double* gh8, void* out, hipStream_t s) {
     Gate4c g;
@@ -756,6 +842,44 @@ hipError_t launch_mps_env_left(const void* in, const void* A, const void* B, int
 hipError_t launch_mps_env_right(const void* rc, const void* A, const void* B, int xa, int ua, int yb, int vb, void* out, hipStream_t s) {
     mps_env_right_kernel<<<1, 256, sizeof(cplx) * (size_t)ua * yb, s>>>(static_cast<const cplx*>(rc), static_cast<const cplx*>(A), static_cast<const cplx*>(B),
                                                                         xa, ua, yb, vb, static_cast<cplx*>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_mpsb_gate1(const BGate1* tab, int lanes, int max_ne, hipStream_t s) {
+    mps_gate1_batch_kernel<<<dim3((unsigned)((max_ne + 127) / 128), lanes), 128, 0, s>>>(tab);
+    return hipGetLastError();
+}
+hipError_t launch_mpsb_theta(const BTheta* tab, int lanes, int max_lr, hipStream_t s) {
+    mps_theta_batch_kernel<<<dim3((unsigned)((max_lr + 127) / 128), lanes), 128, 0, s>>>(tab);
+    return hipGetLastError();
+}
+hipError_t launch_mpsb_jacobi(const BJacobi* tab, const void* pairs_all, int lanes, int max_per_round, size_t lds_bytes, double tol, int max_sweeps,
+                              hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_small_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * kSmallMax * kSmallMax * (int)sizeof(cplx));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int threads = std::min(1024, std::max(64, (32 * max_per_round + 63) & ~63));
+    jacobi_small_batch_kernel<<<lanes, threads, lds_bytes, s>>>(tab, static_cast<const int2*>(pairs_all), tol, max_sweeps);
+    return hipGetLastError();
+}
+hipError_t launch_mpsb_split(const BSplit* tab, int lanes, size_t max_total, hipStream_t s) {
+    mps_split_batch_kernel<<<dim3((unsigned)((max_total + 255) / 256), lanes), 256, 0, s>>>(tab);
+    return hipGetLastError();
+}
+hipError_t launch_mpsb_env_left(const BEnv* tab, int lanes, size_t lds_bytes, hipStream_t s) {
+    mps_env_left_batch_kernel<<<lanes, 256, lds_bytes, s>>>(tab);
+    return hipGetLastError();
+}
+hipError_t launch_mpsb_env_right(const BEnv* tab, int lanes, size_t lds_bytes, hipStream_t s) {
+    mps_env_right_batch_kernel<<<lanes, 256, lds_bytes, s>>>(tab);
+    return hipGetLastError();
+}
+hipError_t launch_mpsb_env_dot(const BDot* tab, int lanes, hipStream_t s) {
+    mps_env_dot_batch_kernel<<<lanes, 256, 0, s>>>(tab);
     return hipGetLastError();
 }
 

@@ -408,20 +408,123 @@ def _pool(workers: int):
     return _POOL
 
 
+LOCKSTEP_MAX_BOND = 32   # kCap of csrc/aqc_mps_batch.cpp
+
+
+class LockstepLanes:
+    """``lanes`` problems on one ansatz evaluated together (C ABI ``aqc_mpsb_*``): every step of the gate walk of
+    ``mps_dot_objective.fast_dot_gradient`` (:41-242) is one launch for all lanes and the truncation ranks of all lanes come from one
+    read-back per 2-qubit gate.  Bonds up to ``LOCKSTEP_MAX_BOND`` per lane; a lane that would grow beyond makes ``evaluate`` raise
+    (nothing is truncated silently) and ``evaluate_lanes`` repeats the batch lane by lane on the single-lane engine."""
+
+    def __init__(self, num_qubits: int, lanes: int, device: Optional[int] = None):
+        h = c_void_p()
+        check(_lib.lib().aqc_mpsb_create(_default_device() if device is None else int(device), int(num_qubits), int(lanes), byref(h)))
+        self.handle, self.num_qubits, self.lanes = h, int(num_qubits), int(lanes)
+        self._targets = self._lhs = None
+
+    def _handles(self, states):
+        lst = list(states) if isinstance(states, (list, tuple)) else [states]
+        if len(lst) not in (1, self.lanes):
+            raise ValueError("one state per lane, or one for all lanes")
+        arr = (c_void_p * len(lst))(*[m.handle for m in lst])
+        return lst, arr, int(len(lst) == 1)
+
+    def set_targets(self, targets) -> "LockstepLanes":
+        lst, arr, shared = self._handles(targets)
+        check(_lib.lib().aqc_mpsb_set_targets(self.handle, arr, shared))
+        self._targets = [id(m) for m in lst]
+        return self
+
+    def set_lhs(self, lhs) -> "LockstepLanes":
+        lst, arr, shared = self._handles(lhs)
+        check(_lib.lib().aqc_mpsb_set_lhs(self.handle, arr, shared))
+        self._lhs = [id(m) for m in lst]
+        return self
+
+    def evaluate(self, circ, thetas, *, trunc_thr: float = 0.0, max_bond: int = 0, block_range: Optional[Tuple[int, int]] = None,
+                 front_layer: bool = True, details: bool = False):
+        """(h[lanes], grads[lanes][T]) -- per lane the values of ``v_dagger_mul_mps`` + ``dot`` + ``fast_dot_gradient_mps``;
+        with ``details`` also (discarded weight, largest bond) of every lane's V^H|target>."""
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        if th.shape != (self.lanes, circ.num_thetas):
+            raise ValueError("thetas: expects shape (lanes, circ.num_thetas)")
+        if circ.num_qubits != self.num_qubits:
+            raise ValueError("circuit and lanes differ in the number of qubits")
+        desc, keep = _describe(circ)
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        if block_range is not None and not 0 <= lo <= hi <= circ.num_blocks:
+            raise ValueError("invalid block range")
+        h = np.zeros(self.lanes, dtype=np.complex128)
+        grads = np.zeros((self.lanes, circ.num_thetas), dtype=np.complex128)
+        disc = np.zeros(self.lanes, dtype=np.float64)
+        bonds = np.zeros(self.lanes, dtype=np.int32)
+        check(_lib.lib().aqc_mpsb_eval(self.handle, byref(desc), dptr(th), float(trunc_thr), int(max_bond), lo, hi, int(bool(front_layer)),
+                                       dptr(h), dptr(grads), dptr(disc), bonds.ctypes.data_as(POINTER(c_int32))))
+        del keep
+        return (h, grads, disc, bonds) if details else (h, grads)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            _lib.lib().aqc_mpsb_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_LOCKSTEP_CACHE: dict = {}   # (device, qubits, lanes) -> LockstepLanes; the batches of a running optimisation come back every iteration
+
+
+def _lockstep_for(num_qubits: int, lanes: int, device: int, targets, lhs) -> LockstepLanes:
+    key = (device, num_qubits, lanes)
+    ls = _LOCKSTEP_CACHE.get(key)
+    if ls is None:
+        if len(_LOCKSTEP_CACHE) >= 4:
+            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
+        ls = _LOCKSTEP_CACHE[key] = LockstepLanes(num_qubits, lanes, device)
+    # the operands are copied into the lanes: always refreshed (n small device-to-device copies per lane), a state edited in place between
+    # two evaluations is seen
+    ls.set_targets(targets)
+    ls.set_lhs(lhs)
+    return ls
+
+
 def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float = 0.0, max_bond: int = 0,
-                   block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, workers: int = 0):
+                   block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, workers: int = 0, method: str = "auto"):
     """One objective+gradient evaluation per lane on the native engine: lane b computes vh_b = V(thetas[b])^H |targets[b]>
-    (v_dagger_mul_mps), h_b = <lhs[b]|vh_b> and the complex gradient of <V lhs[b]|targets[b]> (fast_dot_gradient_mps), all lanes
-    concurrently on ``workers`` host threads (default: one per lane, at most 16).  ``targets`` / ``lhs``: one DeviceMPS per lane, or a
-    single one shared by all lanes (operands are only read).  Returns (h[B] complex, grads[B][T] complex)."""
+    (v_dagger_mul_mps), h_b = <lhs[b]|vh_b> and the complex gradient of <V lhs[b]|targets[b]> (fast_dot_gradient_mps).
+    ``targets`` / ``lhs``: one DeviceMPS per lane, or a single one shared by all lanes (operands are only read).
+    ``method``: "lockstep" -- all lanes walk the circuit together, one launch per step (``LockstepLanes``; bonds <= 32);
+    "threads" -- every lane on the single-lane engine, lanes concurrently on ``workers`` host threads (default: one per lane, at most
+    16); "auto" -- lockstep when the operands' bonds allow it, and the thread lanes if a lane outgrows the lockstep bond.
+    Returns (h[B] complex, grads[B][T] complex)."""
     th = np.ascontiguousarray(thetas, dtype=np.float64)
     if th.ndim != 2 or th.shape[1] != circ.num_thetas:
         raise ValueError("thetas: expects shape (lanes, circ.num_thetas)")
+    if method not in ("auto", "lockstep", "threads"):
+        raise ValueError("method: 'auto', 'lockstep' or 'threads'")
     lanes = th.shape[0]
     tg = list(targets) if isinstance(targets, (list, tuple)) else [targets] * lanes
     lh = list(lhs) if isinstance(lhs, (list, tuple)) else [lhs] * lanes
     if len(tg) != lanes or len(lh) != lanes:
         raise ValueError("one target and one lhs state per lane (or one for all)")
+
+    if method != "threads" and (method == "lockstep" or lanes > 1):
+        distinct = {id(m): m for m in tg + lh}.values()
+        fits = circ.num_qubits >= 2 and max_bond <= LOCKSTEP_MAX_BOND and all(int(m.bond_dims.max()) <= LOCKSTEP_MAX_BOND for m in distinct)
+        if fits or method == "lockstep":
+            try:
+                shared_t = targets if not isinstance(targets, (list, tuple)) else tg
+                shared_l = lhs if not isinstance(lhs, (list, tuple)) else lh
+                ls = _lockstep_for(circ.num_qubits, lanes, _default_device(), shared_t, shared_l)
+                return ls.evaluate(circ, th, trunc_thr=trunc_thr, max_bond=max_bond, block_range=block_range, front_layer=front_layer)
+            except RuntimeError as err:
+                if method == "lockstep" or "lockstep lanes" not in str(err):
+                    raise
 
     def one(b: int):
         vh = v_dagger_mul_mps(circ, th[b], tg[b], trunc_thr=trunc_thr, max_bond=max_bond)

@@ -219,6 +219,25 @@ int aqc_mps_apply_circuit(aqc_mps* mps, const aqc_circuit* circ, const double* t
  * come back in a single transfer.  block_from < 0: all blocks.  lvec and vh_phi are left intact. */
 int aqc_mps_fast_dot_gradient(const aqc_circuit* circ, const aqc_mps* lvec, const aqc_mps* vh_phi, const double* thetas,
                               double trunc_thr, int max_bond, int block_from, int block_to, int front_layer, double* grad);
+/* ---- lockstep lanes of the MPS objective: `lanes` independent problems that share one ansatz (the seeds / restarts / targets
+ * the reference evaluates one per job, job_executor.py:141 around mps_dot_objective.py:41) evaluated TOGETHER.  Every step of the
+ * gate walk is one launch for all lanes (grid dimension = lane) and the truncation ranks of all lanes are decided from one
+ * read-back per 2-qubit gate.  Bonds up to 32 per lane; a lane whose bond would grow beyond that makes the call fail (never a
+ * silent truncation) and the caller falls back to aqc_mps_fast_dot_gradient lane by lane.  Truncation rule, arithmetic and
+ * outputs per lane are those of aqc_mps_apply_circuit + aqc_mps_dot + aqc_mps_fast_dot_gradient. */
+typedef struct aqc_mpsb aqc_mpsb;
+int aqc_mpsb_create(int device, int num_qubits, int lanes, aqc_mpsb** out);
+int aqc_mpsb_destroy(aqc_mpsb* b);
+/* |phi_l> of every lane (the objective's target, objective_base.py:112 set_target) and <lhs_l| (its left-hand state |0> or the
+ * surrogate's low-entangled state, objective_lhs_sur_fast_mps_trotter.py:99); shared != 0: handles[0] serves every lane */
+int aqc_mpsb_set_targets(aqc_mpsb* b, aqc_mps* const* handles, int shared);
+int aqc_mpsb_set_lhs(aqc_mpsb* b, aqc_mps* const* handles, int shared);
+/* per lane l with thetas[l][T]: vh = V(theta_l)^H|phi_l> (v_dagger_mul_mps, mps_operations.py:350), h[l] = <lhs_l|vh> (c128) and
+ * grad[l][T] (c128) = fast_dot_gradient(circ, theta_l, lhs_l, vh, trunc_thr, block_range, front_layer) (mps_dot_objective.py:41).
+ * discarded[l] (optional) = weight truncated while forming vh, max_bond_out[l] (optional) = its largest bond. */
+int aqc_mpsb_eval(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from,
+                  int block_to, int front_layer, double* h /* [lanes] c128 */, double* grad /* [lanes][T] c128 */,
+                  double* discarded /* [lanes] or NULL */, int32_t* max_bond_out /* [lanes] or NULL */);
 /* one-sided Jacobi SVD on the device (the kernel behind aqc_mps_gate2): A (m x n row-major) = U diag(S) Vh,
  * k = min(m, n), S descending, U (m x k), Vh (k x n); *sweeps (optional) = Jacobi sweeps used */
 int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, double* vh, int* sweeps);

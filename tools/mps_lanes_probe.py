@@ -58,3 +58,21 @@ for lanes in (1, 2, 4, 8, 16):
     print(f"lanes {lanes:2d}: {reps * lanes / dt:8.2f} evals/s  ({dt / reps * 1e3:7.1f} ms per round)", flush=True)
     for b, t in ls[1:]:
         b.close(); t.close()
+
+# the same batch in lockstep (aqc_mpsb_*): one launch per step of the walk for all lanes
+from aqc_research_amd.mps_engine import LockstepLanes   # noqa: E402
+
+for lanes in (1, 4, 16, 64, 256):
+    ths = np.stack([th0 + 0.02 * rng.standard_normal(th0.size) for _ in range(lanes)])
+    lk = LockstepLanes(n, lanes).set_targets(lane0[1]).set_lhs(lane0[0])
+    h, g = lk.evaluate(circ, ths, trunc_thr=thr)
+    if lanes == 1:
+        ref = evaluate(lane0, ths[0])
+        print(f"lockstep vs single lane: |dh| {abs(h[0] - ref[0]):.2e}  max|dg| {np.abs(g[0] - ref[1]).max():.2e}", flush=True)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lk.evaluate(circ, ths, trunc_thr=thr)
+    dt = time.perf_counter() - t0
+    print(f"lockstep lanes {lanes:3d}: {reps * lanes / dt:8.2f} evals/s  ({dt / reps * 1e3:7.1f} ms per round)", flush=True)
+    lk.close()

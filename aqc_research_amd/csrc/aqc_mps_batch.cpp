@@ -63,12 +63,11 @@ struct aqc_mpsb {
     bool have_target = false, have_lhs = false;
     double2* work = nullptr;     // [L][kWork]
     double2* vmat = nullptr;     // [L][kWork]
-    double* sigma = nullptr;     // [L][kSig]
-    char* ordlam = nullptr;      // [L][kStage]
-    double* h_sigma = nullptr;   // pinned mirrors
-    char* h_ordlam = nullptr;
-    char* d_ring = nullptr;      // descriptor tables: kRing slots, device copy and pinned staging
-    char* h_ring = nullptr;
+    // pinned host memory the kernels read and write directly: the singular values of a gate come back with the kernel itself (one
+    // synchronisation, no copy call), the host's rank decision (column order | new Schmidt values) is read by the split kernel in place
+    double* h_sigma = nullptr;   // [L][kSig]
+    char* h_ordlam = nullptr;    // [L][kStage]
+    char* h_ring = nullptr;      // descriptor tables: kRing slots
     size_t slot_bytes = 0;
     unsigned turn = 0;
     int pending = 0;             // tables handed to the stream since its last synchronisation
@@ -108,7 +107,7 @@ void destroy(aqc_mpsb* b) {
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
     for (Lanes* s : {&b->target, &b->lhs, &b->vh, &b->w, &b->z}) s->release();
-    for (void* p : {(void*)b->work, (void*)b->vmat, (void*)b->sigma, (void*)b->ordlam, (void*)b->d_ring, b->d_pairs, (void*)b->env_l, (void*)b->env_r,
+    for (void* p : {(void*)b->work, (void*)b->vmat, b->d_pairs, (void*)b->env_l, (void*)b->env_r,
                     (void*)b->e0, (void*)b->e1, (void*)b->vals})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)b->h_sigma, (void*)b->h_ordlam, (void*)b->h_ring})
@@ -123,8 +122,10 @@ int sync(aqc_mpsb* b) {
     return 0;
 }
 
-// descriptor table of one launch: pinned staging slot -> device slot, asynchronously.  A slot is written again kRing tables later;
-// the stream is synchronised before that can overtake a copy or a kernel that still reads it.
+// descriptor table of one launch, written into a slot of the pinned ring: the kernel's workgroups read their lane's entry straight from
+// host memory (a few hundred bytes per lane over the bus; a copy of the table to the device cost a runtime call per launch: 1,014 ->
+// 1,633 evals/s at 256 lanes of the 32-qubit workload).  A slot is written again kRing tables later; the stream is synchronised before that
+// can overtake a kernel that still reads it.
 template <typename D>
 int push(aqc_mpsb* b, const std::vector<D>& descs, const D** out) {
     const size_t bytes = sizeof(D) * descs.size();
@@ -132,11 +133,9 @@ int push(aqc_mpsb* b, const std::vector<D>& descs, const D** out) {
     if (b->pending >= kRing - 2 && sync(b)) return 1;
     const unsigned i = b->turn++ % kRing;
     char* h = b->h_ring + (size_t)i * b->slot_bytes;
-    char* d = b->d_ring + (size_t)i * b->slot_bytes;
     memcpy(h, descs.data(), bytes);
-    HIP_OK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, b->st));
     ++b->pending;
-    *out = reinterpret_cast<const D*>(d);
+    *out = reinterpret_cast<const D*>(h);
     return 0;
 }
 
@@ -148,21 +147,25 @@ int clone(aqc_mpsb* b, const Lanes& src, Lanes& dst) {
     return 0;
 }
 
-// T_q <- g_l T_q for every lane
-int gate1_all(aqc_mpsb* b, Lanes& s, int q, const std::vector<M2>& g) {
-    std::vector<BGate1> tab(b->L);
+// T_q <- g_l T_q for every lane of `s` (and of `s2`, when given: the two operands of the gradient walk take every 1-qubit gate together)
+int gate1_all(aqc_mpsb* b, Lanes& s, int q, const std::vector<M2>& g, Lanes* s2 = nullptr) {
+    const int states = s2 ? 2 : 1;
+    std::vector<BGate1> tab((size_t)states * b->L);
     int max_ne = 1;
-    for (int l = 0; l < b->L; ++l) {
-        BGate1& d = tab[l];
-        d.t = s.site(l, q);
-        d.ne = s.dim(l, q) * s.dim(l, q + 1);
-        d.pad = 0;
-        pack(g[l], d.g);
-        max_ne = std::max(max_ne, d.ne);
+    for (int k = 0; k < states; ++k) {
+        Lanes& x = k ? *s2 : s;
+        for (int l = 0; l < b->L; ++l) {
+            BGate1& d = tab[(size_t)k * b->L + l];
+            d.t = x.site(l, q);
+            d.ne = x.dim(l, q) * x.dim(l, q + 1);
+            d.pad = 0;
+            pack(g[l], d.g);
+            max_ne = std::max(max_ne, d.ne);
+        }
     }
     const BGate1* dev = nullptr;
     if (push(b, tab, &dev)) return 1;
-    HIP_OK(launch_mpsb_gate1(dev, b->L, max_ne, b->st));
+    HIP_OK(launch_mpsb_gate1(dev, states * b->L, max_ne, b->st));
     return 0;
 }
 
@@ -190,7 +193,7 @@ int gate_adjacent_all(aqc_mpsb* b, Lanes& s, int q, const double* g32, bool per_
         for (int i = 0; i < 16; ++i) t.m[i] = make_double2(g[2 * i], g[2 * i + 1]);
         max_lr = std::max(max_lr, chil * chir);
         BJacobi& j = jc[l];
-        j.W = t.work; j.V = b->vmat + (size_t)l * kWork; j.sigma = b->sigma + (size_t)l * kSig;
+        j.W = t.work; j.V = b->vmat + (size_t)l * kWork; j.sigma = b->h_sigma + (size_t)l * kSig;
         j.rows = wrows[l]; j.cols = wcols[l];
         j.rounds = b->rounds[wcols[l]]; j.per_round = b->per_round[wcols[l]]; j.pairs_off = b->pairs_off[wcols[l]]; j.pad = 0;
         max_pr = std::max(max_pr, j.per_round);
@@ -202,7 +205,6 @@ int gate_adjacent_all(aqc_mpsb* b, Lanes& s, int q, const double* g32, bool per_
     HIP_OK(launch_mpsb_theta(d_th, L, max_lr, b->st));
     if (push(b, jc, &d_jc)) return 1;
     HIP_OK(launch_mpsb_jacobi(d_jc, b->d_pairs, L, max_pr, lds, 1e-15, 60, b->st));
-    HIP_OK(hipMemcpyAsync(b->h_sigma, b->sigma, sizeof(double) * (size_t)L * kSig, hipMemcpyDeviceToHost, b->st));
     if (sync(b)) return 1;
     // order, rank and truncation per lane (the rule of gate_adjacent)
     std::vector<BSplit> sp(L);
@@ -237,17 +239,17 @@ int gate_adjacent_all(aqc_mpsb* b, Lanes& s, int q, const double* g32, bool per_
         for (int j = 0; j < k; ++j) lam[j] = sigma[ord[j]] * rescale;
         BSplit& d = sp[l];
         d.W = b->work + (size_t)l * kWork; d.V = b->vmat + (size_t)l * kWork;
-        d.ord = reinterpret_cast<const int*>(b->ordlam + (size_t)l * kStage);
-        d.sigma = b->sigma + (size_t)l * kSig;
+        const char* stage = b->h_ordlam + (size_t)l * kStage;
+        d.ord = reinterpret_cast<const int*>(stage);
+        d.sigma = b->h_sigma + (size_t)l * kSig;
         d.lam_left = q > 0 ? s.lambda(l, q - 1) : nullptr;
         d.tq = s.site(l, q); d.tq1 = s.site(l, q + 1);
-        d.lam_new = reinterpret_cast<const double*>(b->ordlam + (size_t)l * kStage + 256);
+        d.lam_new = reinterpret_cast<const double*>(stage + 256);
         d.lam_dst = s.lambda(l, q);
         d.rescale = rescale; d.chil = chil; d.chir = chir; d.k = k; d.mode = mode[l];
         max_total = std::max(max_total, (size_t)2 * chil * k + (size_t)k * 2 * chir);
         s.dim(l, q + 1) = k;
     }
-    HIP_OK(hipMemcpyAsync(b->ordlam, b->h_ordlam, (size_t)L * kStage, hipMemcpyHostToDevice, b->st));
     const BSplit* d_sp = nullptr;
     if (push(b, sp, &d_sp)) return 1;
     HIP_OK(launch_mpsb_split(d_sp, L, max_total, b->st));
@@ -416,7 +418,7 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, const double* thetas, int T,
     std::vector<std::pair<int, cd>> rec;
     if (env_init(b)) return 1;
     auto both = [&](int q, const std::vector<M2>& g) -> int {
-        if (gate1_all(b, b->w, q, g) || gate1_all(b, b->z, q, g)) return 1;
+        if (gate1_all(b, b->w, q, g, &b->z)) return 1;
         env_touched(b, q, q);
         return 0;
     };
@@ -533,8 +535,6 @@ int aqc_mpsb_create(int device, int num_qubits, int lanes, aqc_mpsb** out) {
     b->slot_bytes = L * std::max({sizeof(BTheta), sizeof(BSplit), sizeof(BEnv), sizeof(BJacobi), sizeof(BGate1), sizeof(BDot)});
     b->nvals = 3 * num_qubits + 5 * 1;   // grown per circuit in aqc_mpsb_eval
     if (hipMalloc((void**)&b->work, sizeof(double2) * L * kWork) != hipSuccess || hipMalloc((void**)&b->vmat, sizeof(double2) * L * kWork) != hipSuccess ||
-        hipMalloc((void**)&b->sigma, sizeof(double) * L * kSig) != hipSuccess || hipMalloc((void**)&b->ordlam, L * kStage) != hipSuccess ||
-        hipMalloc((void**)&b->d_ring, b->slot_bytes * kRing) != hipSuccess ||
         hipMalloc((void**)&b->env_l, sizeof(double2) * L * (num_qubits + 1) * kEnv) != hipSuccess ||
         hipMalloc((void**)&b->env_r, sizeof(double2) * L * num_qubits * kEnv) != hipSuccess ||
         hipMalloc((void**)&b->e0, sizeof(double2) * L * kEnv) != hipSuccess || hipMalloc((void**)&b->e1, sizeof(double2) * L * kEnv) != hipSuccess ||

@@ -59,7 +59,7 @@ WORKLOADS = {
     # one step = one Gauss-Seidel sweep over all 735 parameters for every lane (lane = random restart with its own target)
     "cd5_cyc180": dict(n=5, blocks=180, kind="cd", ncols=32, desc="5-qubit coordinate descent (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks, 735 parameters): one coord_descent_single_sweep per lane and step, lanes = random restarts with their own target unitary"),
     # beyond dense reach: the native MPS engine (truncated two-site SVDs on the device, no 2^n buffer anywhere), lanes on host threads
-    "mps32_trotter2_engine": dict(n=32, layers=2, kind="mps_engine", trunc_thr=1e-6, lanes=8, desc="32-qubit ASP, 2nd-order Trotter ansatz (2 layers, 840 parameters), MPS-dot objective+gradient on the native MPS engine at the reference's default trunc_thr = 1e-6 (V^H by truncated two-site SVDs, gate-by-gate gradient), targets = 6-layer Trotter states (bond <= 16)"),
+    "mps32_trotter2_engine": dict(n=32, layers=2, kind="mps_engine", trunc_thr=1e-6, lanes=256, desc="32-qubit ASP, 2nd-order Trotter ansatz (2 layers, 840 parameters), MPS-dot objective+gradient on the native MPS engine at the reference's default trunc_thr = 1e-6 (V^H by truncated two-site SVDs, gate-by-gate gradient), targets = 6-layer Trotter states (bond <= 16)"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
 
@@ -454,16 +454,21 @@ def run_mps_engine(args, w, env, full):
     tth = init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=evol, delta=1.0)
     rng = np.random.default_rng(99 + env.rank)
     basis = me.DeviceMPS.basis_state(n, neel, device=env.local_rank)
-    targets = []
-    for b in range(B):   # a different target per lane: the Trotter state of slightly different evolution parameters
+    distinct = []
+    for b in range(min(B, 8)):   # eight different targets shared round-robin by the lanes: Trotter states of slightly different evolution times
         tb = init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=evol * (1.0 + 0.01 * b), delta=1.0)
-        targets.append(me.v_mul_mps(tcirc, tb, basis, trunc_thr=1e-12))
-    bonds = int(max(t.bond_dims.max() for t in targets))
+        distinct.append(me.v_mul_mps(tcirc, tb, basis, trunc_thr=1e-12))
+    targets = [distinct[b % len(distinct)] for b in range(B)]
+    bonds = int(max(t.bond_dims.max() for t in distinct))
 
     def thetas(i):
         return th0[None, :] + 0.02 * np.random.default_rng(1000 * i + env.rank).standard_normal((B, T))
 
-    h, g = me.evaluate_lanes(circ, thetas(0), targets, basis, trunc_thr=thr)
+    h, g = me.evaluate_lanes(circ, thetas(0), targets, basis, trunc_thr=thr, method="lockstep")
+    # the lockstep lanes against the single-lane engine (same arithmetic, lane by lane) on a few lanes of the first step
+    nchk = min(B, 4)
+    hs, gs = me.evaluate_lanes(circ, thetas(0)[:nchk], targets[:nchk], basis, trunc_thr=thr, method="threads")
+    lane_err = float(max(np.abs(h[:nchk] - hs).max(), np.abs(g[:nchk] - gs).max()))
     # consistency of value and gradient (engine against itself): d|h|^2/dtheta_k by a central difference on lane 0
     k, eps = 3 * n + 7, 1e-5
     tp, tm = thetas(0)[0].copy(), thetas(0)[0].copy()
@@ -475,11 +480,11 @@ def run_mps_engine(args, w, env, full):
     an = 2.0 * float(np.real(np.conj(h[0]) * g[0, k]))
     consistency = abs(fd - an)
     for i in range(W):
-        me.evaluate_lanes(circ, thetas(1 + i), targets, basis, trunc_thr=thr)
+        me.evaluate_lanes(circ, thetas(1 + i), targets, basis, trunc_thr=thr, method="lockstep")
     env.comm.barrier()
     t0 = time.perf_counter()
     for i in range(K):
-        h, g = me.evaluate_lanes(circ, thetas(10 + i), targets, basis, trunc_thr=thr)
+        h, g = me.evaluate_lanes(circ, thetas(10 + i), targets, basis, trunc_thr=thr, method="lockstep")
     env.comm.barrier()
     wall = time.perf_counter() - t0
     if env.comm.size > 1:
@@ -487,7 +492,12 @@ def run_mps_engine(args, w, env, full):
     t1 = time.perf_counter()
     me.evaluate_lanes(circ, thetas(50)[:1], targets[:1], basis, trunc_thr=thr)
     one = time.perf_counter() - t1
-    for m in targets + [basis]:
+    nthr = min(B, 16)   # the same batch shape on host threads (one single-lane engine per lane), for the record
+    me.evaluate_lanes(circ, thetas(60)[:nthr], targets[:nthr], basis, trunc_thr=thr, method="threads")
+    t2 = time.perf_counter()
+    me.evaluate_lanes(circ, thetas(61)[:nthr], targets[:nthr], basis, trunc_thr=thr, method="threads")
+    thr_rate = nthr / (time.perf_counter() - t2)
+    for m in distinct + [basis]:
         m.close()
     if env.rank != 0:
         return None
@@ -496,13 +506,15 @@ def run_mps_engine(args, w, env, full):
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["desc"], "n_qubits": n, "num_thetas": T, "batch_per_gpu": B, "path": "MPS front door (mps_dot_objective), native MPS engine",
                    "mps_trunc_thr": thr, "target_max_bond": bonds, "mean_fidelity_term": float(np.mean(np.abs(h) ** 2)), "ranks_seen": env.ranks_seen,
-                   "lanes": "host threads, one stream per lane (mps_engine.evaluate_lanes)"},
+                   "lanes": "lockstep (aqc_mpsb_eval): one launch per step of the gate walk for all lanes, bonds <= 32"},
         "roofline": None,
         "parity_maxerr": None, "parity_lanes_checked": 0,
         "parity_note": "truncated MPS arithmetic is parity-unpinned (qiskit-aer absent); value / gradient consistency of the engine: "
                        f"|central difference - analytic| = {consistency:.2e} on one parameter",
         "value_gradient_consistency": consistency,
+        "lockstep_vs_single_lane_maxerr": lane_err, "lockstep_lanes_checked": nchk,
         "single_lane": {"ms_per_eval": one * 1e3, "evals_per_s": 1.0 / one},
+        "host_thread_lanes": {"lanes": nthr, "evals_per_s": thr_rate},
     }
 
 
@@ -766,7 +778,8 @@ def brief(o):
          "workload": o["config"]["workload"], "roofline_frac": r.get("frac"), "roofline_kernel": r.get("kernel"),
          "sweep_avg_launch_ms": r.get("avg_launch_ms"), "parity_maxerr": o.get("parity_maxerr"),
          "parity_lanes_checked": o.get("parity_lanes_checked")}
-    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane", "value_gradient_consistency", "parity_note"):
+    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane", "host_thread_lanes", "lockstep_vs_single_lane_maxerr",
+              "value_gradient_consistency", "parity_note"):
         if k in o:
             b[k] = o[k]
         elif k in o["config"]:

@@ -182,30 +182,36 @@ hipError_t launch_svd_load(const void* a, int m, int n, int mode, void* work, hi
 hipError_t launch_svd_assemble(const void* W, const void* V, const int* ord, const double* sigma, int m, int n, int k, int mode, void* u, void* vh,
                                double* s_sorted, hipStream_t s);
 bool svd_fits_small(int rows, int cols);
-hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, const void* pairs, int rounds, int per_round, double tol, int max_sweeps,
-                               int* sweeps_out, double* sigma_out, hipStream_t s);   // sigma_out (may be null): the column norms at the end
+hipError_t launch_jacobi_small(void* W, int rows, void* V, int cols, double tol, int max_sweeps, int* sweeps_out, double* sigma_out,
+                               hipStream_t s);   // sigma_out (may be null): the column norms at the end
 bool svd_fits_block(int rows, int cols);
 int svd_block_size();
 hipError_t launch_jacobi_block(void* W, int rows, void* V, int cols, const void* bpairs, int rounds, int per_round, double tol, int max_sweeps,
                                const double* fro2, int* rot, unsigned* bar, int* status, hipStream_t s);
 hipError_t launch_svd_norms(const void* W, int rows, int cols, double* sigma, hipStream_t s);
 hipError_t launch_mps_theta(const void* theta0, const double* lam_left, int chil, int chir, const double* g16, int mode, void* work, hipStream_t s);
-// ---- lockstep MPS lanes (aqc_mps_batch.cpp): per-lane descriptors of the batched small-bond kernels.  One launch serves every lane of a
-// batch (grid dimension = lane); a lane's operands and its bond dimensions come from its descriptor.
-struct BGate1 { void* t; int ne; int pad; double g[8]; };                                   // T[2][ne] <- g T
-struct BTheta { const void* tq; const void* tq1; const double* lam_left; void* work; int chil, chim, chir, mode; double2 m[16]; };
-struct BJacobi { void* W; void* V; double* sigma; int rows, cols, rounds, per_round, pairs_off, pad; };   // sigma: [cols] norms | fro2 | sweeps
-struct BSplit { const void* W; const void* V; const int* ord; const double* sigma; const double* lam_left; void* tq; void* tq1;
-                const double* lam_new; double* lam_dst; double rescale; int chil, chir, k, mode; };
-struct BEnv { const void* in; const void* A; const void* B; void* out; int xa, ua, yb, vb, has_op, pad; double2 m[4]; };
-struct BDot { const void* e; const void* rc; void* out; int count, pad; };
-hipError_t launch_mpsb_gate1(const BGate1* tab, int lanes, int max_ne, hipStream_t s);
-hipError_t launch_mpsb_theta(const BTheta* tab, int lanes, int max_lr, hipStream_t s);
-hipError_t launch_mpsb_jacobi(const BJacobi* tab, const void* pairs_all, int lanes, int max_per_round, size_t lds_bytes, double tol, int max_sweeps, hipStream_t s);
-hipError_t launch_mpsb_split(const BSplit* tab, int lanes, size_t max_total, hipStream_t s);
-hipError_t launch_mpsb_env_left(const BEnv* tab, int lanes, size_t lds_bytes, hipStream_t s);
-hipError_t launch_mpsb_env_right(const BEnv* tab, int lanes, size_t lds_bytes, hipStream_t s);
-hipError_t launch_mpsb_env_dot(const BDot* tab, int lanes, hipStream_t s);
+// ---- device-resident lanes (aqc_mps_batch.cpp): L MPS in flat storage whose bond dimensions live on the device.  A launch takes only
+// lane-independent arguments (site, gate kind, parameter indices); a lane's workgroup reads its own bond dimensions and thetas, so the
+// host never waits for a rank decision and the whole walk of an evaluation is one uninterrupted sequence of launches.
+constexpr int kLaneCap = 32;                        // largest bond dimension of a lane
+constexpr int kLaneSite = 2 * kLaneCap * kLaneCap;  // complex elements reserved per site tensor
+constexpr int kLaneEnv = kLaneCap * kLaneCap;       // ... per environment
+constexpr int kLaneNoConv = 1, kLaneOverflow = 2, kLaneZero = 4, kLaneLdsShort = 8;   // status bits of a lane
+struct LaneMps { void* T; double* lam; int* dims; double* discarded; int n, pad; };   // T[L][n][kLaneSite], lam[L][max(n-1,1)][kLaneCap], dims[L][n+1]
+struct LaneRot { int kind /* 0 none, 1 rz, 2 ry, 3 rx */, idx; double scale; };        // angle = scale * thetas[lane][idx], or = scale when idx < 0
+struct LaneGate1 { LaneRot r[3]; };                                                    // the product r[0] r[1] r[2]
+struct LaneGate2 { int kind /* 0 swap, 1 cx, 2 cz, 3 cp */, idx, flip, pad; double scale; };   // cp angle = scale * thetas[lane][idx]; flip: control on site q + 1
+hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, int q, const LaneGate1& g, const double* thetas, int T, int lanes, int bond_hint,
+                              hipStream_t s);
+hipError_t launch_lanes_gate2(const LaneMps& m, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond, int* status,
+                              int* peak, int lanes, int bond_hint, hipStream_t s);
+hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,
+                                 const double* gh8, int lanes, hipStream_t s);
+hipError_t launch_lanes_env_right(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride, int lanes,
+                                  hipStream_t s);
+hipError_t launch_lanes_env_dot(const LaneMps& w, const LaneMps& z, int hi, const void* e, size_t e_stride, const void* rc, size_t rc_stride, void* vals,
+                                int nvals, int slot, int lanes, hipStream_t s);
+hipError_t launch_lanes_env_init(void* env_l, size_t l_stride, void* env_r_last, size_t r_stride, int lanes, hipStream_t s);
 // environment steps of <(ops) w|z> for small bonds, one launch per site (aqc_svd.hip); gh8: 2x2 (row-major, 4 c128) applied to z's site or null
 bool mps_env_fits_small(int xa, int ua, int yb, int vb);
 hipError_t launch_mps_env_left(const void* in, const void* A, const void* B, int xa, int ua, int yb, int vb, const double* gh8, void* out, hipStream_t s);

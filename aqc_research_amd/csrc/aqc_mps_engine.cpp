@@ -101,7 +101,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
     const bool blocked_ok = !(env_blocked && atoi(env_blocked) == 0);
     const bool small = svd_fits_small(rows, cols);
     const bool blocked = !small && blocked_ok && svd_fits_block(rows, cols);
-    if (sw.cached_cols != cols || sw.cached_blocked != (int)blocked) {
+    if (!small && (sw.cached_cols != cols || sw.cached_blocked != (int)blocked)) {   // (the one-workgroup kernel works its pairing out itself)
         if (blocked) block_tournament((cols + svd_block_size() - 1) / svd_block_size(), sw.h_pairs, sw.rounds, sw.per_round);
         else tournament(cols, sw.h_pairs, sw.rounds, sw.per_round);
         if (sw.pairs.reserve(std::max<size_t>(sw.h_pairs.size(), 2) * sizeof(int))) return 1;
@@ -118,7 +118,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
     int sweeps = 0;
     int status[2] = {0, 0};
     if (small) {   // one launch: matrix and V live in the LDS of one workgroup
-        HIP_OK(launch_jacobi_small(W, rows, V, cols, sw.pairs.p, sw.rounds, sw.per_round, tol, 60, flag, static_cast<double*>(sw.sigma.p), st));
+        HIP_OK(launch_jacobi_small(W, rows, V, cols, tol, 60, flag, static_cast<double*>(sw.sigma.p), st));
     } else if (blocked) {   // one cooperative launch: persistent workgroups, 16 columns at a time in LDS
         HIP_OK(launch_svd_identity(V, cols, st));
         HIP_OK(launch_svd_fro2(W, (size_t)rows * cols, fro2, st));

@@ -412,10 +412,11 @@ LOCKSTEP_MAX_BOND = 32   # kCap of csrc/aqc_mps_batch.cpp
 
 
 class LockstepLanes:
-    """``lanes`` problems on one ansatz evaluated together (C ABI ``aqc_mpsb_*``): every step of the gate walk of
-    ``mps_dot_objective.fast_dot_gradient`` (:41-242) is one launch for all lanes and the truncation ranks of all lanes come from one
-    read-back per 2-qubit gate.  Bonds up to ``LOCKSTEP_MAX_BOND`` per lane; a lane that would grow beyond makes ``evaluate`` raise
-    (nothing is truncated silently) and ``evaluate_lanes`` repeats the batch lane by lane on the single-lane engine."""
+    """``lanes`` problems on one ansatz evaluated together and device-resident (C ABI ``aqc_mpsb_*``): every step of the gate walk of
+    ``mps_dot_objective.fast_dot_gradient`` (:41-242) is one launch for all lanes; a truncated 2-qubit gate is one workgroup per lane
+    (two-site tensor, SVD, rank decision, new tensors), the lane's bond dimensions never leave the device and the host enqueues a
+    whole evaluation without waiting.  Bonds up to ``LOCKSTEP_MAX_BOND`` per lane; a lane that would grow beyond makes ``evaluate``
+    raise (nothing is truncated silently) and ``evaluate_lanes`` repeats the batch lane by lane on the single-lane engine."""
 
     def __init__(self, num_qubits: int, lanes: int, device: Optional[int] = None):
         h = c_void_p()
@@ -529,7 +530,7 @@ def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float =
     def one(b: int):
         vh = v_dagger_mul_mps(circ, th[b], tg[b], trunc_thr=trunc_thr, max_bond=max_bond)
         try:
-            h = lh[b].dot(vh)
+            h = np.conj(vh.dot(lh[b]))   # <lhs|vh> on vh's own scratch and stream: an lhs state shared by the lanes is only read
             g = fast_dot_gradient_mps(circ, th[b], lh[b], vh, trunc_thr=trunc_thr, max_bond=max_bond, block_range=block_range,
                                       front_layer=front_layer)
         finally:

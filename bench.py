@@ -59,7 +59,7 @@ WORKLOADS = {
     # one step = one Gauss-Seidel sweep over all 735 parameters for every lane (lane = random restart with its own target)
     "cd5_cyc180": dict(n=5, blocks=180, kind="cd", ncols=32, desc="5-qubit coordinate descent (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks, 735 parameters): one coord_descent_single_sweep per lane and step, lanes = random restarts with their own target unitary"),
     # beyond dense reach: the native MPS engine (truncated two-site SVDs on the device, no 2^n buffer anywhere), lanes on host threads
-    "mps32_trotter2_engine": dict(n=32, layers=2, kind="mps_engine", trunc_thr=1e-6, lanes=256, desc="32-qubit ASP, 2nd-order Trotter ansatz (2 layers, 840 parameters), MPS-dot objective+gradient on the native MPS engine at the reference's default trunc_thr = 1e-6 (V^H by truncated two-site SVDs, gate-by-gate gradient), targets = 6-layer Trotter states (bond <= 16)"),
+    "mps32_trotter2_engine": dict(n=32, layers=2, kind="mps_engine", trunc_thr=1e-6, lanes=1024, desc="32-qubit ASP, 2nd-order Trotter ansatz (2 layers, 840 parameters), MPS-dot objective+gradient on the native MPS engine at the reference's default trunc_thr = 1e-6 (V^H by truncated two-site SVDs, gate-by-gate gradient), targets = 6-layer Trotter states (bond <= 16)"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
 
@@ -506,7 +506,7 @@ def run_mps_engine(args, w, env, full):
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["desc"], "n_qubits": n, "num_thetas": T, "batch_per_gpu": B, "path": "MPS front door (mps_dot_objective), native MPS engine",
                    "mps_trunc_thr": thr, "target_max_bond": bonds, "mean_fidelity_term": float(np.mean(np.abs(h) ** 2)), "ranks_seen": env.ranks_seen,
-                   "lanes": "lockstep (aqc_mpsb_eval): one launch per step of the gate walk for all lanes, bonds <= 32"},
+                   "lanes": "lockstep, device-resident (aqc_mpsb_eval): one launch per step of the gate walk for all lanes, rank decisions on the device, bonds <= 32"},
         "roofline": None,
         "parity_maxerr": None, "parity_lanes_checked": 0,
         "parity_note": "truncated MPS arithmetic is parity-unpinned (qiskit-aer absent); value / gradient consistency of the engine: "

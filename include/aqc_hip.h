@@ -220,11 +220,14 @@ int aqc_mps_apply_circuit(aqc_mps* mps, const aqc_circuit* circ, const double* t
 int aqc_mps_fast_dot_gradient(const aqc_circuit* circ, const aqc_mps* lvec, const aqc_mps* vh_phi, const double* thetas,
                               double trunc_thr, int max_bond, int block_from, int block_to, int front_layer, double* grad);
 /* ---- lockstep lanes of the MPS objective: `lanes` independent problems that share one ansatz (the seeds / restarts / targets
- * the reference evaluates one per job, job_executor.py:141 around mps_dot_objective.py:41) evaluated TOGETHER.  Every step of the
- * gate walk is one launch for all lanes (grid dimension = lane) and the truncation ranks of all lanes are decided from one
- * read-back per 2-qubit gate.  Bonds up to 32 per lane; a lane whose bond would grow beyond that makes the call fail (never a
- * silent truncation) and the caller falls back to aqc_mps_fast_dot_gradient lane by lane.  Truncation rule, arithmetic and
- * outputs per lane are those of aqc_mps_apply_circuit + aqc_mps_dot + aqc_mps_fast_dot_gradient. */
+ * the reference evaluates one per job, job_executor.py:141 around mps_dot_objective.py:41) evaluated TOGETHER and device-resident:
+ * every step of the gate walk is one launch for all lanes (grid dimension = lane); a truncated 2-qubit gate is one workgroup per
+ * lane (two-site tensor, Jacobi SVD, rank / truncation decision, new tensors -- the lane's bond dimensions never leave the device);
+ * gate matrices are formed by the kernels from thetas[lane][index].  The host enqueues the whole evaluation without waiting and
+ * reads all results in one transfer.  Bonds up to 32 per lane; a lane whose bond would grow beyond that makes the call fail (never
+ * a silent truncation) and the caller falls back to aqc_mps_fast_dot_gradient lane by lane.  Truncation rule and outputs per lane
+ * are those of aqc_mps_apply_circuit + aqc_mps_dot + aqc_mps_fast_dot_gradient (sums of the rule are taken in a different order:
+ * last-bit differences). */
 typedef struct aqc_mpsb aqc_mpsb;
 int aqc_mpsb_create(int device, int num_qubits, int lanes, aqc_mpsb** out);
 int aqc_mpsb_destroy(aqc_mpsb* b);

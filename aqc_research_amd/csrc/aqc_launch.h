@@ -203,14 +203,17 @@ struct LaneGate1 { LaneRot r[3]; };                                             
 struct LaneGate2 { int kind /* 0 swap, 1 cx, 2 cz, 3 cp */, idx, flip, pad; double scale; };   // cp angle = scale * thetas[lane][idx]; flip: control on site q + 1
 hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, int q, const LaneGate1& g, const double* thetas, int T, int lanes, int bond_hint,
                               hipStream_t s);
-hipError_t launch_lanes_gate2(const LaneMps& m, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond, int* status,
-                              int* peak, int lanes, int bond_hint, hipStream_t s);
+hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond,
+                              int* status, int* peak, int lanes, int bond_hint, hipStream_t s);   // m2 (may be null): a second state that takes the same gate
 hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,
                                  const double* gh8, int lanes, hipStream_t s);
 hipError_t launch_lanes_env_right(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride, int lanes,
                                   hipStream_t s);
 hipError_t launch_lanes_env_dot(const LaneMps& w, const LaneMps& z, int hi, const void* e, size_t e_stride, const void* rc, size_t rc_stride, void* vals,
                                 int nvals, int slot, int lanes, hipStream_t s);
+// rotation g on site q of both operands + vals[lane][slot] = <P w|z>, P on site q (gh8 = P^H), from the environments L[q] and R[q]
+hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneGate1& g, const double* thetas, int T, const void* env_l, size_t l_stride,
+                                  const void* env_r, size_t r_stride, const double* gh8, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s);
 hipError_t launch_lanes_env_init(void* env_l, size_t l_stride, void* env_r_last, size_t r_stride, int lanes, hipStream_t s);
 // environment steps of <(ops) w|z> for small bonds, one launch per site (aqc_svd.hip); gh8: 2x2 (row-major, 4 c128) applied to z's site or null
 bool mps_env_fits_small(int xa, int ua, int yb, int vb);

@@ -105,21 +105,22 @@ int gate1_all(aqc_mpsb* b, Lanes& s, int q, const LaneGate1& g, int T, Lanes* s2
     return 0;
 }
 
-int gate_adjacent_all(aqc_mpsb* b, Lanes& s, int q, const LaneGate2& g, int T, double trunc_thr, int max_bond) {
-    HIP_OK(launch_lanes_gate2(s.dev, q, g, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L, b->L, b->hint, b->st));
+int gate_adjacent_all(aqc_mpsb* b, Lanes& s, Lanes* s2, int q, const LaneGate2& g, int T, double trunc_thr, int max_bond) {
+    HIP_OK(launch_lanes_gate2(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L, b->L, b->hint, b->st));
     return 0;
 }
 
-// entangler of a block (control c, target t) on any pair of qubits: swaps bring the upper one next to the lower one and back
-int gate2_pair_all(aqc_mpsb* b, Lanes& s, int ctrl, int targ, int kind, int idx, double scale, int T, double trunc_thr, int max_bond) {
+// entangler of a block (control c, target t) on any pair of qubits of `s` (and of `s2`, when given: the two operands of the gradient walk
+// take every gate in one launch): swaps bring the upper one next to the lower one and back
+int gate2_pair_all(aqc_mpsb* b, Lanes& s, Lanes* s2, int ctrl, int targ, int kind, int idx, double scale, int T, double trunc_thr, int max_bond) {
     const LaneGate2 swap{0, -1, 0, 0, 0.0};
     const int lo = std::min(ctrl, targ), hi = std::max(ctrl, targ);
     for (int p = hi - 1; p > lo; --p)
-        if (gate_adjacent_all(b, s, p, swap, T, trunc_thr, max_bond)) return 1;
+        if (gate_adjacent_all(b, s, s2, p, swap, T, trunc_thr, max_bond)) return 1;
     const LaneGate2 g{kind, idx, ctrl > targ ? 1 : 0, 0, scale};
-    if (gate_adjacent_all(b, s, lo, g, T, trunc_thr, max_bond)) return 1;
+    if (gate_adjacent_all(b, s, s2, lo, g, T, trunc_thr, max_bond)) return 1;
     for (int p = lo + 1; p < hi; ++p)
-        if (gate_adjacent_all(b, s, p, swap, T, trunc_thr, max_bond)) return 1;
+        if (gate_adjacent_all(b, s, s2, p, swap, T, trunc_thr, max_bond)) return 1;
     return 0;
 }
 
@@ -139,7 +140,7 @@ int apply_circuit_all(aqc_mpsb* b, Lanes& s, const aqc_circuit* c, int T, bool i
         for (const BlockRef& blk : blocks) {
             const int p = 3 * n + tpb * blk.j;
             if (c->trotter && blk.i % 3 == 0 && gate1_all(b, s, blk.c, pre, T)) return 1;
-            if (gate2_pair_all(b, s, blk.c, blk.t, ek, cp ? p + 4 : -1, 1.0, T, trunc_thr, max_bond)) return 1;
+            if (gate2_pair_all(b, s, nullptr, blk.c, blk.t, ek, cp ? p + 4 : -1, 1.0, T, trunc_thr, max_bond)) return 1;
             if (gate1_all(b, s, blk.c, g1(rot(RZ, p + 1, 1.0), rot(RY, p, 1.0)), T)) return 1;
             if (gate1_all(b, s, blk.t, g1(rot(rt, p + 3, 1.0), rot(RY, p + 2, 1.0)), T)) return 1;
             if (c->trotter && blk.i % 3 == 2 && gate1_all(b, s, blk.t, post, T)) return 1;
@@ -151,7 +152,7 @@ int apply_circuit_all(aqc_mpsb* b, Lanes& s, const aqc_circuit* c, int T, bool i
             if (c->trotter && blk.i % 3 == 2 && gate1_all(b, s, blk.t, pre, T)) return 1;
             if (gate1_all(b, s, blk.t, g1(rot(RY, p + 2, -1.0), rot(rt, p + 3, -1.0)), T)) return 1;
             if (gate1_all(b, s, blk.c, g1(rot(RY, p, -1.0), rot(RZ, p + 1, -1.0)), T)) return 1;
-            if (gate2_pair_all(b, s, blk.c, blk.t, ek, cp ? p + 4 : -1, -1.0, T, trunc_thr, max_bond)) return 1;
+            if (gate2_pair_all(b, s, nullptr, blk.c, blk.t, ek, cp ? p + 4 : -1, -1.0, T, trunc_thr, max_bond)) return 1;
             if (c->trotter && blk.i % 3 == 0 && gate1_all(b, s, blk.c, post, T)) return 1;
         }
         for (int q = 0; q < n; ++q)
@@ -179,10 +180,9 @@ int step_left_all(aqc_mpsb* b, int p, const double2* in, size_t in_stride, const
     HIP_OK(launch_lanes_env_left(b->w.dev, b->z.dev, p, in, in_stride, out, out_stride, op ? g8 : nullptr, b->L, b->st));
     return 0;
 }
-// vals[l][slot] = <(G_1 on q_1)(G_2 on q_2) w_l | z_l>, q_1 < q_2 (nops = 1: only q_1)
-int dot_all(aqc_mpsb* b, int slot, int nops, const int* q, const M2* const* g) {
-    if (slot >= b->nvals) return failf("inner-product slot out of range");
-    const int lo = q[0], hi = q[nops - 1], n = b->n;
+// left environments up to site lo, right environments down to site hi
+int env_advance(aqc_mpsb* b, int lo, int hi) {
+    const int n = b->n;
     for (; b->valid_l < lo; ++b->valid_l) {
         const int p = b->valid_l;
         if (step_left_all(b, p, b->env_l + (size_t)p * kLaneEnv, kEnvL(n), nullptr, b->env_l + (size_t)(p + 1) * kLaneEnv, kEnvL(n))) return 1;
@@ -192,6 +192,13 @@ int dot_all(aqc_mpsb* b, int slot, int nops, const int* q, const M2* const* g) {
         HIP_OK(launch_lanes_env_right(b->w.dev, b->z.dev, p, b->env_r + (size_t)p * kLaneEnv, kEnvR(n), b->env_r + (size_t)(p - 1) * kLaneEnv, kEnvR(n), b->L,
                                       b->st));
     }
+    return 0;
+}
+// vals[l][slot] = <(G_1 on q_1)(G_2 on q_2) w_l | z_l>, q_1 < q_2 (nops = 1: only q_1)
+int dot_all(aqc_mpsb* b, int slot, int nops, const int* q, const M2* const* g) {
+    if (slot >= b->nvals) return failf("inner-product slot out of range");
+    const int lo = q[0], hi = q[nops - 1], n = b->n;
+    if (env_advance(b, lo, hi)) return 1;
     const double2* cur = b->env_l + (size_t)lo * kLaneEnv;
     size_t cur_stride = kEnvL(n);
     double2* pp[2] = {b->e0, b->e1};
@@ -226,14 +233,27 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int
         rec.emplace_back(tindex, factor);
         return 0;
     };
+    // rotation on site q of both operands + its inner product 0.5j <P w|z>: one launch (the environments do not involve site q)
+    auto rotate_and_record = [&](int tindex, int q, const LaneGate1& g, const M2* op) -> int {
+        const int slot = 1 + (int)rec.size();
+        if (slot >= b->nvals) return failf("inner-product slot out of range");
+        if (env_advance(b, q, q)) return 1;
+        const M2 gh = {{std::conj(op->m[0]), std::conj(op->m[2]), std::conj(op->m[1]), std::conj(op->m[3])}};
+        double g8[8];
+        pack(gh, g8);
+        HIP_OK(launch_lanes_grad_step(b->w.dev, b->z.dev, q, g, b->thetas, T, b->env_l + (size_t)q * kLaneEnv, kEnvL(n), b->env_r + (size_t)q * kLaneEnv, kEnvR(n),
+                                      g8, b->e0, b->vals, b->nvals, slot, b->L, b->st));
+        env_touched(b, q, q);
+        rec.emplace_back(tindex, cd(0, 0.5));
+        return 0;
+    };
     for (int q = 0; q < n; ++q) {
         const int slots[3] = {2, 1, 0};
         for (int k = 0; k < 3; ++k) {
             const int slot = slots[k];
             const bool is_y = slot == 1;
-            if (both(q, g1(rot(is_y ? RY : RZ, 3 * q + slot, 1.0)))) return 1;
-            const M2* op = is_y ? &kPauliY : &kPauliZ;
-            if (front_layer && record(3 * q + slot, cd(0, 0.5), 1, &q, &op)) return 1;
+            const LaneGate1 g = g1(rot(is_y ? RY : RZ, 3 * q + slot, 1.0));
+            if (front_layer ? rotate_and_record(3 * q + slot, q, g, is_y ? &kPauliY : &kPauliZ) : both(q, g)) return 1;
         }
     }
     const LaneGate1 pre = g1(rot(RZ, -1, -half_pi)), post = g1(rot(RZ, -1, half_pi));
@@ -246,15 +266,14 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int
             const M2* gg[2] = {&kProj1, &kProj1};
             if (record(base + 4, cd(0, -1.0), 2, qq, gg)) return 1;
         }
-        if (gate2_pair_all(b, b->z, blk.c, blk.t, ek, cp ? base + 4 : -1, 1.0, T, trunc_thr, max_bond) ||
-            gate2_pair_all(b, b->w, blk.c, blk.t, ek, cp ? base + 4 : -1, 1.0, T, trunc_thr, max_bond)) return 1;
+        if (gate2_pair_all(b, b->z, &b->w, blk.c, blk.t, ek, cp ? base + 4 : -1, 1.0, T, trunc_thr, max_bond)) return 1;
         env_touched(b, std::min(blk.c, blk.t), std::max(blk.c, blk.t));
         const int qs[4] = {blk.c, blk.c, blk.t, blk.t};
         const int kinds[4] = {RY, RZ, RY, cx ? RX : RZ};
         const M2* ps[4] = {&kPauliY, &kPauliZ, &kPauliY, cx ? &kPauliX : &kPauliZ};
         for (int k = 0; k < 4; ++k) {
-            if (both(qs[k], g1(rot(kinds[k], base + k, 1.0)))) return 1;
-            if (live && record(base + k, cd(0, 0.5), 1, &qs[k], &ps[k])) return 1;
+            const LaneGate1 g = g1(rot(kinds[k], base + k, 1.0));
+            if (live ? rotate_and_record(base + k, qs[k], g, ps[k]) : both(qs[k], g)) return 1;
         }
         if (c->trotter && blk.i % 3 == 2 && both(blk.t, post)) return 1;
     }
@@ -263,28 +282,41 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int
 
 int load_lanes(aqc_mpsb* b, Lanes& dst, aqc_mps* const* src, int shared) {
     if (!src) return failf("null MPS list");
-    std::vector<int> dims_all((size_t)b->L * (b->n + 1));
-    std::vector<double> disc(b->L);
+    const int n = b->n, L = b->L, distinct = shared ? 1 : L;
+    std::vector<int> dims_all((size_t)L * (n + 1));
+    std::vector<double> disc(L);
     dst.max_dim_in = 1;
-    for (int l = 0; l < b->L; ++l) {
-        const aqc_mps* m = src[shared ? 0 : l];
+    for (int l = 0; l < distinct; ++l) {
+        const aqc_mps* m = src[l];
         if (!m) return failf("null MPS handle (lane %d)", l);
-        if (aqc_mps_num_qubits(m) != b->n) return failf("lane %d: the MPS has %d qubits, the batch %d", l, aqc_mps_num_qubits(m), b->n);
-        std::vector<int32_t> dims(b->n + 1);
+        if (aqc_mps_num_qubits(m) != n) return failf("lane %d: the MPS has %d qubits, the batch %d", l, aqc_mps_num_qubits(m), n);
+        std::vector<int32_t> dims(n + 1);
         if (aqc_mps_dims(m, dims.data())) return 1;
-        for (int q = 0; q <= b->n; ++q) {
+        for (int q = 0; q <= n; ++q) {
             if (dims[q] > kLaneCap)
                 return failf("lane %d: bond dimension %d exceeds the %d of the lockstep lanes (use the single-lane engine)", l, dims[q], kLaneCap);
-            dims_all[(size_t)l * (b->n + 1) + q] = dims[q];
+            dims_all[(size_t)l * (n + 1) + q] = dims[q];
             dst.max_dim_in = std::max(dst.max_dim_in, (int)dims[q]);
         }
         disc[l] = aqc_mps_discarded_weight(m);
-        for (int q = 0; q < b->n; ++q) {
+        for (int q = 0; q < n; ++q) {
             const void* site = nullptr;
             const double* lam = nullptr;
             if (mps_peek(m, q, &site, &lam)) return 1;
             HIP_OK(hipMemcpyAsync(dst.site(l, q), site, sizeof(double2) * 2 * dims[q] * dims[q + 1], hipMemcpyDeviceToDevice, b->st));
-            if (q < b->n - 1) HIP_OK(hipMemcpyAsync(dst.lambda(l, q), lam, sizeof(double) * dims[q + 1], hipMemcpyDeviceToDevice, b->st));
+            if (q < n - 1) HIP_OK(hipMemcpyAsync(dst.lambda(l, q), lam, sizeof(double) * dims[q + 1], hipMemcpyDeviceToDevice, b->st));
+        }
+    }
+    if (shared) {   // one state for all lanes: lane 0 is replicated by doubling (lanes [0, c) -> [c, 2c)), 2 log2(L) copies instead of 2 n L
+        for (int l = 1; l < L; ++l) {
+            std::copy(dims_all.begin(), dims_all.begin() + (n + 1), dims_all.begin() + (size_t)l * (n + 1));
+            disc[l] = disc[0];
+        }
+        const size_t t_lane = sizeof(double2) * (size_t)n * kLaneSite, lam_lane = sizeof(double) * (size_t)dst.nb * kLaneCap;
+        for (int c = 1; c < L; c *= 2) {
+            const int cnt = std::min(c, L - c);
+            HIP_OK(hipMemcpyAsync(static_cast<char*>(dst.dev.T) + t_lane * c, dst.dev.T, t_lane * cnt, hipMemcpyDeviceToDevice, b->st));
+            HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(dst.dev.lam) + lam_lane * c, dst.dev.lam, lam_lane * cnt, hipMemcpyDeviceToDevice, b->st));
         }
     }
     HIP_OK(hipMemcpyAsync(dst.dev.dims, dims_all.data(), sizeof(int) * dims_all.size(), hipMemcpyHostToDevice, b->st));

@@ -864,30 +864,34 @@ __device__ __forceinline__ void lane_rot(const LaneRot& r, const double* __restr
 }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
-__global__ __launch_bounds__(128) void lanes_gate1_kernel(LaneMps a, LaneMps b, int nstates, int q, LaneGate1 g, const double* __restrict__ thetas, int T,
-                                                          int lanes) {
-    const int l = blockIdx.y % lanes, which = blockIdx.y / lanes;
-    const LaneMps& m = which ? b : a;
-    (void)nstates;
-    const int* dims = m.dims + (size_t)l * (m.n + 1);
-    const int ne = dims[q] * dims[q + 1];
-    cplx u[4];
-    lane_rot(g.r[0], thetas + (size_t)l * T, u);
+// u = r[0] r[1] r[2] of the lane
+__device__ __forceinline__ void lane_gate1_matrix(const LaneGate1& g, const double* __restrict__ th, cplx* u) {
+    lane_rot(g.r[0], th, u);
 #pragma unroll
     for (int k = 1; k < 3; ++k)
         if (g.r[k].kind) {
             cplx v[4];
-            lane_rot(g.r[k], thetas + (size_t)l * T, v);
+            lane_rot(g.r[k], th, v);
             const cplx p0 = cadd(cmul(u[0], v[0]), cmul(u[1], v[2])), p1 = cadd(cmul(u[0], v[1]), cmul(u[1], v[3]));
             const cplx p2 = cadd(cmul(u[2], v[0]), cmul(u[3], v[2])), p3 = cadd(cmul(u[2], v[1]), cmul(u[3], v[3]));
             u[0] = p0; u[1] = p1; u[2] = p2; u[3] = p3;
         }
-    cplx* t = static_cast<cplx*>(m.T) + ((size_t)l * m.n + q) * kLaneSite;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
+}
+__device__ __forceinline__ void lane_apply_gate1(cplx* __restrict__ t, int ne, const cplx* u, int first, int step) {   // T[2][ne] <- u T
+    for (int i = first; i < ne; i += step) {
         const cplx a0 = t[i], a1 = t[ne + i];
         t[i] = cadd(cmul(u[0], a0), cmul(u[1], a1));
         t[ne + i] = cadd(cmul(u[2], a0), cmul(u[3], a1));
     }
+}
+__global__ __launch_bounds__(128) void lanes_gate1_kernel(LaneMps a, LaneMps b, int q, LaneGate1 g, const double* __restrict__ thetas, int T, int lanes) {
+    const int l = blockIdx.y % lanes;
+    const LaneMps& m = blockIdx.y < (unsigned)lanes ? a : b;
+    const int* dims = m.dims + (size_t)l * (m.n + 1);
+    cplx u[4];
+    lane_gate1_matrix(g, thetas + (size_t)l * T, u);
+    lane_apply_gate1(static_cast<cplx*>(m.T) + ((size_t)l * m.n + q) * kLaneSite, dims[q] * dims[q + 1], u, blockIdx.x * blockDim.x + threadIdx.x,
+                     gridDim.x * blockDim.x);
 }
 
 #ifdef AQC_TUNING   // in-kernel stamps (diagnostic builds only): where the time of lanes_gate2_kernel goes (workgroup 0)
@@ -902,9 +906,9 @@ __device__ unsigned long long g_gate2_stamps[16];
 // One truncated 2-qubit gate on the sites (q, q + 1) of every lane, the whole of it in ONE workgroup per lane: two-site tensor with the gate
 // -> Jacobi work matrix in LDS, the sweeps, singular values, order / rank / truncation (the rule of gate_adjacent, aqc_mps_engine.cpp, on the
 // lane's own values), new site tensors, Schmidt values and bond dimension.
-__global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m, int q, LaneGate2 g, const double* __restrict__ thetas, int T, double trunc_thr,
-                                                           int max_bond, double tol, int max_sweeps, int* __restrict__ status, int* __restrict__ peak,
-                                                           unsigned lds_elems) {
+__global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m1, int lanes, int q, LaneGate2 g, const double* __restrict__ thetas, int T,
+                                                           double trunc_thr, int max_bond, double tol, int max_sweeps, int* __restrict__ status,
+                                                           int* __restrict__ peak, unsigned lds_elems) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ cplx gm[16];
     __shared__ double sig[2 * kLaneCap];
@@ -912,7 +916,9 @@ __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m, int q, Lan
     __shared__ double sorted[2 * kLaneCap];
     __shared__ int k_sh;
     __shared__ double rescale_sh;
-    const int l = blockIdx.x, tid = threadIdx.x, n = m.n;
+    const int l = blockIdx.x % lanes, tid = threadIdx.x;
+    const LaneMps& m = blockIdx.x < (unsigned)lanes ? m0 : m1;   // (the two operands of the gradient walk take every gate in one launch)
+    const int n = m.n;
 #ifdef AQC_TUNING
     unsigned long long last_ = 0;
 #endif
@@ -1070,6 +1076,42 @@ __global__ __launch_bounds__(256) void lanes_env_dot_kernel(LaneMps w, LaneMps z
     }
     if (threadIdx.x == 0) vals[(size_t)l * nvals + slot] = make_double2(sr[0], si[0]);
 }
+// One parameter of the gradient walk in ONE launch: the rotation on site q of both operands, then <P w|z> with the Pauli P on that site from
+// the environments on either side: E = step(L[q], site q seen through P^H), vals[lane][slot] = sum E conj(R[q]).  (They were three launches.)
+__global__ __launch_bounds__(256) void lanes_grad_step_kernel(LaneMps w, LaneMps z, int q, LaneGate1 g, const double* __restrict__ thetas, int T,
+                                                              const cplx* __restrict__ env_l, size_t l_stride, const cplx* __restrict__ env_r, size_t r_stride,
+                                                              Gate4c gh, cplx* __restrict__ scratch, cplx* __restrict__ vals, int nvals, int slot) {
+    const int l = blockIdx.x, n = w.n, tid = threadIdx.x;
+    const int* dw = w.dims + (size_t)l * (n + 1);
+    const int* dz = z.dims + (size_t)l * (n + 1);
+    const int xa = dw[q], ua = dw[q + 1], yb = dz[q], vb = dz[q + 1];
+    cplx* A = static_cast<cplx*>(w.T) + ((size_t)l * n + q) * kLaneSite;
+    cplx* B = static_cast<cplx*>(z.T) + ((size_t)l * n + q) * kLaneSite;
+    {
+        cplx u[4];
+        lane_gate1_matrix(g, thetas + (size_t)l * T, u);
+        lane_apply_gate1(A, xa * ua, u, tid, 256);
+        lane_apply_gate1(B, yb * vb, u, tid, 256);
+    }
+    __syncthreads();   // (workgroup-scope release / acquire: the environment step below reads what other threads have just written)
+    cplx* e = scratch + (size_t)l * kLaneEnv;
+    mps_env_left_body(env_l + (size_t)l * l_stride, A, B, xa, ua, yb, vb, 1, gh, e);
+    __shared__ double sr[256], si[256];
+    const cplx* rc = env_r + (size_t)l * r_stride;
+    double re = 0.0, im = 0.0;
+    for (int i = tid; i < ua * vb; i += 256) {
+        const cplx a = e[i], b = rc[i];
+        re += a.x * b.x + a.y * b.y;
+        im += a.y * b.x - a.x * b.y;
+    }
+    sr[tid] = re; si[tid] = im;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sr[tid] += sr[tid + s]; si[tid] += si[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) vals[(size_t)l * nvals + slot] = make_double2(sr[0], si[0]);
+}
 __global__ void lanes_env_init_kernel(cplx* env_l, size_t l_stride, cplx* env_r_last, size_t r_stride, int lanes) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= lanes) return;
@@ -1080,11 +1122,11 @@ __global__ void lanes_env_init_kernel(cplx* env_l, size_t l_stride, cplx* env_r_
 hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, int q, const LaneGate1& g, const double* thetas, int T, int lanes, int bond_hint,
                               hipStream_t s) {
     const int blocks = std::max(1, (bond_hint * bond_hint + 127) / 128);
-    lanes_gate1_kernel<<<dim3(blocks, lanes * (b ? 2 : 1)), 128, 0, s>>>(a, b ? *b : a, b ? 2 : 1, q, g, thetas, T, lanes);
+    lanes_gate1_kernel<<<dim3(blocks, lanes * (b ? 2 : 1)), 128, 0, s>>>(a, b ? *b : a, q, g, thetas, T, lanes);
     return hipGetLastError();
 }
-hipError_t launch_lanes_gate2(const LaneMps& m, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond, int* status,
-                              int* peak, int lanes, int bond_hint, hipStream_t s) {
+hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond,
+                              int* status, int* peak, int lanes, int bond_hint, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lanes_gate2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1097,9 +1139,11 @@ hipError_t launch_lanes_gate2(const LaneMps& m, int q, const LaneGate2& g, const
     // A half-wave per column pair of the largest work matrix the launch is sized for while the lanes do not fill the chip (shortest
     // rounds); half of that once there are several workgroups per CU (typical matrices are well below the largest, idle waves only cost
     // barrier time and occupancy: 6.4 k -> 7.4 k evals/s at 1024 lanes of the 32-qubit workload, 7.6 k -> 9.6 k at 4096)
-    const int per_bond = lanes > 512 ? 16 : 32;
+    const int groups = lanes * (m2 ? 2 : 1);
+    const int per_bond = groups > 512 ? 16 : 32;
     const int threads = std::min(1024, std::max(64, (per_bond * h + 63) & ~63));
-    lanes_gate2_kernel<<<lanes, threads, lds_elems * sizeof(cplx), s>>>(m, q, g, thetas, T, trunc_thr, max_bond, 1e-15, 60, status, peak, lds_elems);
+    lanes_gate2_kernel<<<groups, threads, lds_elems * sizeof(cplx), s>>>(m, m2 ? *m2 : m, lanes, q, g, thetas, T, trunc_thr, max_bond, 1e-15, 60, status, peak,
+                                                                         lds_elems);
     return hipGetLastError();
 }
 hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,
@@ -1119,6 +1163,15 @@ hipError_t launch_lanes_env_dot(const LaneMps& w, const LaneMps& z, int hi, cons
                                 int nvals, int slot, int lanes, hipStream_t s) {
     lanes_env_dot_kernel<<<lanes, 256, 0, s>>>(w, z, hi, static_cast<const cplx*>(e), e_stride, static_cast<const cplx*>(rc), rc_stride,
                                                static_cast<cplx*>(vals), nvals, slot);
+    return hipGetLastError();
+}
+hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneGate1& g, const double* thetas, int T, const void* env_l, size_t l_stride,
+                                  const void* env_r, size_t r_stride, const double* gh8, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s) {
+    Gate4c gh;
+    for (int i = 0; i < 4; ++i) gh.m[i] = make_double2(gh8[2 * i], gh8[2 * i + 1]);
+    lanes_grad_step_kernel<<<lanes, 256, sizeof(cplx) * kLaneEnv, s>>>(w, z, q, g, thetas, T, static_cast<const cplx*>(env_l), l_stride,
+                                                                        static_cast<const cplx*>(env_r), r_stride, gh, static_cast<cplx*>(scratch),
+                                                                        static_cast<cplx*>(vals), nvals, slot);
     return hipGetLastError();
 }
 hipError_t launch_lanes_env_init(void* env_l, size_t l_stride, void* env_r_last, size_t r_stride, int lanes, hipStream_t s) {

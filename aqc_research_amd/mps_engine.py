@@ -91,6 +91,7 @@ class DeviceMPS:
     def __init__(self, handle: c_void_p):
         self.handle = handle
         self._L = _lib.lib()
+        self.version = 0   # counts the in-place changes of the state (copies held elsewhere, e.g. by LockstepLanes, go stale)
 
     @classmethod
     def from_qiskit(cls, qiskit_mps, device: Optional[int] = None, trunc_thr: float = 0.0, assume_canonical: bool = False) -> "DeviceMPS":
@@ -171,6 +172,7 @@ class DeviceMPS:
         if g.shape != (2, 2):
             raise ValueError("expects a 2x2 gate")
         check(self._L.aqc_mps_gate1(self.handle, int(qubit), dptr(g)))
+        self.version += 1
         return self
 
     def gate2(self, gate4, ctrl: int, targ: int, trunc_thr: float = 0.0, max_bond: int = 0) -> "DeviceMPS":
@@ -178,6 +180,7 @@ class DeviceMPS:
         if g.shape != (4, 4):
             raise ValueError("expects a 4x4 gate")
         check(self._L.aqc_mps_gate2(self.handle, int(ctrl), int(targ), dptr(g), float(trunc_thr), int(max_bond)))
+        self.version += 1
         return self
 
     def dot(self, other: "DeviceMPS") -> np.complex128:
@@ -267,6 +270,7 @@ def _apply_circuit(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: float
     desc, keep = _describe(circ)
     th = _thetas(circ, thetas)
     check(_lib.lib().aqc_mps_apply_circuit(mps.handle, byref(desc), dptr(th), int(inverse), float(trunc_thr), int(max_bond)))
+    mps.version += 1
     del keep
     return mps
 
@@ -432,15 +436,22 @@ class LockstepLanes:
         return lst, arr, int(len(lst) == 1)
 
     def set_targets(self, targets) -> "LockstepLanes":
+        """Copies |phi_l> of every lane into the lanes (one state per lane, or one for all).  A call with the very states of the
+        previous one, unchanged since (``DeviceMPS.version``), is free: the batches of an optimisation come back every iteration."""
         lst, arr, shared = self._handles(targets)
-        check(_lib.lib().aqc_mpsb_set_targets(self.handle, arr, shared))
-        self._targets = [id(m) for m in lst]
+        stamp = [(m, m.version) for m in lst]   # (holds the states: their identities stay unique)
+        if self._targets is None or len(stamp) != len(self._targets) or any(a is not b or va != vb for (a, va), (b, vb) in zip(stamp, self._targets)):
+            check(_lib.lib().aqc_mpsb_set_targets(self.handle, arr, shared))
+            self._targets = stamp
         return self
 
     def set_lhs(self, lhs) -> "LockstepLanes":
+        """The same for the left-hand states <lhs_l|."""
         lst, arr, shared = self._handles(lhs)
-        check(_lib.lib().aqc_mpsb_set_lhs(self.handle, arr, shared))
-        self._lhs = [id(m) for m in lst]
+        stamp = [(m, m.version) for m in lst]
+        if self._lhs is None or len(stamp) != len(self._lhs) or any(a is not b or va != vb for (a, va), (b, vb) in zip(stamp, self._lhs)):
+            check(_lib.lib().aqc_mpsb_set_lhs(self.handle, arr, shared))
+            self._lhs = stamp
         return self
 
     def evaluate(self, circ, thetas, *, trunc_thr: float = 0.0, max_bond: int = 0, block_range: Optional[Tuple[int, int]] = None,
@@ -469,6 +480,7 @@ class LockstepLanes:
         if getattr(self, "handle", None):
             _lib.lib().aqc_mpsb_destroy(self.handle)
             self.handle = None
+            self._targets = self._lhs = None
 
     def __del__(self):
         try:
@@ -487,8 +499,7 @@ def _lockstep_for(num_qubits: int, lanes: int, device: int, targets, lhs) -> Loc
         if len(_LOCKSTEP_CACHE) >= 4:
             _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
         ls = _LOCKSTEP_CACHE[key] = LockstepLanes(num_qubits, lanes, device)
-    # the operands are copied into the lanes: always refreshed (n small device-to-device copies per lane), a state edited in place between
-    # two evaluations is seen
+    # the operands are copied into the lanes; the copies are refreshed when a state was replaced or edited in place (DeviceMPS.version)
     ls.set_targets(targets)
     ls.set_lhs(lhs)
     return ls

@@ -851,7 +851,10 @@ def measure(workload, args, env, full):
         distinct = [np.linalg.qr(rng.standard_normal((1 << n, ncols)) + 1j * rng.standard_normal((1 << n, ncols)))[0] for _ in range(min(B, 8))]
         targets = np.stack([distinct[b % len(distinct)] * np.exp(2j * np.pi * b / max(B, 1)) for b in range(B)])   # (a lane's own phase)
         ws.upload(BUF_Y, targets)
-        ws.set_identity(BUF_X)
+        if ncols == 1 << n:
+            ws.set_identity(BUF_X)
+        else:
+            ws.upload(BUF_X, np.ascontiguousarray(np.broadcast_to(np.eye(1 << n, ncols, dtype=complex), (B, 1 << n, ncols))))
     nsets = min(K + W, 64)       # thetas change every step (nothing is served from a cache); the bank is cycled
     bank = np.pi * (2 * rng.random((nsets, B, T)) - 1)
     ws.theta_bank(bank)

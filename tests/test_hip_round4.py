@@ -399,6 +399,12 @@ def test_lockstep_lanes_match_the_single_lane_engine_and_the_dense_oracle(entang
         assert abs(h2[b] - h1) < 1e-12 and maxdiff(g2[b], g1) < 1e-12
         tpb = 5 if entangler == "cp" else 4
         assert np.all(g2[b][: 3 * n] == 0) and np.all(g2[b][3 * n + 5 * tpb:] == 0) and np.all(g2[b][3 * n: 3 * n + 2 * tpb] == 0)
+    # a state edited in place is copied into the lanes again (DeviceMPS.version), an unchanged one is not
+    targets[0].gate1(np.array([[0, 1], [1, 0]], dtype=complex), 2)
+    h3, g3 = me.evaluate_lanes(circ, ths, targets, lhs, method="lockstep")
+    h1, g1, *_ = _single_lane_reference(me, circ, ths[0], targets[0], lhs[0])
+    assert abs(h3[0] - h1) < 1e-12 and maxdiff(g3[0], g1) < 1e-12 and abs(h3[0] - h[0]) > 1e-6
+    assert abs(h3[1] - h[1]) < 1e-14 and maxdiff(g3[1], g[1]) < 1e-14
     for m in targets + lhs:
         m.close()
 

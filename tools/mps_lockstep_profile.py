@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few lockstep evaluations of the 32-qubit engine workload for a kernel trace:
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lockstep -- python3 tools/mps_lockstep_profile.py [lanes] [reps]"""
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lockstep -- python3 tools/mps_lockstep_profile.py [lanes] [reps] [distinct targets]"""
 import sys
 import time
 
@@ -20,10 +20,12 @@ th0 = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=0.6 * la
 tcirc = TrotterAnsatz(n, make_trotter_like_circuit(n, 3 * layers), second_order=True)
 tth = init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=0.6 * layers, delta=1.0)
 basis = DeviceMPS.basis_state(n, neel_state_index(n))
-target = v_mul_mps(tcirc, tth, basis, trunc_thr=1e-12)
+distinct = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # number of different targets shared round-robin by the lanes
+targets = [v_mul_mps(tcirc, init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=0.6 * layers * (1.0 + 0.01 * b), delta=1.0), basis,
+                     trunc_thr=1e-12) for b in range(distinct)]
 rng = np.random.default_rng(3)
 ths = np.stack([th0 + 0.02 * rng.standard_normal(th0.size) for _ in range(lanes)])
-lk = LockstepLanes(n, lanes).set_targets(target).set_lhs(basis)
+lk = LockstepLanes(n, lanes).set_targets(targets[0] if distinct == 1 else [targets[b % distinct] for b in range(lanes)]).set_lhs(basis)
 def run():
     try:
         lk.evaluate(circ, ths, trunc_thr=thr)
@@ -37,7 +39,9 @@ t0 = time.perf_counter()
 for _ in range(reps):
     run()
 dt = (time.perf_counter() - t0) / reps
-print(f"lockstep lanes {lanes}: {lanes / dt:.1f} evals/s, {dt * 1e3:.1f} ms per round", flush=True)
+h, g, disc, bonds = lk.evaluate(circ, ths, trunc_thr=thr, details=True)
+print(f"lockstep lanes {lanes} ({distinct} targets): {lanes / dt:.1f} evals/s, {dt * 1e3:.1f} ms per round; largest bond of V^H|target> {bonds.max()}, "
+      f"mean |h|^2 {np.mean(np.abs(h) ** 2):.4f}", flush=True)
 from aqc_research_amd import _lib   # noqa: E402
 
 if hasattr(_lib.lib(), "aqc_dbg_gate2_stamps"):   # tuning builds (AQC_HIP_LIB=.../libaqc_hip_tuning.so): in-kernel stamps

@@ -6,7 +6,7 @@ AMD GPU is usable, calls raise -- there is no CPU fallback.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 import numpy as np
 
@@ -82,6 +82,9 @@ SIGNATURES = {
     "aqc_mpsb_set_targets": (c_int, [_P, POINTER(_P), c_int]),
     "aqc_mpsb_set_lhs": (c_int, [_P, POINTER(_P), c_int]),
     "aqc_mpsb_eval": (c_int, [_P, _P, _D, c_double, c_int, c_int, c_int, c_int, _D, _D, _D, POINTER(c_int32)]),
+    "aqc_mpsb_set_lhs_basis": (c_int, [_P, POINTER(c_uint8)]),
+    "aqc_mpsb_vh": (c_int, [_P, _P, _D, c_double, c_int, c_int, c_int, _D, _D, POINTER(c_int32)]),
+    "aqc_mpsb_grad": (c_int, [_P, _P, c_int, c_int, c_int, _D]),
     "aqc_gate_dot": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int, _D, _D, _D]),
     "aqc_ws_mps_upload": (c_int, [_P, c_int, POINTER(c_int32), _D, _D]),
     "aqc_ws_mps_to_vec": (c_int, [_P, c_int, c_int, c_int]),

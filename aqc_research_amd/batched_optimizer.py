@@ -18,7 +18,7 @@ import numpy as np
 from .engine import BUF_X, BUF_X2, BUF_Y, HipContext, Workspace
 from .model_sp_lhs.objective_base import ThinStateHandler
 
-__all__ = ["BatchedSurrogateObjective", "BatchedSketchingObjective", "batched_lbfgs"]
+__all__ = ["BatchedSurrogateObjective", "BatchedMpsSurrogateObjective", "BatchedSketchingObjective", "batched_lbfgs"]
 
 
 class _RawResults:
@@ -211,6 +211,89 @@ class BatchedSurrogateObjective:
 
     def close(self) -> None:
         self.ws.close()
+
+
+class BatchedMpsSurrogateObjective:
+    """``BatchedSurrogateObjective`` for registers beyond dense reach: B lanes of the surrogate state-preparation objective with
+    the targets as MPS (``SpSurrogateObjectiveFastMpsTrotter``, objective_lhs_sur_fast_mps_trotter.py:99-227, one object per job in
+    the reference) on the lockstep lanes of the native MPS engine (``mps_engine.LockstepLanes``, bonds <= 32).
+
+    One evaluation = two phases on 2B lanes (lane B + l is problem l seen from its leading flip state): V^H|target_l> once per
+    problem plus the amplitudes of |state_0> and of its n single-flip states; the state machine of objective_lhs_sur_max.py:99-191
+    (10 % hysteresis, smoothed weight) on the host; then both gradient walks -- from |state_0> and from the leading state -- together,
+    combined as c_0 g_0 + c_max g_max (:147-175).  ``targets``: one ``DeviceMPS`` per lane, or one for all lanes."""
+
+    _gamma = 0.1  # objective_lhs_sur_max.py:40
+
+    def __init__(self, circ, targets, *, base_index: int = 0, trunc_thr: float = 1e-6, max_bond: int = 0,
+                 block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, device: Optional[int] = None, lanes: Optional[int] = None):
+        from .mps_engine import LockstepLanes
+
+        tg = list(targets) if isinstance(targets, (list, tuple)) else None
+        if tg is None and (lanes is None or lanes < 1):
+            raise ValueError("one target for all lanes needs the number of lanes")
+        self.circ, self.batch, self.T, self.n = circ, int(len(tg) if tg is not None else lanes), circ.num_thetas, circ.num_qubits
+        self._trunc, self._max_bond = float(trunc_thr), int(max_bond)
+        self._block_range = None if block_range is None else (int(block_range[0]), int(block_range[1]))
+        self._front = bool(front_layer or block_range is None or tuple(block_range) == (0, circ.num_blocks))
+        base = int(base_index)
+        self._base_bits = np.array([(base >> q) & 1 for q in range(self.n)], dtype=np.uint8)
+        self.lanes = LockstepLanes(self.n, 2 * self.batch, device)
+        self.lanes.set_targets(tg + tg if tg is not None else targets)
+        self.num_evals = 0
+        self._lhs_of = None
+        self.reset_state()
+
+    def reset_state(self) -> None:
+        """A fresh objective (weight 1, |state_0> leads): the next job of a driver."""
+        self.weight = np.ones(self.batch)
+        self.max_no = np.zeros(self.batch, dtype=np.int64)
+        self.fidelity = np.full(self.batch, -1.0)
+        self.last_hs = None
+
+    def _lhs_bits(self, max_no: np.ndarray) -> np.ndarray:
+        bits = np.tile(self._base_bits, (2 * self.batch, 1))
+        lead = np.nonzero(max_no)[0]
+        bits[self.batch + lead, max_no[lead] - 1] ^= 1            # state i >= 1 flips qubit i - 1 (objective_base.py:42-255)
+        return bits
+
+    def _upload_lhs(self, max_no: np.ndarray) -> None:
+        if self._lhs_of is None or (self._lhs_of != max_no).any():
+            self.lanes.set_lhs_basis(self._lhs_bits(max_no))
+            self._lhs_of = max_no.copy()
+
+    def value_and_grad(self, thetas: np.ndarray, update_state: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """f[B], g[B][T] at thetas[B][T]; ``update_state`` as in ``BatchedSurrogateObjective.value_and_grad``."""
+        th = np.ascontiguousarray(thetas, dtype=np.float64).reshape(self.batch, self.T)
+        B = self.batch
+        self.num_evals += B
+        self._upload_lhs(self.max_no)
+        amps = self.lanes.apply_vh(self.circ, np.concatenate([th, th]), trunc_thr=self._trunc, max_bond=self._max_bond, flips=True, half=True)
+        hs = amps[:B]                                              # hs[l][i] = <state_i|V^H|target_l>
+        hs2 = np.abs(hs) ** 2
+        rows = np.arange(B)
+        max_no, w = self.max_no, self.weight
+        if update_state:                                           # hysteresis (:113-117) and weight smoothing (:186)
+            max_no = max_no.copy()
+            best = hs2[rows, max_no]
+            for i in range(hs2.shape[1]):
+                better = 1.1 * best < hs2[:, i]
+                best = np.where(better, hs2[:, i], best)
+                max_no = np.where(better, i, max_no)
+            f_old = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[rows, max_no]
+            w = w + self._gamma * (np.sqrt(np.abs(f_old)) - w)
+            self._upload_lhs(max_no)
+            self.max_no, self.weight, self.fidelity = max_no, w, hs2[:, 0].copy()
+        f = 1.0 - (1.0 - w) * hs2[:, 0] - w * hs2[rows, max_no]
+        lead = max_no != 0
+        c0 = np.where(lead, -2.0 * (1.0 - w), -2.0) * np.conj(hs[:, 0])
+        cm = np.where(lead, -2.0 * w, 0.0) * np.conj(hs[rows, max_no])
+        g = self.lanes.gradient(self.circ, block_range=self._block_range, front_layer=self._front)
+        self.last_hs = hs
+        return f, (c0[:, None] * g[:B] + cm[:, None] * g[B:]).real
+
+    def close(self) -> None:
+        self.lanes.close()
 
 
 def batched_lbfgs(fun: Callable[[np.ndarray, bool], Tuple[np.ndarray, np.ndarray]], x0: np.ndarray, *, maxiter: int = 100,

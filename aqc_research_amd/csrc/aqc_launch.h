@@ -214,6 +214,7 @@ hipError_t launch_lanes_env_dot(const LaneMps& w, const LaneMps& z, int hi, cons
 // rotation g on site q of both operands + vals[lane][slot] = <P w|z>, P on site q (gh8 = P^H), from the environments L[q] and R[q]
 hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneGate1& g, const double* thetas, int T, const void* env_l, size_t l_stride,
                                   const void* env_r, size_t r_stride, const double* gh8, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s);
+hipError_t launch_lanes_basis(const LaneMps& m, const unsigned char* bits /* [lanes][n] */, int lanes, hipStream_t s);   // product basis states
 hipError_t launch_lanes_env_init(void* env_l, size_t l_stride, void* env_r_last, size_t r_stride, int lanes, hipStream_t s);
 // environment steps of <(ops) w|z> for small bonds, one launch per site (aqc_svd.hip); gh8: 2x2 (row-major, 4 c128) applied to z's site or null
 bool mps_env_fits_small(int xa, int ua, int yb, int vb);

@@ -73,7 +73,14 @@ struct aqc_mpsb {
     size_t h_out_bytes = 0;
     int nvals = 0, valid_l = 0, valid_r = 0;
     int hint = kLaneCap;         // bonds the launches are sized for
-    int peak_seen = 0;           // largest bond a gate of the previous evaluation produced (0: none yet)
+    int peak_vh = 0, peak_grad = 0;   // largest bond the gates of the last V^H / gradient phase produced (0: none yet)
+    int active = 0;              // lanes the gate launches cover (all, or the first half while V^H runs for lanes that repeat it)
+    int cur_T = 0, cur_max_bond = 0;   // what the last aqc_mpsb_vh / eval ran with (the gradient phase continues from it)
+    double cur_trunc = 0.0;
+    bool vh_ready = false;
+    uint8_t* bits = nullptr;     // basis-state patterns of aqc_mpsb_set_lhs_basis and their pinned staging
+    uint8_t* h_bits = nullptr;
+    size_t bits_cap = 0;
 };
 
 namespace {
@@ -83,9 +90,9 @@ void destroy(aqc_mpsb* b) {
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
     for (Lanes* s : {&b->target, &b->lhs, &b->vh, &b->w, &b->z}) s->release();
-    for (void* p : {(void*)b->thetas, (void*)b->status, (void*)b->env_l, (void*)b->env_r, (void*)b->e0, (void*)b->e1, (void*)b->vals})
+    for (void* p : {(void*)b->thetas, (void*)b->status, (void*)b->env_l, (void*)b->env_r, (void*)b->e0, (void*)b->e1, (void*)b->vals, (void*)b->bits})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)b->h_thetas, (void*)b->h_out})
+    for (void* p : {(void*)b->h_thetas, (void*)b->h_out, (void*)b->h_bits})
         if (p) (void)hipHostFree(p);
     if (b->st) (void)hipStreamDestroy(b->st);
     delete b;
@@ -101,12 +108,12 @@ LaneGate1 g1(LaneRot a, LaneRot b = LaneRot{0, -1, 0.0}, LaneRot c = LaneRot{0, 
 constexpr int RZ = 1, RY = 2, RX = 3;
 
 int gate1_all(aqc_mpsb* b, Lanes& s, int q, const LaneGate1& g, int T, Lanes* s2 = nullptr) {
-    HIP_OK(launch_lanes_gate1(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, b->L, b->hint, b->st));
+    HIP_OK(launch_lanes_gate1(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, b->active, b->hint, b->st));
     return 0;
 }
 
 int gate_adjacent_all(aqc_mpsb* b, Lanes& s, Lanes* s2, int q, const LaneGate2& g, int T, double trunc_thr, int max_bond) {
-    HIP_OK(launch_lanes_gate2(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L, b->L, b->hint, b->st));
+    HIP_OK(launch_lanes_gate2(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L, b->active, b->hint, b->st));
     return 0;
 }
 
@@ -214,8 +221,8 @@ int dot_all(aqc_mpsb* b, int slot, int nops, const int* q, const M2* const* g) {
 }
 
 // the gate-by-gate gradient walk of mps_dot_objective.py:41-242 on every lane: w = lhs, z = vh (both consumed); the inner products go
-// to slots 1, 2, ... of vals (slot 0 holds <lhs|vh>); rec = (theta index, factor) per slot
-int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int max_bond, int lo_blk, int hi_blk, bool front_layer,
+// to slots slot0, slot0 + 1, ... of vals; rec = (theta index, factor) per slot
+int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int max_bond, int lo_blk, int hi_blk, bool front_layer, int slot0,
                  std::vector<std::pair<int, cd>>& rec) {
     const int n = b->n, tpb = c->entangler == AQC_CP ? 5 : 4;
     const bool cx = c->entangler == AQC_CX, cp = c->entangler == AQC_CP;
@@ -229,13 +236,13 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int
         return 0;
     };
     auto record = [&](int tindex, cd factor, int nops, const int* q, const M2* const* g) -> int {
-        if (dot_all(b, 1 + (int)rec.size(), nops, q, g)) return 1;
+        if (dot_all(b, slot0 + (int)rec.size(), nops, q, g)) return 1;
         rec.emplace_back(tindex, factor);
         return 0;
     };
     // rotation on site q of both operands + its inner product 0.5j <P w|z>: one launch (the environments do not involve site q)
     auto rotate_and_record = [&](int tindex, int q, const LaneGate1& g, const M2* op) -> int {
-        const int slot = 1 + (int)rec.size();
+        const int slot = slot0 + (int)rec.size();
         if (slot >= b->nvals) return failf("inner-product slot out of range");
         if (env_advance(b, q, q)) return 1;
         const M2 gh = {{std::conj(op->m[0]), std::conj(op->m[2]), std::conj(op->m[1]), std::conj(op->m[3])}};
@@ -333,6 +340,129 @@ int hint_for(int loaded, int produced) {
     return kLaneCap;
 }
 
+
+// validates, sizes the per-evaluation buffers for `circ` (inner-product slots: amplitudes, then one per parameter) and uploads thetas
+int begin(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int num_amps, int* T_out) {
+    if (check_circuit(circ, b->n)) return 1;
+    if (!(trunc_thr >= 0.0)) return failf("trunc_thr must be non-negative");
+    if (max_bond > kLaneCap) return failf("the lockstep lanes keep bonds up to %d", kLaneCap);
+    HIP_OK(hipSetDevice(b->device));
+    const int n = b->n, L = b->L, tpb = circ->entangler == AQC_CP ? 5 : 4, T = 3 * n + tpb * circ->num_blocks;
+    const int need = num_amps + 3 * n + tpb * (int)blocks_of(circ).size();
+    const auto out_size = [&](int nv) { return sizeof(double2) * (size_t)L * nv + sizeof(int) * 2 * (size_t)L + sizeof(double) * (size_t)L + sizeof(int) * (size_t)L * (n + 1); };
+    if (need > b->nvals || T > b->T_cap) {
+        HIP_OK(hipStreamSynchronize(b->st));
+        if (b->vals) HIP_OK(hipFree(b->vals));
+        if (b->thetas) HIP_OK(hipFree(b->thetas));
+        if (b->h_thetas) HIP_OK(hipHostFree(b->h_thetas));
+        if (b->h_out) HIP_OK(hipHostFree(b->h_out));
+        b->vals = nullptr; b->thetas = nullptr; b->h_thetas = nullptr; b->h_out = nullptr;
+        const int nv = std::max(need, b->nvals), tc = std::max({T, b->T_cap, 1});
+        b->nvals = 0; b->T_cap = 0;
+        HIP_OK(hipMalloc((void**)&b->vals, sizeof(double2) * (size_t)L * nv));
+        HIP_OK(hipMalloc((void**)&b->thetas, sizeof(double) * (size_t)L * tc));
+        HIP_OK(hipHostMalloc((void**)&b->h_thetas, sizeof(double) * (size_t)L * tc, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void**)&b->h_out, out_size(nv), hipHostMallocDefault));
+        b->nvals = nv; b->T_cap = tc;
+    }
+    HIP_OK(hipStreamSynchronize(b->st));   // (the staging buffer may still feed the previous upload)
+    memcpy(b->h_thetas, thetas, sizeof(double) * (size_t)L * T);
+    HIP_OK(hipMemcpyAsync(b->thetas, b->h_thetas, sizeof(double) * (size_t)L * T, hipMemcpyHostToDevice, b->st));
+    b->cur_T = T; b->cur_trunc = trunc_thr; b->cur_max_bond = max_bond;
+    b->vh_ready = false;
+    b->hint = b->peak_vh + b->peak_grad == 0 ? kLaneCap   // first evaluation: full size
+                                             : hint_for(std::max(b->target.max_dim_in, b->lhs.max_dim_in), std::max(b->peak_vh, b->peak_grad));
+    *T_out = T;
+    return 0;
+}
+
+// lanes [L/2, L) of `s` <- lanes [0, L/2)
+int replicate_half(aqc_mpsb* b, Lanes& s) {
+    const size_t h = (size_t)b->L / 2, n = s.n;
+    HIP_OK(hipMemcpyAsync(static_cast<double2*>(s.dev.T) + h * n * kLaneSite, s.dev.T, sizeof(double2) * h * n * kLaneSite, hipMemcpyDeviceToDevice, b->st));
+    HIP_OK(hipMemcpyAsync(s.dev.lam + h * s.nb * kLaneCap, s.dev.lam, sizeof(double) * h * s.nb * kLaneCap, hipMemcpyDeviceToDevice, b->st));
+    HIP_OK(hipMemcpyAsync(s.dev.discarded + h, s.dev.discarded, sizeof(double) * h, hipMemcpyDeviceToDevice, b->st));
+    HIP_OK(hipMemcpyAsync(s.dev.dims + h * (n + 1), s.dev.dims, sizeof(int) * h * (n + 1), hipMemcpyDeviceToDevice, b->st));
+    return 0;
+}
+
+// vh = V^H target on every lane (the first half when the second repeats it), (w, z) = (lhs, vh) with fresh environments, and the
+// amplitudes <lhs|vh> (slot 0), <X_q lhs|vh> (slots 1 + q)
+int enqueue_vh(aqc_mpsb* b, const aqc_circuit* circ, int T, bool half, int num_amps) {
+    const int n = b->n, L = b->L;
+    HIP_OK(hipMemsetAsync(b->status, 0, sizeof(int) * 2 * (size_t)L, b->st));
+    if (clone(b, b->target, b->vh)) return 1;
+    b->active = half ? L / 2 : L;
+    const int rc = apply_circuit_all(b, b->vh, circ, T, true, b->cur_trunc, b->cur_max_bond);
+    b->active = L;
+    if (rc) return 1;
+    if (half && replicate_half(b, b->vh)) return 1;
+    if (clone(b, b->lhs, b->w) || clone(b, b->vh, b->z)) return 1;
+    if (env_init(b)) return 1;
+    for (int k = 1; k < num_amps; ++k) {   // flips first: site 0 upwards, the right environments are built once on the way down to site 0
+        const int q = k - 1;
+        const M2* g = &kPauliX;
+        if (dot_all(b, k, 1, &q, &g)) return 1;
+    }
+    const int q = n - 1;
+    const M2 eye = {{1.0, 0.0, 0.0, 1.0}};
+    const M2* g = &eye;
+    return dot_all(b, 0, 1, &q, &g);
+}
+
+// results of the enqueued work -> pinned host memory; 0 ok, 2 = a lane outgrew the launch size (the caller repeats at full size), 1 error
+int finish(aqc_mpsb* b, bool may_retry, int* peak_out) {
+    const int n = b->n, L = b->L;
+    char* h_vals = b->h_out;
+    char* h_status = h_vals + sizeof(double2) * (size_t)L * b->nvals;
+    char* h_disc = h_status + sizeof(int) * 2 * (size_t)L;
+    char* h_dims = h_disc + sizeof(double) * (size_t)L;
+    HIP_OK(hipMemcpyAsync(h_vals, b->vals, sizeof(double2) * (size_t)L * b->nvals, hipMemcpyDeviceToHost, b->st));
+    HIP_OK(hipMemcpyAsync(h_status, b->status, sizeof(int) * 2 * (size_t)L, hipMemcpyDeviceToHost, b->st));
+    HIP_OK(hipMemcpyAsync(h_disc, b->vh.dev.discarded, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, b->st));
+    HIP_OK(hipMemcpyAsync(h_dims, b->vh.dev.dims, sizeof(int) * (size_t)L * (n + 1), hipMemcpyDeviceToHost, b->st));
+    HIP_OK(hipStreamSynchronize(b->st));
+    const int* st = reinterpret_cast<const int*>(h_status);
+    int flags = 0, peak = 1;
+    for (int l = 0; l < L; ++l) { flags |= st[l]; peak = std::max(peak, st[L + l]); }
+    if ((flags & kLaneLdsShort) && may_retry && b->hint < kLaneCap) {
+        b->hint = kLaneCap;
+        return 2;
+    }
+    *peak_out = peak;
+    for (int l = 0; l < L; ++l) {
+        if (st[l] & kLaneOverflow)
+            return failf("lane %d: a bond grows beyond the %d of the lockstep lanes (set max_bond <= %d or use the single-lane engine)", l, kLaneCap, kLaneCap);
+        if (st[l] & kLaneNoConv) return failf("Jacobi SVD: no convergence within 60 sweeps (lane %d of the lockstep lanes)", l);
+        if (st[l] & kLaneZero) return failf("2-qubit gate produced a zero or non-finite state (lane %d of the lockstep lanes)", l);
+        if (st[l] & kLaneLdsShort) return failf("internal: workgroup of the lockstep lanes too small at full size (lane %d)", l);
+    }
+    return 0;
+}
+
+struct Readback {
+    const cd* vals; const double* disc; const int* dims;
+    int max_dim(int l, int n) const {
+        int mx = 1;
+        for (int q = 0; q <= n; ++q) mx = std::max(mx, dims[(size_t)l * (n + 1) + q]);
+        return mx;
+    }
+};
+Readback readback(const aqc_mpsb* b) {
+    const size_t L = b->L;
+    const char* h_vals = b->h_out;
+    const char* h_disc = h_vals + sizeof(double2) * L * b->nvals + sizeof(int) * 2 * L;
+    return Readback{reinterpret_cast<const cd*>(h_vals), reinterpret_cast<const double*>(h_disc), reinterpret_cast<const int*>(h_disc + sizeof(double) * L)};
+}
+// grad[lane][T] from the recorded inner products (slots slot0, slot0 + 1, ...)
+void assemble(const aqc_mpsb* b, const Readback& r, const std::vector<std::pair<int, cd>>& rec, int slot0, int T, cd* grad) {
+    for (int l = 0; l < b->L; ++l) {
+        cd* g = grad + (size_t)l * T;
+        std::fill(g, g + T, cd(0.0, 0.0));
+        for (size_t i = 0; i < rec.size(); ++i) g[rec[i].first] += rec[i].second * r.vals[(size_t)l * b->nvals + slot0 + i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -346,7 +476,7 @@ int aqc_mpsb_create(int device, int num_qubits, int lanes, aqc_mpsb** out) {
     if (num_qubits < 2 || num_qubits > 4096 || lanes < 1 || lanes > 32767) return failf("number of qubits / lanes out of range");
     HIP_OK(hipSetDevice(device));
     aqc_mpsb* b = new aqc_mpsb();
-    b->device = device; b->n = num_qubits; b->L = lanes;
+    b->device = device; b->n = num_qubits; b->L = lanes; b->active = lanes;
     auto bad = [&]() { destroy(b); return 1; };
     if (hipStreamCreate(&b->st) != hipSuccess) { failf("hipStreamCreate failed"); return bad(); }
     for (Lanes* s : {&b->target, &b->lhs, &b->vh, &b->w, &b->z})
@@ -384,98 +514,118 @@ int aqc_mpsb_set_lhs(aqc_mpsb* b, aqc_mps* const* lhs, int shared) {
     return 0;
 }
 
+/* lhs states of all lanes = computational-basis states, built on the device: bits[lane][n] (0 / 1), bit q = qubit q = site q */
+int aqc_mpsb_set_lhs_basis(aqc_mpsb* b, const uint8_t* bits) {
+    if (!b || !bits) return failf("null argument");
+    HIP_OK(hipSetDevice(b->device));
+    const size_t bytes = (size_t)b->L * b->n;
+    if (bytes > b->bits_cap) {
+        HIP_OK(hipStreamSynchronize(b->st));
+        if (b->bits) HIP_OK(hipFree(b->bits));
+        if (b->h_bits) HIP_OK(hipHostFree(b->h_bits));
+        b->bits = nullptr; b->h_bits = nullptr; b->bits_cap = 0;
+        HIP_OK(hipMalloc((void**)&b->bits, bytes));
+        HIP_OK(hipHostMalloc((void**)&b->h_bits, bytes, hipHostMallocDefault));
+        b->bits_cap = bytes;
+    }
+    HIP_OK(hipStreamSynchronize(b->st));   // (the staging buffer may still feed the previous upload)
+    memcpy(b->h_bits, bits, bytes);
+    HIP_OK(hipMemcpyAsync(b->bits, b->h_bits, bytes, hipMemcpyHostToDevice, b->st));
+    HIP_OK(launch_lanes_basis(b->lhs.dev, b->bits, b->L, b->st));
+    b->lhs.max_dim_in = 1;
+    b->have_lhs = true;
+    return 0;
+}
+
+/* Phase 1 of an evaluation: vh_l = V(theta_l)^H|phi_l> for every lane, kept in the batch, and the amplitudes
+ * amps[lane][0] = <lhs_l|vh_l>, amps[lane][1 + q] = <X_q lhs_l|vh_l> (num_amps = 1 or 1 + n: with a basis state as lhs these are the
+ * amplitudes of the flip states of objective_lhs_sur_max.py:82-117).  half != 0: lanes [L/2, L) repeat the targets and thetas of lanes
+ * [0, L/2) (the same problems with another lhs state): V^H runs on the first half only and is copied. */
+int aqc_mpsb_vh(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int half, int num_amps, double* amps,
+                double* discarded_out, int32_t* max_bond_out) {
+    if (!b || !circ || !thetas || !amps) return failf("null argument");
+    if (!b->have_target || !b->have_lhs) return failf("set the targets and the lhs states of the lanes first");
+    if (num_amps != 1 && num_amps != 1 + b->n) return failf("num_amps: 1 (<lhs|vh>) or 1 + n (and the single-flip amplitudes)");
+    if (half && (b->L & 1)) return failf("half: the batch needs an even number of lanes");
+    int T = 0;
+    if (begin(b, circ, thetas, trunc_thr, max_bond, num_amps, &T)) return 1;
+    const int L = b->L;
+    for (int attempt = 0;; ++attempt) {
+        if (enqueue_vh(b, circ, T, half != 0, num_amps)) return 1;
+        const int rc = finish(b, attempt == 0, &b->peak_vh);
+        if (rc == 2) continue;
+        if (rc) return 1;
+        break;
+    }
+    const Readback r = readback(b);
+    cd* out = reinterpret_cast<cd*>(amps);
+    for (int l = 0; l < L; ++l) {
+        for (int k = 0; k < num_amps; ++k) out[(size_t)l * num_amps + k] = r.vals[(size_t)l * b->nvals + k];
+        if (discarded_out) discarded_out[l] = r.disc[l];
+        if (max_bond_out) max_bond_out[l] = r.max_dim(l, b->n);
+    }
+    b->vh_ready = true;
+    return 0;
+}
+
+/* Phase 2: the gate-by-gate gradient walk of every lane from its CURRENT lhs state (it may have been replaced since phase 1) and the
+ * vh, thetas, trunc_thr and max_bond of the last aqc_mpsb_vh (same circuit). */
+int aqc_mpsb_grad(aqc_mpsb* b, const aqc_circuit* circ, int block_from, int block_to, int front_layer, double* grad_out) {
+    if (!b || !circ || !grad_out) return failf("null argument");
+    if (!b->vh_ready) return failf("aqc_mpsb_grad follows aqc_mpsb_vh");
+    if (!b->have_lhs) return failf("set the lhs states of the lanes first");
+    if (check_circuit(circ, b->n)) return 1;
+    HIP_OK(hipSetDevice(b->device));
+    const int n = b->n, L = b->L, tpb = circ->entangler == AQC_CP ? 5 : 4, T = 3 * n + tpb * circ->num_blocks;
+    if (T != b->cur_T || 3 * n + tpb * (int)blocks_of(circ).size() > b->nvals) return failf("aqc_mpsb_grad: not the circuit of the last aqc_mpsb_vh");
+    if (block_from < 0) { block_from = 0; block_to = circ->num_blocks; }
+    if (block_from > block_to || block_to > circ->num_blocks) return failf("invalid block range");
+    std::vector<std::pair<int, cd>> rec;
+    b->hint = b->peak_vh + b->peak_grad == 0 ? kLaneCap : hint_for(std::max(b->target.max_dim_in, b->lhs.max_dim_in), std::max(b->peak_vh, b->peak_grad));
+    for (int attempt = 0;; ++attempt) {
+        HIP_OK(hipMemsetAsync(b->status, 0, sizeof(int) * 2 * (size_t)L, b->st));
+        if (clone(b, b->lhs, b->w) || clone(b, b->vh, b->z)) return 1;
+        if (env_init(b)) return 1;
+        if (gradient_all(b, circ, T, b->cur_trunc, b->cur_max_bond, block_from, block_to, front_layer != 0, 0, rec)) return 1;
+        const int rc = finish(b, attempt == 0, &b->peak_grad);
+        if (rc == 2) continue;
+        if (rc) return 1;
+        break;
+    }
+    const Readback r = readback(b);
+    assemble(b, r, rec, 0, T, reinterpret_cast<cd*>(grad_out));
+    return 0;
+}
+
+/* both phases in one call, one wait: h[lane] = <lhs_l|vh_l> and the gradient */
 int aqc_mpsb_eval(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from, int block_to,
                   int front_layer, double* h_out, double* grad_out, double* discarded_out, int32_t* max_bond_out) {
     if (!b || !circ || !thetas || !h_out || !grad_out) return failf("null argument");
     if (!b->have_target || !b->have_lhs) return failf("set the targets and the lhs states of the lanes first");
-    if (check_circuit(circ, b->n)) return 1;
-    if (!(trunc_thr >= 0.0)) return failf("trunc_thr must be non-negative");
-    if (max_bond > kLaneCap) return failf("the lockstep lanes keep bonds up to %d", kLaneCap);
-    HIP_OK(hipSetDevice(b->device));
-    const int n = b->n, L = b->L, tpb = circ->entangler == AQC_CP ? 5 : 4, T = 3 * n + tpb * circ->num_blocks;
-    const int nblk = (int)blocks_of(circ).size();
-    const int need = 1 + 3 * n + tpb * nblk;
+    int T = 0;
+    if (begin(b, circ, thetas, trunc_thr, max_bond, 1, &T)) return 1;
+    const int L = b->L;
     if (block_from < 0) { block_from = 0; block_to = circ->num_blocks; }
     if (block_from > block_to || block_to > circ->num_blocks) return failf("invalid block range");
-    const size_t out_bytes = sizeof(double2) * (size_t)L * need + sizeof(int) * 2 * (size_t)L + sizeof(double) * (size_t)L + sizeof(int) * (size_t)L * (n + 1);
-    if (need > b->nvals || T > b->T_cap || out_bytes > b->h_out_bytes) {
-        HIP_OK(hipStreamSynchronize(b->st));
-        if (b->vals) HIP_OK(hipFree(b->vals));
-        if (b->thetas) HIP_OK(hipFree(b->thetas));
-        if (b->h_thetas) HIP_OK(hipHostFree(b->h_thetas));
-        if (b->h_out) HIP_OK(hipHostFree(b->h_out));
-        b->vals = nullptr; b->thetas = nullptr; b->h_thetas = nullptr; b->h_out = nullptr; b->nvals = 0; b->T_cap = 0; b->h_out_bytes = 0;
-        const int nv = std::max(need, b->nvals), tc = std::max(T, 1);
-        const size_t ob = sizeof(double2) * (size_t)L * nv + sizeof(int) * 2 * (size_t)L + sizeof(double) * (size_t)L + sizeof(int) * (size_t)L * (n + 1);
-        HIP_OK(hipMalloc((void**)&b->vals, sizeof(double2) * (size_t)L * nv));
-        HIP_OK(hipMalloc((void**)&b->thetas, sizeof(double) * (size_t)L * tc));
-        HIP_OK(hipHostMalloc((void**)&b->h_thetas, sizeof(double) * (size_t)L * tc, hipHostMallocDefault));
-        HIP_OK(hipHostMalloc((void**)&b->h_out, ob, hipHostMallocDefault));
-        b->nvals = nv; b->T_cap = tc; b->h_out_bytes = ob;
-    }
-    memcpy(b->h_thetas, thetas, sizeof(double) * (size_t)L * T);
-    HIP_OK(hipMemcpyAsync(b->thetas, b->h_thetas, sizeof(double) * (size_t)L * T, hipMemcpyHostToDevice, b->st));
-    char* h_vals = b->h_out;
-    char* h_status = h_vals + sizeof(double2) * (size_t)L * b->nvals;
-    char* h_disc = h_status + sizeof(int) * 2 * (size_t)L;
-    char* h_dims = h_disc + sizeof(double) * (size_t)L;
     std::vector<std::pair<int, cd>> rec;
-    const int in_peak = std::max(b->target.max_dim_in, b->lhs.max_dim_in);
-    b->hint = b->peak_seen == 0 ? kLaneCap : hint_for(in_peak, b->peak_seen);   // first evaluation: full size
     for (int attempt = 0;; ++attempt) {
-        HIP_OK(hipMemsetAsync(b->status, 0, sizeof(int) * 2 * (size_t)L, b->st));
-        // vh = V^H target
-        if (clone(b, b->target, b->vh)) return 1;
-        if (apply_circuit_all(b, b->vh, circ, T, true, trunc_thr, max_bond)) return 1;
-        // h = <lhs | vh> (slot 0), then the gradient walk on (w, z) = (lhs, vh)
-        if (clone(b, b->lhs, b->w) || clone(b, b->vh, b->z)) return 1;
-        if (env_init(b)) return 1;
-        {
-            const int q = n - 1;
-            const M2 eye = {{1.0, 0.0, 0.0, 1.0}};
-            const M2* g = &eye;
-            if (dot_all(b, 0, 1, &q, &g)) return 1;
-        }
-        if (gradient_all(b, circ, T, trunc_thr, max_bond, block_from, block_to, front_layer != 0, rec)) return 1;
-        HIP_OK(hipMemcpyAsync(h_vals, b->vals, sizeof(double2) * (size_t)L * b->nvals, hipMemcpyDeviceToHost, b->st));
-        HIP_OK(hipMemcpyAsync(h_status, b->status, sizeof(int) * 2 * (size_t)L, hipMemcpyDeviceToHost, b->st));
-        HIP_OK(hipMemcpyAsync(h_disc, b->vh.dev.discarded, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, b->st));
-        HIP_OK(hipMemcpyAsync(h_dims, b->vh.dev.dims, sizeof(int) * (size_t)L * (n + 1), hipMemcpyDeviceToHost, b->st));
-        HIP_OK(hipStreamSynchronize(b->st));
-        const int* st = reinterpret_cast<const int*>(h_status);
-        int flags = 0, peak = 1;
-        for (int l = 0; l < L; ++l) { flags |= st[l]; peak = std::max(peak, st[L + l]); }
-        if ((flags & kLaneLdsShort) && attempt == 0 && b->hint < kLaneCap) {   // a lane outgrew the launch size: once more at full size
-            b->hint = kLaneCap;
-            continue;
-        }
-        b->peak_seen = std::max(peak, 1);
-        for (int l = 0; l < L; ++l) {
-            if (st[l] & kLaneOverflow)
-                return failf("lane %d: a bond grows beyond the %d of the lockstep lanes (set max_bond <= %d or use the single-lane engine)", l, kLaneCap, kLaneCap);
-            if (st[l] & kLaneNoConv) return failf("Jacobi SVD: no convergence within 60 sweeps (lane %d of the lockstep lanes)", l);
-            if (st[l] & kLaneZero) return failf("2-qubit gate produced a zero or non-finite state (lane %d of the lockstep lanes)", l);
-            if (st[l] & kLaneLdsShort) return failf("internal: workgroup of the lockstep lanes too small at full size (lane %d)", l);
-        }
+        if (enqueue_vh(b, circ, T, false, 1)) return 1;   // leaves (w, z) = (lhs, vh) with their environments started
+        if (gradient_all(b, circ, T, trunc_thr, max_bond, block_from, block_to, front_layer != 0, 1, rec)) return 1;
+        const int rc = finish(b, attempt == 0, &b->peak_vh);
+        if (rc == 2) continue;
+        if (rc) return 1;
         break;
     }
-    const cd* vals = reinterpret_cast<const cd*>(h_vals);
+    b->peak_grad = 0;   // (peak_vh covers the whole evaluation here)
+    b->vh_ready = true;
+    const Readback r = readback(b);
     cd* hh = reinterpret_cast<cd*>(h_out);
-    cd* grad = reinterpret_cast<cd*>(grad_out);
-    const double* disc = reinterpret_cast<const double*>(h_disc);
-    const int* dims = reinterpret_cast<const int*>(h_dims);
     for (int l = 0; l < L; ++l) {
-        hh[l] = vals[(size_t)l * b->nvals];
-        cd* g = grad + (size_t)l * T;
-        std::fill(g, g + T, cd(0.0, 0.0));
-        for (size_t i = 0; i < rec.size(); ++i) g[rec[i].first] += rec[i].second * vals[(size_t)l * b->nvals + 1 + i];
-        if (discarded_out) discarded_out[l] = disc[l];
-        if (max_bond_out) {
-            int mx = 1;
-            for (int q = 0; q <= n; ++q) mx = std::max(mx, dims[(size_t)l * (n + 1) + q]);
-            max_bond_out[l] = mx;
-        }
+        hh[l] = r.vals[(size_t)l * b->nvals];
+        if (discarded_out) discarded_out[l] = r.disc[l];
+        if (max_bond_out) max_bond_out[l] = r.max_dim(l, b->n);
     }
+    assemble(b, r, rec, 1, T, reinterpret_cast<cd*>(grad_out));
     return 0;
 }
 

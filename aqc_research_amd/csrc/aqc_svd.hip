@@ -1112,6 +1112,20 @@ __global__ __launch_bounds__(256) void lanes_grad_step_kernel(LaneMps w, LaneMps
     }
     if (tid == 0) vals[(size_t)l * nvals + slot] = make_double2(sr[0], si[0]);
 }
+// every lane <- the computational-basis state bits[lane][site]: site tensors [2][1][1], Schmidt values 1, bond dimensions 1
+__global__ void lanes_basis_kernel(LaneMps m, const unsigned char* __restrict__ bits, int lanes) {
+    const int l = blockIdx.x, n = m.n, nb = n > 1 ? n - 1 : 1;
+    for (int q = threadIdx.x; q <= n; q += blockDim.x) {
+        m.dims[(size_t)l * (n + 1) + q] = 1;
+        if (q == n) break;
+        cplx* t = static_cast<cplx*>(m.T) + ((size_t)l * n + q) * kLaneSite;
+        const int bit = bits[(size_t)l * n + q] ? 1 : 0;
+        t[0] = make_double2(bit ? 0.0 : 1.0, 0.0);
+        t[1] = make_double2(bit ? 1.0 : 0.0, 0.0);
+        if (q < n - 1) m.lam[((size_t)l * nb + q) * kLaneCap] = 1.0;
+    }
+    if (threadIdx.x == 0) m.discarded[l] = 0.0;
+}
 __global__ void lanes_env_init_kernel(cplx* env_l, size_t l_stride, cplx* env_r_last, size_t r_stride, int lanes) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= lanes) return;
@@ -1172,6 +1186,10 @@ hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, con
     lanes_grad_step_kernel<<<lanes, 256, sizeof(cplx) * kLaneEnv, s>>>(w, z, q, g, thetas, T, static_cast<const cplx*>(env_l), l_stride,
                                                                         static_cast<const cplx*>(env_r), r_stride, gh, static_cast<cplx*>(scratch),
                                                                         static_cast<cplx*>(vals), nvals, slot);
+    return hipGetLastError();
+}
+hipError_t launch_lanes_basis(const LaneMps& m, const unsigned char* bits, int lanes, hipStream_t s) {
+    lanes_basis_kernel<<<lanes, 64, 0, s>>>(m, bits, lanes);
     return hipGetLastError();
 }
 hipError_t launch_lanes_env_init(void* env_l, size_t l_stride, void* env_r_last, size_t r_stride, int lanes, hipStream_t s) {

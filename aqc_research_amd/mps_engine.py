@@ -476,6 +476,43 @@ class LockstepLanes:
         del keep
         return (h, grads, disc, bonds) if details else (h, grads)
 
+    def set_lhs_basis(self, bits) -> "LockstepLanes":
+        """lhs state of every lane = the computational-basis state ``bits[lane][qubit]`` (0 / 1), built on the device."""
+        arr = np.ascontiguousarray(bits, dtype=np.uint8)
+        if arr.shape != (self.lanes, self.num_qubits):
+            raise ValueError("bits: expects shape (lanes, num_qubits)")
+        check(_lib.lib().aqc_mpsb_set_lhs_basis(self.handle, arr.ctypes.data_as(POINTER(ctypes.c_uint8))))
+        self._lhs = None
+        return self
+
+    def apply_vh(self, circ, thetas, *, trunc_thr: float = 0.0, max_bond: int = 0, flips: bool = False, half: bool = False, details: bool = False):
+        """Phase 1 of ``evaluate``: vh_l = V(thetas[l])^H|target_l> stays in the lanes; returns amps[lanes][1 (+ n)] with
+        amps[l][0] = <lhs_l|vh_l> and, with ``flips``, amps[l][1 + q] = <X_q lhs_l|vh_l>.  ``half``: lanes [lanes/2, lanes) repeat targets
+        and thetas of the first half -- V^H runs once for both.  ``gradient`` continues from here."""
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        if th.shape != (self.lanes, circ.num_thetas) or circ.num_qubits != self.num_qubits:
+            raise ValueError("thetas: expects shape (lanes, circ.num_thetas) on a circuit of the lanes' size")
+        desc, keep = _describe(circ)
+        na = 1 + self.num_qubits if flips else 1
+        amps = np.zeros((self.lanes, na), dtype=np.complex128)
+        disc = np.zeros(self.lanes, dtype=np.float64)
+        bonds = np.zeros(self.lanes, dtype=np.int32)
+        check(_lib.lib().aqc_mpsb_vh(self.handle, byref(desc), dptr(th), float(trunc_thr), int(max_bond), int(bool(half)), na, dptr(amps), dptr(disc),
+                                     bonds.ctypes.data_as(POINTER(c_int32))))
+        del keep
+        return (amps, disc, bonds) if details else amps
+
+    def gradient(self, circ, *, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> np.ndarray:
+        """Phase 2: grads[lanes][T] (complex) of <V lhs_l|target_l> from the CURRENT lhs states and the vh of ``apply_vh``."""
+        desc, keep = _describe(circ)
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        if block_range is not None and not 0 <= lo <= hi <= circ.num_blocks:
+            raise ValueError("invalid block range")
+        grads = np.zeros((self.lanes, circ.num_thetas), dtype=np.complex128)
+        check(_lib.lib().aqc_mpsb_grad(self.handle, byref(desc), lo, hi, int(bool(front_layer)), dptr(grads)))
+        del keep
+        return grads
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             _lib.lib().aqc_mpsb_destroy(self.handle)

@@ -235,12 +235,24 @@ int aqc_mpsb_destroy(aqc_mpsb* b);
  * surrogate's low-entangled state, objective_lhs_sur_fast_mps_trotter.py:99); shared != 0: handles[0] serves every lane */
 int aqc_mpsb_set_targets(aqc_mpsb* b, aqc_mps* const* handles, int shared);
 int aqc_mpsb_set_lhs(aqc_mpsb* b, aqc_mps* const* handles, int shared);
+/* lhs states of all lanes = computational-basis states built on the device: bits[lane][n] (0 / 1), bit q = qubit q (the |state_i> of
+ * objective_base.py:42-255: |0>, X_q|0> on top of a basis preparation such as the Neel pattern) */
+int aqc_mpsb_set_lhs_basis(aqc_mpsb* b, const uint8_t* bits);
 /* per lane l with thetas[l][T]: vh = V(theta_l)^H|phi_l> (v_dagger_mul_mps, mps_operations.py:350), h[l] = <lhs_l|vh> (c128) and
  * grad[l][T] (c128) = fast_dot_gradient(circ, theta_l, lhs_l, vh, trunc_thr, block_range, front_layer) (mps_dot_objective.py:41).
  * discarded[l] (optional) = weight truncated while forming vh, max_bond_out[l] (optional) = its largest bond. */
 int aqc_mpsb_eval(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from,
                   int block_to, int front_layer, double* h /* [lanes] c128 */, double* grad /* [lanes][T] c128 */,
                   double* discarded /* [lanes] or NULL */, int32_t* max_bond_out /* [lanes] or NULL */);
+/* The same in two phases, for objectives that choose the lhs state after seeing amplitudes (objective_lhs_sur_max.py:82-191: the
+ * leading flip state).  Phase 1: vh of every lane, kept in the batch, and amps[lane][0] = <lhs_l|vh_l>, amps[lane][1 + q] =
+ * <X_q lhs_l|vh_l> (num_amps = 1 or 1 + n; with a basis state as lhs: the amplitudes of its single-flip states, :99-111).
+ * half != 0: lanes [lanes/2, lanes) repeat targets and thetas of the first half (the same problems seen from a second lhs state):
+ * V^H runs on the first half only and is copied.  Phase 2: the gradient walk from the CURRENT lhs states (they may have been
+ * replaced since phase 1) and the vh, thetas, trunc_thr, max_bond of phase 1 (same circuit). */
+int aqc_mpsb_vh(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int half, int num_amps,
+                double* amps /* [lanes][num_amps] c128 */, double* discarded /* [lanes] or NULL */, int32_t* max_bond_out /* or NULL */);
+int aqc_mpsb_grad(aqc_mpsb* b, const aqc_circuit* circ, int block_from, int block_to, int front_layer, double* grad /* [lanes][T] c128 */);
 /* one-sided Jacobi SVD on the device (the kernel behind aqc_mps_gate2): A (m x n row-major) = U diag(S) Vh,
  * k = min(m, n), S descending, U (m x k), Vh (k x n); *sweeps (optional) = Jacobi sweeps used */
 int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, double* vh, int* sweeps);

@@ -466,3 +466,43 @@ def test_lockstep_lanes_refuse_to_truncate_silently_and_auto_falls_back():
         assert abs(h[b] - h1) < 1e-12 and maxdiff(g[b], g1) < 1e-12
     for m in targets + [basis]:
         m.close()
+
+
+def test_batched_mps_surrogate_objective_matches_the_dense_batched_objective():
+    """BatchedMpsSurrogateObjective (lockstep lanes of the MPS engine, two phases: V^H + flip amplitudes, then both gradient walks)
+    against BatchedSurrogateObjective on the dense kernels (itself pinned by the oracle): values, gradients and the state machine of
+    objective_lhs_sur_max.py:99-191 -- one lane starts next to a flip state, so the leading state changes on the way."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd import mps_engine as me
+    from aqc_research_amd.batched_optimizer import BatchedMpsSurrogateObjective, BatchedSurrogateObjective
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index
+
+    n, lanes = 10, 3
+    rng = np.random.default_rng(731)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 2), second_order=True)
+    neel = neel_state_index(n)
+    th_star = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=0.8, delta=1.0)
+    dense = []
+    for b in range(lanes):   # lane b: V(th*)|neel> for b = 0, 2; V(th*) X_4|neel> for b = 1
+        x = np.zeros(1 << n, complex)
+        x[neel ^ (1 << 4) if b == 1 else neel] = 1
+        v = orc.v_mul_vec(circ, th_star + 0.1 * b * orc.rand_thetas(circ.num_thetas, rng) / np.pi, x)
+        dense.append(v / np.linalg.norm(v))
+    from aqc_research_amd.mps_operations import vector_to_exact_mps
+
+    targets = [me.DeviceMPS.from_qiskit(vector_to_exact_mps(v)) for v in dense]
+    ref = BatchedSurrogateObjective(circ, np.stack(dense), base_index=neel)
+    obj = BatchedMpsSurrogateObjective(circ, targets, base_index=neel, trunc_thr=0.0)
+    th = np.stack([th_star + 0.03 * orc.rand_thetas(circ.num_thetas, rng) / np.pi for _ in range(lanes)])
+    for step, upd in enumerate((True, False, True, True)):
+        f0, g0 = ref.value_and_grad(th, update_state=upd)
+        f1, g1 = obj.value_and_grad(th, update_state=upd)
+        assert maxdiff(f1, f0) < TOL and maxdiff(g1, g0) < TOL
+        assert list(obj.max_no) == list(ref.max_no) and maxdiff(obj.weight, ref.weight) < 1e-12
+        th = th - 0.05 * g0
+    assert obj.max_no[1] == 5 and obj.max_no[0] == 0      # lane 1 is led by the flip of qubit 4 (state 5), lane 0 by |state_0>
+    ref.close()
+    obj.close()
+    for m in targets:
+        m.close()

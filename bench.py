@@ -59,6 +59,7 @@ WORKLOADS = {
     # one step = one Gauss-Seidel sweep over all 735 parameters for every lane (lane = random restart with its own target)
     "cd5_cyc180": dict(n=5, blocks=180, kind="cd", ncols=32, desc="5-qubit coordinate descent (docs/aqc.ipynb ansatz: cyclic_spin, 180 blocks, 735 parameters): one coord_descent_single_sweep per lane and step, lanes = random restarts with their own target unitary"),
     # beyond dense reach: the native MPS engine (truncated two-site SVDs on the device, no 2^n buffer anywhere), lanes on host threads
+    "mps32_trotter2_opt": dict(n=32, layers=2, kind="mps_opt", trunc_thr=1e-6, lanes=64, maxiter=12, desc="32-qubit ASP horizon as the reference's driver runs it (time_evol_best_init.py:221-334 with objective sur_fast_mps_trotter): 64 restarts of a 2-layer 2nd-order Trotter ansatz (840 parameters) against a 6-layer Trotter target, surrogate objective on the native MPS engine at trunc_thr = 1e-6, all restarts optimised together by one vectorised L-BFGS"),
     "mps32_trotter2_engine": dict(n=32, layers=2, kind="mps_engine", trunc_thr=1e-6, lanes=1024, desc="32-qubit ASP, 2nd-order Trotter ansatz (2 layers, 840 parameters), MPS-dot objective+gradient on the native MPS engine at the reference's default trunc_thr = 1e-6 (V^H by truncated two-site SVDs, gate-by-gate gradient), targets = 6-layer Trotter states (bond <= 16)"),
     "mps16_l40_chi256": dict(n=16, blocks=40, kind="generic", chi=256, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=256 (a different one per lane every step), contracted to dense on the device every evaluation"),
 }
@@ -518,6 +519,70 @@ def run_mps_engine(args, w, env, full):
     }
 
 
+def run_mps_opt(args, w, env, full):
+    """--workload mps32_trotter2_opt: what the lockstep lanes are for.  One step = one whole optimisation of B restarts (random
+    perturbations of the Trotter point) of a horizon beyond dense reach: BatchedMpsSurrogateObjective (the surrogate objective of
+    objective_lhs_sur_fast_mps_trotter.py:99-227, V^H once per restart + both gradient walks on 2B lockstep lanes) under
+    batched_lbfgs.  The reference runs one such optimisation per joblib process on qiskit-aer (job_executor.py:141)."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd import mps_engine as me
+    from aqc_research_amd.batched_optimizer import BatchedMpsSurrogateObjective, batched_lbfgs
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+    from aqc_research_amd.model_sp_lhs.trotter import init_ansatz_to_trotter, neel_state_index
+
+    n, layers, thr, maxiter = w["n"], w["layers"], float(w["trunc_thr"]), int(w["maxiter"])
+    B = args.batch if args.batch > 0 and full else w["lanes"]
+    K = max(1, min(args.steps, 3)) if full else 1
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, layers), second_order=True)
+    T = circ.num_thetas
+    neel = neel_state_index(n)
+    evol = 0.6 * layers
+    th0 = init_ansatz_to_trotter(circ, np.zeros(T), evol_time=evol, delta=1.0)
+    tcirc = TrotterAnsatz(n, make_trotter_like_circuit(n, 3 * layers), second_order=True)
+    tth = init_ansatz_to_trotter(tcirc, np.zeros(tcirc.num_thetas), evol_time=evol, delta=1.0)
+    basis = me.DeviceMPS.basis_state(n, neel, device=env.local_rank)
+    target = me.v_mul_mps(tcirc, tth, basis, trunc_thr=1e-12)
+    obj = BatchedMpsSurrogateObjective(circ, target, lanes=B, base_index=neel, trunc_thr=thr, device=env.local_rank)
+
+    def start(i):
+        return th0[None, :] + 0.05 * np.random.default_rng(500 * i + env.rank).standard_normal((B, T))
+
+    obj.reset_state()
+    obj.value_and_grad(start(0))            # warm-up: sizes the lanes' launches
+    fid0 = obj.fidelity.copy()
+    env.comm.barrier()
+    t0 = time.perf_counter()
+    evals = 0
+    fid = None
+    for i in range(K):
+        obj.reset_state()
+        before = obj.num_evals
+        res = batched_lbfgs(obj.value_and_grad, start(i), maxiter=maxiter)
+        evals += obj.num_evals - before
+        fid = obj.fidelity.copy()
+    env.comm.barrier()
+    wall = time.perf_counter() - t0
+    if env.comm.size > 1:
+        wall = float(env.comm.allreduce(np.array([wall]), "max")[0])
+    obj.close()
+    for m in (target, basis):
+        m.close()
+    if env.rank != 0:
+        return None
+    return {
+        "metric": "objective+gradient evals/sec", "value": evals * env.n_gpus / wall, "unit": "evals/s", "n_gpus": env.n_gpus, "steps": K, "warmup": 1,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": w["desc"], "n_qubits": n, "num_thetas": T, "batch_per_gpu": B, "path": "BatchedMpsSurrogateObjective under batched_lbfgs (lockstep lanes of the native MPS engine)",
+                   "mps_trunc_thr": thr, "lbfgs_maxiter": maxiter, "evals_per_optimisation": evals / (K * B), "iterations": [int(res["nit"].min()), int(res["nit"].max())],
+                   "fidelity_start_mean": float(np.mean(fid0)), "fidelity_end_mean": float(np.mean(fid)), "fidelity_end_min": float(np.min(fid)),
+                   "ranks_seen": env.ranks_seen},
+        "roofline": None, "parity_maxerr": None, "parity_lanes_checked": 0,
+        "parity_note": "truncated MPS arithmetic is parity-unpinned (qiskit-aer absent); the objective is tested against the dense batched objective at "
+                       "10 qubits (tests/test_hip_round4.py)",
+        "optimisations_per_s": K * B * env.n_gpus / wall,
+    }
+
+
 def ParametricCircuit_for(w):
     return build_circuit(dict(w, kind="cyclic"))
 
@@ -766,7 +831,7 @@ def main():
 # the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
 # MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
 CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "mat10_l40_k16", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
-               "sv20_trotter2", "cfg4_jobs", "mat10_l40", "mps32_trotter2_engine"]
+               "sv20_trotter2", "cfg4_jobs", "mat10_l40", "mps32_trotter2_engine", "mps32_trotter2_opt"]
 
 
 def brief(o):
@@ -778,7 +843,8 @@ def brief(o):
          "workload": o["config"]["workload"], "roofline_frac": r.get("frac"), "roofline_kernel": r.get("kernel"),
          "sweep_avg_launch_ms": r.get("avg_launch_ms"), "parity_maxerr": o.get("parity_maxerr"),
          "parity_lanes_checked": o.get("parity_lanes_checked")}
-    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane", "host_thread_lanes", "lockstep_vs_single_lane_maxerr",
+    for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane", "host_thread_lanes", "lockstep_vs_single_lane_maxerr", "optimisations_per_s",
+              "fidelity_start_mean", "fidelity_end_mean", "lbfgs_maxiter",
               "value_gradient_consistency", "parity_note"):
         if k in o:
             b[k] = o[k]
@@ -801,6 +867,8 @@ def measure(workload, args, env, full):
         return run_cd(args, w, env, full)
     if w["kind"] == "mps_engine":
         return run_mps_engine(args, w, env, full)
+    if w["kind"] == "mps_opt":
+        return run_mps_opt(args, w, env, full)
     if w["kind"] == "jobs":
         out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=(args.steps if full else 1))
         out["config"]["ranks_seen"] = ranks_seen

@@ -32,6 +32,14 @@ for name in os.listdir(SRC):
         copy(name, tag)
 copy(os.path.join("kt", "kt_kernel_stats.csv"), "r04_sv16_l40_b1024_kernel_stats.csv")
 copy(os.path.join("kt_cfg4", "kt_kernel_stats.csv"), "r04_cfg4_jobs_kernel_stats.csv")
+copy(os.path.join("kt_lockstep", "kt_kernel_stats.csv"), "r04_lockstep_mps32_b256_kernel_stats.csv")
+if have("lockstep_lanes.log"):   # lockstep lanes of the 32-qubit engine workload: rates per lane count, the run under rocprofv3, in-kernel stamps
+    with open(os.path.join(DST, "r04_lockstep_mps32_lanes.txt"), "w") as g:
+        g.write("# tools/mps_lockstep_profile.py (32 qubits, 2-layer 2nd-order Trotter ansatz, trunc_thr 1e-6, one target shared by the lanes), " + today + "\n")
+        for name in ("lockstep_lanes.log", "lockstep_under_rocprof.log", "lockstep_stamps.log"):
+            if have(name):
+                g.write("".join(line for line in open(os.path.join(SRC, name)) if line.startswith(("lockstep lanes", "aqc_hip stamps"))))
+    print("wrote lockstep lanes")
 if have("gpu_tests.log"):
     with open(os.path.join(SRC, "gpu_tests.log")) as f, open(os.path.join(DST, "r04_gpu_tests_tail.txt"), "w") as g:
         g.write("".join(f.readlines()[-4:]))

@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04ev
 mkdir -p $O
-parts="${@:-tests bench trace pmc sq workloads cfg4}"
+parts="${@:-tests bench trace pmc sq workloads cfg4 lockstep}"
 for part in $parts; do case $part in
 tests)
   python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || true
@@ -26,7 +26,7 @@ sq)
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT -d $O/sq3 -o s --output-format csv -- python3 tools/prof_run3.py > $O/sq3.log 2>&1 || echo "sq3 counters not available"
   echo "sq done" ;;
 workloads)
-  for w in cd5_cyc180 mps32_trotter2_engine mat10_l40_k16; do
+  for w in cd5_cyc180 mps32_trotter2_engine mps32_trotter2_opt mat10_l40_k16; do
     python bench.py --workload $w --steps 40 --warmup 10 --sustain-seconds 0 > $O/bench_$w.json 2> $O/bench_$w.err
     echo "bench $w done"
   done ;;
@@ -34,4 +34,14 @@ cfg4)
   timeout -k 10 400 python bench.py --workload cfg4_jobs --steps 2 --warmup 1 > $O/bench_cfg4_jobs.json 2> $O/bench_cfg4_jobs.err || echo "cfg4_jobs failed"
   rocprofv3 --kernel-trace --stats -d $O/kt_cfg4 -o kt --output-format csv -- python3 bench.py --workload cfg4_jobs --steps 1 --warmup 1 > $O/bench_cfg4_under_rocprof.json 2> $O/kt_cfg4.err || echo "cfg4 trace failed"
   echo "cfg4 done" ;;
+lockstep)
+  rm -f $O/lockstep_lanes.log
+  for lanes in 1 16 256 1024 4096; do
+    timeout -k 10 300 python tools/mps_lockstep_profile.py $lanes 2 >> $O/lockstep_lanes.log 2>&1
+  done
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_lockstep -o kt --output-format csv -- python3 tools/mps_lockstep_profile.py 256 3 > $O/lockstep_under_rocprof.log 2>&1
+  if [ -f aqc_research_amd/libaqc_hip_tuning.so ]; then
+    AQC_HIP_LIB=$GRAFT_REPO_ROOT/aqc_research_amd/libaqc_hip_tuning.so timeout -k 10 300 python tools/mps_lockstep_profile.py 256 3 > $O/lockstep_stamps.log 2>&1 || echo "stamps failed"
+  fi
+  echo "lockstep done" ;;
 esac; done

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import numpy as np
 
 from ..job_executor import run_jobs
-from ..mps_operations import DenseBackedMPS, check_mps, mps_dot, no_truncation_threshold
+from ..mps_operations import DenseBackedMPS, check_mps, mps_dot, mps_to_vector, no_truncation_threshold
 from ..optimizer import AqcOptimizer, EarlyStopper, GradientAmplifier, TimeoutChecker
 from ..parametric_circuit import first_layer_included, layer_to_block_range
 from .objective_base import basis_mask_of_circuit
@@ -270,8 +270,9 @@ def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
     opts: UserOptions = cfg["opts"]
     h = cfg["horizon"]
     n = opts.num_qubits
-    if opts.use_mps:
-        raise ValueError("random restarts (num_seeds > 1) run on the state-vector objective: use objective='sur_max'")
+    if opts.use_mps and not opts.vectorised_lbfgs:
+        raise ValueError("random restarts (num_seeds > 1) of an MPS objective run under the vectorised L-BFGS (vectorised_lbfgs=True); "
+                         "the per-restart scipy optimizers work on the state-vector objective 'sur_max'")
     tgt = generate_target(opts, h - 1)
     evol_time, target = tgt.evol_time, tgt.t1_gt
     fid_thr, fid_t1_vs_gt = _calc_fidelity_threshold(tgt, opts.fidelity_thr)
@@ -303,11 +304,22 @@ def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
         for s in range(1, opts.num_seeds):
             rng = np.random.default_rng(opts.seed + 1000 * h + 7 * (s + 1))
             starts[s] += opts.theta_jitter * np.pi * (2.0 * rng.random(trotter_thetas.size) - 1.0)
-        bo = BatchedSurrogateObjective(circ, np.tile(target, (opts.num_seeds, 1)), base_index=ini, device=opts.device)
-        if opts.device_lbfgs:
+        target_dev = None
+        if opts.use_mps and n > _DENSE_MAX_QUBITS:   # beyond dense reach: the restarts are lockstep lanes of the native MPS engine (bonds <= 32)
+            from ..batched_optimizer import BatchedMpsSurrogateObjective
+            from ..mps_engine import DeviceMPS
+
+            target_dev = DeviceMPS.from_qiskit(target, device=opts.device, trunc_thr=float(opts.trunc_thr), assume_canonical=True)
+            bo = BatchedMpsSurrogateObjective(circ, target_dev, lanes=opts.num_seeds, base_index=ini, trunc_thr=float(opts.trunc_thr), device=opts.device)
+        else:
+            dense = (target.dense_state if isinstance(target, DenseBackedMPS) else mps_to_vector(target)) if opts.use_mps else target
+            bo = BatchedSurrogateObjective(circ, np.tile(dense, (opts.num_seeds, 1)), base_index=ini, device=opts.device)
+        if opts.device_lbfgs and target_dev is None:
             res = bo.minimize_on_device(starts, maxiter=opts.maxiter, fidelity_thr=fid_thr)
         else:
             res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= fid_thr)
+        if target_dev is not None:
+            target_dev.close()
         fids = bo.fidelity.copy()
         evals = bo.num_evals
         bo.close()

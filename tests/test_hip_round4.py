@@ -506,3 +506,22 @@ def test_batched_mps_surrogate_objective_matches_the_dense_batched_objective():
     obj.close()
     for m in targets:
         m.close()
+
+
+def test_seeded_horizons_of_the_mps_objective_run_on_the_lockstep_lanes(monkeypatch):
+    """Random restarts of a horizon with objective = sur_fast_mps_trotter: up to 24 qubits on the dense batched objective (the
+    target's dense state), beyond on the lockstep lanes of the MPS engine (BatchedMpsSurrogateObjective) -- forced here at 10
+    qubits by lowering the dense limit; with trunc_thr -> 0 both routes and the state-vector objective give the same restarts."""
+    from aqc_research_amd.model_sp_lhs import time_evol as te
+
+    kw = dict(num_qubits=10, num_horizons=1, num_layers_inc=1, maxiter=8, fidelity_thr=0.999, num_seeds=3, vectorised_lbfgs=True, seed=5,
+              trunc_thr=1e-14, trunc_thr_target=1e-14)
+    ref = te.run_simulation(te.UserOptions(objective="sur_max", **kw))[0]
+    dense = te.run_simulation(te.UserOptions(objective="sur_fast_mps_trotter", **kw))[0]
+    monkeypatch.setattr(te, "_DENSE_MAX_QUBITS", 8)
+    eng = te.run_simulation(te.UserOptions(objective="sur_fast_mps_trotter", **kw))[0]
+    for r in (dense, eng):
+        assert r["status"] == "ok" and len(r["fidelities"]) == 3
+        assert maxdiff(np.array(r["fidelities"]), np.array(ref["fidelities"])) < 1e-6 and r["best_restart"] == ref["best_restart"]
+    with pytest.raises(ValueError, match="vectorised"):
+        te._seeded_horizon_job(0, {"opts": te.UserOptions(objective="sur_fast_mps_trotter", **dict(kw, vectorised_lbfgs=False)), "horizon": 1})

@@ -58,6 +58,9 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
         self._target_dev = DeviceMPS.from_qiskit(target, device=self._mps_device(), trunc_thr=self._trunc_thr)
         self._vh = None
         self._basis_dev = {}
+        if getattr(self, "_lk", None) is not None:
+            self._lk.close()
+        self._lk, self._lk_refused, self._lk_live = None, False, False
 
     def _mps_device(self) -> int:
         from ..engine import default_device
@@ -66,6 +69,25 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
         return default_device() if d is None else int(d)
 
     # ---- native MPS mode: no dense state anywhere (objective_lhs_sur_fast_mps_trotter.py:114-227) ----------
+    # Two lockstep lanes of the engine (mps_engine.LockstepLanes; bonds <= 32): lane 0 sees the problem from |state_0>, lane 1 from the
+    # leading flip state.  V^H|target> runs once and stays on the device with its bond dimensions, the amplitudes of all n + 1 states
+    # come back with it, the two sweeps of :162-227 run together.  Larger bonds: the single-lane engine (one ABI call per piece).
+    def _lanes(self):
+        if self._lk is None and not self._lk_refused:
+            from ..mps_engine import LOCKSTEP_MAX_BOND, LockstepLanes
+
+            if int(self._target_dev.bond_dims.max()) > LOCKSTEP_MAX_BOND or self._num_states != self._circuit.num_qubits + 1:
+                self._lk_refused = True
+            else:
+                self._lk = LockstepLanes(self._circuit.num_qubits, 2, self._mps_device()).set_targets(self._target_dev)
+        return self._lk
+
+    def _lane_bits(self, state_a: int, state_b: int):
+        import numpy as np
+
+        idx = self._state_handler.state_indices
+        return np.array([[(int(idx[s]) >> q) & 1 for q in range(self._circuit.num_qubits)] for s in (state_a, state_b)], dtype=np.uint8)
+
     def _basis(self, state_no: int):
         from ..mps_engine import DeviceMPS
 
@@ -77,18 +99,37 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
     def _evaluate(self, thetas) -> None:
         if not self._native_mps:
             return super()._evaluate(thetas)
+        import numpy as np
+
         from ..mps_engine import v_dagger_mul_mps
 
+        self._grad0 = None
+        self._lk_live = False
+        lk = self._lanes()
+        if lk is not None:
+            try:
+                lk.set_lhs_basis(self._lane_bits(0, self._max_no))
+                th = np.ascontiguousarray(thetas, dtype=np.float64)
+                self._hs[:] = lk.apply_vh(self._circuit, np.stack([th, th]), trunc_thr=self._trunc_thr, flips=True, half=True)[0]
+                self._lk_live = True
+                return
+            except RuntimeError as err:
+                if "lockstep lanes" not in str(err):
+                    raise
+                lk.close()          # a bond outgrew the lanes: this objective stays on the single-lane engine
+                self._lk, self._lk_refused = None, True
         if self._vh is not None:
             self._vh.close()
         self._vh = v_dagger_mul_mps(self._circuit, thetas, self._target_dev, trunc_thr=self._trunc_thr)   # V^H|target>
         for i in range(self._num_states):
             self._hs[i] = self._basis(i).dot(self._vh)                                                   # <state_i|V^H|target>
-        self._grad0 = None
 
     def _sweep(self, state_no: int, front: bool):
         if not self._native_mps:
             return super()._sweep(state_no, front)
+        if self._lk_live:
+            self._lk.set_lhs_basis(self._lane_bits(state_no, state_no))
+            return self._lk.gradient(self._circuit, block_range=self._block_range, front_layer=front)[0]
         from ..mps_engine import fast_dot_gradient_mps
 
         return fast_dot_gradient_mps(self._circuit, self._last_thetas, self._basis(state_no), self._vh, trunc_thr=self._trunc_thr,
@@ -97,5 +138,9 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
     def _sweep_combined(self, c_0: complex, c_max: complex, front: bool):
         if not self._native_mps:
             return super()._sweep_combined(c_0, c_max, front)
-        # native MPS engine: the two product-state sweeps of the reference (a combined lhs would be a bond-2 MPS)
+        if self._lk_live:   # both sweeps of the reference together, one lane each
+            self._lk.set_lhs_basis(self._lane_bits(0, self._max_no))
+            g = self._lk.gradient(self._circuit, block_range=self._block_range, front_layer=front)
+            return c_0 * g[0] + c_max * g[1]
+        # single-lane engine: the two product-state sweeps of the reference (a combined lhs would be a bond-2 MPS)
         return c_0 * self._sweep(0, front) + c_max * self._sweep(self._max_no, front)

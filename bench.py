@@ -498,6 +498,21 @@ def run_mps_engine(args, w, env, full):
     t2 = time.perf_counter()
     me.evaluate_lanes(circ, thetas(61)[:nthr], targets[:nthr], basis, trunc_thr=thr, method="threads")
     thr_rate = nthr / (time.perf_counter() - t2)
+    # what an unmodified caller of the reference's objective gets at this size: SpSurrogateObjectiveFastMpsTrotter (objective() + gradient()
+    # pairs as an optimizer issues them, objective_lhs_sur_fast_mps_trotter.py:99-227) -- two lockstep lanes inside
+    from aqc_research_amd.model_sp_lhs.objective_lhs_sur_fast_mps_trotter import SpSurrogateObjectiveFastMpsTrotter
+
+    user = dict(num_qubits=n, max_flips=1, state_prep_func=lambda _n: neel, enable_optim_stats=False, verbose=0, maxiter=5, trunc_thr=thr,
+                device=env.local_rank)
+    objv = SpSurrogateObjectiveFastMpsTrotter(user_parameters=user, circ=circ)
+    objv.set_target(distinct[0].to_qiskit())
+    objv.objective(thetas(70)[0]); objv.gradient(thetas(70)[0])
+    t3 = time.perf_counter()
+    npairs = 3
+    for i in range(npairs):
+        objv.objective(thetas(71 + i)[0]); objv.gradient(thetas(71 + i)[0])
+    pair = (time.perf_counter() - t3) / npairs
+    pair_route = "two lockstep lanes" if getattr(objv, "_lk_live", False) else "single-lane engine"
     for m in distinct + [basis]:
         m.close()
     if env.rank != 0:
@@ -516,6 +531,8 @@ def run_mps_engine(args, w, env, full):
         "lockstep_vs_single_lane_maxerr": lane_err, "lockstep_lanes_checked": nchk,
         "single_lane": {"ms_per_eval": one * 1e3, "evals_per_s": 1.0 / one},
         "host_thread_lanes": {"lanes": nthr, "evals_per_s": thr_rate},
+        "front_door_single_lane": {"object": "SpSurrogateObjectiveFastMpsTrotter.objective() + .gradient()", "route": pair_route, "ms_per_pair": pair * 1e3,
+                                   "pairs_per_s": 1.0 / pair},
     }
 
 

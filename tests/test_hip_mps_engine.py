@@ -254,8 +254,27 @@ def test_mps_objective_native_mode_matches_dense_mode(monkeypatch):
         assert o._native_mps == (method == "mps")
         f0 = o.objective(th); g0 = o.gradient(th); f1 = o.objective(th + 0.02); g1 = o.gradient(th + 0.02)
         seq[method] = (f0, g0, f1, g1)
+        assert bool(getattr(o, "_lk_live", False)) == (method == "mps")   # the engine route runs on two lockstep lanes
     for a, b in zip(seq["dense"], seq["mps"]):
         assert maxdiff(np.atleast_1d(a), np.atleast_1d(b)) < 1e-8
+    # a register whose V^H|target> outgrows the lanes' bond (12 qubits, exact arithmetic, generic angles: bonds up to 64): the objective
+    # notices on the first evaluation and stays on the single-lane engine
+    n2 = 12
+    circ2 = TrotterAnsatz(n2, make_trotter_like_circuit(n2, 4), second_order=True)
+    th2 = orc.rand_thetas(circ2.num_thetas, rng)
+    tgt2 = orc.random_mps(n2, 16, rng)
+    seq2 = {}
+    for method in ("dense", "mps"):
+        monkeypatch.setenv("AQC_MPS_METHOD", method)
+        user = dict(num_qubits=n2, max_flips=1, enable_optim_stats=False, verbose=0, maxiter=5, trunc_thr=1e-16)
+        o = SpSurrogateObjectiveFastMpsTrotter(user_parameters=user, circ=circ2)
+        o.set_target(tgt2)
+        seq2[method] = (o.objective(th2), o.gradient(th2))
+        if method == "mps":
+            assert o._native_mps and not o._lk_live and o._lk_refused
+    nrm2 = abs(orc.mps_dot(tgt2, tgt2))
+    for a, b in zip(seq2["dense"], seq2["mps"]):
+        assert maxdiff(np.atleast_1d(a), np.atleast_1d(b)) < 1e-8 * max(1.0, nrm2)
 
     monkeypatch.setenv("AQC_MPS_METHOD", "auto")
     n = 30
@@ -295,7 +314,7 @@ def test_lbfgs_on_the_native_mps_objective_32_qubits():
     th0 = th_true + 0.03 * rng.standard_normal(th_true.size)
     f0 = objv.objective(th0)
     res = AqcOptimizer(optimizer_name="lbfgs", maxiter=6).optimize(objv, circ, th0)
-    assert objv._native_mps and f0 > 1e-3
+    assert objv._native_mps and objv._lk_live and f0 > 1e-3
     assert res["cost"] < 0.2 * f0 and res["fidelity"] > 1 - 0.2 * f0
 
 

@@ -201,10 +201,15 @@ struct LaneMps { void* T; double* lam; int* dims; double* discarded; int n, pad;
 struct LaneRot { int kind /* 0 none, 1 rz, 2 ry, 3 rx */, idx; double scale; };        // angle = scale * thetas[lane][idx], or = scale when idx < 0
 struct LaneGate1 { LaneRot r[3]; };                                                    // the product r[0] r[1] r[2]
 struct LaneGate2 { int kind /* 0 swap, 1 cx, 2 cz, 3 cp */, idx, flip, pad; double scale; };   // cp angle = scale * thetas[lane][idx]; flip: control on site q + 1
-hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, int q, const LaneGate1& g, const double* thetas, int T, int lanes, int bond_hint,
-                              hipStream_t s);
-hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond,
-                              int* status, int* peak, int lanes, int bond_hint, hipStream_t s);   // m2 (may be null): a second state that takes the same gate
+struct LaneOp1 { int q, pad; LaneGate1 g; };   // a 1-qubit gate on site q
+struct LaneOp2 { int q, pad; LaneGate2 g; };   // a 2-qubit gate on the sites (q, q + 1)
+// One gate (`one`), or -- ops != null -- `nops` gates on pairwise disjoint sites from a table in device memory, all in one launch (gates of
+// one layer of the circuit touch disjoint tensors and bond dimensions: any order, and so also "at once", gives the same bits).
+// b / m2 (may be null): a second state that takes the same gates.
+hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, const LaneOp1* ops, int nops, const LaneOp1& one, const double* thetas, int T, int lanes,
+                              int bond_hint, hipStream_t s);
+hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, const LaneOp2* ops, int nops, const LaneOp2& one, const double* thetas, int T,
+                              double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s);
 hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,
                                  const double* gh8, int lanes, hipStream_t s);
 hipError_t launch_lanes_env_right(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride, int lanes,

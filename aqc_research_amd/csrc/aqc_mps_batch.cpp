@@ -19,6 +19,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 
@@ -52,12 +53,21 @@ struct Lanes {   // L MPS of n sites, flat device storage with fixed strides; T_
     void release() { if (base) (void)hipFree(base); base = nullptr; }
 };
 
+// the gates of V or V^H in levels of pairwise disjoint gates (apply_circuit_all below), cached per circuit
+struct Level { int off1, n1, off2, n2; };
+struct Schedule {
+    std::vector<Level> levels;
+    LaneOp1* ops1 = nullptr;   // device tables, level after level
+    LaneOp2* ops2 = nullptr;
+};
+
 }  // namespace
 
 struct aqc_mpsb {
     int device = 0, n = 0, L = 0;
     hipStream_t st = nullptr;
     Lanes target, lhs, vh, w, z;
+    std::map<std::string, Schedule> schedules;
     bool have_target = false, have_lhs = false;
     double* thetas = nullptr;    // [L][T] on the device
     double* h_thetas = nullptr;  // pinned staging of the same
@@ -90,6 +100,7 @@ void destroy(aqc_mpsb* b) {
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
     for (Lanes* s : {&b->target, &b->lhs, &b->vh, &b->w, &b->z}) s->release();
+    for (auto& kv : b->schedules) { if (kv.second.ops1) (void)hipFree(kv.second.ops1); if (kv.second.ops2) (void)hipFree(kv.second.ops2); }
     for (void* p : {(void*)b->thetas, (void*)b->status, (void*)b->env_l, (void*)b->env_r, (void*)b->e0, (void*)b->e1, (void*)b->vals, (void*)b->bits})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)b->h_thetas, (void*)b->h_out, (void*)b->h_bits})
@@ -108,12 +119,13 @@ LaneGate1 g1(LaneRot a, LaneRot b = LaneRot{0, -1, 0.0}, LaneRot c = LaneRot{0, 
 constexpr int RZ = 1, RY = 2, RX = 3;
 
 int gate1_all(aqc_mpsb* b, Lanes& s, int q, const LaneGate1& g, int T, Lanes* s2 = nullptr) {
-    HIP_OK(launch_lanes_gate1(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, b->active, b->hint, b->st));
+    HIP_OK(launch_lanes_gate1(s.dev, s2 ? &s2->dev : nullptr, nullptr, 1, LaneOp1{q, 0, g}, b->thetas, T, b->active, b->hint, b->st));
     return 0;
 }
 
 int gate_adjacent_all(aqc_mpsb* b, Lanes& s, Lanes* s2, int q, const LaneGate2& g, int T, double trunc_thr, int max_bond) {
-    HIP_OK(launch_lanes_gate2(s.dev, s2 ? &s2->dev : nullptr, q, g, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L, b->active, b->hint, b->st));
+    HIP_OK(launch_lanes_gate2(s.dev, s2 ? &s2->dev : nullptr, nullptr, 1, LaneOp2{q, 0, g}, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L,
+                              b->active, b->hint, b->st));
     return 0;
 }
 
@@ -133,37 +145,123 @@ int gate2_pair_all(aqc_mpsb* b, Lanes& s, Lanes* s2, int ctrl, int targ, int kin
 
 int entangler_kind(const aqc_circuit* c) { return c->entangler == AQC_CX ? 1 : (c->entangler == AQC_CZ ? 2 : 3); }
 
-// V(theta_l) or V(theta_l)^H on every lane (apply_circuit of aqc_mps_engine.cpp; core_operations.py:671-708, :787-818)
-int apply_circuit_all(aqc_mpsb* b, Lanes& s, const aqc_circuit* c, int T, bool inverse, double trunc_thr, int max_bond) {
-    const int n = b->n, tpb = c->entangler == AQC_CP ? 5 : 4;
+// V(theta_l) or V(theta_l)^H on every lane (apply_circuit of aqc_mps_engine.cpp; core_operations.py:671-708, :787-818), layer by layer:
+// the gates in program order (long-range entanglers already routed by swaps) are levelled as soon as possible -- a gate goes one level
+// above the last gate on any of its sites.  The gates of a level act on pairwise disjoint site tensors, Schmidt vectors and bond
+// dimensions, so they run in ONE launch per kind (1-qubit, 2-qubit) and leave exactly the bits the one-after-the-other order leaves:
+// a brickwork layer of n / 2 entanglers is one launch of n / 2 x lanes workgroups instead of n / 2 dependent launches.
+void emit_circuit(const aqc_circuit* c, int n, bool inverse, std::vector<std::pair<int, LaneOp1>>& o1, std::vector<std::pair<int, LaneOp2>>& o2) {
+    // (first = position in program order, shared by both lists)
+    const int tpb = c->entangler == AQC_CP ? 5 : 4;
     const bool cx = c->entangler == AQC_CX, cp = c->entangler == AQC_CP;
     const std::vector<BlockRef> blocks = blocks_of(c);
     const double half_pi = 1.5707963267948966;
     const int ek = entangler_kind(c), rt = cx ? RX : RZ;
     const LaneGate1 pre = g1(rot(RZ, -1, -half_pi)), post = g1(rot(RZ, -1, half_pi));
+    int pos = 0;
+    auto one = [&](int q, const LaneGate1& g) { o1.emplace_back(pos++, LaneOp1{q, 0, g}); };
+    auto two = [&](int ctrl, int targ, int idx, double scale) {   // swaps bring the upper qubit next to the lower one and back
+        const LaneGate2 swap{0, -1, 0, 0, 0.0};
+        const int lo = std::min(ctrl, targ), hi = std::max(ctrl, targ);
+        for (int p = hi - 1; p > lo; --p) o2.emplace_back(pos++, LaneOp2{p, 0, swap});
+        o2.emplace_back(pos++, LaneOp2{lo, 0, LaneGate2{ek, idx, ctrl > targ ? 1 : 0, 0, scale}});
+        for (int p = lo + 1; p < hi; ++p) o2.emplace_back(pos++, LaneOp2{p, 0, swap});
+    };
     if (!inverse) {
-        for (int q = 0; q < n; ++q)
-            if (gate1_all(b, s, q, g1(rot(RZ, 3 * q, 1.0), rot(RY, 3 * q + 1, 1.0), rot(RZ, 3 * q + 2, 1.0)), T)) return 1;
+        for (int q = 0; q < n; ++q) one(q, g1(rot(RZ, 3 * q, 1.0), rot(RY, 3 * q + 1, 1.0), rot(RZ, 3 * q + 2, 1.0)));
         for (const BlockRef& blk : blocks) {
             const int p = 3 * n + tpb * blk.j;
-            if (c->trotter && blk.i % 3 == 0 && gate1_all(b, s, blk.c, pre, T)) return 1;
-            if (gate2_pair_all(b, s, nullptr, blk.c, blk.t, ek, cp ? p + 4 : -1, 1.0, T, trunc_thr, max_bond)) return 1;
-            if (gate1_all(b, s, blk.c, g1(rot(RZ, p + 1, 1.0), rot(RY, p, 1.0)), T)) return 1;
-            if (gate1_all(b, s, blk.t, g1(rot(rt, p + 3, 1.0), rot(RY, p + 2, 1.0)), T)) return 1;
-            if (c->trotter && blk.i % 3 == 2 && gate1_all(b, s, blk.t, post, T)) return 1;
+            if (c->trotter && blk.i % 3 == 0) one(blk.c, pre);
+            two(blk.c, blk.t, cp ? p + 4 : -1, 1.0);
+            one(blk.c, g1(rot(RZ, p + 1, 1.0), rot(RY, p, 1.0)));
+            one(blk.t, g1(rot(rt, p + 3, 1.0), rot(RY, p + 2, 1.0)));
+            if (c->trotter && blk.i % 3 == 2) one(blk.t, post);
         }
     } else {
         for (auto it = blocks.rbegin(); it != blocks.rend(); ++it) {
             const BlockRef& blk = *it;
             const int p = 3 * n + tpb * blk.j;
-            if (c->trotter && blk.i % 3 == 2 && gate1_all(b, s, blk.t, pre, T)) return 1;
-            if (gate1_all(b, s, blk.t, g1(rot(RY, p + 2, -1.0), rot(rt, p + 3, -1.0)), T)) return 1;
-            if (gate1_all(b, s, blk.c, g1(rot(RY, p, -1.0), rot(RZ, p + 1, -1.0)), T)) return 1;
-            if (gate2_pair_all(b, s, nullptr, blk.c, blk.t, ek, cp ? p + 4 : -1, -1.0, T, trunc_thr, max_bond)) return 1;
-            if (c->trotter && blk.i % 3 == 0 && gate1_all(b, s, blk.c, post, T)) return 1;
+            if (c->trotter && blk.i % 3 == 2) one(blk.t, pre);
+            one(blk.t, g1(rot(RY, p + 2, -1.0), rot(rt, p + 3, -1.0)));
+            one(blk.c, g1(rot(RY, p, -1.0), rot(RZ, p + 1, -1.0)));
+            two(blk.c, blk.t, cp ? p + 4 : -1, -1.0);
+            if (c->trotter && blk.i % 3 == 0) one(blk.c, post);
         }
-        for (int q = 0; q < n; ++q)
-            if (gate1_all(b, s, q, g1(rot(RZ, 3 * q + 2, -1.0), rot(RY, 3 * q + 1, -1.0), rot(RZ, 3 * q, -1.0)), T)) return 1;
+        for (int q = 0; q < n; ++q) one(q, g1(rot(RZ, 3 * q + 2, -1.0), rot(RY, 3 * q + 1, -1.0), rot(RZ, 3 * q, -1.0)));
+    }
+}
+
+int build_schedule(aqc_mpsb* b, const aqc_circuit* c, bool inverse, Schedule& out) {
+    const int n = b->n;
+    std::vector<std::pair<int, LaneOp1>> o1;
+    std::vector<std::pair<int, LaneOp2>> o2;
+    emit_circuit(c, n, inverse, o1, o2);
+    // as-soon-as-possible levels in program order
+    std::vector<int> site_level(n, -1), lev1(o1.size()), lev2(o2.size());
+    size_t i1 = 0, i2 = 0;
+    int depth = 0;
+    while (i1 < o1.size() || i2 < o2.size()) {
+        if (i2 >= o2.size() || (i1 < o1.size() && o1[i1].first < o2[i2].first)) {
+            const int q = o1[i1].second.q;
+            lev1[i1] = ++site_level[q];
+            depth = std::max(depth, lev1[i1] + 1);
+            ++i1;
+        } else {
+            const int q = o2[i2].second.q;
+            const int lv = std::max(site_level[q], site_level[q + 1]) + 1;
+            site_level[q] = site_level[q + 1] = lev2[i2] = lv;
+            depth = std::max(depth, lv + 1);
+            ++i2;
+        }
+    }
+    std::vector<LaneOp1> t1;
+    std::vector<LaneOp2> t2;
+    out.levels.assign(depth, Level{0, 0, 0, 0});
+    for (int lv = 0; lv < depth; ++lv) {
+        Level& L = out.levels[lv];
+        L.off1 = (int)t1.size(); L.off2 = (int)t2.size();
+        for (size_t i = 0; i < o1.size(); ++i) if (lev1[i] == lv) t1.push_back(o1[i].second);
+        for (size_t i = 0; i < o2.size(); ++i) if (lev2[i] == lv) t2.push_back(o2[i].second);
+        L.n1 = (int)t1.size() - L.off1; L.n2 = (int)t2.size() - L.off2;
+    }
+    if (!t1.empty()) {
+        HIP_OK(hipMalloc((void**)&out.ops1, sizeof(LaneOp1) * t1.size()));
+        HIP_OK(hipMemcpy(out.ops1, t1.data(), sizeof(LaneOp1) * t1.size(), hipMemcpyHostToDevice));
+    }
+    if (!t2.empty()) {
+        HIP_OK(hipMalloc((void**)&out.ops2, sizeof(LaneOp2) * t2.size()));
+        HIP_OK(hipMemcpy(out.ops2, t2.data(), sizeof(LaneOp2) * t2.size(), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+std::string circuit_key(const aqc_circuit* c, bool inverse) {
+    std::string k(reinterpret_cast<const char*>(&c->num_qubits), sizeof(int32_t) * 5);
+    k.append(reinterpret_cast<const char*>(c->blocks), sizeof(int32_t) * 2 * (size_t)std::max(c->num_blocks, 0));
+    k.push_back(inverse ? 1 : 0);
+    return k;
+}
+
+int apply_circuit_all(aqc_mpsb* b, Lanes& s, const aqc_circuit* c, int T, bool inverse, double trunc_thr, int max_bond) {
+    const std::string key = circuit_key(c, inverse);
+    auto it = b->schedules.find(key);
+    if (it == b->schedules.end()) {
+        if (b->schedules.size() >= 16) {   // (a driver walks a few horizons; nothing keeps more than a handful of circuits alive)
+            HIP_OK(hipStreamSynchronize(b->st));
+            for (auto& kv : b->schedules) { if (kv.second.ops1) (void)hipFree(kv.second.ops1); if (kv.second.ops2) (void)hipFree(kv.second.ops2); }
+            b->schedules.clear();
+        }
+        Schedule sch;
+        if (build_schedule(b, c, inverse, sch)) return 1;
+        it = b->schedules.emplace(key, std::move(sch)).first;
+    }
+    const Schedule& sch = it->second;
+    for (const Level& lv : sch.levels) {
+        if (lv.n1)
+            HIP_OK(launch_lanes_gate1(s.dev, nullptr, sch.ops1 + lv.off1, lv.n1, LaneOp1{}, b->thetas, T, b->active, b->hint, b->st));
+        if (lv.n2)
+            HIP_OK(launch_lanes_gate2(s.dev, nullptr, sch.ops2 + lv.off2, lv.n2, LaneOp2{}, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L,
+                                      b->active, b->hint, b->st));
     }
     return 0;
 }

@@ -884,19 +884,21 @@ __device__ __forceinline__ void lane_apply_gate1(cplx* __restrict__ t, int ne, c
         t[ne + i] = cadd(cmul(u[2], a0), cmul(u[3], a1));
     }
 }
-__global__ __launch_bounds__(128) void lanes_gate1_kernel(LaneMps a, LaneMps b, int q, LaneGate1 g, const double* __restrict__ thetas, int T, int lanes) {
+__global__ __launch_bounds__(128) void lanes_gate1_kernel(LaneMps a, LaneMps b, const LaneOp1* __restrict__ ops, LaneOp1 one, const double* __restrict__ thetas,
+                                                          int T, int lanes) {   // blockIdx.y = state and lane, blockIdx.z = gate of the table
     const int l = blockIdx.y % lanes;
     const LaneMps& m = blockIdx.y < (unsigned)lanes ? a : b;
+    const LaneOp1 op = ops ? ops[blockIdx.z] : one;
     const int* dims = m.dims + (size_t)l * (m.n + 1);
     cplx u[4];
-    lane_gate1_matrix(g, thetas + (size_t)l * T, u);
-    lane_apply_gate1(static_cast<cplx*>(m.T) + ((size_t)l * m.n + q) * kLaneSite, dims[q] * dims[q + 1], u, blockIdx.x * blockDim.x + threadIdx.x,
+    lane_gate1_matrix(op.g, thetas + (size_t)l * T, u);
+    lane_apply_gate1(static_cast<cplx*>(m.T) + ((size_t)l * m.n + op.q) * kLaneSite, dims[op.q] * dims[op.q + 1], u, blockIdx.x * blockDim.x + threadIdx.x,
                      gridDim.x * blockDim.x);
 }
 
 #ifdef AQC_TUNING   // in-kernel stamps (diagnostic builds only): where the time of lanes_gate2_kernel goes (workgroup 0)
 __device__ unsigned long long g_gate2_stamps[16];
-#define G2_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+#define G2_STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     if (slot) atomicAdd(&g_gate2_stamps[slot], now_ - last_); else atomicAdd(&g_gate2_stamps[0], 1ull); last_ = now_; } } while (0)
 #define G2_COUNT(slot, v) atomicAdd(&g_gate2_stamps[slot], (unsigned long long)(v))
 #else
@@ -906,9 +908,9 @@ __device__ unsigned long long g_gate2_stamps[16];
 // One truncated 2-qubit gate on the sites (q, q + 1) of every lane, the whole of it in ONE workgroup per lane: two-site tensor with the gate
 // -> Jacobi work matrix in LDS, the sweeps, singular values, order / rank / truncation (the rule of gate_adjacent, aqc_mps_engine.cpp, on the
 // lane's own values), new site tensors, Schmidt values and bond dimension.
-__global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m1, int lanes, int q, LaneGate2 g, const double* __restrict__ thetas, int T,
-                                                           double trunc_thr, int max_bond, double tol, int max_sweeps, int* __restrict__ status,
-                                                           int* __restrict__ peak, unsigned lds_elems) {
+__global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m1, int lanes, const LaneOp2* __restrict__ ops, LaneOp2 one,
+                                                           const double* __restrict__ thetas, int T, double trunc_thr, int max_bond, double tol, int max_sweeps,
+                                                           int* __restrict__ status, int* __restrict__ peak, unsigned lds_elems) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ cplx gm[16];
     __shared__ double sig[2 * kLaneCap];
@@ -918,11 +920,13 @@ __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m
     __shared__ double rescale_sh;
     const int l = blockIdx.x % lanes, tid = threadIdx.x;
     const LaneMps& m = blockIdx.x < (unsigned)lanes ? m0 : m1;   // (the two operands of the gradient walk take every gate in one launch)
-    const int n = m.n;
+    const LaneOp2 op = ops ? ops[blockIdx.y] : one;              // (blockIdx.y: the gates of one layer, on disjoint sites)
+    const int n = m.n, q = op.q;
+    const LaneGate2& g = op.g;
 #ifdef AQC_TUNING
     unsigned long long last_ = 0;
 #endif
-    G2_STAMP(0);
+    G2_STAMP(0);   // (tuning builds stamp workgroup 0 of the first gate)
     int* dims = m.dims + (size_t)l * (n + 1);
     const int chil = dims[q], chim = dims[q + 1], chir = dims[q + 2];
     const int rows = 2 * chil, cols = 2 * chir, mode = cols <= rows ? 0 : 1;
@@ -969,7 +973,7 @@ __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m
     G2_STAMP(3);
     const int sweeps = jacobi_lds_core(sw, sv, wr, wc, tol, max_sweeps, fro2);
     G2_STAMP(4);
-    if (blockIdx.x == 0 && tid == 0) { G2_COUNT(8, sweeps); G2_COUNT(9, wc); G2_COUNT(10, wr); G2_COUNT(12, sweeps * (wc + (wc & 1) - 1)); }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { G2_COUNT(8, sweeps); G2_COUNT(9, wc); G2_COUNT(10, wr); G2_COUNT(12, sweeps * (wc + (wc & 1) - 1)); }
     for (int c = tid; c < wc; c += blockDim.x) sig[c] = lds_column_norm(sw, wr, c);
     __syncthreads();
     G2_STAMP(5);
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
             rescale = kept > 0.0 ? sqrt(total / kept) : 1.0;
-            if (j == 0) m.discarded[l] += total - kept;
+            if (j == 0) atomicAdd(&m.discarded[l], total - kept);   // (the gates of a layer run side by side: several may add to the lane's weight)
         }
         if (j == 0) {
             k_sh = k; rescale_sh = rescale;
@@ -1133,14 +1137,14 @@ __global__ void lanes_env_init_kernel(cplx* env_l, size_t l_stride, cplx* env_r_
     env_r_last[(size_t)l * r_stride] = make_double2(1.0, 0.0);
 }
 
-hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, int q, const LaneGate1& g, const double* thetas, int T, int lanes, int bond_hint,
-                              hipStream_t s) {
+hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, const LaneOp1* ops, int nops, const LaneOp1& one, const double* thetas, int T, int lanes,
+                              int bond_hint, hipStream_t s) {
     const int blocks = std::max(1, (bond_hint * bond_hint + 127) / 128);
-    lanes_gate1_kernel<<<dim3(blocks, lanes * (b ? 2 : 1)), 128, 0, s>>>(a, b ? *b : a, q, g, thetas, T, lanes);
+    lanes_gate1_kernel<<<dim3(blocks, lanes * (b ? 2 : 1), ops ? nops : 1), 128, 0, s>>>(a, b ? *b : a, ops, one, thetas, T, lanes);
     return hipGetLastError();
 }
-hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, int q, const LaneGate2& g, const double* thetas, int T, double trunc_thr, int max_bond,
-                              int* status, int* peak, int lanes, int bond_hint, hipStream_t s) {
+hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, const LaneOp2* ops, int nops, const LaneOp2& one, const double* thetas, int T,
+                              double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lanes_gate2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1153,11 +1157,11 @@ hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, int q, const 
     // A half-wave per column pair of the largest work matrix the launch is sized for while the lanes do not fill the chip (shortest
     // rounds); half of that once there are several workgroups per CU (typical matrices are well below the largest, idle waves only cost
     // barrier time and occupancy: 6.4 k -> 7.4 k evals/s at 1024 lanes of the 32-qubit workload, 7.6 k -> 9.6 k at 4096)
-    const int groups = lanes * (m2 ? 2 : 1);
-    const int per_bond = groups > 512 ? 16 : 32;
+    const int groups = lanes * (m2 ? 2 : 1), gates = ops ? nops : 1;
+    const int per_bond = groups * gates > 512 ? 16 : 32;
     const int threads = std::min(1024, std::max(64, (per_bond * h + 63) & ~63));
-    lanes_gate2_kernel<<<groups, threads, lds_elems * sizeof(cplx), s>>>(m, m2 ? *m2 : m, lanes, q, g, thetas, T, trunc_thr, max_bond, 1e-15, 60, status, peak,
-                                                                         lds_elems);
+    lanes_gate2_kernel<<<dim3(groups, gates), threads, lds_elems * sizeof(cplx), s>>>(m, m2 ? *m2 : m, lanes, ops, one, thetas, T, trunc_thr, max_bond, 1e-15, 60,
+                                                                                      status, peak, lds_elems);
     return hipGetLastError();
 }
 hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,

@@ -9,8 +9,9 @@ namespace aqc {
 // data-parallel-primitive moves inside a row of 16 lanes, gfx950's row / half swaps across rows
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (every pattern used here reads a valid lane: with bound_ctrl set the "old" operand is dead and costs no v_mov to initialise)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // v_permlane16_swap (v, v): first result = rows (0, 0, 2, 2) of v, second = rows (1, 1, 3, 3): their sum is v[l] + v[l ^ 16];

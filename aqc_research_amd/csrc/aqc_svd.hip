@@ -156,8 +156,8 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
                     pq = make_int2(min(pa, pb), max(pa, pb));
                 }
                 if (pq.y < cols) {
-                    cplx* wp = sw + (size_t)pq.x * rows;
-                    cplx* wq = sw + (size_t)pq.y * rows;
+                    cplx* wp = sw + pq.x * rows;   // (32-bit index arithmetic: these are LDS addresses)
+                    cplx* wq = sw + pq.y * rows;
                     double a = 0.0, b = 0.0, gr = 0.0, gi = 0.0;
                     for (int i = lane; i < rows; i += 32) {
                         const cplx x = wp[i], y = wq[i];
@@ -173,7 +173,7 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
                     }
                     const double g2 = gr * gr + gi * gi;
                     if (g2 > tol * tol * a * b && g2 != 0.0 && fmin(a, b) > negligible) {
-                        if (lane == 0) atomicAdd(&rotated, 1);
+                        if (lane == 0) rotated = 1;   // (a flag: every writer stores the same value)
                         // Rotation (x, y) <- (c x - s e y, conj(s e) x + c y), e = conj(gamma) / |gamma|, tan = t = sign(d) 2|gamma| / (|d| + h),
                         // h = sqrt(d^2 + 4|gamma|^2), d = b - a: diagonalises the pair's Gram matrix.  The parameters come from the hardware
                         // reciprocal / reciprocal-square-root estimates refined by Newton steps (a few fused multiply-adds each) in place of
@@ -187,8 +187,8 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
                         const double c = rsqrt_refined<2>(1.0 + g2 * u2 * u2);
                         const double f = d >= 0.0 ? c * u2 : -c * u2;
                         const double sr = f * gr, si = -f * gi;                     // s e
-                        cplx* vp = sv + (size_t)pq.x * cols;
-                        cplx* vq = sv + (size_t)pq.y * cols;
+                        cplx* vp = sv + pq.x * cols;
+                        cplx* vq = sv + pq.y * cols;
                         for (int i = lane; i < rows + cols; i += 32) {
                             cplx* xp = i < rows ? wp + i : vp + (i - rows);
                             cplx* yp = i < rows ? wq + i : vq + (i - rows);

@@ -549,7 +549,7 @@ def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float =
     ``targets`` / ``lhs``: one DeviceMPS per lane, or a single one shared by all lanes (operands are only read).
     ``method``: "lockstep" -- all lanes walk the circuit together, one launch per step (``LockstepLanes``; bonds <= 32);
     "threads" -- every lane on the single-lane engine, lanes concurrently on ``workers`` host threads (default: one per lane, at most
-    16); "auto" -- lockstep when the operands' bonds allow it, and the thread lanes if a lane outgrows the lockstep bond.
+    16); "auto" -- lockstep when the operands' bonds allow it (also for one lane), and the thread lanes if a lane outgrows the lockstep bond.
     Returns (h[B] complex, grads[B][T] complex)."""
     th = np.ascontiguousarray(thetas, dtype=np.float64)
     if th.ndim != 2 or th.shape[1] != circ.num_thetas:
@@ -562,7 +562,7 @@ def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float =
     if len(tg) != lanes or len(lh) != lanes:
         raise ValueError("one target and one lhs state per lane (or one for all)")
 
-    if method != "threads" and (method == "lockstep" or lanes > 1):
+    if method != "threads":   # (a single lane as well: its walk is 5x shorter on the lockstep kernels than on the single-lane engine's launch chain)
         distinct = {id(m): m for m in tg + lh}.values()
         fits = circ.num_qubits >= 2 and max_bond <= LOCKSTEP_MAX_BOND and all(int(m.bond_dims.max()) <= LOCKSTEP_MAX_BOND for m in distinct)
         if fits or method == "lockstep":

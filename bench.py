@@ -490,9 +490,13 @@ def run_mps_engine(args, w, env, full):
     wall = time.perf_counter() - t0
     if env.comm.size > 1:
         wall = float(env.comm.allreduce(np.array([wall]), "max")[0])
+    me.evaluate_lanes(circ, thetas(49)[:1], targets[:1], basis, trunc_thr=thr)   # (sizes the one-lane batch's launches)
     t1 = time.perf_counter()
     me.evaluate_lanes(circ, thetas(50)[:1], targets[:1], basis, trunc_thr=thr)
     one = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    me.evaluate_lanes(circ, thetas(51)[:1], targets[:1], basis, trunc_thr=thr, method="threads")
+    one_engine = time.perf_counter() - t1
     nthr = min(B, 16)   # the same batch shape on host threads (one single-lane engine per lane), for the record
     me.evaluate_lanes(circ, thetas(60)[:nthr], targets[:nthr], basis, trunc_thr=thr, method="threads")
     t2 = time.perf_counter()
@@ -529,8 +533,9 @@ def run_mps_engine(args, w, env, full):
                        f"|central difference - analytic| = {consistency:.2e} on one parameter",
         "value_gradient_consistency": consistency,
         "lockstep_vs_single_lane_maxerr": lane_err, "lockstep_lanes_checked": nchk,
-        "single_lane": {"ms_per_eval": one * 1e3, "evals_per_s": 1.0 / one},
-        "host_thread_lanes": {"lanes": nthr, "evals_per_s": thr_rate},
+        "single_lane": {"ms_per_eval": one * 1e3, "evals_per_s": 1.0 / one, "route": "one lockstep lane",
+                        "single_lane_engine_ms_per_eval": one_engine * 1e3},
+        "host_thread_lanes": {"lanes": nthr, "evals_per_s": thr_rate, "route": "single-lane engine per lane, host threads"},
         "front_door_single_lane": {"object": "SpSurrogateObjectiveFastMpsTrotter.objective() + .gradient()", "route": pair_route, "ms_per_pair": pair * 1e3,
                                    "pairs_per_s": 1.0 / pair},
     }

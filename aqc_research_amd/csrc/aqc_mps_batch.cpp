@@ -635,6 +635,52 @@ int aqc_mpsb_set_lhs_basis(aqc_mpsb* b, const uint8_t* bits) {
     return 0;
 }
 
+/* v_mul_mps / v_dagger_mul_mps (mps_operations.py:326-371) for every lane: the working state of the batch <- V(theta_l)|phi_l> (inverse = 0) or
+ * V(theta_l)^H|phi_l> (inverse = 1), layer by layer (apply_circuit_all); aqc_mpsb_export hands a lane's result out.  No lhs states needed. */
+int aqc_mpsb_apply_circuit(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, int inverse, double trunc_thr, int max_bond, double* discarded_out,
+                           int32_t* max_bond_out) {
+    if (!b || !circ || !thetas) return failf("null argument");
+    if (!b->have_target) return failf("set the states of the lanes first (aqc_mpsb_set_targets)");
+    int T = 0;
+    if (begin(b, circ, thetas, trunc_thr, max_bond, 1, &T)) return 1;
+    for (int attempt = 0;; ++attempt) {
+        HIP_OK(hipMemsetAsync(b->status, 0, sizeof(int) * 2 * (size_t)b->L, b->st));
+        if (clone(b, b->target, b->vh)) return 1;
+        if (apply_circuit_all(b, b->vh, circ, T, inverse != 0, trunc_thr, max_bond)) return 1;
+        const int rc = finish(b, attempt == 0, &b->peak_vh);
+        if (rc == 2) continue;
+        if (rc) return 1;
+        break;
+    }
+    const Readback r = readback(b);
+    for (int l = 0; l < b->L; ++l) {
+        if (discarded_out) discarded_out[l] = r.disc[l];
+        if (max_bond_out) max_bond_out[l] = r.max_dim(l, b->n);
+    }
+    b->vh_ready = inverse != 0;
+    return 0;
+}
+
+/* lane `lane` of the working state (the result of aqc_mpsb_apply_circuit / aqc_mpsb_vh) as a single-lane MPS of its own */
+int aqc_mpsb_export(aqc_mpsb* b, int lane, aqc_mps** out) {
+    if (!b || !out) return failf("null argument");
+    if (lane < 0 || lane >= b->L) return failf("lane out of range");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(hipStreamSynchronize(b->st));
+    const int n = b->n;
+    std::vector<int> dims(n + 1);
+    double discarded = 0.0;
+    HIP_OK(hipMemcpy(dims.data(), b->vh.dev.dims + (size_t)lane * (n + 1), sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&discarded, b->vh.dev.discarded + lane, sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<const void*> sites(n);
+    std::vector<const double*> lams(std::max(n - 1, 1), nullptr);
+    for (int q = 0; q < n; ++q) {
+        sites[q] = b->vh.site(lane, q);
+        if (q < n - 1) lams[q] = b->vh.lambda(lane, q);
+    }
+    return mps_adopt(b->device, n, dims.data(), sites.data(), lams.data(), discarded, out);
+}
+
 /* Phase 1 of an evaluation: vh_l = V(theta_l)^H|phi_l> for every lane, kept in the batch, and the amplitudes
  * amps[lane][0] = <lhs_l|vh_l>, amps[lane][1 + q] = <X_q lhs_l|vh_l> (num_amps = 1 or 1 + n: with a basis state as lhs these are the
  * amplitudes of the flip states of objective_lhs_sur_max.py:82-117).  half != 0: lanes [L/2, L) repeat the targets and thetas of lanes

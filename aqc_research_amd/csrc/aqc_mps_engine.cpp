@@ -550,6 +550,30 @@ int aqc::mps_peek(const aqc_mps* m, int q, const void** site, const double** lam
     return 0;
 }
 
+int aqc::mps_adopt(int device, int n, const int* dims, const void* const* sites, const double* const* lams, double discarded, aqc_mps** out) {
+    aqc_mps* m = nullptr;
+    if (new_mps(device, n, &m)) return 1;
+    m->dims.assign(dims, dims + n + 1);
+    m->discarded = discarded;
+    for (int q = 0; q < n; ++q) {
+        const size_t ne = site_elems(m, q);
+        if (reserve_site(m, q, ne) || hipMemcpyAsync(m->t[q], sites[q], sizeof(double2) * ne, hipMemcpyDeviceToDevice, m->stream) != hipSuccess) {
+            destroy(m);
+            return failf("MPS copy failed");
+        }
+        if (q < n - 1) {
+            std::vector<double> lam(dims[q + 1]);
+            if (hipMemcpy(lam.data(), lams[q], sizeof(double) * lam.size(), hipMemcpyDeviceToHost) != hipSuccess || set_lambda(m, q, lam)) {
+                destroy(m);
+                return failf("MPS copy failed");
+            }
+        }
+    }
+    if (hipStreamSynchronize(m->stream) != hipSuccess) { destroy(m); return failf("MPS copy failed"); }
+    *out = m;
+    return 0;
+}
+
 extern "C" {
 
 int aqc_mps_create(int device, int n, const int32_t* dims, const double* gammas, const double* lambdas, aqc_mps** out) {
@@ -606,6 +630,7 @@ int aqc_mps_clone(const aqc_mps* src, aqc_mps** out) {
 }
 
 int aqc_mps_num_qubits(const aqc_mps* m) { return m ? m->n : -1; }
+int aqc_mps_device(const aqc_mps* m) { return m ? m->device : -1; }
 
 int aqc_mps_dims(const aqc_mps* m, int32_t* dims) {
     if (!m || !dims) return failf("null argument");

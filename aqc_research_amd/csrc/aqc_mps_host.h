@@ -17,6 +17,9 @@ namespace aqc {
 // device pointers of site q of a single-lane MPS (T_q, and the Schmidt vector of bond q when q < n - 1) after its stream has drained:
 // how the lockstep lanes take a copy of a state built by the single-lane engine (defined in aqc_mps_engine.cpp)
 int mps_peek(const aqc_mps* m, int q, const void** site, const double** lam);
+// the reverse: a new single-lane MPS from tensors that live on the device (site q: [2][dims[q]][dims[q+1]] complex, T_q = Gamma_q lambda_q;
+// lams[q]: the dims[q+1] Schmidt values of bond q), copied
+int mps_adopt(int device, int n, const int* dims, const void* const* sites, const double* const* lams, double discarded, aqc_mps** out);
 }  // namespace aqc
 
 namespace {

@@ -120,7 +120,7 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
                 self._lk, self._lk_refused = None, True
         if self._vh is not None:
             self._vh.close()
-        self._vh = v_dagger_mul_mps(self._circuit, thetas, self._target_dev, trunc_thr=self._trunc_thr)   # V^H|target>
+        self._vh = v_dagger_mul_mps(self._circuit, thetas, self._target_dev, trunc_thr=self._trunc_thr, method="single")   # V^H|target>
         for i in range(self._num_states):
             self._hs[i] = self._basis(i).dot(self._vh)                                                   # <state_i|V^H|target>
 

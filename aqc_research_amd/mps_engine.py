@@ -311,13 +311,64 @@ def _apply_circuit_gatewise(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_t
     return mps
 
 
-def v_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_bond: int = 0) -> DeviceMPS:
-    """V(thetas)|mps> on a copy (mps_operations.py:326-346)."""
+def _apply_on_a_lane(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: float, max_bond: int) -> Optional[DeviceMPS]:
+    """The circuit on a copy of ``mps`` through ONE lockstep lane (``LockstepLanes.apply_circuit``: the gates of a circuit layer in one
+    launch, ranks decided on the device -- a 32-qubit Trotter circuit in a few milliseconds where the single-lane engine's launch chain
+    takes tens); None when the state, the bond cap or a bond met on the way does not fit the lanes (bonds <= 32)."""
+    n = circ.num_qubits
+    if n < 2 or max_bond > LOCKSTEP_MAX_BOND or mps.num_qubits != n or int(mps.bond_dims.max()) > LOCKSTEP_MAX_BOND:
+        return None
+    import threading
+
+    dev = int(_lib.lib().aqc_mps_device(mps.handle))
+    key = (dev, n, 1, "apply", threading.get_ident())   # (a lane of its own per host thread: the thread lanes of evaluate_lanes call in parallel)
+    ls = _LOCKSTEP_CACHE.get(key)
+    if ls is None:
+        if len(_LOCKSTEP_CACHE) >= 6:
+            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
+        ls = _LOCKSTEP_CACHE[key] = LockstepLanes(n, 1, dev)
+    try:
+        ls.set_targets(mps)
+        ls.apply_circuit(circ, np.asarray(thetas, dtype=np.float64)[None, :], inverse=inverse, trunc_thr=trunc_thr, max_bond=max_bond)
+        return ls.export(0)
+    except RuntimeError as err:
+        if "lockstep lanes" not in str(err):
+            raise
+        return None
+
+
+def _apply_method(method: Optional[str]) -> str:
+    import os
+
+    method = os.environ.get("AQC_MPS_APPLY", "auto") if method is None else method
+    if method not in ("auto", "single", "lockstep"):
+        raise ValueError("method (or AQC_MPS_APPLY): 'auto', 'single' or 'lockstep'")
+    return method
+
+
+def v_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_bond: int = 0, method: Optional[str] = None) -> DeviceMPS:
+    """V(thetas)|mps> on a copy (mps_operations.py:326-346).  ``method``: "single" -- the single-lane engine (one whole-circuit ABI
+    call, any bond); "lockstep" / "auto" -- through one lockstep lane while bonds stay <= 32 ("auto" falls back to "single"); None:
+    the environment's AQC_MPS_APPLY, else "auto"."""
+    method = _apply_method(method)
+    if method != "single":
+        out = _apply_on_a_lane(circ, thetas, mps, False, trunc_thr, max_bond)
+        if out is not None:
+            return out
+        if method == "lockstep":
+            raise RuntimeError("aqc_hip: the state or a bond on the way exceeds the lockstep lanes (bonds <= 32)")
     return _apply_circuit(circ, thetas, mps.clone(), False, trunc_thr, max_bond)
 
 
-def v_dagger_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_bond: int = 0) -> DeviceMPS:
-    """V(thetas)^H|mps> on a copy (mps_operations.py:349-371)."""
+def v_dagger_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_bond: int = 0, method: Optional[str] = None) -> DeviceMPS:
+    """V(thetas)^H|mps> on a copy (mps_operations.py:349-371); ``method`` as in ``v_mul_mps``."""
+    method = _apply_method(method)
+    if method != "single":
+        out = _apply_on_a_lane(circ, thetas, mps, True, trunc_thr, max_bond)
+        if out is not None:
+            return out
+        if method == "lockstep":
+            raise RuntimeError("aqc_hip: the state or a bond on the way exceeds the lockstep lanes (bonds <= 32)")
     return _apply_circuit(circ, thetas, mps.clone(), True, trunc_thr, max_bond)
 
 
@@ -502,6 +553,26 @@ class LockstepLanes:
         del keep
         return (amps, disc, bonds) if details else amps
 
+    def apply_circuit(self, circ, thetas, *, inverse: bool = False, trunc_thr: float = 0.0, max_bond: int = 0, details: bool = False):
+        """The lanes' working state <- V(thetas[l])|target_l> (or V^H with ``inverse``): ``v_mul_mps`` / ``v_dagger_mul_mps`` for every lane,
+        the gates of a circuit layer in one launch.  ``export(lane)`` hands a result out; no lhs states needed."""
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        if th.shape != (self.lanes, circ.num_thetas) or circ.num_qubits != self.num_qubits:
+            raise ValueError("thetas: expects shape (lanes, circ.num_thetas) on a circuit of the lanes' size")
+        desc, keep = _describe(circ)
+        disc = np.zeros(self.lanes, dtype=np.float64)
+        bonds = np.zeros(self.lanes, dtype=np.int32)
+        check(_lib.lib().aqc_mpsb_apply_circuit(self.handle, byref(desc), dptr(th), int(bool(inverse)), float(trunc_thr), int(max_bond), dptr(disc),
+                                                bonds.ctypes.data_as(POINTER(c_int32))))
+        del keep
+        return (disc, bonds) if details else None
+
+    def export(self, lane: int) -> DeviceMPS:
+        """Lane ``lane`` of the working state (after ``apply_circuit`` / ``apply_vh``) as a ``DeviceMPS`` of its own."""
+        h = c_void_p()
+        check(_lib.lib().aqc_mpsb_export(self.handle, int(lane), byref(h)))
+        return DeviceMPS(h)
+
     def gradient(self, circ, *, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> np.ndarray:
         """Phase 2: grads[lanes][T] (complex) of <V lhs_l|target_l> from the CURRENT lhs states and the vh of ``apply_vh``."""
         desc, keep = _describe(circ)
@@ -576,7 +647,7 @@ def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float =
                     raise
 
     def one(b: int):
-        vh = v_dagger_mul_mps(circ, th[b], tg[b], trunc_thr=trunc_thr, max_bond=max_bond)
+        vh = v_dagger_mul_mps(circ, th[b], tg[b], trunc_thr=trunc_thr, max_bond=max_bond, method="single")
         try:
             h = np.conj(vh.dot(lh[b]))   # <lhs|vh> on vh's own scratch and stream: an lhs state shared by the lanes is only read
             g = fast_dot_gradient_mps(circ, th[b], lh[b], vh, trunc_thr=trunc_thr, max_bond=max_bond, block_range=block_range,

@@ -192,6 +192,7 @@ int aqc_mps_create(int device, int n, const int32_t* dims, const double* gammas,
 int aqc_mps_destroy(aqc_mps* mps);
 int aqc_mps_clone(const aqc_mps* src, aqc_mps** out);
 int aqc_mps_num_qubits(const aqc_mps* mps);
+int aqc_mps_device(const aqc_mps* mps);   /* the HIP device the state lives on */
 int aqc_mps_dims(const aqc_mps* mps, int32_t* dims /* n+1 */);
 double aqc_mps_discarded_weight(const aqc_mps* mps);
 int aqc_mps_export(aqc_mps* mps, double* gammas, double* lambdas);
@@ -244,6 +245,12 @@ int aqc_mpsb_set_lhs_basis(aqc_mpsb* b, const uint8_t* bits);
 int aqc_mpsb_eval(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from,
                   int block_to, int front_layer, double* h /* [lanes] c128 */, double* grad /* [lanes][T] c128 */,
                   double* discarded /* [lanes] or NULL */, int32_t* max_bond_out /* [lanes] or NULL */);
+/* v_mul_mps / v_dagger_mul_mps(circ, thetas, mps, trunc_thr) (mps_operations.py:326-371) for every lane: the batch's working state <-
+ * V(theta_l)|phi_l> (inverse = 0) or V(theta_l)^H|phi_l> (inverse = 1), the gates of a circuit layer in one launch; aqc_mpsb_export hands
+ * lane `lane` of it out as a single-lane MPS of its own (caller destroys it). */
+int aqc_mpsb_apply_circuit(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, int inverse, double trunc_thr, int max_bond,
+                           double* discarded /* [lanes] or NULL */, int32_t* max_bond_out /* [lanes] or NULL */);
+int aqc_mpsb_export(aqc_mpsb* b, int lane, aqc_mps** out);
 /* The same in two phases, for objectives that choose the lhs state after seeing amplitudes (objective_lhs_sur_max.py:82-191: the
  * leading flip state).  Phase 1: vh of every lane, kept in the batch, and amps[lane][0] = <lhs_l|vh_l>, amps[lane][1 + q] =
  * <X_q lhs_l|vh_l> (num_amps = 1 or 1 + n; with a basis state as lhs: the amplitudes of its single-flip states, :99-111).

@@ -10,6 +10,13 @@ from tests.helpers import TOL, maxdiff
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["single", "auto"])
+def _apply_route(request, monkeypatch):
+    """Every test of the engine runs twice: whole circuits (v_mul_mps / v_dagger_mul_mps) on the single-lane engine, and -- the default --
+    layer by layer on one lockstep lane wherever bonds stay <= 32."""
+    monkeypatch.setenv("AQC_MPS_APPLY", request.param)
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 3), (3, 7), (16, 16), (40, 64), (64, 40), (128, 128), (200, 72), (66, 300), (512, 512),
                                    (100, 513)])
 def test_jacobi_svd(shape):

@@ -317,11 +317,16 @@ def test_mps_engine_builds_a_32_qubit_trotter_target_without_truncation():
     circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 6), second_order=True)
     th = init_ansatz_to_trotter(circ, np.zeros(circ.num_thetas), evol_time=1.2, delta=1.0)
     basis = me.DeviceMPS.basis_state(n, neel_state_index(n))
-    a = me.v_mul_mps(circ, th, basis, trunc_thr=1e-12)
+    a = me.v_mul_mps(circ, th, basis, trunc_thr=1e-12, method="single")
     b = me._apply_circuit_gatewise(circ, th, basis.clone(), False, 1e-12, 0)
     assert abs(a.dot(a) - 1.0) < 1e-9 and abs(abs(a.dot(b)) - 1.0) < 1e-9
     assert a.bond_dims.max() <= 32 and list(a.bond_dims) == list(b.bond_dims)
-    for m in (a, b, basis):
+    # the same circuit layer by layer on one lockstep lane (what v_mul_mps does by default while bonds stay <= 32), handed out as an MPS
+    c = me.v_mul_mps(circ, th, basis, trunc_thr=1e-12, method="lockstep")
+    assert list(c.bond_dims) == list(a.bond_dims) and abs(c.dot(a) - 1.0) < 1e-11 and abs(c.discarded_weight - a.discarded_weight) < 1e-12
+    back = me.v_dagger_mul_mps(circ, th, c, trunc_thr=1e-12, method="lockstep")
+    assert abs(abs(back.dot(basis)) - 1.0) < 1e-9
+    for m in (a, b, c, back, basis):
         m.close()
 
 
@@ -346,7 +351,7 @@ def test_mps_engine_lanes_on_host_threads_match_single_lane_calls():
     x = np.zeros(1 << n, complex)
     x[neel] = 1
     for b in range(lanes):
-        vh = me.v_dagger_mul_mps(circ, ths[b], targets[b])
+        vh = me.v_dagger_mul_mps(circ, ths[b], targets[b], method="single")
         assert abs(h[b] - basis.dot(vh)) < 1e-13
         assert maxdiff(g[b], me.fast_dot_gradient_mps(circ, ths[b], basis, vh)) < 1e-13
         vh.close()
@@ -359,7 +364,7 @@ def test_mps_engine_lanes_on_host_threads_match_single_lane_calls():
 
 def _single_lane_reference(me, circ, th, target, lhs, **kw):
     grad_kw = dict(kw)
-    vh = me.v_dagger_mul_mps(circ, th, target, trunc_thr=kw.get("trunc_thr", 0.0), max_bond=kw.get("max_bond", 0))
+    vh = me.v_dagger_mul_mps(circ, th, target, trunc_thr=kw.get("trunc_thr", 0.0), max_bond=kw.get("max_bond", 0), method="single")
     try:
         apply_kw = {k: grad_kw[k] for k in ("trunc_thr", "max_bond") if k in grad_kw}
         return lhs.dot(vh), me.fast_dot_gradient_mps(circ, th, lhs, vh, **grad_kw), vh.discarded_weight, int(vh.bond_dims.max()), apply_kw

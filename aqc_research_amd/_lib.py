@@ -85,6 +85,7 @@ SIGNATURES = {
     "aqc_mpsb_set_lhs_basis": (c_int, [_P, POINTER(c_uint8)]),
     "aqc_mpsb_vh": (c_int, [_P, _P, _D, c_double, c_int, c_int, c_int, _D, _D, POINTER(c_int32)]),
     "aqc_mpsb_grad": (c_int, [_P, _P, c_int, c_int, c_int, _D]),
+    "aqc_mpsb_gradient_of": (c_int, [_P, _P, _D, c_double, c_int, c_int, c_int, c_int, _D]),
     "aqc_mpsb_apply_circuit": (c_int, [_P, _P, _D, c_int, c_double, c_int, _D, POINTER(c_int32)]),
     "aqc_mpsb_export": (c_int, [_P, c_int, POINTER(_P)]),
     "aqc_mps_device": (c_int, [_P]),

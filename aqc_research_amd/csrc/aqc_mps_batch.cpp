@@ -741,6 +741,31 @@ int aqc_mpsb_grad(aqc_mpsb* b, const aqc_circuit* circ, int block_from, int bloc
     return 0;
 }
 
+/* fast_dot_gradient(circ, thetas, lvec, vh_phi, trunc_thr, block_range, front_layer) (mps_dot_objective.py:41-242) for every lane, with
+ * vh_phi_l ALREADY formed by the caller: the states set by aqc_mpsb_set_targets are taken as vh_phi_l, those of aqc_mpsb_set_lhs as lvec_l. */
+int aqc_mpsb_gradient_of(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from, int block_to,
+                         int front_layer, double* grad_out) {
+    if (!b || !circ || !thetas || !grad_out) return failf("null argument");
+    if (!b->have_target || !b->have_lhs) return failf("set the vh_phi states (aqc_mpsb_set_targets) and the lhs states of the lanes first");
+    int T = 0;
+    if (begin(b, circ, thetas, trunc_thr, max_bond, 0, &T)) return 1;
+    if (block_from < 0) { block_from = 0; block_to = circ->num_blocks; }
+    if (block_from > block_to || block_to > circ->num_blocks) return failf("invalid block range");
+    std::vector<std::pair<int, cd>> rec;
+    for (int attempt = 0;; ++attempt) {
+        HIP_OK(hipMemsetAsync(b->status, 0, sizeof(int) * 2 * (size_t)b->L, b->st));
+        if (clone(b, b->lhs, b->w) || clone(b, b->target, b->z)) return 1;
+        if (env_init(b)) return 1;
+        if (gradient_all(b, circ, T, trunc_thr, max_bond, block_from, block_to, front_layer != 0, 0, rec)) return 1;
+        const int rc = finish(b, attempt == 0, &b->peak_grad);
+        if (rc == 2) continue;
+        if (rc) return 1;
+        break;
+    }
+    assemble(b, readback(b), rec, 0, T, reinterpret_cast<cd*>(grad_out));
+    return 0;
+}
+
 /* both phases in one call, one wait: h[lane] = <lhs_l|vh_l> and the gradient */
 int aqc_mpsb_eval(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from, int block_to,
                   int front_layer, double* h_out, double* grad_out, double* discarded_out, int32_t* max_bond_out) {

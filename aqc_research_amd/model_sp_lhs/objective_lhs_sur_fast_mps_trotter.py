@@ -133,7 +133,7 @@ class SpSurrogateObjectiveFastMpsTrotter(SpSurrogateObjectiveMax):
         from ..mps_engine import fast_dot_gradient_mps
 
         return fast_dot_gradient_mps(self._circuit, self._last_thetas, self._basis(state_no), self._vh, trunc_thr=self._trunc_thr,
-                                     block_range=self._block_range, front_layer=front)
+                                     block_range=self._block_range, front_layer=front, method="single")
 
     def _sweep_combined(self, c_0: complex, c_max: complex, front: bool):
         if not self._native_mps:

@@ -373,18 +373,43 @@ def v_dagger_mul_mps(circ, thetas, mps: DeviceMPS, trunc_thr: float = 0.0, max_b
 
 
 def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, trunc_thr: float = 0.0, max_bond: int = 0,
-                          block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> np.ndarray:
+                          block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True, method: Optional[str] = None) -> np.ndarray:
     """Complex gradient of <V lvec|phi> given vh_phi = V^H|phi>, gate by gate on two MPS
     (mps_dot_objective.py:41-242): w <- lvec, z <- vh_phi; every gate is applied to both and each parametrised
     rotation records 0.5j <P w|z>; the CPhase derivative is -1j <P11 w|z> taken before the gate.
-    ONE ABI call (``aqc_mps_fast_dot_gradient``): the walk, the cached environments behind the inner products and the
-    single download of all of them live on the C side."""
+    ONE ABI call: the walk, the cached environments behind the inner products and the single download of all of them live on the
+    C side -- on one lockstep lane (``aqc_mpsb_gradient_of``) while bonds stay <= 32, on the single-lane engine
+    (``aqc_mps_fast_dot_gradient``) otherwise; ``method`` as in ``v_mul_mps``."""
     desc, keep = _describe(circ)
     th = _thetas(circ, thetas)
     lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
     if block_range is not None and not 0 <= lo <= hi <= circ.num_blocks:
         raise ValueError("invalid block range")
     grad = np.zeros(circ.num_thetas, dtype=np.complex128)
+    method = _apply_method(method)
+    n = circ.num_qubits
+    if (method != "single" and n >= 2 and max_bond <= LOCKSTEP_MAX_BOND and lvec.num_qubits == n == vh_phi.num_qubits
+            and max(int(lvec.bond_dims.max()), int(vh_phi.bond_dims.max())) <= LOCKSTEP_MAX_BOND):
+        import threading
+
+        dev = int(_lib.lib().aqc_mps_device(vh_phi.handle))   # one lockstep lane: the walk is a chain of fused steps instead of ~10 launches per gate
+        key = (dev, n, 1, "gradient", threading.get_ident())
+        ls = _LOCKSTEP_CACHE.get(key)
+        if ls is None:
+            if len(_LOCKSTEP_CACHE) >= 6:
+                _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
+            ls = _LOCKSTEP_CACHE[key] = LockstepLanes(n, 1, dev)
+        try:
+            ls.set_targets(vh_phi).set_lhs(lvec)
+            check(_lib.lib().aqc_mpsb_gradient_of(ls.handle, byref(desc), dptr(th), float(trunc_thr), int(max_bond), lo, hi, int(bool(front_layer)),
+                                                  dptr(grad)))
+            del keep
+            return grad
+        except RuntimeError as err:
+            if method == "lockstep" or "lockstep lanes" not in str(err):
+                raise
+    elif method == "lockstep":
+        raise RuntimeError("aqc_hip: the operands exceed the lockstep lanes (bonds <= 32)")
     check(_lib.lib().aqc_mps_fast_dot_gradient(byref(desc), lvec.handle, vh_phi.handle, dptr(th), float(trunc_thr), int(max_bond),
                                                lo, hi, int(bool(front_layer)), dptr(grad)))
     del keep
@@ -651,7 +676,7 @@ def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float =
         try:
             h = np.conj(vh.dot(lh[b]))   # <lhs|vh> on vh's own scratch and stream: an lhs state shared by the lanes is only read
             g = fast_dot_gradient_mps(circ, th[b], lh[b], vh, trunc_thr=trunc_thr, max_bond=max_bond, block_range=block_range,
-                                      front_layer=front_layer)
+                                      front_layer=front_layer, method="single")
         finally:
             vh.close()
         return h, g

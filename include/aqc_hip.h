@@ -260,6 +260,10 @@ int aqc_mpsb_export(aqc_mpsb* b, int lane, aqc_mps** out);
 int aqc_mpsb_vh(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int half, int num_amps,
                 double* amps /* [lanes][num_amps] c128 */, double* discarded /* [lanes] or NULL */, int32_t* max_bond_out /* or NULL */);
 int aqc_mpsb_grad(aqc_mpsb* b, const aqc_circuit* circ, int block_from, int block_to, int front_layer, double* grad /* [lanes][T] c128 */);
+/* fast_dot_gradient with vh_phi formed by the caller, as the reference's function takes it (mps_dot_objective.py:41): the states given to
+ * aqc_mpsb_set_targets ARE vh_phi_l = V^H|phi_l>, those given to aqc_mpsb_set_lhs the lvec_l */
+int aqc_mpsb_gradient_of(aqc_mpsb* b, const aqc_circuit* circ, const double* thetas, double trunc_thr, int max_bond, int block_from,
+                         int block_to, int front_layer, double* grad /* [lanes][T] c128 */);
 /* one-sided Jacobi SVD on the device (the kernel behind aqc_mps_gate2): A (m x n row-major) = U diag(S) Vh,
  * k = min(m, n), S descending, U (m x k), Vh (k x n); *sweeps (optional) = Jacobi sweeps used */
 int aqc_svd(int device, int m, int n, const double* a, double* u, double* s, double* vh, int* sweeps);

@@ -353,7 +353,7 @@ def test_mps_engine_lanes_on_host_threads_match_single_lane_calls():
     for b in range(lanes):
         vh = me.v_dagger_mul_mps(circ, ths[b], targets[b], method="single")
         assert abs(h[b] - basis.dot(vh)) < 1e-13
-        assert maxdiff(g[b], me.fast_dot_gradient_mps(circ, ths[b], basis, vh)) < 1e-13
+        assert maxdiff(g[b], me.fast_dot_gradient_mps(circ, ths[b], basis, vh, method="single")) < 1e-13
         vh.close()
         dense = orc.v_dagger_mul_vec(circ, ths[b], orc.mps_to_vector(tmps[b]))
         assert abs(h[b] - dense[neel]) < TOL
@@ -367,7 +367,7 @@ def _single_lane_reference(me, circ, th, target, lhs, **kw):
     vh = me.v_dagger_mul_mps(circ, th, target, trunc_thr=kw.get("trunc_thr", 0.0), max_bond=kw.get("max_bond", 0), method="single")
     try:
         apply_kw = {k: grad_kw[k] for k in ("trunc_thr", "max_bond") if k in grad_kw}
-        return lhs.dot(vh), me.fast_dot_gradient_mps(circ, th, lhs, vh, **grad_kw), vh.discarded_weight, int(vh.bond_dims.max()), apply_kw
+        return lhs.dot(vh), me.fast_dot_gradient_mps(circ, th, lhs, vh, method="single", **grad_kw), vh.discarded_weight, int(vh.bond_dims.max()), apply_kw
     finally:
         vh.close()
 

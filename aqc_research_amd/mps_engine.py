@@ -325,7 +325,7 @@ def _apply_on_a_lane(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: flo
     ls = _LOCKSTEP_CACHE.get(key)
     if ls is None:
         if len(_LOCKSTEP_CACHE) >= 6:
-            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
+            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)))   # (freed when its last user lets go: another thread may be inside a call on it)
         ls = _LOCKSTEP_CACHE[key] = LockstepLanes(n, 1, dev)
     try:
         ls.set_targets(mps)
@@ -397,7 +397,7 @@ def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, t
         ls = _LOCKSTEP_CACHE.get(key)
         if ls is None:
             if len(_LOCKSTEP_CACHE) >= 6:
-                _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
+                _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)))   # (freed when its last user lets go: another thread may be inside a call on it)
             ls = _LOCKSTEP_CACHE[key] = LockstepLanes(n, 1, dev)
         try:
             ls.set_targets(vh_phi).set_lhs(lvec)
@@ -630,7 +630,7 @@ def _lockstep_for(num_qubits: int, lanes: int, device: int, targets, lhs) -> Loc
     ls = _LOCKSTEP_CACHE.get(key)
     if ls is None:
         if len(_LOCKSTEP_CACHE) >= 4:
-            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE))).close()
+            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)))   # (freed when its last user lets go: another thread may be inside a call on it)
         ls = _LOCKSTEP_CACHE[key] = LockstepLanes(num_qubits, lanes, device)
     # the operands are copied into the lanes; the copies are refreshed when a state was replaced or edited in place (DeviceMPS.version)
     ls.set_targets(targets)

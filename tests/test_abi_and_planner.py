@@ -109,3 +109,23 @@ def test_fails_loudly_without_gpu():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300).stdout
     assert "RAISED" in out and "no CPU fallback" in out, out
+
+
+def test_mps_lanes_fail_loudly_without_gpu():
+    """The lockstep lanes of the MPS engine have no CPU path either: creating a batch (and a single-lane state) raises."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from aqc_research_amd import mps_engine as me\n"
+        "for make in (lambda: me.LockstepLanes(6, 4), lambda: me.DeviceMPS.basis_state(6, 3)):\n"
+        "    try:\n"
+        "        make()\n"
+        "        print('CREATED')\n"
+        "    except RuntimeError as e:\n"
+        "        print('RAISED', e)\n" % ROOT
+    )
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300).stdout
+    assert out.count("RAISED") == 2 and out.count("no CPU fallback") == 2 and "CREATED" not in out, out

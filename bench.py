@@ -831,8 +831,8 @@ def main():
             t_cfg = time.perf_counter()
             try:
                 configs[name] = brief(measure(name, args, env, full=False))
-            except SystemExit as exc:   # a failed short run must not take the headline with it: it is reported as failed
-                configs[name] = {"error": str(exc)}
+            except (SystemExit, Exception) as exc:   # a failed short run must not take the headline with it: it is reported as failed
+                configs[name] = {"error": f"{type(exc).__name__}: {exc}"}
             configs[name]["wall_s_incl_setup"] = time.perf_counter() - t_cfg
             print(f"bench.py: config {name}: {json.dumps(configs[name])}", file=sys.stderr, flush=True)
         out["configs"] = configs

@@ -15,7 +15,7 @@
 // Workgroups are sized for the bonds seen so far (`hint`: LDS and threads for bonds <= 4 / 6 / 8 / ... / 32); a lane that outgrows
 // the launch raises a status bit and the evaluation is repeated at full size -- never a wrong result.  Bonds above 32 (a work
 // matrix larger than 64 x 64 does not fit one workgroup's LDS) are refused: the caller goes to the single-lane engine.
-// Arithmetic and truncation rule are the single-lane engine's (same device bodies, aqc_svd.hip), lane by lane.
+// Arithmetic and truncation rule are the single-lane engine's (same device bodies, aqc_mps_dev.h), lane by lane.
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>

@@ -112,7 +112,7 @@ int jacobi_svd(SvdWork& sw, void* W, int rows, void* V, int cols, hipStream_t st
     }
     constexpr int kFlagInts = 64 + 4;   // [0..63] rotations per sweep | [64] barrier | [65] sweeps used | [66] barrier timeout
     if (sw.flag.reserve(sizeof(int) * kFlagInts) || sw.sigma.reserve(sizeof(double) * (std::max(cols, 1) + 2))) return 1;   // sigma | fro2 | sweeps
-    double* fro2 = static_cast<double*>(sw.sigma.p) + std::max(cols, 1);   // scale of the negligible-column rule (aqc_svd.hip: kNegligible2)
+    double* fro2 = static_cast<double*>(sw.sigma.p) + std::max(cols, 1);   // scale of the negligible-column rule (aqc_mps_dev.h: kNegligible2)
     int* flag = static_cast<int*>(sw.flag.p);
     const double tol = 1e-15;
     int sweeps = 0;

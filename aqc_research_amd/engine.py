@@ -419,13 +419,42 @@ def _mps_fingerprint(mps) -> tuple:
     return tuple(out)
 
 
-def _ws_mps_slot_for(self, mps) -> int:
+def _mps_bond_dims(mps) -> tuple:
+    return tuple(int(np.shape(g0)[1]) for g0, _ in mps[0][:-1])
+
+
+def _pad_mps(mps, bonds):
+    """The same state with every bond widened to ``bonds`` by zero rows / columns of the tensors (Schmidt entries 1 on the padding: they
+    multiply zeros) -- exact, and it gives the lanes of a batch ONE common shape."""
+    gam, lam = mps
+    n = len(gam)
+    dims = (1,) + tuple(bonds) + (1,)
+    out_g = []
+    for q, (g0, g1) in enumerate(gam):
+        pair = []
+        for g in (g0, g1):
+            a = np.zeros((dims[q], dims[q + 1]), dtype=np.complex128)
+            g = np.asarray(g)
+            a[: g.shape[0], : g.shape[1]] = g
+            pair.append(a)
+        out_g.append(tuple(pair))
+    out_l = []
+    for q in range(n - 1):
+        v = np.ones(dims[q + 1])
+        src = np.asarray(lam[q], dtype=np.float64).ravel()
+        v[: src.size] = src
+        out_l.append(v)
+    return out_g, out_l
+
+
+def _ws_mps_slot_for(self, mps, bonds=None) -> int:
     """Slot holding a device-resident copy of `mps`: uploaded on first sight, found again by the tuple's identity plus a
     cheap fingerprint of its tensors (mps_dot_objective.py:41 receives the same target tuple on every call of an
-    optimisation; the reference re-loads it into the simulator each time, :100-101).  Least recently used slot is recycled."""
+    optimisation; the reference re-loads it into the simulator each time, :100-101).  Least recently used slot is recycled.
+    ``bonds``: bond dimensions the resident copy is zero-padded to (``_pad_mps``; None: as they are)."""
     cache = self.__dict__.setdefault("_mps_cache", {})        # id(mps) -> [slot, fingerprint, tick, keep-alive reference]
     self._mps_tick = getattr(self, "_mps_tick", 0) + 1
-    fp = _mps_fingerprint(mps)
+    fp = (_mps_fingerprint(mps), None if bonds is None or tuple(bonds) == _mps_bond_dims(mps) else tuple(bonds))
     ent = cache.get(id(mps))
     if ent is not None and ent[1] == fp:
         ent[2] = self._mps_tick
@@ -437,7 +466,7 @@ def _ws_mps_slot_for(self, mps) -> int:
     else:
         victim = min(cache, key=lambda k: cache[k][2])
         slot = cache.pop(victim)[0]
-    self.mps_upload(slot, mps)
+    self.mps_upload(slot, mps if fp[1] is None else _pad_mps(mps, fp[1]))
     cache[id(mps)] = [slot, fp, self._mps_tick, mps]
     # the fingerprint only samples the tensors: the resident copy is kept honest by making the cached arrays read-only --
     # an in-place edit now raises instead of silently evaluating against the stale device copy (pass new arrays to change a
@@ -454,17 +483,24 @@ def _ws_mps_slot_for(self, mps) -> int:
 
 def _ws_mps_to_vec_batch(self, mps_list, buf: int, lanes=None) -> None:
     """Dense states of `mps_list` (QiskitMPS tuples, one per lane) into lanes `lanes` (default 0..len-1) of `buf`: resident
-    copies through the slot cache, lanes that share a tuple share its slot, ONE contraction chain for all lanes."""
+    copies through the slot cache, lanes that share a tuple share its slot, ONE contraction chain for all lanes (operands of different
+    bond dimensions are zero-padded to a common shape)."""
     lanes = np.arange(len(mps_list), dtype=np.int32) if lanes is None else np.ascontiguousarray(lanes, dtype=np.int32)
     if lanes.size != len(mps_list):
         raise ValueError("one lane per MPS")
     if len({id(m) for m in mps_list}) > _MPS_SLOTS - _MPS_FIRST_CACHED:
         raise ValueError(f"at most {_MPS_SLOTS - _MPS_FIRST_CACHED} distinct MPS per batched contraction")
+    # Truncated canonical tensors (the reference's trunc_thr = 1e-6) differ from target to target by a few bond entries, and the native
+    # call runs one contraction chain per distinct shape: the resident copies are zero-padded to the widest bonds among the lanes, so the
+    # whole batch is one chain again (config 3 at 1e-6: 62.9 k -> the 1e-16 rate)
+    distinct = {id(m): m for m in mps_list}
+    shapes = {_mps_bond_dims(m) for m in distinct.values()}
+    bonds = tuple(max(b) for b in zip(*shapes)) if len(shapes) > 1 else None
     by_id = {}
     slots = np.empty(len(mps_list), dtype=np.int32)
     for i, m in enumerate(mps_list):
         if id(m) not in by_id:
-            by_id[id(m)] = self.mps_slot_for(m)
+            by_id[id(m)] = self.mps_slot_for(m, bonds)
         slots[i] = by_id[id(m)]
     i32 = ctypes.POINTER(c_int32)
     check(self._L.aqc_ws_mps_to_vec_batch(self.handle, int(slots.size), slots.ctypes.data_as(i32), buf, lanes.ctypes.data_as(i32)))

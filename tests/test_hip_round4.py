@@ -86,8 +86,9 @@ def test_mps_objective_truncated_engine_stays_within_the_discarded_weight_bound(
 
 
 def test_mps_to_vec_batch_with_mixed_bond_dimensions():
-    """Lanes whose MPS operands differ in their bond dimensions (truncated canonical tensors do) go through one launch chain
-    per distinct dimension vector; every lane must still receive ITS state (mps_operations.py:159-189 per lane)."""
+    """Lanes whose MPS operands differ in their bond dimensions (truncated canonical tensors do): the workspace pads the resident copies
+    with zeros to a common shape (one contraction chain; the native call alone would run one chain per distinct shape) -- every lane
+    must still receive ITS state (mps_operations.py:159-189 per lane); the same operands unpadded through the native grouping."""
     from aqc_research_amd import ParametricCircuit
     from aqc_research_amd.circuit_structures import create_ansatz_structure
     from aqc_research_amd.engine import BUF_Y, HipContext, Workspace
@@ -104,6 +105,20 @@ def test_mps_to_vec_batch_with_mixed_bond_dimensions():
         out = ws.download(BUF_Y)
         for i, m in enumerate(lanes):
             assert maxdiff(out[i], orc.mps_to_vector(m)) < TOL
+    # the native call on operands of different shapes (no padding: slots filled one by one)
+    import ctypes
+
+    distinct = [a, b, c, zero]
+    for k, m in enumerate(distinct):
+        ws.mps_upload(k, m)
+    slots = np.array([next(k for k, d in enumerate(distinct) if d is m) for m in lanes], dtype=np.int32)
+    ids = np.arange(len(lanes), dtype=np.int32)
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    assert ws._L.aqc_ws_mps_to_vec_batch(ws.handle, len(lanes), slots.ctypes.data_as(i32), BUF_Y, ids.ctypes.data_as(i32)) == 0
+    ws._touch(BUF_Y)
+    out = ws.download(BUF_Y)
+    for i, m in enumerate(lanes):
+        assert maxdiff(out[i], orc.mps_to_vector(m)) < TOL
     ws.close()
 
 

@@ -245,8 +245,12 @@ def _apply_to_mps(circ, thetas, mps_vec, inverse: bool, trunc_thr) -> QiskitMPS:
     from . import mps_engine                # large registers / real truncation: gate by gate on the MPS
 
     m = mps_engine.DeviceMPS.from_qiskit(mps_vec, trunc_thr=thr)
-    try:
-        return mps_engine._apply_circuit(circ, thetas, m, inverse, thr, 0).to_qiskit()
+    try:   # (one lockstep lane while bonds stay <= 32 -- the gates of a circuit layer in one launch --, the single-lane engine otherwise)
+        out = (mps_engine.v_dagger_mul_mps if inverse else mps_engine.v_mul_mps)(circ, thetas, m, trunc_thr=thr)
+        try:
+            return out.to_qiskit()
+        finally:
+            out.close()
     finally:
         m.close()
 

@@ -67,6 +67,18 @@ __device__ __forceinline__ double halfwave_sum4(double v0, double v1, double v2,
     v += lane_xor12(v);
     return add_xor16(v);
 }
+// ... and over a ROW of 16 lanes (the same steps without the last, cross-row one): for work that fits 16 lanes, four groups per wave
+__device__ __forceinline__ double row_sum4(double v0, double v1, double v2, double v3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
+    double k0 = b0 ? v2 : v0, k1 = b0 ? v3 : v1;
+    k0 += dpp<0xB1>(s0);
+    k1 += dpp<0xB1>(s1);
+    double v = (b1 ? k1 : k0) + dpp<0x4E>(b1 ? k0 : k1);
+    v += lane_xor4(v);
+    v += lane_xor12(v);
+    return v;
+}
 template <int K> __device__ __forceinline__ double quad_bcast(double v) { return dpp<K * 0x55>(v); }   // quad_perm [K, K, K, K]
 
 }  // namespace aqc

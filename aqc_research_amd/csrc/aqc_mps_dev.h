@@ -41,9 +41,12 @@ __device__ __forceinline__ double rcp_refined(double y) {
 // cols / 2 half-waves a round takes several passes.  fro2: Frobenius norm squared of the matrix (scale of kNegligible2).
 // Pairing: the round-robin tournament over n2 = even(cols) seats (seat 0 stays, the others move one seat per round; a seat >= cols is a
 // bye), worked out from (round, pair) -- a table in global memory put a load of several hundred cycles at the head of every round.
-__device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __restrict__ sv, int rows, int cols, double tol, int max_sweeps, double fro2) {
+// G lanes per column pair: 32 (a half-wave), or 16 (a row: four pairs per wave) for work matrices of up to 16 rows -- most of a walk's
+// matrices at bonds <= 8 --, which halves the waves that compete for the vector pipes once several workgroups share a CU.
+template <int G>
+__device__ __forceinline__ int jacobi_lds_sweeps(cplx* __restrict__ sw, cplx* __restrict__ sv, int rows, int cols, double tol, int max_sweeps, double fro2) {
     __shared__ int rotated;
-    const int tid = threadIdx.x, grp = tid >> 5, lane = tid & 31, ngrp = blockDim.x >> 5;
+    const int tid = threadIdx.x, grp = tid / G, lane = tid % G, ngrp = blockDim.x / G;
     const int n2 = cols + (cols & 1), rounds = n2 - 1, per_round = n2 >> 1;
     const double negligible = kNegligible2 * fro2;
     int sweep = 0;
@@ -63,7 +66,7 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
                     cplx* wp = sw + pq.x * rows;   // (32-bit index arithmetic: these are LDS addresses)
                     cplx* wq = sw + pq.y * rows;
                     double a = 0.0, b = 0.0, gr = 0.0, gi = 0.0;
-                    for (int i = lane; i < rows; i += 32) {
+                    for (int i = lane; i < rows; i += G) {
                         const cplx x = wp[i], y = wq[i];
                         a += x.x * x.x + x.y * x.y;
                         b += y.x * y.x + y.y * y.y;
@@ -72,7 +75,7 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
                     }
                     {   // the four sums over the half-wave in 6 exchange steps on the vector ALU (aqc_lanes.h; it was a 5-step
                         // butterfly of four values through the LDS crossbar: 40 ds_bpermute per round), then every lane takes all four
-                        const double v = halfwave_sum4(a, b, gr, gi, lane);   // slots of a quad: 0 a, 1 gr, 2 b, 3 gi
+                        const double v = G == 32 ? halfwave_sum4(a, b, gr, gi, lane) : row_sum4(a, b, gr, gi, lane);   // slots of a quad: 0 a, 1 gr, 2 b, 3 gi
                         a = quad_bcast<0>(v); gr = quad_bcast<1>(v); b = quad_bcast<2>(v); gi = quad_bcast<3>(v);
                     }
                     const double g2 = gr * gr + gi * gi;
@@ -93,7 +96,7 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
                         const double sr = f * gr, si = -f * gi;                     // s e
                         cplx* vp = sv + pq.x * cols;
                         cplx* vq = sv + pq.y * cols;
-                        for (int i = lane; i < rows + cols; i += 32) {
+                        for (int i = lane; i < rows + cols; i += G) {
                             cplx* xp = i < rows ? wp + i : vp + (i - rows);
                             cplx* yp = i < rows ? wq + i : vq + (i - rows);
                             const cplx x = *xp, y = *yp;
@@ -110,6 +113,9 @@ __device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __re
         if (any == 0) { ++sweep; break; }
     }
     return sweep;
+}
+__device__ __forceinline__ int jacobi_lds_core(cplx* __restrict__ sw, cplx* __restrict__ sv, int rows, int cols, double tol, int max_sweeps, double fro2) {
+    return rows <= 16 ? jacobi_lds_sweeps<16>(sw, sv, rows, cols, tol, max_sweeps, fro2) : jacobi_lds_sweeps<32>(sw, sv, rows, cols, tol, max_sweeps, fro2);
 }
 // |column c| of sw, fixed order (the singular value once the sweeps have converged)
 __device__ __forceinline__ double lds_column_norm(const cplx* __restrict__ sw, int rows, int c) {

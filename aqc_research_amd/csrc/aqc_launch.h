@@ -216,9 +216,11 @@ hipError_t launch_lanes_env_right(const LaneMps& w, const LaneMps& z, int p, con
                                   hipStream_t s);
 hipError_t launch_lanes_env_dot(const LaneMps& w, const LaneMps& z, int hi, const void* e, size_t e_stride, const void* rc, size_t rc_stride, void* vals,
                                 int nvals, int slot, int lanes, hipStream_t s);
-// rotation g on site q of both operands + vals[lane][slot] = <P w|z>, P on site q (gh8 = P^H), from the environments L[q] and R[q]
-hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneGate1& g, const double* thetas, int T, const void* env_l, size_t l_stride,
-                                  const void* env_r, size_t r_stride, const double* gh8, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s);
+// up to three parameters on the SAME site: per parameter k the rotation g[k] on site q of both operands, then vals[lane][slot + k] = <P_k w|z>
+// (gh[k] = P_k^H, 2 x 2 row-major c128) from the environments L[q] and R[q]
+struct LaneSteps { LaneGate1 g[3]; double gh[3][8]; int count, pad; };
+hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneSteps& steps, const double* thetas, int T, const void* env_l,
+                                  size_t l_stride, const void* env_r, size_t r_stride, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s);
 hipError_t launch_lanes_basis(const LaneMps& m, const unsigned char* bits /* [lanes][n] */, int lanes, hipStream_t s);   // product basis states
 hipError_t launch_lanes_env_init(void* env_l, size_t l_stride, void* env_r_last, size_t r_stride, int lanes, hipStream_t s);
 // environment steps of <(ops) w|z> for small bonds, one launch per site (aqc_svd.hip); gh8: 2x2 (row-major, 4 c128) applied to z's site or null

@@ -338,27 +338,34 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int
         rec.emplace_back(tindex, factor);
         return 0;
     };
-    // rotation on site q of both operands + its inner product 0.5j <P w|z>: one launch (the environments do not involve site q)
-    auto rotate_and_record = [&](int tindex, int q, const LaneGate1& g, const M2* op) -> int {
+    // consecutive parameters on one site q: per parameter the rotation on both operands + its inner product 0.5j <P w|z>, up to three of them
+    // in one launch (the environments do not involve site q: they are advanced once, in front)
+    auto rotate_and_record = [&](int q, int count, const int* tindex, const LaneGate1* g, const M2* const* op) -> int {
         const int slot = slot0 + (int)rec.size();
-        if (slot >= b->nvals) return failf("inner-product slot out of range");
+        if (slot + count > b->nvals) return failf("inner-product slot out of range");
         if (env_advance(b, q, q)) return 1;
-        const M2 gh = {{std::conj(op->m[0]), std::conj(op->m[2]), std::conj(op->m[1]), std::conj(op->m[3])}};
-        double g8[8];
-        pack(gh, g8);
-        HIP_OK(launch_lanes_grad_step(b->w.dev, b->z.dev, q, g, b->thetas, T, b->env_l + (size_t)q * kLaneEnv, kEnvL(n), b->env_r + (size_t)q * kLaneEnv, kEnvR(n),
-                                      g8, b->e0, b->vals, b->nvals, slot, b->L, b->st));
+        LaneSteps st{};
+        st.count = count;
+        for (int k = 0; k < count; ++k) {
+            st.g[k] = g[k];
+            const M2 gh = {{std::conj(op[k]->m[0]), std::conj(op[k]->m[2]), std::conj(op[k]->m[1]), std::conj(op[k]->m[3])}};
+            pack(gh, st.gh[k]);
+        }
+        HIP_OK(launch_lanes_grad_step(b->w.dev, b->z.dev, q, st, b->thetas, T, b->env_l + (size_t)q * kLaneEnv, kEnvL(n), b->env_r + (size_t)q * kLaneEnv, kEnvR(n),
+                                      b->e0, b->vals, b->nvals, slot, b->L, b->st));
         env_touched(b, q, q);
-        rec.emplace_back(tindex, cd(0, 0.5));
+        for (int k = 0; k < count; ++k) rec.emplace_back(tindex[k], cd(0, 0.5));
         return 0;
     };
-    for (int q = 0; q < n; ++q) {
-        const int slots[3] = {2, 1, 0};
-        for (int k = 0; k < 3; ++k) {
-            const int slot = slots[k];
-            const bool is_y = slot == 1;
-            const LaneGate1 g = g1(rot(is_y ? RY : RZ, 3 * q + slot, 1.0));
-            if (front_layer ? rotate_and_record(3 * q + slot, q, g, is_y ? &kPauliY : &kPauliZ) : both(q, g)) return 1;
+    for (int q = 0; q < n; ++q) {   // front layer: Rz(t2), Ry(t1), Rz(t0), rightmost first (core_operations.py:921-935)
+        const int tix[3] = {3 * q + 2, 3 * q + 1, 3 * q};
+        const LaneGate1 gs[3] = {g1(rot(RZ, tix[0], 1.0)), g1(rot(RY, tix[1], 1.0)), g1(rot(RZ, tix[2], 1.0))};
+        const M2* ops[3] = {&kPauliZ, &kPauliY, &kPauliZ};
+        if (front_layer) {
+            if (rotate_and_record(q, 3, tix, gs, ops)) return 1;
+        } else {
+            for (int k = 0; k < 3; ++k)
+                if (both(q, gs[k])) return 1;
         }
     }
     const LaneGate1 pre = g1(rot(RZ, -1, -half_pi)), post = g1(rot(RZ, -1, half_pi));
@@ -376,9 +383,13 @@ int gradient_all(aqc_mpsb* b, const aqc_circuit* c, int T, double trunc_thr, int
         const int qs[4] = {blk.c, blk.c, blk.t, blk.t};
         const int kinds[4] = {RY, RZ, RY, cx ? RX : RZ};
         const M2* ps[4] = {&kPauliY, &kPauliZ, &kPauliY, cx ? &kPauliX : &kPauliZ};
-        for (int k = 0; k < 4; ++k) {
-            const LaneGate1 g = g1(rot(kinds[k], base + k, 1.0));
-            if (live ? rotate_and_record(base + k, qs[k], g, ps[k]) : both(qs[k], g)) return 1;
+        const int tix[4] = {base, base + 1, base + 2, base + 3};
+        const LaneGate1 gs[4] = {g1(rot(kinds[0], base, 1.0)), g1(rot(kinds[1], base + 1, 1.0)), g1(rot(kinds[2], base + 2, 1.0)), g1(rot(kinds[3], base + 3, 1.0))};
+        if (live) {   // the two rotations of the control, then the two of the target: one launch per qubit
+            if (rotate_and_record(blk.c, 2, tix, gs, ps) || rotate_and_record(blk.t, 2, tix + 2, gs + 2, ps + 2)) return 1;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (both(qs[k], gs[k])) return 1;
         }
         if (c->trotter && blk.i % 3 == 2 && both(blk.t, post)) return 1;
     }

@@ -239,41 +239,48 @@ __global__ __launch_bounds__(256) void lanes_env_dot_kernel(LaneMps w, LaneMps z
     }
     if (threadIdx.x == 0) vals[(size_t)l * nvals + slot] = make_double2(sr[0], si[0]);
 }
-// One parameter of the gradient walk in ONE launch: the rotation on site q of both operands, then <P w|z> with the Pauli P on that site from
-// the environments on either side: E = step(L[q], site q seen through P^H), vals[lane][slot] = sum E conj(R[q]).  (They were three launches.)
-__global__ __launch_bounds__(256) void lanes_grad_step_kernel(LaneMps w, LaneMps z, int q, LaneGate1 g, const double* __restrict__ thetas, int T,
+// Up to three consecutive parameters of the gradient walk that sit on the SAME site, in ONE launch: per parameter the rotation on site q of
+// both operands, then <P w|z> with its Pauli P on that site from the environments on either side (they do not involve site q and are shared):
+// E = step(L[q], site q seen through P^H), vals[lane][slot + k] = sum E conj(R[q]).  (A parameter was three launches, then one.)
+__global__ __launch_bounds__(256) void lanes_grad_step_kernel(LaneMps w, LaneMps z, int q, LaneSteps st, const double* __restrict__ thetas, int T,
                                                               const cplx* __restrict__ env_l, size_t l_stride, const cplx* __restrict__ env_r, size_t r_stride,
-                                                              Gate4c gh, cplx* __restrict__ scratch, cplx* __restrict__ vals, int nvals, int slot) {
+                                                              cplx* __restrict__ scratch, cplx* __restrict__ vals, int nvals, int slot) {
     const int l = blockIdx.x, n = w.n, tid = threadIdx.x;
     const int* dw = w.dims + (size_t)l * (n + 1);
     const int* dz = z.dims + (size_t)l * (n + 1);
     const int xa = dw[q], ua = dw[q + 1], yb = dz[q], vb = dz[q + 1];
     cplx* A = static_cast<cplx*>(w.T) + ((size_t)l * n + q) * kLaneSite;
     cplx* B = static_cast<cplx*>(z.T) + ((size_t)l * n + q) * kLaneSite;
-    {
-        cplx u[4];
-        lane_gate1_matrix(g, thetas + (size_t)l * T, u);
-        lane_apply_gate1(A, xa * ua, u, tid, 256);
-        lane_apply_gate1(B, yb * vb, u, tid, 256);
-    }
-    __syncthreads();   // (workgroup-scope release / acquire: the environment step below reads what other threads have just written)
     cplx* e = scratch + (size_t)l * kLaneEnv;
-    mps_env_left_body(env_l + (size_t)l * l_stride, A, B, xa, ua, yb, vb, 1, gh, e);
-    __shared__ double sr[256], si[256];
     const cplx* rc = env_r + (size_t)l * r_stride;
-    double re = 0.0, im = 0.0;
-    for (int i = tid; i < ua * vb; i += 256) {
-        const cplx a = e[i], b = rc[i];
-        re += a.x * b.x + a.y * b.y;
-        im += a.y * b.x - a.x * b.y;
-    }
-    sr[tid] = re; si[tid] = im;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { sr[tid] += sr[tid + s]; si[tid] += si[tid + s]; }
+    __shared__ double sr[256], si[256];
+    for (int k = 0; k < st.count; ++k) {
+        {
+            cplx u[4];
+            lane_gate1_matrix(st.g[k], thetas + (size_t)l * T, u);
+            lane_apply_gate1(A, xa * ua, u, tid, 256);
+            lane_apply_gate1(B, yb * vb, u, tid, 256);
+        }
+        __syncthreads();   // (workgroup-scope release / acquire: the environment step below reads what other threads have just written)
+        Gate4c gh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gh.m[i] = make_double2(st.gh[k][2 * i], st.gh[k][2 * i + 1]);
+        mps_env_left_body(env_l + (size_t)l * l_stride, A, B, xa, ua, yb, vb, 1, gh, e);
+        double re = 0.0, im = 0.0;
+        for (int i = tid; i < ua * vb; i += 256) {
+            const cplx a = e[i], b = rc[i];
+            re += a.x * b.x + a.y * b.y;
+            im += a.y * b.x - a.x * b.y;
+        }
+        sr[tid] = re; si[tid] = im;
         __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) { sr[tid] += sr[tid + s]; si[tid] += si[tid + s]; }
+            __syncthreads();
+        }
+        if (tid == 0) vals[(size_t)l * nvals + slot + k] = make_double2(sr[0], si[0]);
+        __syncthreads();   // (sr / si and the scratch are reused by the next parameter)
     }
-    if (tid == 0) vals[(size_t)l * nvals + slot] = make_double2(sr[0], si[0]);
 }
 // every lane <- the computational-basis state bits[lane][site]: site tensors [2][1][1], Schmidt values 1, bond dimensions 1
 __global__ void lanes_basis_kernel(LaneMps m, const unsigned char* __restrict__ bits, int lanes) {
@@ -342,12 +349,10 @@ hipError_t launch_lanes_env_dot(const LaneMps& w, const LaneMps& z, int hi, cons
                                                static_cast<cplx*>(vals), nvals, slot);
     return hipGetLastError();
 }
-hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneGate1& g, const double* thetas, int T, const void* env_l, size_t l_stride,
-                                  const void* env_r, size_t r_stride, const double* gh8, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s) {
-    Gate4c gh;
-    for (int i = 0; i < 4; ++i) gh.m[i] = make_double2(gh8[2 * i], gh8[2 * i + 1]);
-    lanes_grad_step_kernel<<<lanes, 256, sizeof(cplx) * kLaneEnv, s>>>(w, z, q, g, thetas, T, static_cast<const cplx*>(env_l), l_stride,
-                                                                        static_cast<const cplx*>(env_r), r_stride, gh, static_cast<cplx*>(scratch),
+hipError_t launch_lanes_grad_step(const LaneMps& w, const LaneMps& z, int q, const LaneSteps& steps, const double* thetas, int T, const void* env_l,
+                                  size_t l_stride, const void* env_r, size_t r_stride, void* scratch, void* vals, int nvals, int slot, int lanes, hipStream_t s) {
+    lanes_grad_step_kernel<<<lanes, 256, sizeof(cplx) * kLaneEnv, s>>>(w, z, q, steps, thetas, T, static_cast<const cplx*>(env_l), l_stride,
+                                                                        static_cast<const cplx*>(env_r), r_stride, static_cast<cplx*>(scratch),
                                                                         static_cast<cplx*>(vals), nvals, slot);
     return hipGetLastError();
 }

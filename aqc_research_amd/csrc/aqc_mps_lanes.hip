@@ -114,9 +114,10 @@ __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m
     cplx* tq = static_cast<cplx*>(m.T) + ((size_t)l * n + q) * kLaneSite;
     cplx* tq1 = tq + kLaneSite;
     const int nb = n > 1 ? n - 1 : 1;
-    const double* lam_left = q > 0 ? m.lam + ((size_t)l * nb + (q - 1)) * kLaneCap : nullptr;
-    // the two site tensors come in once, coalesced (the dot products of the two-site tensor read every element 2 chi times: from global
-    // memory, one dependent load after the other, that was a third of the kernel)
+    // the two site tensors and the Schmidt values of the left bond come in once, coalesced (the dot products of the two-site tensor read
+    // every element 2 chi times: from global memory, one dependent load after the other, that was a third of the kernel)
+    __shared__ double lam_left[kLaneCap];
+    if (tid < chil) lam_left[tid] = q > 0 ? m.lam[((size_t)l * nb + (q - 1)) * kLaneCap + tid] : 1.0;
     for (int i = tid; i < nq; i += blockDim.x) sv[i] = tq[i];
     for (int i = tid; i < nq1; i += blockDim.x) sv[nq + i] = tq1[i];
     __syncthreads();

@@ -150,20 +150,23 @@ __device__ __forceinline__ void mps_theta_fused_body(const cplx* __restrict__ tq
     const int m = 2 * chil, n = 2 * chir;
     const double sc = lam_left ? lam_left[l] : 1.0;
     cplx in[4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const cplx* x = tq + ((size_t)a * chil + l) * chim;
-            const cplx* y = tq1 + (size_t)b * chim * chir + r;
-            double re = 0.0, im = 0.0;
-            for (int k = 0; k < chim; ++k) {
-                const cplx u = x[k], v = y[(size_t)k * chir];
-                re += u.x * v.x - u.y * v.y;
-                im += u.x * v.y + u.y * v.x;
-            }
-            in[2 * a + b] = make_double2(sc * re, sc * im);
+    {   // the four dot products over the middle bond in one pass: four loads and four independent accumulations per k (every sum in the
+        // order of k, as four separate loops would form it)
+        const cplx* x0 = tq + l * chim;
+        const cplx* x1 = tq + (chil + l) * chim;
+        const cplx* y0 = tq1 + r;
+        const cplx* y1 = tq1 + chim * chir + r;
+        double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < chim; ++k) {
+            const cplx u0 = x0[k], u1 = x1[k], v0 = y0[k * chir], v1 = y1[k * chir];
+            re[0] += u0.x * v0.x - u0.y * v0.y; im[0] += u0.x * v0.y + u0.y * v0.x;
+            re[1] += u0.x * v1.x - u0.y * v1.y; im[1] += u0.x * v1.y + u0.y * v1.x;
+            re[2] += u1.x * v0.x - u1.y * v0.y; im[2] += u1.x * v0.y + u1.y * v0.x;
+            re[3] += u1.x * v1.x - u1.y * v1.y; im[3] += u1.x * v1.y + u1.y * v1.x;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) in[i] = make_double2(sc * re[i], sc * im[i]);
+    }
     cplx out[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

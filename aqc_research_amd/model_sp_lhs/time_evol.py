@@ -304,22 +304,41 @@ def _seeded_horizon_job(job_index: int, cfg: Dict) -> Dict:
         for s in range(1, opts.num_seeds):
             rng = np.random.default_rng(opts.seed + 1000 * h + 7 * (s + 1))
             starts[s] += opts.theta_jitter * np.pi * (2.0 * rng.random(trotter_thetas.size) - 1.0)
-        target_dev = None
+        target_dev = bo = None
         if opts.use_mps and n > _DENSE_MAX_QUBITS:   # beyond dense reach: the restarts are lockstep lanes of the native MPS engine (bonds <= 32)
             from ..batched_optimizer import BatchedMpsSurrogateObjective
             from ..mps_engine import DeviceMPS
 
             target_dev = DeviceMPS.from_qiskit(target, device=opts.device, trunc_thr=float(opts.trunc_thr), assume_canonical=True)
-            bo = BatchedMpsSurrogateObjective(circ, target_dev, lanes=opts.num_seeds, base_index=ini, trunc_thr=float(opts.trunc_thr), device=opts.device)
+            try:
+                bo = BatchedMpsSurrogateObjective(circ, target_dev, lanes=opts.num_seeds, base_index=ini, trunc_thr=float(opts.trunc_thr), device=opts.device)
+                res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= fid_thr)
+            except RuntimeError as err:
+                if "lockstep lanes" not in str(err):
+                    raise
+                if bo is not None:
+                    bo.close()
+                bo = None            # a bond beyond the lanes' 32 (long horizons: the untruncated target alone can exceed it)
+            finally:
+                target_dev.close()
+            if bo is None:           # ... the restarts one after the other on the objective's single-lane route, as the reference runs a job
+                recs = []
+                for s_no in range(opts.num_seeds):
+                    objv = _create_objective(opts=opts, circ=circ, target=target, layer_range=(0, circ.num_layers))
+                    r = AqcOptimizer(optimizer_name="lbfgs", maxiter=int(opts.maxiter), verbose=opts.verbose).optimize(
+                        objv, circ, starts[s_no], stopper=EarlyStopper(fidelity_thr=fid_thr), timeout=TimeoutChecker(time_limit=opts.time_limit))
+                    recs.append(r)
+                best = int(np.argmax([r["fidelity"] for r in recs]))
+                return dict(common, fidelity=float(recs[best]["fidelity"]), cost=float(recs[best]["cost"]), thetas=recs[best]["thetas"].copy(),
+                            best_restart=best, fidelities=[float(r["fidelity"]) for r in recs], num_fun_ev=int(sum(r["num_fun_ev"] for r in recs)),
+                            route="single-lane engine, one restart after the other")
         else:
             dense = (target.dense_state if isinstance(target, DenseBackedMPS) else mps_to_vector(target)) if opts.use_mps else target
             bo = BatchedSurrogateObjective(circ, np.tile(dense, (opts.num_seeds, 1)), base_index=ini, device=opts.device)
-        if opts.device_lbfgs and target_dev is None:
-            res = bo.minimize_on_device(starts, maxiter=opts.maxiter, fidelity_thr=fid_thr)
-        else:
-            res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= fid_thr)
-        if target_dev is not None:
-            target_dev.close()
+            if opts.device_lbfgs:
+                res = bo.minimize_on_device(starts, maxiter=opts.maxiter, fidelity_thr=fid_thr)
+            else:
+                res = batched_lbfgs(bo.value_and_grad, starts, maxiter=opts.maxiter, stop=lambda f, x: bo.fidelity >= fid_thr)
         fids = bo.fidelity.copy()
         evals = bo.num_evals
         bo.close()

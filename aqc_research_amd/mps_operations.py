@@ -67,6 +67,9 @@ def _workspace(n: int):
     return HipContext.of(_Circ(n)).workspace(1, 1)
 
 
+_DOT_ON_WORKSPACE_MAX = 24   # registers up to this size contract MPS on the (cached) dense workspace of their size
+
+
 def mps_to_vector(qiskit_mps) -> np.ndarray:
     """Dense state of an MPS; index bit q <-> site q (mps_operations.py:159-189)."""
     if not check_mps(qiskit_mps):
@@ -85,6 +88,15 @@ def mps_dot(qiskit_mps1, qiskit_mps2) -> np.complex128:
         raise ValueError("not a valid MPS in Qiskit format")
     if len(qiskit_mps1[0]) != len(qiskit_mps2[0]):
         raise ValueError("MPS with different numbers of qubits")
+    if len(qiskit_mps1[0]) > _DOT_ON_WORKSPACE_MAX:   # beyond dense reach: the transfer-matrix chain of the MPS engine, no 2^n workspace behind it
+        from .mps_engine import DeviceMPS
+
+        a, b = DeviceMPS.from_qiskit(qiskit_mps1), DeviceMPS.from_qiskit(qiskit_mps2)
+        try:
+            return np.complex128(a.dot(b))
+        finally:
+            a.close()
+            b.close()
     ws = _workspace(len(qiskit_mps1[0]))
     ws.mps_upload(0, qiskit_mps1)
     ws.mps_upload(1, qiskit_mps2)

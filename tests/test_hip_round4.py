@@ -557,3 +557,18 @@ def test_horizon_driver_beyond_dense_reach():
     assert r["status"] == "ok" and r["use_mps"] and r["num_layers"] == 1 and r["thetas"].size == 3 * 26 + 4 * 75
     assert 0.0 < r["fid_t1_vs_gt"] <= 1.0 + 1e-9 and 0.0 < r["fid_a1_vs_gt"] <= 1.0 + 1e-9
     assert r["fid_a1_vs_gt"] >= r["fidelity_trotter_init"] - 1e-6        # the optimisation does not lose what the Trotter point had
+
+
+def test_seeded_horizon_falls_back_when_the_target_outgrows_the_lanes(monkeypatch):
+    """A long evolution makes the untruncated target's bonds exceed the lockstep lanes' 32 (12 qubits: up to 64): the restarts of the
+    horizon then run one after the other on the objective's single-lane route and the record says so."""
+    from aqc_research_amd.model_sp_lhs import time_evol as te
+
+    monkeypatch.setattr(te, "_DENSE_MAX_QUBITS", 8)
+    opts = te.UserOptions(num_qubits=12, num_horizons=1, evol_time_step=6.0, trotter_steps_per_horizon=12, num_layers_inc=1, maxiter=2,
+                          objective="sur_fast_mps_trotter", fidelity_thr=0.9999, num_seeds=2, vectorised_lbfgs=True, trunc_thr=1e-12)
+    tgt = te.generate_target(opts, 0)
+    assert max(np.shape(g0)[1] for g0, _ in tgt.t1_gt[0]) > 32
+    r = te.run_simulation(opts)[0]
+    assert r["status"] == "ok" and r["route"].startswith("single-lane") and len(r["fidelities"]) == 2
+    assert all(0.0 <= f <= 1.0 + 1e-9 for f in r["fidelities"])

@@ -573,3 +573,32 @@ def test_seeded_horizon_falls_back_when_the_target_outgrows_the_lanes(monkeypatc
     r = te.run_simulation(opts)[0]
     assert r["status"] == "ok" and r["route"].startswith("single-lane") and len(r["fidelities"]) == 2
     assert all(0.0 <= f <= 1.0 + 1e-9 for f in r["fidelities"])
+
+
+def test_function_level_mps_front_door_at_34_qubits():
+    """The reference's own functions on QiskitMPS tuples beyond every dense limit (mps_operations.py:192-213,326-371;
+    mps_dot_objective.py:41-242,245-516): v_mul_mps, v_dagger_mul_mps, mps_dot, fast_dot_gradient, a single-gate function and dot_z agree with
+    each other -- the gradient with central differences of <V(theta) 0|phi>, dot_z with the gradient entry of its rotation."""
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd import mps_dot_objective as mdo
+    from aqc_research_amd import mps_operations as mpo
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+
+    n = 34
+    rng = np.random.default_rng(734)
+    circ = TrotterAnsatz(n, make_trotter_like_circuit(n, 1), second_order=False)
+    th = 0.3 * orc.rand_thetas(circ.num_thetas, rng)
+    zero = ([(np.ones((1, 1), complex), np.zeros((1, 1), complex)) for _ in range(n)], [np.ones(1) for _ in range(n - 1)])
+    phi = mpo.v_mul_mps(circ, th + 0.05, zero, trunc_thr=1e-14)
+    assert mpo.check_mps(phi) and mpo.mps_num_qubits(phi) == n and abs(mpo.mps_dot(phi, phi) - 1.0) < 1e-9
+    vh = mpo.v_dagger_mul_mps(circ, th, phi, trunc_thr=1e-14)
+    g = mdo.fast_dot_gradient(circ, th, zero, vh, trunc_thr=1e-14)
+    assert g.shape == (circ.num_thetas,) and np.isfinite(g).all()
+    for t in (2, 3 * n + 5):
+        e = np.zeros_like(th); e[t] = 1e-5
+        f = [mpo.mps_dot(mpo.v_mul_mps(circ, th + s * e, zero, trunc_thr=1e-14), phi) for s in (+1, -1)]
+        assert abs((f[0] - f[1]) / 2e-5 - g[t]) < 1e-7
+    # theta 2 is the first rotation applied to qubit 0 (Rz): its gradient entry is 0.5j <Z_0 0|V^H phi> = dot_z(0, |0>, vh)
+    assert abs(mdo.dot_z(0, zero, vh) - g[2]) < 1e-9
+    w = mdo.cx_mul_mps(0.0, 3, 4, mdo.rx_mul_mps(0.7, 3, zero), trunc_thr=1e-14)
+    assert abs(mpo.mps_dot(w, w) - 1.0) < 1e-12 and max(np.shape(g0)[1] for g0, _ in w[0]) == 2

@@ -602,3 +602,40 @@ def test_function_level_mps_front_door_at_34_qubits():
     assert abs(mdo.dot_z(0, zero, vh) - g[2]) < 1e-9
     w = mdo.cx_mul_mps(0.0, 3, 4, mdo.rx_mul_mps(0.7, 3, zero), trunc_thr=1e-14)
     assert abs(mpo.mps_dot(w, w) - 1.0) < 1e-12 and max(np.shape(g0)[1] for g0, _ in w[0]) == 2
+
+
+def test_lockstep_lanes_against_the_single_lane_engine_on_random_problems():
+    """tools/lockstep_fuzz.py in small: random registers, entanglers, block layouts with long-range pairs, targets / lhs states of random
+    bonds, truncation thresholds, bond caps, block ranges -- every lane of the lockstep walk equals the single-lane engine's (or the
+    lockstep call refuses because a bond passes 32, never answers differently)."""
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd import mps_engine as me
+
+    rng = np.random.default_rng(29)
+    compared = 0
+    for _ in range(24):
+        n = int(rng.integers(3, 11))
+        ent = ("cx", "cz", "cp")[int(rng.integers(0, 3))]
+        nb = int(rng.integers(1, 3 * n))
+        ctrl = rng.integers(0, n, nb)
+        circ = ParametricCircuit(n, entangler=ent, blocks=np.stack([ctrl, (ctrl + rng.integers(1, n, nb)) % n]))
+        lanes = int(rng.integers(1, 4))
+        thr = (0.0, 1e-10, 1e-6, 1e-3)[int(rng.integers(0, 4))]
+        cap = (0, 0, 3, 8)[int(rng.integers(0, 4))]
+        ths = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(lanes)])
+        targets = [me.DeviceMPS.from_qiskit(orc.random_mps(n, int(rng.integers(1, 9)), rng), trunc_thr=thr) for _ in range(lanes)]
+        lhs = [me.DeviceMPS.from_qiskit(orc.random_mps(n, int(rng.integers(1, 4)), rng), trunc_thr=thr) for _ in range(lanes)]
+        lo = int(rng.integers(0, nb))
+        kw = dict(trunc_thr=thr, max_bond=cap, block_range=None if rng.random() < 0.5 else (lo, int(rng.integers(lo, nb + 1))),
+                  front_layer=bool(rng.random() < 0.7))
+        try:
+            h, g = me.evaluate_lanes(circ, ths, targets, lhs, method="lockstep", **kw)
+        except RuntimeError as err:
+            assert "lockstep lanes" in str(err)
+            continue
+        hs, gs = me.evaluate_lanes(circ, ths, targets, lhs, method="threads", **kw)
+        assert maxdiff(h, hs) < 1e-11 and maxdiff(g, gs) < 1e-11, (n, ent, nb, lanes, thr, cap, kw)
+        compared += 1
+        for m in targets + lhs:
+            m.close()
+    assert compared >= 18

@@ -1,0 +1,207 @@
+// Internal declarations shared by the translation units behind the C ABI (include/aqc_hip.h):
+//   aqc_api.cpp        contexts, workspaces, buffers, thetas, small results, one-shot entry points
+//   aqc_ws_plan.cpp    lowering of stage plans to device tables (micro-ops, sub-stage slot tables), mirrored V^H plans
+//   aqc_ws_sweep.cpp   V / V^H launches, the w/z sweep (dense and sparse-lhs routes), aqc_ws_eval
+//   aqc_ws_optim.cpp   device-resident L-BFGS and the one-call surrogate evaluation
+//   aqc_ws_extra.cpp   zgemm, gate-level building blocks, coordinate descent, MPS helpers
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/aqc_hip.h"
+#include "aqc_device.h"
+#include "aqc_launch.h"
+#include "aqc_plan.h"
+
+namespace aqc {
+
+int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));   // sets the thread's error message; returns 1
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return ::aqc::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+inline int ceil_log2(int v) {
+    int b = 0;
+    while ((1 << b) < v) ++b;
+    return b;
+}
+
+struct DevPlan {
+    Plan plan;
+    std::vector<DevStage> h_stages;
+    std::vector<DevOp> h_ops;
+    std::vector<DevSub> h_subs;   // register-blocked kernels
+    std::vector<DevMop> h_mops;
+    DevStage* d_stages = nullptr;
+    DevOp* d_ops = nullptr;
+    DevSub* d_subs = nullptr;
+    DevMop* d_mops = nullptr;
+    int k = 0, ntiles = 0, reg_bits = 0;
+    bool v2 = false;              // run the register-blocked kernels
+    // matrix-core kernels (family 3)
+    bool v3 = false;
+    std::vector<DevSub3> h_subs3;
+    std::vector<DevGrp> h_grps;
+    DevSub3* d_subs3 = nullptr;
+    DevGrp* d_grps = nullptr;
+    double* d_umat = nullptr;     // [batch][nsubs][12][64]
+    double2* d_rpart = nullptr;   // sweep plan only: [batch][nsubs][ntiles][256]
+    bool u_valid = false;         // d_umat matches the coefficients in use
+    int family() const { return v3 ? 3 : (v2 ? 2 : 1); }
+};
+
+// aqc_ws_plan.cpp
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma = false, bool presplit = false);
+int upload_plan(DevPlan& p);
+Plan mirror_plan(const Plan& plan);   // the same stages and sub-stages walked backwards: the plan of V^H whose intermediate states are the sweep's
+
+}  // namespace aqc
+
+// the two handle types of the C ABI live in the global namespace (include/aqc_hip.h)
+using aqc::DevPlan; using aqc::Program; using aqc::UJob;
+
+struct aqc_ctx {
+    Program prog;
+    std::mutex mu;
+    // lowered plans (host side: stages, sub-stages, micro-ops) by (which, col_bits, tile bits, low bits, family): workspaces
+    // of the same shape -- one per batch of jobs in the drivers -- share the planning work (the sub-stage search of a
+    // deep Trotter ansatz takes a few tenths of a second)
+    std::map<std::vector<int>, DevPlan> plan_cache;
+    std::map<int, aqc_ws*> oneshot;  // ncols -> batch-1 workspace used by the host-pointer entry points
+};
+
+struct aqc_ws {
+    aqc_ctx* ctx = nullptr;
+    int device = 0, batch = 1, ncols = 1, pitch = 1, col_bits = 0, nbits = 0, threads = 256;
+    size_t lane_elems = 0;  // 2^nbits
+    hipStream_t stream = nullptr;
+    DevPlan fwd, inv, sweep;
+    double* d_thetas = nullptr;       // parameters in use (own buffer or a slice of the bank)
+    double* d_thetas_own = nullptr;
+    double* d_theta_bank = nullptr;
+    int bank_sets = 0, gather_count = 0;
+    double* d_coef = nullptr;
+    double2* bufs[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* h_pin = nullptr;           // pinned staging: thetas | grads | gathered
+    size_t pin_thetas = 0, pin_grads = 0, pin_small = 0;
+    double2* d_partial = nullptr;
+    double2* d_grads = nullptr;
+    double* mirror_grads = nullptr;    // set by aqc_ws_eval around its launches: pinned host copies written by the kernels
+    double* mirror_small = nullptr;
+    double2* d_small = nullptr;  // gather / vdot results
+    double2* d_vdot_part = nullptr;
+    double2* d_vdot_out = nullptr;
+    long long* d_index = nullptr;
+    long long* d_tmp_index = nullptr;   // one-shot gather / vdot: never disturb the persistent gather set-up
+    double2* d_tmp_small = nullptr;
+    size_t tmp_index_cap = 0, tmp_small_cap = 0;
+    long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
+    long long* d_combo_prev[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // set_combo: positions written last time
+    bool combo_valid[AQC_NUM_BUFS] = {false, false, false, false, false, false};   // buffer holds exactly that sparse pattern
+    // aqc_ws_surrogate_eval: device block [f B | fidelity B | weight B | hs 2 B S | max_no B ints], its pinned mirror
+    void* d_sur = nullptr;
+    void* h_sur = nullptr;
+    int sur_states = 0;
+    double* d_sur_real = nullptr;     // real parts of the gradient when only those are asked for
+    size_t sur_real_cap = 0;
+    long long* d_combo_index = nullptr;   // [batch][2] staging of set_combo
+    double2* d_combo_coef = nullptr;      // [batch][2]
+    size_t small_cap = 0, index_cap = 0;
+    int* d_theta_slots = nullptr;
+    int* d_slot_theta = nullptr;       // slot -> theta when every theta has exactly one slot (grads_direct), see rgrad_kernel
+    bool grads_direct = false;
+    int* d_slot_ntiles = nullptr;
+    int nslots = 0, vdot_parts = 0;
+    bool coef_valid = false;
+    bool need_coef = false;           // something besides the stage kernels reads d_coef (coordinate descent)
+    // aqc_ws_eval as a HIP graph: the whole chain (thetas H2D, U builder, V^H stages, gather, sweep stages, gradient walk,
+    // D2H copies) captured once per call signature and replayed -- one launch instead of ~11 host calls per evaluation
+    std::map<std::vector<long long>, hipGraphExec_t> graphs;
+    bool capturing = false;
+    UJob* d_ujobs = nullptr;          // family 3: [V^H subs | sweep subs | V subs]
+    struct MpsSlot {
+        std::vector<int> dims;          // n + 1 bond dimensions
+        std::vector<size_t> offset;     // element offset of site q inside d_t
+        double2* d_t = nullptr;         // [q][2][dims[q]][dims[q+1]], lambda folded in
+        size_t cap = 0;                 // capacity of d_t (grow-only: re-uploads of the same shape allocate nothing)
+    } mps[AQC_MPS_SLOTS];
+    double* d_mps_lam = nullptr;        // staging of the packed Schmidt vectors (grow-only)
+    size_t mps_lam_cap = 0;
+    double2* d_mps_scratch = nullptr;
+    size_t mps_scratch_cap = 0;
+    // device pointer tables of the batched MPS -> dense contraction: a few resident sets, found again by their contents (an
+    // optimisation converts the same operands into the same lanes evaluation after evaluation: no upload, no synchronisation)
+    struct MpsTabs { std::vector<const void*> host; const void** dev = nullptr; size_t cap = 0; unsigned long long tick = 0; };
+    // coordinate descent as one persistent launch: the walk's step list, thetas [batch][T] and objective values on the device
+    void* d_cd_prog = nullptr;
+    int cd_nsteps = 0;
+    double* d_cd_thetas = nullptr;
+    double* d_cd_fobj = nullptr;
+    size_t cd_fobj_cap = 0;
+    MpsTabs mps_tabs[32];   // resident pointer-table sets (one per distinct chain: operands x lanes x bond dimensions)
+    unsigned long long mps_tabs_tick = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    hipStream_t copy_stream = nullptr;        // aqc_ws_results_async: result copies run beside the next evaluation's kernels
+    hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+    hipStream_t mps_stream = nullptr;         // batched MPS -> dense: the right half's chain runs beside the left half's
+    hipEvent_t ev_mps_fork = nullptr, ev_mps_join = nullptr;
+    bool copy_pending = false;                // the producers of the next evaluation wait for ev_copied before they overwrite the results
+    const double* theta_host = nullptr;      // aqc_ws_eval: pinned thetas the next U build reads directly (and copies to d_thetas)
+    bool gather_rides = false;               // aqc_ws_eval: the next gradient walk also performs the registered gather (see there)
+    bool profile = false;
+    int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
+    double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
+};
+
+namespace aqc {
+
+struct ProfScope {  // brackets one launch with events when profiling is on
+    aqc_ws* ws;
+    int kind;
+    ProfScope(aqc_ws* w, int k) : ws(w), kind(k) {
+        if (ws->profile) (void)hipEventRecord(ws->pev0, ws->stream);
+    }
+    ~ProfScope() {
+        if (!ws->profile) return;
+        float ms = 0.f;
+        if (hipEventRecord(ws->pev1, ws->stream) == hipSuccess && hipEventSynchronize(ws->pev1) == hipSuccess &&
+            hipEventElapsedTime(&ms, ws->pev0, ws->pev1) == hipSuccess) {
+            ws->prof_count[kind] += 1;
+            ws->prof_ms[kind] += ms;
+        }
+    }
+};
+
+// aqc_api.cpp
+int check_buf(const aqc_ws* ws, int buf);
+int ensure_small(aqc_ws* ws, size_t n_cplx);
+int ensure_tmp(aqc_ws* ws, size_t n_index, size_t n_cplx);
+int ensure_index(aqc_ws* ws, size_t n);
+int ensure_coef(aqc_ws* ws);
+int copy_in(aqc_ws* ws, double2* dst, const double* src, size_t rows);
+int copy_out(aqc_ws* ws, double* dst, const double2* src, size_t rows);
+int results_guard(aqc_ws* ws);
+// aqc_ws_sweep.cpp
+int ensure_umat(aqc_ws* ws, DevPlan& p);
+int run_coef(aqc_ws* ws);
+int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);
+void drop_graphs(aqc_ws* ws);
+
+}  // namespace aqc

@@ -1,0 +1,360 @@
+// C ABI (include/aqc_hip.h): V / V^H launches, the w/z sweep and the one-call evaluation.
+#include "aqc_ws.h"
+
+using namespace aqc;
+
+namespace aqc {
+
+// family 3: the 16 x 16 unitaries of the plan's sub-stages for the coefficients in use
+// Jobs are laid out [V^H | sweep | V]: the objective+gradient path (V^H then the sweep) is built by one launch.
+int ensure_umat(aqc_ws* ws, DevPlan& p) {
+    if (!p.v3 || p.u_valid) return 0;
+    const int T = ws->ctx->prog.num_thetas();
+    const int ninv = ws->inv.v3 ? (int)ws->inv.h_subs3.size() : 0, nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
+    const int nfwd = ws->fwd.v3 ? (int)ws->fwd.h_subs3.size() : 0;
+    ProfScope ps(ws, AQC_K_COEF);
+    if (&p == &ws->fwd) {
+        HIP_OK(launch_ubuild(ws->d_ujobs + ninv + nsw, nfwd, ws->d_thetas, T, ws->batch, ws->stream));
+        p.u_valid = true;
+    } else {
+        // aqc_ws_eval (small batches): the thetas are read from its pinned staging buffer and land in HBM through this kernel
+        HIP_OK(launch_ubuild(ws->d_ujobs, ninv + nsw, ws->theta_host ? ws->theta_host : ws->d_thetas, T, ws->batch, ws->stream,
+                             ws->theta_host ? ws->d_thetas : nullptr));
+        ws->theta_host = nullptr;
+        ws->inv.u_valid = ws->sweep.u_valid = true;
+    }
+    return 0;
+}
+
+int run_coef(aqc_ws* ws) {
+    const Program& prog = ws->ctx->prog;
+    ws->fwd.u_valid = ws->inv.u_valid = ws->sweep.u_valid = false;
+    ws->coef_valid = true;
+    if (ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef) return 0;   // the matrix-core path reads the thetas directly
+    ProfScope ps(ws, AQC_K_COEF);
+    HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
+    return 0;
+}
+
+int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
+    DevPlan& p = inverse ? ws->inv : ws->fwd;
+    const Program& prog = ws->ctx->prog;
+    if (p.v3) {
+        if (ensure_umat(ws, p)) return 1;
+        for (size_t s = 0; s < p.h_stages.size(); ++s) {
+            Stage3Args a;
+            memset(&a, 0, sizeof a);
+            a.stage = p.h_stages[s];
+            a.subs = p.d_subs3;
+            a.umat = p.d_umat;
+            a.nsubs_total = (int)p.h_subs3.size();
+            a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
+            a.out0 = ws->bufs[dst_buf];
+            a.lane_stride = ws->lane_elems;
+            a.ntiles = p.ntiles;
+            a.batch = ws->batch;
+#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the V / V^H workgroups of this launch, on stderr
+            static unsigned long long* d_stamps_a = nullptr;
+            const size_t nwg = (size_t)p.ntiles * ws->batch;
+            if (env_int("AQC_STAMPS", 0) != 0 && nwg <= 65536) {
+                if (!d_stamps_a) HIP_OK(hipMalloc((void**)&d_stamps_a, sizeof(unsigned long long) * 65536 * kStampSlots));
+                HIP_OK(hipMemsetAsync(d_stamps_a, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream));
+                a.stamps = d_stamps_a;
+            }
+#endif
+            {
+                ProfScope ps(ws, AQC_K_APPLY);
+                HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+            }
+#ifdef AQC_TUNING
+            if (a.stamps) {
+                std::vector<unsigned long long> h(nwg * kStampSlots);
+                HIP_OK(hipStreamSynchronize(ws->stream));
+                HIP_OK(hipMemcpy(h.data(), d_stamps_a, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                double load = 0, loop = 0, store = 0, bar = 0;
+                const int ns = p.h_stages[s].nsubs;
+                for (size_t w = 0; w < nwg; ++w) {
+                    const unsigned long long* t = h.data() + w * kStampSlots;
+                    load += (double)(t[1] - t[0]); loop += (double)(t[2] - t[1]); store += (double)(t[3] - t[2]);
+                    for (int i = 0; i < ns && 5 + i < kStampSlots; ++i) bar += (double)(t[5 + i] - t[4 + i]);
+                }
+                fprintf(stderr, "aqc_hip stamps: V/V^H stage %zu (%d sub-stages, %zu workgroups): load %.0f + sub-stage loop %.0f (%.0f per sub-stage, of which "
+                        "waiting at its barrier %.0f) + store %.0f cycles per workgroup\n", s, ns, nwg, load / nwg, loop / nwg, loop / nwg / std::max(ns, 1),
+                        bar / nwg / std::max(ns, 1), store / nwg);
+            }
+#endif
+        }
+        return 0;
+    }
+    for (size_t s = 0; s < p.h_stages.size(); ++s) {
+        StageArgs a;
+        memset(&a, 0, sizeof a);
+        a.stage = p.d_stages + s;
+        a.ops = p.d_ops;
+        a.subs = p.d_subs;
+        a.mops = p.d_mops;
+        a.coef = ws->d_coef;
+        a.ncoef = prog.n + prog.num_blocks + 1;
+        a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
+        a.out0 = ws->bufs[dst_buf];
+        a.lane_stride = ws->lane_elems;
+        a.final_stage = (s + 1 == p.h_stages.size()) ? 1 : 0;
+        ProfScope ps(ws, AQC_K_APPLY);
+        if (p.v2) HIP_OK(launch_apply2(prog.entangler, p.ntiles, ws->batch, p.k, ws->stream, a));
+        else HIP_OK(launch_apply(prog.entangler, inverse, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
+    }
+    return 0;
+}
+
+void drop_graphs(aqc_ws* ws) {
+    for (auto& kv : ws->graphs) (void)hipGraphExecDestroy(kv.second);
+    ws->graphs.clear();
+}
+
+}  // namespace aqc
+
+extern "C" {
+
+int aqc_ws_apply(aqc_ws* ws, int inverse, int src_buf, int dst_buf) {
+    if (check_buf(ws, src_buf) || check_buf(ws, dst_buf)) return 1;
+    ws->combo_valid[dst_buf] = false;
+    if (ensure_coef(ws)) return 1;
+    HIP_OK(hipSetDevice(ws->device));
+    return run_apply(ws, inverse != 0, src_buf, dst_buf);
+}
+
+int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
+    return aqc_ws_grad_from(ws, AQC_BUF_X, block_from, block_to, front_layer);
+}
+
+
+int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer) {
+    if (check_buf(ws, x_buf)) return 1;
+    if (results_guard(ws)) return 1;
+    if (x_buf == AQC_BUF_W || x_buf == AQC_BUF_ZW || x_buf == AQC_BUF_Z) return fail("lhs buffer must not be Z, W or ZW");
+    if (ensure_coef(ws)) return 1;
+    const Program& prog = ws->ctx->prog;
+    if (block_from < 0) { block_from = 0; block_to = prog.num_blocks; }
+    if (prog.num_blocks > 0 && !(0 <= block_from && block_from < block_to && block_to <= prog.num_blocks))
+        return fail("invalid block_range [%d, %d)", block_from, block_to);
+    HIP_OK(hipSetDevice(ws->device));
+    DevPlan& p = ws->sweep;
+    if (p.v3) {
+        if (ensure_umat(ws, p)) return 1;
+        const int nsubs = (int)p.h_subs3.size();
+        for (size_t s = 0; s < p.h_stages.size(); ++s) {
+            Stage3Args a;
+            memset(&a, 0, sizeof a);
+            a.stage = p.h_stages[s];
+            a.subs = p.d_subs3;
+            a.umat = p.d_umat;
+            a.nsubs_total = nsubs;
+            a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
+            a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
+            a.out0 = ws->bufs[AQC_BUF_W];
+            a.out1 = ws->bufs[AQC_BUF_ZW];
+            a.lane_stride = ws->lane_elems;
+            a.rpart = p.d_rpart;
+            a.ntiles = p.ntiles;
+            a.batch = ws->batch;
+            a.chunk = sweep3_chunk(p.ntiles, ws->batch, p.k);
+            a.nparts = sweep3_nparts(p.ntiles, ws->batch, p.k);
+            a.store_out = s + 1 < p.h_stages.size() ? 1 : 0;
+            if (a.stage.nsubs > 0) stage3_first_offsets(a, p.h_subs3[a.stage.sub_begin]);
+#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the sweep workgroups of this launch, on stderr
+            static unsigned long long* d_stamps = nullptr;
+            const size_t nwg = (size_t)p.ntiles * ws->batch;
+            const bool stamps = env_int("AQC_STAMPS", 0) != 0;
+            a.debug = env_int("AQC_DEBUG_SKIP", 0);
+            if (stamps) {
+                if (!d_stamps) HIP_OK(hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 65536 * kStampSlots));
+                if (nwg <= 65536) { HIP_OK(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream)); a.stamps = d_stamps; }
+            }
+#endif
+            {
+                ProfScope ps(ws, AQC_K_SWEEP);
+                HIP_OK(launch_sweep3(p.ntiles, ws->batch, p.k, ws->stream, a));
+            }
+#ifdef AQC_TUNING
+            if (a.stamps) {
+                std::vector<unsigned long long> h(nwg * kStampSlots);
+                HIP_OK(hipStreamSynchronize(ws->stream));
+                HIP_OK(hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                const int ns = p.h_stages[s].nsubs;
+                // the 2^12 sweep is persistent: a workgroup's per-sub-stage stamps are those of its LAST item, slot S-4 its end,
+                // slots S-6 / S-5 bracket its last hand-over to a prefetched tile
+                double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0, turn = 0;
+                size_t live = 0;
+                unsigned long long first_start = ~0ull, last_start = 0, first_end = ~0ull, last_end = 0, wg_min = ~0ull, wg_max = 0;
+                for (size_t w = 0; w < nwg; ++w) {
+                    const unsigned long long* t = h.data() + w * kStampSlots;
+                    if (t[kStampSlots - 4] == 0) continue;   // no workgroup with this index (persistent grid)
+                    ++live;
+                    first_start = std::min(first_start, t[0]); last_start = std::max(last_start, t[0]);
+                    first_end = std::min(first_end, t[kStampSlots - 4]); last_end = std::max(last_end, t[kStampSlots - 4]);
+                    wg_min = std::min(wg_min, t[kStampSlots - 4] - t[0]); wg_max = std::max(wg_max, t[kStampSlots - 4] - t[0]);
+                    load += (double)(t[1] - t[0]);
+                    store += (double)(t[kStampSlots - 1] - t[kStampSlots - 2]);
+                    total += (double)(t[kStampSlots - 4] - t[0]);
+                    if (t[kStampSlots - 5]) turn += (double)(t[kStampSlots - 5] - t[kStampSlots - 6]);
+                    for (int i = 0; i < ns && 5 + 4 * i < kStampSlots - 6; ++i) {
+                        if (i) top += (double)(t[2 + 4 * i] - t[5 + 4 * (i - 1)]);
+                        mf += (double)(t[3 + 4 * i] - t[2 + 4 * i]);
+                        bar += (double)(t[4 + 4 * i] - t[3 + 4 * i]);
+                        red += (double)(t[5 + 4 * i] - t[4 + 4 * i]);
+                    }
+                }
+                const double n = (double)std::max<size_t>(live, 1), items = (double)nwg / n;
+                fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups x %.1f items): total %.0f cycles per item = first load %.0f/items + "
+                        "per sub-stage [top %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f + hand-over %.0f\n", s, ns, live, items,
+                        total / n / items, load / n, top / n / std::max(ns - 1, 1), mf / n / ns, bar / n / ns, red / n / ns, store / n, turn / n);
+                fprintf(stderr, "aqc_hip stamps: stage %zu workgroup lifetimes (s_memtime ticks): min %llu max %llu; starts spread over %llu, ends over %llu; "
+                        "first start -> last end %llu\n", s, wg_min, wg_max, last_start - first_start, last_end - first_end, last_end - first_start);
+            }
+#endif
+        }
+        ProfScope ps(ws, AQC_K_FINALIZE);
+        HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
+                            ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream,
+                            ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads, ws->mirror_grads,
+                            ws->gather_rides ? GatherJob{ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->d_small, ws->mirror_small}
+                                             : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},
+                            sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k)));
+#ifdef AQC_TUNING
+        if (env_int("AQC_STAMPS", 0) != 0) { HIP_OK(hipStreamSynchronize(ws->stream)); rgrad_print_stamps(nsubs); }
+#endif
+        if (!ws->grads_direct)   // some theta collects two slots (2nd-order Trotter half-layers, core_operations.py:966-968)
+            HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
+                                   1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
+        return 0;
+    }
+    for (size_t s = 0; s < p.h_stages.size(); ++s) {
+        StageArgs a;
+        memset(&a, 0, sizeof a);
+        a.stage = p.d_stages + s;
+        a.ops = p.d_ops;
+        a.subs = p.d_subs;
+        a.mops = p.d_mops;
+        a.coef = ws->d_coef;
+        a.ncoef = prog.n + prog.num_blocks + 1;
+        a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
+        a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
+        a.out0 = ws->bufs[AQC_BUF_W];
+        a.out1 = ws->bufs[AQC_BUF_ZW];
+        a.lane_stride = ws->lane_elems;
+        a.partial = ws->d_partial;
+        a.nslots = ws->nslots;
+        a.ntiles_max = p.ntiles;
+#ifdef AQC_TUNING   // timing experiments only (tools/tune.py); never part of the shipped library
+        a.debug = env_int("AQC_DEBUG_SKIP", 0);
+#endif
+        a.from = block_from;
+        a.to = block_to;
+        a.front = front_layer ? 1 : 0;
+        ProfScope ps(ws, AQC_K_SWEEP);
+        if (p.v2) HIP_OK(launch_sweep2(prog.entangler, p.ntiles, ws->batch, p.k, p.reg_bits, ws->stream, a));
+        else HIP_OK(launch_sweep(prog.entangler, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
+    }
+    ProfScope ps(ws, AQC_K_FINALIZE);
+    HIP_OK(launch_finalize(ws->d_partial, ws->d_theta_slots, ws->d_slot_ntiles, ws->d_grads, prog.num_thetas(), ws->nslots,
+                           p.ntiles, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
+    return 0;
+}
+
+int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered, int x_buf, int block_from, int block_to,
+                int front_layer, double* grads) {
+    if (!ws) return fail("null workspace");
+    HIP_OK(hipSetDevice(ws->device));
+    if (ws->copy_pending) {   // result copies of an earlier aqc_ws_results_async: this call reuses the pinned buffer and may replay a graph
+        HIP_OK(hipStreamSynchronize(ws->copy_stream));
+        ws->copy_pending = false;
+    }
+    const Program& prog = ws->ctx->prog;
+    const size_t nth = (size_t)ws->batch * prog.num_thetas();
+    double* pin_th = ws->h_pin;
+    double* pin_gr = ws->h_pin + ws->pin_thetas;
+    double* pin_sm = pin_gr + ws->pin_grads;
+    size_t nsm = 0;
+    if (gathered) {
+        if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
+        nsm = (size_t)ws->batch * ws->gather_count;
+        if (2 * nsm > ws->pin_small) return fail("too many gathered amplitudes for the staging buffer");
+    }
+    if (!thetas && (do_vdag || grads) && ensure_coef(ws)) return 1;
+    if (check_buf(ws, x_buf)) return 1;
+    // Small results skip the device-to-host copy nodes: the producing kernels write a second copy straight into the pinned
+    // staging buffer (two nodes and their dependencies less on the single-evaluation critical path).
+    const bool zero_copy = sizeof(double2) * (nth + nsm) <= 65536;
+    struct MirrorScope {
+        aqc_ws* w;
+        MirrorScope(aqc_ws* w_, double* g, double* s) : w(w_) { w->mirror_grads = g; w->mirror_small = s; }
+        ~MirrorScope() {   // also on the error paths of enqueue(): no stale pinned thetas / riding gather in the next call
+            w->mirror_grads = nullptr; w->mirror_small = nullptr; w->theta_host = nullptr; w->gather_rides = false;
+        }
+    } mirror_scope(ws, zero_copy ? pin_gr : nullptr, zero_copy ? pin_sm : nullptr);
+    auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
+        if (thetas) {
+            ws->d_thetas = ws->d_thetas_own;
+            // matrix-core path, small batch: no copy node -- the U builder (first kernel of V^H or of the sweep) reads the pinned
+            // thetas over the bus and stores them to HBM for the gradient walk
+            const bool direct_thetas = zero_copy && (do_vdag || grads) && ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef &&
+                                       (do_vdag ? ws->inv.v3 : true);
+            if (!direct_thetas) HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, ws->stream));
+            if (run_coef(ws)) return 1;
+            ws->theta_host = direct_thetas ? pin_th : nullptr;
+        }
+        if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        // with a gradient in the same call the gather (it only reads Z, which the sweep leaves intact) rides along as one
+        // extra workgroup per lane of the gradient-walk kernel: one node less on the single-evaluation critical path
+        const bool ride = gathered && grads && zero_copy && ws->sweep.v3;
+        if (gathered && !ride) {
+            if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+            if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
+        }
+        ws->gather_rides = ride;
+        if (grads) {
+            if (aqc_ws_grad_from(ws, x_buf, block_from, block_to, front_layer)) return 1;
+            if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_gr, ws->d_grads, sizeof(double2) * nth, hipMemcpyDeviceToHost, ws->stream));
+        }
+        ws->gather_rides = false;
+        ws->theta_host = nullptr;
+        return 0;
+    };
+    if (thetas) memcpy(pin_th, thetas, sizeof(double) * nth);
+    static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
+    if (thetas && graphs_on && !ws->profile) {
+        const std::vector<long long> key = {do_vdag, gathered ? 1 : 0, grads ? 1 : 0, x_buf, block_from, block_to, front_layer,
+                                            (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin};
+        auto it = ws->graphs.find(key);
+        if (it == ws->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            HIP_OK(hipStreamSynchronize(ws->stream));
+            HIP_OK(hipStreamBeginCapture(ws->stream, hipStreamCaptureModeThreadLocal));
+            ws->capturing = true;
+            const int rc = enqueue();
+            ws->capturing = false;
+            const hipError_t e = hipStreamEndCapture(ws->stream, &graph);
+            if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+            if (e != hipSuccess || !graph) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+            if (ws->graphs.size() >= 16) drop_graphs(ws);
+            it = ws->graphs.emplace(key, exec).first;
+        }
+        ws->d_thetas = ws->d_thetas_own;   // host-side state that enqueue() would have set
+        ws->coef_valid = true;
+        ws->fwd.u_valid = false;
+        ws->inv.u_valid = ws->sweep.u_valid = (do_vdag || grads) && ws->inv.v3 && ws->sweep.v3;
+        HIP_OK(hipGraphLaunch(it->second, ws->stream));
+    } else if (enqueue()) {
+        return 1;
+    }
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    if (gathered) memcpy(gathered, pin_sm, sizeof(double2) * nsm);
+    if (grads) memcpy(grads, pin_gr, sizeof(double2) * nth);
+    return 0;
+}
+
+}  // extern "C"

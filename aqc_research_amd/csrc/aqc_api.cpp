@@ -286,8 +286,25 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         out = it->second;   // host vectors copied; device pointers are null in the cache
     };
     cached_plan(2, ka, false, (want_v2 || want_v3) ? 4 : 0, false, ws->fwd);
-    cached_plan(0, ka, true, (want_v2 || want_v3) ? 4 : 0, false, ws->inv);
     cached_plan(1, ks, false, want_v3 ? 4 : (want_v2 ? (env_int("AQC_SWEEP_REG_BITS", 4) == 3 ? 3 : 4) : 0), true, ws->sweep);
+    // V^H: on the matrix-core path with equal tile sizes, the SWEEP's plan walked backwards (same stages, same sub-stages, same
+    // cost), so that the states between its stages are the states z takes between the sweep's stages -- see aqc_ws_sweep.cpp
+    ws->inv_mirrored = want_v3 && ka == ks && ws->sweep.v3 && ws->sweep.plan.stages.size() >= 2 && env_int("AQC_MIRROR_PLAN", 1) != 0;
+    if (ws->inv_mirrored) {
+        const std::vector<int> key = {3, ws->col_bits, ks, low_bits, 4, 0, 1};
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto it = ctx->plan_cache.find(key);
+        if (it == ctx->plan_cache.end()) {
+            DevPlan fresh;
+            lower_plan(prog, mirror_plan(ws->sweep.plan), fresh, 4, false, true, true);
+            it = ctx->plan_cache.emplace(key, std::move(fresh)).first;
+        }
+        ws->inv = it->second;
+    } else {
+        cached_plan(0, ka, true, (want_v2 || want_v3) ? 4 : 0, false, ws->inv);
+    }
+    ws->sparse_enabled = env_int("AQC_SPARSE_SWEEP", 1) != 0;
+    ws->sparse_min_items = env_int("AQC_SPARSE_MIN_ITEMS", 512);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -393,6 +410,9 @@ int aqc_ws_destroy(aqc_ws* ws) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->d_combo_prev[b]) (void)hipFree(ws->d_combo_prev[b]);
+    for (void* q : {(void*)ws->d_sw_items, (void*)ws->d_sw_clear, (void*)ws->d_sw_counts, (void*)ws->d_sw_lane_parts, (void*)ws->d_sw_prev_tiles,
+                    (void*)ws->w2, (void*)ws->zw2})
+        if (q) (void)hipFree(q);
     if (ws->d_sur) (void)hipFree(ws->d_sur);
     if (ws->d_sur_real) (void)hipFree(ws->d_sur_real);
     if (ws->h_sur) (void)hipHostFree(ws->h_sur);
@@ -429,6 +449,7 @@ int aqc_ws_set_thetas(aqc_ws* ws, const double* thetas) {
 int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
     if (check_buf(ws, buf)) return 1;
     ws->combo_valid[buf] = false;
+    touch_buf(ws, buf);
     if (!src) return fail("null source");
     HIP_OK(hipSetDevice(ws->device));
     return copy_in(ws, ws->bufs[buf], src, (size_t)ws->batch << ws->ctx->prog.n);
@@ -437,6 +458,7 @@ int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
 int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src) {
     if (check_buf(ws, buf)) return 1;
     ws->combo_valid[buf] = false;
+    touch_buf(ws, buf);
     if (!src) return fail("null source");
     if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
     HIP_OK(hipSetDevice(ws->device));
@@ -446,6 +468,7 @@ int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src) {
 int aqc_ws_broadcast(aqc_ws* ws, int buf, const double* src) {
     if (check_buf(ws, buf)) return 1;
     ws->combo_valid[buf] = false;
+    touch_buf(ws, buf);
     if (!src) return fail("null source");
     HIP_OK(hipSetDevice(ws->device));
     if (copy_in(ws, ws->bufs[buf], src, (size_t)1 << ws->ctx->prog.n)) return 1;
@@ -464,6 +487,7 @@ int aqc_ws_copy_lane(aqc_ws* dst_ws, int dst_buf, int dst_lane, aqc_ws* src_ws, 
     if (dst_lane < 0 || dst_lane >= dst_ws->batch || src_lane < 0 || src_lane >= src_ws->batch) return fail("lane out of range");
     HIP_OK(hipSetDevice(dst_ws->device));
     dst_ws->combo_valid[dst_buf] = false;
+    touch_buf(dst_ws, dst_buf);
     if (src_ws->stream != dst_ws->stream) HIP_OK(hipStreamSynchronize(src_ws->stream));   // the source is complete
     HIP_OK(hipMemcpyAsync(dst_ws->bufs[dst_buf] + (size_t)dst_lane * dst_ws->lane_elems, src_ws->bufs[src_buf] + (size_t)src_lane * src_ws->lane_elems,
                           sizeof(double2) * dst_ws->lane_elems, hipMemcpyDeviceToDevice, dst_ws->stream));
@@ -488,6 +512,7 @@ int aqc_ws_download_lane(aqc_ws* ws, int buf, int lane, double* dst) {
 int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
     if (check_buf(ws, buf)) return 1;
     ws->combo_valid[buf] = false;
+    touch_buf(ws, buf);
     if (!index) return fail("null index");
     HIP_OK(hipSetDevice(ws->device));
     const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
@@ -500,14 +525,26 @@ int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
     HIP_OK(hipMemcpyAsync(ws->d_basis_index, elem.data(), sizeof(long long) * ws->batch, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     HIP_OK(hipMemsetAsync(ws->bufs[buf], 0, sizeof(double2) * (size_t)ws->batch * ws->lane_elems, ws->stream));
-    ProfScope ps(ws, AQC_K_MISC);
-    HIP_OK(launch_scatter_one(ws->bufs[buf], ws->lane_elems, ws->batch, ws->d_basis_index, ws->stream));
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_scatter_one(ws->bufs[buf], ws->lane_elems, ws->batch, ws->d_basis_index, ws->stream));
+    }
+    // the buffer now holds exactly this sparse pattern: the same record aqc_ws_set_combo keeps (positions written, second one
+    // absent), so that a later set_combo clears one element per lane instead of the buffer and the sweep knows the support
+    std::vector<long long> supp(2 * (size_t)ws->batch, -1);
+    for (int b = 0; b < ws->batch; ++b) supp[2 * (size_t)b] = elem[b];
+    if (!ws->d_combo_prev[buf]) HIP_OK(hipMalloc((void**)&ws->d_combo_prev[buf], sizeof(long long) * 2 * ws->batch));
+    HIP_OK(hipMemcpyAsync(ws->d_combo_prev[buf], supp.data(), sizeof(long long) * supp.size(), hipMemcpyHostToDevice, ws->stream));
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    ws->combo_valid[buf] = true;
+    ++ws->supp_version[buf];
     return 0;
 }
 
 int aqc_ws_set_identity(aqc_ws* ws, int buf) {
     if (check_buf(ws, buf)) return 1;
     ws->combo_valid[buf] = false;
+    touch_buf(ws, buf);
     const int dim = 1 << ws->ctx->prog.n;
     if (ws->ncols != dim) return fail("identity needs a square workspace (ncols == 2^n)");
     HIP_OK(hipSetDevice(ws->device));
@@ -550,6 +587,8 @@ int aqc_ws_set_combo(aqc_ws* ws, int buf, const int64_t* index, const double* co
     ProfScope ps(ws, AQC_K_MISC);
     HIP_OK(launch_scatter_two(ws->bufs[buf], ws->lane_elems, B, ws->d_combo_index, ws->d_combo_coef, ws->d_combo_prev[buf], ws->stream));
     ws->combo_valid[buf] = true;
+    ++ws->supp_version[buf];
+    touch_buf(ws, buf);
     return 0;
 }
 

@@ -228,7 +228,21 @@ __device__ __forceinline__ size_t tile_base3(const DevStage& st, unsigned tile) 
 // In-kernel stamps of the one-tile-per-workgroup form showed the sub-stage loop at the matrix pipe's rate, and a fifth to
 // a third of a workgroup's life in the tile load before and the store after it (every workgroup of a wave of tiles loads at
 // the same moment: an HBM burst with idle matrix cores).
-template <int K>
+// LIST: the work items come from a device table (Stage3Args::items / nitems: a subset of the (tile, lane) pairs, see the
+// sparse-lhs sweep in aqc_ws_sweep.cpp) instead of being all of them; the grid is sized for the largest possible list and
+// workgroups beyond its length leave at once.
+__device__ __forceinline__ int uniform_load(const int* p) { return __builtin_amdgcn_readfirstlane(*p); }
+struct ItemAt { int bl, tile, slot; };
+template <bool LIST>
+__device__ __forceinline__ ItemAt item_at(const Stage3Args& a, int wi) {
+    if (LIST) {
+        const TileItem* it = a.items + wi;
+        return ItemAt{uniform_load(&it->lane), uniform_load(&it->tile), uniform_load(&it->slot)};
+    }
+    const int bl = wi / a.ntiles;
+    return ItemAt{bl, wi - bl * a.ntiles, 0};
+}
+template <int K, bool LIST = false>
 __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kernel(const Stage3Args a) {
     using TS = TileShape<K>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,34 +254,37 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int NL = TS::kLoads, NW = TS::kWaves;
     constexpr bool kPersist = K >= 12;      // grid < items only there (launch_apply3)
-    const int nwork = a.ntiles * a.batch;   // items = (tile, lane of the batch), item wi on workgroup wi mod gridDim.x
+    const int nwork = LIST ? uniform_load(a.nitems) : a.ntiles * a.batch;   // items = (tile, lane of the batch), item wi on workgroup wi mod gridDim.x
     const unsigned lo = st.dlo[lane];
     const unsigned lo16 = lo << 4;
     SubRegs cur, nxt;
     SubAddr<TS::kGpw> ad;   // clustered software pipeline, see sweep_mfma_kernel
     dbl2_t pw[NL];          // the prefetched tile: accumulation registers, inline-assembly loads (see sweep_mfma_kernel)
-    int wi = blockIdx.x + (kPersist ? 0 : (int)blockIdx.y * a.ntiles);
+    int wi = blockIdx.x + ((kPersist || LIST) ? 0 : (int)blockIdx.y * a.ntiles);
+    if (LIST && wi >= nwork) return;   // (a whole workgroup, before any barrier)
+    ItemAt it = item_at<LIST>(a, wi);
     {
-        const int bl = wi / a.ntiles;
+        const int bl = it.bl;
         if (st.nsubs > 0) {
             fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)bl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
             fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, NW);
         }
         AQC_STAMP(0);
-        if (!(kApplySkip & 64)) load_tiles3<K, 1>(tw, nullptr, a.in0 + (size_t)bl * a.lane_stride + tile_base3(st, wi - bl * a.ntiles), nullptr, st, lo, wave);
+        if (!(kApplySkip & 64)) load_tiles3<K, 1>(tw, nullptr, a.in0 + (size_t)bl * a.lane_stride + tile_base3(st, it.tile), nullptr, st, lo, wave);
     }
     // Every load so far has landed before the loop: otherwise the compiler's wait-count analysis, merging the loop
     // entry with the back edge, makes the first use of `cur` inside the loop wait for the prefetch of `nxt` as well.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     AQC_STAMP(1);
     for (;;) {
-    const int bl = wi / a.ntiles;
-    const size_t lane_off = (size_t)bl * a.lane_stride + tile_base3(st, wi - bl * a.ntiles);
+    const int bl = it.bl;
+    const size_t lane_off = (size_t)bl * a.lane_stride + tile_base3(st, it.tile);
     const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
     const int nwi = wi + (int)gridDim.x;
     const bool more = kPersist && st.nsubs > 0 && nwi < nwork;
-    const int nbl = more ? nwi / a.ntiles : 0;
-    const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
+    const ItemAt nit = more ? item_at<LIST>(a, nwi) : ItemAt{0, 0, 0};
+    const int nbl = nit.bl;
+    const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nit.tile) : 0;
     for (int si = 0; si < st.nsubs; ++si) {
         AQC_STAMP(4 + si);
         if (!(kApplySkip & 512)) __syncthreads();
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(TileShape<K>::kWaves * 64, 2) void apply_mfma_kerne
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes above are not tracked by the compiler
     wi = nwi;
+    it = nit;
     }
 }
 
@@ -382,7 +400,7 @@ __device__ __forceinline__ void wait_prefetched(dbl2_t (&pw)[N], dbl2_t (&pz)[N]
 }
 __device__ __forceinline__ unsigned tile_offset3(const DevStage& st, unsigned local) { return st.dlo[local & 63u] | st.dhi[local >> 6]; }
 template <int K> struct SweepShape : TileShape<K, true> {};   // (no comma inside the __launch_bounds__ macro arguments)
-template <int K>
+template <int K, bool LIST = false>
 __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void sweep_mfma_kernel(const Stage3Args a) {
     using TS = TileShape<K, true>;
     constexpr int kSlots = TS::kWaves > 4 ? 4 : TS::kWaves;   // scratch slots; 8 waves reduce in pairs first
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     // CU, which overlap by themselves (grid = items).
     constexpr bool kPersist = K >= 12;
     constexpr int NL = TS::kLoads, NW = TS::kWaves;
-    const int nwork = a.ntiles * a.batch;
+    const int nwork = LIST ? uniform_load(a.nitems) : a.ntiles * a.batch;
     const unsigned lo = st.dlo[lane];
     SubRegs cur, nxt;
     SubAddr<TS::kGpw> ad;
@@ -422,7 +440,9 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     // gradient walk to read at the headline, 40x less memory at 20 qubits -- by a read-modify-write of the segment's own 4 KB
     // that stays in L2: the old value is requested at the top of the sub-stage (accumulation register, L1 bypassed: the
     // line was written by this workgroup one item earlier) and added where the sum over the waves is formed.
-    const int chunk = kPersist ? a.chunk : 0;
+    // LIST (items from a device table, see apply_mfma_kernel): every item writes the partial slot the table names and nothing
+    // is accumulated over a segment; the chunk follows from the length of the list.
+    const int chunk = kPersist ? (LIST ? (nwork + (int)gridDim.x - 1) / (int)gridDim.x : a.chunk) : 0;
     const int wi_first = kPersist ? (int)blockIdx.x * chunk : (int)blockIdx.x;
     const int wi_end = kPersist ? (wi_first + chunk < nwork ? wi_first + chunk : nwork) : wi_first + 1;
     int wi = wi_first;
@@ -438,11 +458,12 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     unsigned flo16 = 0;        // first sub-stage: byte offset of this lane's operand position inside a tile (+ a.first_hi[group][K-step])
     // element offset of the running item's tile; the next item's is worked out once (a chain of dependent scalar loads)
     // and handed on
-    size_t item_off = (size_t)(wi / a.ntiles) * a.lane_stride + tile_base3(st, wi % a.ntiles);
+    ItemAt it = item_at<LIST>(a, wi);
+    size_t item_off = (size_t)it.bl * a.lane_stride + tile_base3(st, it.tile);
     {
         const size_t off0 = item_off;
         if (st.nsubs > 0) {
-            fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)(wi / a.ntiles) * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
+            fetch_sub<TS::kGpw>(cur, a.subs, a.umat + (size_t)it.bl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
             fetch_k<TS::kGpw>(ad, a.subs, st.sub_begin, wave, NW);
         }
         if (reg_first) {
@@ -464,18 +485,19 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     __syncthreads();
     AQC_STAMP(1);
     for (;;) {
-    const int bl = wi / a.ntiles, tile = wi - bl * a.ntiles;
+    const int bl = it.bl, tile = it.tile;
     const size_t lane_off = item_off;
     const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
     // slot of this item's partial: its tile (one partial per tile), or its segment = number of workgroups that hold earlier
     // tiles of the lane
-    const int part = kPersist ? (int)blockIdx.x - (bl * a.ntiles) / chunk : tile;
-    const bool seg_first = !kPersist || wi == wi_first || tile == 0;   // nothing accumulated yet in this segment
+    const int part = LIST ? it.slot : (kPersist ? (int)blockIdx.x - (bl * a.ntiles) / chunk : tile);
+    const bool seg_first = LIST || !kPersist || wi == wi_first || tile == 0;   // nothing accumulated yet in this segment
     cplx* rpart = a.rpart + (((size_t)bl * a.nsubs_total + st.sub_begin) * a.nparts + part) * 256;
     const int nwi = wi + 1;
     const bool more = reg_first && nwi < wi_end;   // (launch_sweep3 refuses a persistent stage without sub-stages)
-    const int nbl = more ? nwi / a.ntiles : 0;
-    const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nwi - nbl * a.ntiles) : 0;
+    const ItemAt nit = more ? item_at<LIST>(a, nwi) : ItemAt{0, 0, 0};
+    const int nbl = nit.bl;
+    const size_t next_off = more ? (size_t)nbl * a.lane_stride + tile_base3(st, nit.tile) : 0;
     constexpr unsigned ZOFF = tsize * 16;   // byte offset of the z tile (a power of two above every tile address)
     cplx vw[2][4], vz[2][4];   // operands of group j (slot j & 1) and j + 1; group 0 of a sub-stage is requested right after the
                                // barrier that ends the previous one, ahead of the R reduction (its latency hides there)
@@ -687,9 +709,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     // placed after them would sit out their whole write latency; the loads went out sub-stages ago.  (The loads are inline
     // assembly: the register operands tie every later read of the prefetched values to this wait.)
     if (more) wait_prefetched<NL>(pw, pz);
-    if (a.store_out && !(kSweepSkip & 64)) {   // the last stage's w and z are never read again (only the gradient entries are results)
-        store_tile3<K, true>(tw, a.out0 + lane_off, st, lo, wave);
-        store_tile3<K, true>(tz, a.out1 + lane_off, st, lo, wave);
+    if (!(kSweepSkip & 64)) {   // store_out: bit 0 w, bit 1 z.  The last stage's w and z are never read again (only the gradient
+                                // entries are results); a stage whose successor takes z from a checkpoint of V^H stores w alone
+        if (a.store_out & 1) store_tile3<K, true>(tw, a.out0 + lane_off, st, lo, wave);
+        if (a.store_out & 2) store_tile3<K, true>(tz, a.out1 + lane_off, st, lo, wave);
     }
     AQC_STAMP(kStampSlots - 1);
     if (!more) break;
@@ -698,6 +721,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                        // next item's first sub-stage writes its results there; the stores drain under that sub-stage
     AQC_STAMP(kStampSlots - 5);
     wi = nwi;
+    it = nit;
     item_off = next_off;
     }
     AQC_STAMP(kStampSlots - 4);
@@ -916,7 +940,8 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, const DevGrp* grps, int ent, const double* thetas, int T,
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                            int from, int to, int front, const int* slot_theta, cplx* grads, cplx* mirror,
-                                                           const GatherJob gj, int tiles_per_lane, int chunk) {   // ntiles: partial slots per (lane, sub-stage)
+                                                           const GatherJob gj, int tiles_per_lane, int chunk, int sparse_subs,
+                                                           const int* lane_parts) {   // ntiles: partial slots per (lane, sub-stage)
     if ((int)blockIdx.x == nsubs_total) {   // the passenger (see GatherJob): one extra workgroup per lane of the batch
         const cplx* src = static_cast<const cplx*>(gj.buf) + (size_t)blockIdx.y * gj.lane_stride;
         for (int i = threadIdx.x; i < gj.count; i += 64 * WAVES) {
@@ -938,6 +963,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     // that hold tiles of lane b are (b ntiles) / chunk .. ((b + 1) ntiles - 1) / chunk; summed in that fixed order)
     const int nparts_stride = ntiles;
     if (chunk > 0) ntiles = ((b + 1) * tiles_per_lane - 1) / chunk - (b * tiles_per_lane) / chunk + 1;
+    if (si < sparse_subs) ntiles = lane_parts[b];   // sub-stages of a stage that ran over an item list: one partial per item of the lane
     const cplx* rp = rpart + ((size_t)b * nsubs_total + si) * nparts_stride * 256;
     {   // fixed-order sum over the tiles (wave w: tiles w, w + WAVES, ...), 8 tiles (32 loads per lane) in flight at a time;
         // in the few-lane variant wave 0 decodes the last chunk of groups (the first one the walk needs) while its first batch
@@ -1095,6 +1121,10 @@ hipError_t init_kernels3() {
     AQC_TRY(big_lds(apply_mfma_kernel<11>)); AQC_TRY(big_lds(apply_mfma_kernel<12>));
     AQC_TRY(big_lds(sweep_mfma_kernel<8>)); AQC_TRY(big_lds(sweep_mfma_kernel<9>)); AQC_TRY(big_lds(sweep_mfma_kernel<10>));
     AQC_TRY(big_lds(sweep_mfma_kernel<11>)); AQC_TRY(big_lds(sweep_mfma_kernel<12>));
+    AQC_TRY(big_lds((apply_mfma_kernel<8, true>))); AQC_TRY(big_lds((apply_mfma_kernel<9, true>))); AQC_TRY(big_lds((apply_mfma_kernel<10, true>)));
+    AQC_TRY(big_lds((apply_mfma_kernel<11, true>))); AQC_TRY(big_lds((apply_mfma_kernel<12, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<8, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<10, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<11, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<12, true>)));
 #undef AQC_TRY
     return hipSuccess;
 }
@@ -1125,21 +1155,22 @@ hipError_t launch_apply3(int ntiles, int batch, int k, hipStream_t s, const Stag
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
     for (int l = 0; l < 64; ++l)   // 32-bit byte offset per lane in the prefetch (see launch_sweep3)
         if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
+    const bool list = a.items != nullptr;
+    if (list && (!a.nitems || a.max_items < 1)) return hipErrorInvalidValue;
     // 2^12 tiles: persistent workgroups, two per CU, walking over (tile, lane) items; smaller tiles: one item per workgroup
-    const long nwork = (long)ntiles * batch;
+    const long nwork = list ? (long)a.max_items : (long)ntiles * batch;
     static const long persist = []() { const char* e = getenv("AQC_APPLY_PERSIST"); return e ? atol(e) : 2L; }();   // workgroups per CU, 0 = off
     const dim3 grid = (k >= 12 && persist > 0 && a.stage.nsubs > 0) ? dim3((unsigned)std::min<long>(nwork, persist * persistent_sweep_grid()))
-                                                                     : (k >= 12 ? dim3((unsigned)nwork) : dim3(ntiles, batch));
+                                                                     : ((k >= 12 || list) ? dim3((unsigned)nwork) : dim3(ntiles, batch));
+    if (list && k >= 12 && !(persist > 0 && a.stage.nsubs > 0)) return hipErrorInvalidValue;   // (a list launch of 2^12 tiles is persistent)
     const int t = mfma_threads(k, false);
     const size_t l = apply3_lds_bytes(k);
+#define AQC_LAUNCH(KK) case KK: if (list) apply_mfma_kernel<KK, true><<<grid, t, l, s>>>(a); else apply_mfma_kernel<KK, false><<<grid, t, l, s>>>(a); break
     switch (k) {
-        case 8: apply_mfma_kernel<8><<<grid, t, l, s>>>(a); break;
-        case 9: apply_mfma_kernel<9><<<grid, t, l, s>>>(a); break;
-        case 10: apply_mfma_kernel<10><<<grid, t, l, s>>>(a); break;
-        case 11: apply_mfma_kernel<11><<<grid, t, l, s>>>(a); break;
-        case 12: apply_mfma_kernel<12><<<grid, t, l, s>>>(a); break;
+        AQC_LAUNCH(8); AQC_LAUNCH(9); AQC_LAUNCH(10); AQC_LAUNCH(11); AQC_LAUNCH(12);
         default: return hipErrorInvalidValue;
     }
+#undef AQC_LAUNCH
     return hipGetLastError();
 }
 // persistent sweep: items per workgroup (contiguous, lane-major) and partial slots per (lane, sub-stage); 0 / ntiles otherwise
@@ -1154,23 +1185,110 @@ int sweep3_nparts(int ntiles, int batch, int k) {
 }
 hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stage3Args& a) {
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
-    if (a.chunk != sweep3_chunk(ntiles, batch, k) || a.nparts != sweep3_nparts(ntiles, batch, k)) return hipErrorInvalidValue;
+    const bool list = a.items != nullptr;
+    if (list && (!a.nitems || a.max_items < 1)) return hipErrorInvalidValue;
+    if (a.nparts != sweep3_nparts(ntiles, batch, k) || (!list && a.chunk != sweep3_chunk(ntiles, batch, k))) return hipErrorInvalidValue;
     if (k >= 12 && a.stage.nsubs <= 0) return hipErrorInvalidValue;   // the persistent form feeds the first sub-stage from registers
     for (int l = 0; l < 64; ++l)   // the persistent sweep addresses its prefetch with a 32-bit byte offset per lane
         if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
     // 2^12 tiles: one persistent workgroup per CU walking over its items (see the kernel); smaller tiles: one item each
-    const long nwork = (long)ntiles * batch;
-    const dim3 grid((unsigned)(k >= 12 ? (nwork + a.chunk - 1) / a.chunk : nwork));
+    const long nwork = list ? (long)a.max_items : (long)ntiles * batch;
+    const dim3 grid((unsigned)(k >= 12 ? (list ? std::min<long>(nwork, persistent_sweep_grid()) : (nwork + a.chunk - 1) / a.chunk) : nwork));
     const int t = mfma_threads(k, true);
     const size_t l = sweep3_lds_bytes(k);
+#define AQC_LAUNCH(KK) case KK: if (list) sweep_mfma_kernel<KK, true><<<grid, t, l, s>>>(a); else sweep_mfma_kernel<KK, false><<<grid, t, l, s>>>(a); break
     switch (k) {
-        case 8: sweep_mfma_kernel<8><<<grid, t, l, s>>>(a); break;
-        case 9: sweep_mfma_kernel<9><<<grid, t, l, s>>>(a); break;
-        case 10: sweep_mfma_kernel<10><<<grid, t, l, s>>>(a); break;
-        case 11: sweep_mfma_kernel<11><<<grid, t, l, s>>>(a); break;
-        case 12: sweep_mfma_kernel<12><<<grid, t, l, s>>>(a); break;
+        AQC_LAUNCH(8); AQC_LAUNCH(9); AQC_LAUNCH(10); AQC_LAUNCH(11); AQC_LAUNCH(12);
         default: return hipErrorInvalidValue;
     }
+#undef AQC_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- tile lists ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_of_elem(const DevStage& st, long long e) {
+    int t = 0;
+    for (int i = 0; i < st.nub; ++i) t |= (int)((e >> st.ubits[i]) & 1) << i;
+    return t;
+}
+// unique tiles of lane b in first-occurrence order (support first); returns their number
+__device__ __forceinline__ int lane_tiles(const DevStage& st, const long long* supp, int per_lane, const long long* extra, int nextra, int b,
+                                          int (&tiles)[kMaxTileCands]) {
+    int n = 0;
+    auto add = [&](long long e) {
+        if (e < 0) return;
+        const int t = tile_of_elem(st, e);
+        for (int i = 0; i < n; ++i)
+            if (tiles[i] == t) return;
+        tiles[n++] = t;
+    };
+    for (int k = 0; supp && k < per_lane; ++k) add(supp[(size_t)b * per_lane + k]);
+    for (int k = 0; extra && k < nextra; ++k) add(extra[k]);
+    return n;
+}
+__global__ __launch_bounds__(1024) void tile_items_kernel(const DevStage st, const long long* supp, int per_lane, const long long* extra, int nextra,
+                                                          int batch, TileItem* items, int* nitems, int* lane_parts, int* prev_tiles,
+                                                          TileItem* clear_items, int* nclear) {
+    __shared__ int scan_a[1024], scan_b[1024];
+    const int tid = threadIdx.x, per = (batch + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(batch, b0 + per);
+    int tiles[kMaxTileCands];
+    int mine = 0, mine_clear = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int n = lane_tiles(st, supp, per_lane, extra, nextra, b, tiles);
+        mine += n;
+        if (prev_tiles)
+            for (int k = 0; k < 2; ++k) {
+                const int pt = prev_tiles[2 * b + k];
+                bool stale = pt >= 0;
+                for (int i = 0; i < n; ++i) stale = stale && tiles[i] != pt;
+                mine_clear += stale ? 1 : 0;
+            }
+    }
+    scan_a[tid] = mine; scan_b[tid] = mine_clear;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive scans
+        const int va = tid >= d ? scan_a[tid - d] : 0, vb = tid >= d ? scan_b[tid - d] : 0;
+        __syncthreads();
+        scan_a[tid] += va; scan_b[tid] += vb;
+        __syncthreads();
+    }
+    int at = scan_a[tid] - mine, at_clear = scan_b[tid] - mine_clear;
+    if (tid == 1023) { *nitems = scan_a[tid]; if (nclear) *nclear = scan_b[tid]; }
+    for (int b = b0; b < b1; ++b) {
+        const int n = lane_tiles(st, supp, per_lane, extra, nextra, b, tiles);
+        if (lane_parts) lane_parts[b] = n;
+        if (prev_tiles) {
+            for (int k = 0; k < 2; ++k) {
+                const int pt = prev_tiles[2 * b + k];
+                bool stale = pt >= 0;
+                for (int i = 0; i < n; ++i) stale = stale && tiles[i] != pt;
+                if (stale) clear_items[at_clear++] = TileItem{b, pt, 0, 0};
+            }
+            prev_tiles[2 * b] = n > 0 ? tiles[0] : -1;
+            prev_tiles[2 * b + 1] = n > 1 ? tiles[1] : -1;
+        }
+        for (int i = 0; i < n; ++i) items[at++] = TileItem{b, tiles[i], i, 0};
+    }
+}
+hipError_t launch_tile_items(const DevStage& stage, const long long* supp, int per_lane, const long long* extra, int nextra, int batch,
+                             TileItem* items, int* nitems, int* lane_parts, int* prev_tiles, TileItem* clear_items, int* nclear, hipStream_t s) {
+    if ((supp ? per_lane : 0) + (extra ? nextra : 0) > kMaxTileCands || batch < 1) return hipErrorInvalidValue;
+    if (prev_tiles && ((supp ? per_lane : 0) > 2 || (extra && nextra > 0) || !clear_items || !nclear)) return hipErrorInvalidValue;
+    tile_items_kernel<<<1, 1024, 0, s>>>(stage, supp, per_lane, extra, nextra, batch, items, nitems, lane_parts, prev_tiles, clear_items, nclear);
+    return hipGetLastError();
+}
+// buf[item.lane][tile item.tile of the stage] <- 0 for the first *nclear items of the list
+__global__ __launch_bounds__(256) void clear_tiles_kernel(const DevStage st, cplx* buf, size_t lane_stride, const TileItem* clear_items, const int* nclear) {
+    if ((int)blockIdx.x >= *nclear) return;
+    const TileItem it = clear_items[blockIdx.x];
+    cplx* dst = buf + (size_t)it.lane * lane_stride + tile_base3(st, (unsigned)it.tile);
+    for (unsigned l = threadIdx.x; l < (1u << st.k); l += 256) dst[tile_offset3(st, l)] = make_double2(0.0, 0.0);
+}
+hipError_t launch_clear_tiles(const DevStage& stage, void* buf, size_t lane_stride, const TileItem* clear_items, const int* nclear, int max_items,
+                              hipStream_t s) {
+    if (max_items < 1) return hipSuccess;
+    clear_tiles_kernel<<<max_items, 256, 0, s>>>(stage, static_cast<cplx*>(buf), lane_stride, clear_items, nclear);
     return hipGetLastError();
 }
 hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s, double* thetas_copy) {
@@ -1180,7 +1298,8 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 }
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
-                        const int* slot_theta, void* grads, void* mirror, GatherJob gather, int nparts, int chunk) {
+                        const int* slot_theta, void* grads, void* mirror, GatherJob gather, int nparts, int chunk, int sparse_subs,
+                        const int* lane_parts) {
     if (nsubs_total < 1) return hipSuccess;
     const int extra = gather.count > 0 && gather.buf ? 1 : 0;
     const int tiles_per_lane = ntiles;
@@ -1189,11 +1308,11 @@ hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, 
     if (nparts >= 32)
         rgrad_kernel<4><<<dim3(nsubs_total + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                   nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk);
+                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts);
     else
         rgrad_kernel<1><<<dim3(nsubs_total + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk);
+                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts);
     return hipGetLastError();
 }
 

@@ -52,6 +52,7 @@ hipError_t launch_apply2(int ent, int ntiles, int batch, int k, hipStream_t s, c
 hipError_t launch_sweep2(int ent, int ntiles, int batch, int k, int reg_bits, hipStream_t s, const StageArgs& a);
 
 // aqc_kernels3.hip (matrix-core kernels)
+struct TileItem { int lane, tile, slot, pad; };   // one (tile, lane) work item of a stage launch over a SUBSET of the tiles; slot: its partial-R slot
 struct Stage3Args {
     DevStage stage;          // by value: kernel arguments live in the constant address space, so the offset tables are
                              // scalar loads that no store of the kernel can invalidate
@@ -68,7 +69,10 @@ struct Stage3Args {
     int batch;               // lanes of the batch (sweep: work items = ntiles x batch)
     int chunk, nparts;       // sweep: items per persistent workgroup (0: one item per workgroup) and partial-R slots per
                              // (lane, sub-stage) -- sweep3_chunk / sweep3_nparts
-    int store_out;           // sweep: 0 for the last stage (its w and z are never read again)
+    int store_out;           // sweep: bit 0 store w, bit 1 store z; 0 for the last stage (its w and z are never read again)
+    const TileItem* items;   // launch over a subset of the (tile, lane) pairs: device table + its length on the device (null: all pairs);
+    const int* nitems;       // the grid is sized for max_items, the kernels read the actual length
+    int max_items;
     unsigned first_hi[16][4];   // persistent sweep: tile offset (elements) of the FIRST sub-stage's operand of (group, K-step);
                                 // a lane adds the offset of its own (chunk l % 16, amplitude l / 16) position (stage3_first_offsets)
     int debug;               // tuning builds: work-skipping bits for timing experiments (1 LDS writes, 2 LDS reads, 4 R MFMAs, 8 U MFMAs)
@@ -99,7 +103,19 @@ hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, 
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
                         const int* slot_theta = nullptr, void* grads = nullptr, void* mirror = nullptr,
                         GatherJob gather = GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},   // slot_theta: direct mode, see rgrad_kernel
-                        int nparts = 0, int chunk = 0);   // partial-R slots per (lane, sub-stage) and the persistent sweep's chunk
+                        int nparts = 0, int chunk = 0,   // partial-R slots per (lane, sub-stage) and the persistent sweep's chunk
+                        int sparse_subs = 0, const int* lane_parts = nullptr);   // the first sparse_subs sub-stages hold lane_parts[lane] partials (item-list launch)
+// Tile lists on the device (aqc_ws_sweep.cpp).  Per lane, the tiles of `stage` that hold the elements supp[lane][0 .. per_lane)
+// (the support of the lane's sparse lhs state; -1 = none; may be null) and extra[0 .. nextra) (the same for every lane: the
+// registered gather set; may be null), each tile once, in that order -> item list (lane-major, slot = position inside the lane),
+// its length, items per lane.  prev_tiles (may be null; [lane][2], per_lane <= 2, no extras): tiles named by the previous list
+// of this table that the new one drops -> clear list (they hold stale amplitudes in a buffer that is zero elsewhere); updated.
+// One workgroup.
+constexpr int kMaxTileCands = 72;   // per_lane + nextra
+hipError_t launch_tile_items(const DevStage& stage, const long long* supp, int per_lane, const long long* extra, int nextra, int batch,
+                             TileItem* items, int* nitems, int* lane_parts, int* prev_tiles, TileItem* clear_items, int* nclear, hipStream_t s);
+hipError_t launch_clear_tiles(const DevStage& stage, void* buf, size_t lane_stride, const TileItem* clear_items, const int* nclear, int max_items,
+                              hipStream_t s);
 
 // aqc_lbfgs.hip (device-resident multi-start L-BFGS on the lane-batched surrogate objective)
 struct LbState {

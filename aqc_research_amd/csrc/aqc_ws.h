@@ -165,6 +165,22 @@ struct aqc_ws {
     bool copy_pending = false;                // the producers of the next evaluation wait for ev_copied before they overwrite the results
     const double* theta_host = nullptr;      // aqc_ws_eval: pinned thetas the next U build reads directly (and copies to d_thetas)
     bool gather_rides = false;               // aqc_ws_eval: the next gradient walk also performs the registered gather (see there)
+    // mirrored V^H plan, its checkpoint, the sparse-lhs sweep (aqc_ws_sweep.cpp)
+    bool inv_mirrored = false;     // inv = the sweep plan walked backwards: V^H into Z leaves the state before its last stage in ZW ...
+    bool ckpt_valid = false;       // ... and ZW holds it for the thetas in use and the present contents of Z
+    bool w_clean = true;           // W is zero outside the tiles named in d_sw_prev_tiles
+    bool sparse_enabled = true;    // AQC_SPARSE_SWEEP=0: always the dense route
+    long sparse_min_items = 512;   // the sparse route pays from this many (tile, lane) items per stage launch (AQC_SPARSE_MIN_ITEMS)
+    unsigned long long supp_version[AQC_NUM_BUFS] = {0, 0, 0, 0, 0, 0};   // bumped whenever d_combo_prev[buf] (the support of a sparse lhs) changes
+    aqc::TileItem* d_sw_items = nullptr;    // first-stage items of the sparse sweep [2 batch], and the tiles to clear in W
+    aqc::TileItem* d_sw_clear = nullptr;
+    int* d_sw_counts = nullptr;             // [0] items, [1] tiles to clear
+    int* d_sw_lane_parts = nullptr;         // items (= partial-R slots in use) per lane
+    int* d_sw_prev_tiles = nullptr;         // [batch][2] tiles of W written by the list in use
+    int sw_items_buf = -1;                  // the list in d_sw_items belongs to this lhs buffer ...
+    unsigned long long sw_items_version = 0;   // ... at this version of its support
+    double2* w2 = nullptr;                  // second scratch pair of the sparse route (plans of >= 3 stages)
+    double2* zw2 = nullptr;
     bool profile = false;
     int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
     double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
@@ -199,6 +215,11 @@ int copy_in(aqc_ws* ws, double2* dst, const double* src, size_t rows);
 int copy_out(aqc_ws* ws, double* dst, const double2* src, size_t rows);
 int results_guard(aqc_ws* ws);
 // aqc_ws_sweep.cpp
+void touch_buf(aqc_ws* ws, int buf);   // somebody other than the V^H / sweep pair writes the buffer
+bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag);
+int sweep_sparse_prepare(aqc_ws* ws);
+void apply_state_after(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);
+void sweep_state_after(aqc_ws* ws, bool sparse, bool replayed);
 int ensure_umat(aqc_ws* ws, DevPlan& p);
 int run_coef(aqc_ws* ws);
 int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);

@@ -44,7 +44,8 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     LB_OK(hipMalloc((void**)&dd, nd * sizeof(double)));
     LB_OK(hipMalloc((void**)&dc, (3 * BT + 3 * BS) * sizeof(double2)));
     LB_OK(hipMalloc((void**)&di, (size_t)(3 * B + 8) * sizeof(int)));
-    LB_OK(hipMalloc((void**)&dl, (size_t)(3 * B) * sizeof(long long)));
+    LB_OK(hipMalloc((void**)&dl, (size_t)B * sizeof(long long)));
+    if (!ws->d_combo_prev[AQC_BUF_X2]) LB_OK(hipMalloc((void**)&ws->d_combo_prev[AQC_BUF_X2], sizeof(long long) * 2 * B));
     LB_OK(hipHostMalloc((void**)&h_flags, 8 * sizeof(int), hipHostMallocDefault));
     LB_OK(hipMemsetAsync(dd, 0, nd * sizeof(double), st_));
     LB_OK(hipMemsetAsync(di, 0, (size_t)(3 * B + 8) * sizeof(int), st_));
@@ -69,18 +70,18 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     L.active = di; L.done = di + B; L.max_no = di + 2 * B;
     int* d_flags = di + 3 * B;
     L.nit = dl;
-    long long* d_prev = dl + B;   // [B][2]: positions of X2 written by the previous evaluation
+    long long* d_prev = ws->d_combo_prev[AQC_BUF_X2];   // [B][2]: positions of X2 written by the previous evaluation (the support of the lhs states)
     {   // weight = 1, max_no = 0, active = 1, X2 empty
         std::vector<double> ones(B, 1.0);
         std::vector<int> one_i(B, 1);
-        std::vector<long long> neg(3 * (size_t)B, 0);
-        for (int b = 0; b < 2 * B; ++b) neg[B + b] = -1;
         LB_OK(hipMemcpyAsync(L.weight, ones.data(), sizeof(double) * B, hipMemcpyHostToDevice, st_));
         LB_OK(hipMemcpyAsync(L.active, one_i.data(), sizeof(int) * B, hipMemcpyHostToDevice, st_));
-        LB_OK(hipMemcpyAsync(dl, neg.data(), sizeof(long long) * 3 * B, hipMemcpyHostToDevice, st_));
+        LB_OK(hipMemsetAsync(dl, 0, sizeof(long long) * B, st_));
+        LB_OK(hipMemsetAsync(d_prev, 0xff, sizeof(long long) * 2 * B, st_));   // -1: nothing written yet
         LB_OK(hipMemcpyAsync(L.x, x0, sizeof(double) * BT, hipMemcpyHostToDevice, st_));
         LB_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st_));
-        ws->combo_valid[AQC_BUF_X2] = false;
+        ws->combo_valid[AQC_BUF_X2] = true;   // the buffer holds exactly the pattern its record names (nothing, so far)
+        ++ws->supp_version[AQC_BUF_X2];
         LB_OK(hipStreamSynchronize(st_));
     }
     int64_t nfev = 0;
@@ -97,6 +98,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
         if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         HIP_OK(lb_prepare(L, ws->d_small, update, f_o, raw_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
+        ++ws->supp_version[AQC_BUF_X2];   // (the leading flip state is chosen on the device: the support may have moved)
         if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
         HIP_OK(lb_take(L, ws->d_grads, g_o, raw_g, st_));
         ++nfev;
@@ -215,7 +217,10 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
     if (!ws->combo_valid[AQC_BUF_X2]) {   // (outside the replayed part: a whole-buffer clear is a one-off)
         HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st));
         HIP_OK(hipMemsetAsync(ws->d_combo_prev[AQC_BUF_X2], 0xff, sizeof(long long) * 2 * B, st));   // -1: nothing to clear
+        ws->combo_valid[AQC_BUF_X2] = true;   // the buffer holds exactly the pattern its record names
     }
+    const bool sparse = sweep_route_sparse(ws, AQC_BUF_X2, true);   // (decided here: part of the captured graph's key)
+    if (sparse && sweep_sparse_prepare(ws)) return 1;
     const bool real_only = !zero_copy && !grads_out;
     if (real_only && ws->sur_real_cap < nth) {
         HIP_OK(hipStreamSynchronize(st));
@@ -238,6 +243,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
             ProfScope ps(ws, AQC_K_MISC);
             HIP_OK(lb_prepare(L, ws->d_small, update_state, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
                               ws->d_combo_prev[AQC_BUF_X2], st));
+            ++ws->supp_version[AQC_BUF_X2];
         }
         // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
         if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
@@ -258,7 +264,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         const std::vector<long long> key = {1000 + update_state + (zero_copy ? 10 : 0) + (real_only ? 20 : 0), block_from, block_to, front_layer,
                                             (long long)S, (long long)(size_t)ws->d_sur_real,
                                             (long long)(size_t)ws->d_sur, (long long)(size_t)ws->h_sur, (long long)(size_t)ws->h_pin,
-                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2]};
+                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2], sparse ? 1 : 0};
         auto it = ws->graphs.find(key);
         if (it == ws->graphs.end()) {
             hipGraph_t graph = nullptr;
@@ -281,6 +287,10 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         ws->coef_valid = true;
         ws->fwd.u_valid = false;
         ws->inv.u_valid = ws->sweep.u_valid = ws->inv.v3 && ws->sweep.v3;
+        ws->ckpt_valid = false;
+        apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+        ++ws->supp_version[AQC_BUF_X2];
+        sweep_state_after(ws, sparse, true);
         HIP_OK(hipGraphLaunch(it->second, st));
     } else if (enqueue()) {
         return 1;

@@ -1,5 +1,21 @@
 // C ABI (include/aqc_hip.h): V / V^H launches, the w/z sweep and the one-call evaluation.
+//
+// Matrix-core family, two routes for the sweep (grad_of_dot_product, core_operations.py:823-1019):
+//   dense   every stage over all tiles of w and z, in place on the scratch pair (W, ZW) -- any lhs state, any V^H y.
+//   sparse  the lhs state is a combination of <= 2 basis states per lane (aqc_ws_set_basis / aqc_ws_set_combo / the device
+//           L-BFGS: what every surrogate objective sweeps from, objective_base.py:42-255, objective_lhs_sur_max.py:147-191) and
+//           Z = V^H y was produced here, by the MIRRORED plan (the sweep's stages walked backwards).  Then
+//           * during the sweep's first stage w is zero outside the tile(s) of the stage that hold the basis indices: the
+//             stage runs over those tiles only (a device-resident item list; everywhere else W <- U 0 = 0 and R = Z 0^H = 0
+//             exactly, so nothing is lost -- the buffer W is kept zero outside the listed tiles);
+//           * z after the sweep's first stage is (stage-0 gates) V^H y = the state V^H had BEFORE its last stage, which the
+//             mirrored V^H left in ZW (the "checkpoint"): the second stage reads it from there, and the first stage neither
+//             computes nor stores z outside its listed tiles.
+//           At the headline (16 qubits, 2 stages of 7 + 4 sub-stages, x = |0>) the first stage shrinks from 16 tiles per lane
+//           to one: 7/11 of the sweep's matrix work is gone.
 #include "aqc_ws.h"
+
+#include <algorithm>
 
 using namespace aqc;
 
@@ -30,10 +46,108 @@ int run_coef(aqc_ws* ws) {
     const Program& prog = ws->ctx->prog;
     ws->fwd.u_valid = ws->inv.u_valid = ws->sweep.u_valid = false;
     ws->coef_valid = true;
+    ws->ckpt_valid = false;   // ZW (and Z) belong to the previous thetas
     if (ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef) return 0;   // the matrix-core path reads the thetas directly
     ProfScope ps(ws, AQC_K_COEF);
     HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
     return 0;
+}
+
+// somebody other than the V^H / sweep pair below writes buffer `buf`
+void touch_buf(aqc_ws* ws, int buf) {
+    if (buf == AQC_BUF_Z || buf == AQC_BUF_ZW) ws->ckpt_valid = false;
+    if (buf == AQC_BUF_W) ws->w_clean = false;
+}
+
+namespace {
+
+#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the workgroups of one launch, on stderr (tuning builds only)
+unsigned long long* g_stamps = nullptr;
+int stamps_begin(aqc_ws* ws, Stage3Args& a, size_t nwg) {
+    if (env_int("AQC_STAMPS", 0) == 0 || nwg > 65536) return 0;
+    if (!g_stamps) HIP_OK(hipMalloc((void**)&g_stamps, sizeof(unsigned long long) * 65536 * kStampSlots));
+    HIP_OK(hipMemsetAsync(g_stamps, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream));
+    a.stamps = g_stamps;
+    return 0;
+}
+int stamps_apply(aqc_ws* ws, const Stage3Args& a, size_t s, size_t nwg) {
+    if (!a.stamps) return 0;
+    std::vector<unsigned long long> h(nwg * kStampSlots);
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    HIP_OK(hipMemcpy(h.data(), g_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    double load = 0, loop = 0, store = 0, bar = 0;
+    const int ns = a.stage.nsubs;
+    for (size_t w = 0; w < nwg; ++w) {
+        const unsigned long long* t = h.data() + w * kStampSlots;
+        load += (double)(t[1] - t[0]); loop += (double)(t[2] - t[1]); store += (double)(t[3] - t[2]);
+        for (int i = 0; i < ns && 5 + i < kStampSlots; ++i) bar += (double)(t[5 + i] - t[4 + i]);
+    }
+    fprintf(stderr, "aqc_hip stamps: V/V^H stage %zu (%d sub-stages, %zu workgroups): load %.0f + sub-stage loop %.0f (%.0f per sub-stage, of which "
+            "waiting at its barrier %.0f) + store %.0f cycles per workgroup\n", s, ns, nwg, load / nwg, loop / nwg, loop / nwg / std::max(ns, 1),
+            bar / nwg / std::max(ns, 1), store / nwg);
+    return 0;
+}
+int stamps_sweep(aqc_ws* ws, const Stage3Args& a, size_t s, size_t nwg) {
+    if (!a.stamps) return 0;
+    std::vector<unsigned long long> h(nwg * kStampSlots);
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    HIP_OK(hipMemcpy(h.data(), g_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    const int ns = a.stage.nsubs;
+    // the 2^12 sweep is persistent: a workgroup's per-sub-stage stamps are those of its LAST item, slot S-4 its end,
+    // slots S-6 / S-5 bracket its last hand-over to a prefetched tile
+    double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0, turn = 0;
+    size_t live = 0;
+    unsigned long long first_start = ~0ull, last_start = 0, first_end = ~0ull, last_end = 0, wg_min = ~0ull, wg_max = 0;
+    for (size_t w = 0; w < nwg; ++w) {
+        const unsigned long long* t = h.data() + w * kStampSlots;
+        if (t[kStampSlots - 4] == 0) continue;   // no workgroup with this index (persistent grid)
+        ++live;
+        first_start = std::min(first_start, t[0]); last_start = std::max(last_start, t[0]);
+        first_end = std::min(first_end, t[kStampSlots - 4]); last_end = std::max(last_end, t[kStampSlots - 4]);
+        wg_min = std::min(wg_min, t[kStampSlots - 4] - t[0]); wg_max = std::max(wg_max, t[kStampSlots - 4] - t[0]);
+        load += (double)(t[1] - t[0]);
+        store += (double)(t[kStampSlots - 1] - t[kStampSlots - 2]);
+        total += (double)(t[kStampSlots - 4] - t[0]);
+        if (t[kStampSlots - 5]) turn += (double)(t[kStampSlots - 5] - t[kStampSlots - 6]);
+        for (int i = 0; i < ns && 5 + 4 * i < kStampSlots - 6; ++i) {
+            if (i) top += (double)(t[2 + 4 * i] - t[5 + 4 * (i - 1)]);
+            mf += (double)(t[3 + 4 * i] - t[2 + 4 * i]);
+            bar += (double)(t[4 + 4 * i] - t[3 + 4 * i]);
+            red += (double)(t[5 + 4 * i] - t[4 + 4 * i]);
+        }
+    }
+    const double n = (double)std::max<size_t>(live, 1), items = (double)nwg / n;
+    fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups x %.1f items): total %.0f cycles per item = first load %.0f/items + "
+            "per sub-stage [top %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f + hand-over %.0f\n", s, ns, live, items,
+            total / n / items, load / n, top / n / std::max(ns - 1, 1), mf / n / ns, bar / n / ns, red / n / ns, store / n, turn / n);
+    fprintf(stderr, "aqc_hip stamps: stage %zu workgroup lifetimes (s_memtime ticks): min %llu max %llu; starts spread over %llu, ends over %llu; "
+            "first start -> last end %llu\n", s, wg_min, wg_max, last_start - first_start, last_end - first_end, last_end - first_start);
+    return 0;
+}
+#endif
+
+Stage3Args stage3_args(aqc_ws* ws, const DevPlan& p, size_t s) {
+    Stage3Args a;
+    memset(&a, 0, sizeof a);
+    a.stage = p.h_stages[s];
+    a.subs = p.d_subs3;
+    a.umat = p.d_umat;
+    a.nsubs_total = (int)p.h_subs3.size();
+    a.lane_stride = ws->lane_elems;
+    a.ntiles = p.ntiles;
+    a.batch = ws->batch;
+    return a;
+}
+
+}  // namespace
+
+// V^H into Z by the mirrored plan keeps the state before its last stage in ZW (see the head of this file)
+static bool keeps_checkpoint(const aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
+    return inverse && ws->inv_mirrored && ws->inv.v3 && dst_buf == AQC_BUF_Z && src_buf != AQC_BUF_ZW && ws->inv.h_stages.size() >= 2;
+}
+void apply_state_after(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {   // host-side state a V / V^H leaves (also after a graph replay)
+    touch_buf(ws, dst_buf);
+    if (keeps_checkpoint(ws, inverse, src_buf, dst_buf)) { touch_buf(ws, AQC_BUF_ZW); ws->ckpt_valid = true; }
 }
 
 int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
@@ -41,49 +155,26 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
     const Program& prog = ws->ctx->prog;
     if (p.v3) {
         if (ensure_umat(ws, p)) return 1;
-        for (size_t s = 0; s < p.h_stages.size(); ++s) {
-            Stage3Args a;
-            memset(&a, 0, sizeof a);
-            a.stage = p.h_stages[s];
-            a.subs = p.d_subs3;
-            a.umat = p.d_umat;
-            a.nsubs_total = (int)p.h_subs3.size();
-            a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[dst_buf];
-            a.out0 = ws->bufs[dst_buf];
-            a.lane_stride = ws->lane_elems;
-            a.ntiles = p.ntiles;
-            a.batch = ws->batch;
-#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the V / V^H workgroups of this launch, on stderr
-            static unsigned long long* d_stamps_a = nullptr;
+        const bool keep = keeps_checkpoint(ws, inverse, src_buf, dst_buf);
+        const size_t m = p.h_stages.size();
+        for (size_t s = 0; s < m; ++s) {
+            Stage3Args a = stage3_args(ws, p, s);
+            const int mid = keep ? AQC_BUF_ZW : dst_buf;   // where the stages before the last one work
+            a.in0 = s == 0 ? ws->bufs[src_buf] : ws->bufs[mid];
+            a.out0 = s + 1 == m ? ws->bufs[dst_buf] : ws->bufs[mid];
+#ifdef AQC_TUNING
             const size_t nwg = (size_t)p.ntiles * ws->batch;
-            if (env_int("AQC_STAMPS", 0) != 0 && nwg <= 65536) {
-                if (!d_stamps_a) HIP_OK(hipMalloc((void**)&d_stamps_a, sizeof(unsigned long long) * 65536 * kStampSlots));
-                HIP_OK(hipMemsetAsync(d_stamps_a, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream));
-                a.stamps = d_stamps_a;
-            }
+            if (stamps_begin(ws, a, nwg)) return 1;
 #endif
             {
                 ProfScope ps(ws, AQC_K_APPLY);
                 HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
             }
 #ifdef AQC_TUNING
-            if (a.stamps) {
-                std::vector<unsigned long long> h(nwg * kStampSlots);
-                HIP_OK(hipStreamSynchronize(ws->stream));
-                HIP_OK(hipMemcpy(h.data(), d_stamps_a, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-                double load = 0, loop = 0, store = 0, bar = 0;
-                const int ns = p.h_stages[s].nsubs;
-                for (size_t w = 0; w < nwg; ++w) {
-                    const unsigned long long* t = h.data() + w * kStampSlots;
-                    load += (double)(t[1] - t[0]); loop += (double)(t[2] - t[1]); store += (double)(t[3] - t[2]);
-                    for (int i = 0; i < ns && 5 + i < kStampSlots; ++i) bar += (double)(t[5 + i] - t[4 + i]);
-                }
-                fprintf(stderr, "aqc_hip stamps: V/V^H stage %zu (%d sub-stages, %zu workgroups): load %.0f + sub-stage loop %.0f (%.0f per sub-stage, of which "
-                        "waiting at its barrier %.0f) + store %.0f cycles per workgroup\n", s, ns, nwg, load / nwg, loop / nwg, loop / nwg / std::max(ns, 1),
-                        bar / nwg / std::max(ns, 1), store / nwg);
-            }
+            if (stamps_apply(ws, a, s, nwg)) return 1;
 #endif
         }
+        apply_state_after(ws, inverse, src_buf, dst_buf);
         return 0;
     }
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
@@ -103,12 +194,56 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
         if (p.v2) HIP_OK(launch_apply2(prog.entangler, p.ntiles, ws->batch, p.k, ws->stream, a));
         else HIP_OK(launch_apply(prog.entangler, inverse, p.ntiles, ws->batch, ws->threads, p.k, ws->stream, a));
     }
+    apply_state_after(ws, inverse, src_buf, dst_buf);
     return 0;
 }
 
 void drop_graphs(aqc_ws* ws) {
     for (auto& kv : ws->graphs) (void)hipGraphExecDestroy(kv.second);
     ws->graphs.clear();
+}
+
+// ---- the sparse route --------------------------------------------------------------------------------------------
+// Route of the next sweep from x_buf.  will_vdag: a V^H from Y into Z precedes it inside the same call (one-call
+// evaluations decide before they enqueue anything: the decision is part of the key of their captured graph).
+bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag) {
+    const DevPlan& p = ws->sweep;
+    if (!ws->sparse_enabled || !p.v3 || !ws->inv_mirrored || p.h_stages.size() < 2) return false;
+    if (!ws->combo_valid[x_buf] || !ws->d_combo_prev[x_buf]) return false;          // support of the lhs state known on the device
+    if (!(will_vdag ? keeps_checkpoint(ws, true, AQC_BUF_Y, AQC_BUF_Z) : ws->ckpt_valid)) return false;   // z of stage 1 available in ZW
+    return (long)p.ntiles * ws->batch >= ws->sparse_min_items;   // (fewer items than CUs: a stage takes one item's time either way)
+}
+// Allocations and one-off clears of the sparse route: everything that must not sit inside a captured graph.
+int sweep_sparse_prepare(aqc_ws* ws) {
+    const DevPlan& p = ws->sweep;
+    const int B = ws->batch;
+    if (!ws->d_sw_items) {
+        HIP_OK(hipMalloc((void**)&ws->d_sw_items, sizeof(TileItem) * 2 * B));
+        HIP_OK(hipMalloc((void**)&ws->d_sw_clear, sizeof(TileItem) * 2 * B));
+        HIP_OK(hipMalloc((void**)&ws->d_sw_counts, sizeof(int) * 4));
+        HIP_OK(hipMalloc((void**)&ws->d_sw_lane_parts, sizeof(int) * B));
+        HIP_OK(hipMalloc((void**)&ws->d_sw_prev_tiles, sizeof(int) * 2 * B));
+        ws->w_clean = false;
+    }
+    if (p.h_stages.size() >= 3 && !ws->w2) {   // stages from the second one on work on their own pair: W stays zero outside the listed
+        HIP_OK(hipMalloc((void**)&ws->w2, sizeof(double2) * (size_t)B * ws->lane_elems));   // tiles, ZW keeps the checkpoint
+        HIP_OK(hipMalloc((void**)&ws->zw2, sizeof(double2) * (size_t)B * ws->lane_elems));
+    }
+    if (!ws->w_clean) {
+        HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_W], 0, sizeof(double2) * (size_t)B * ws->lane_elems, ws->stream));
+        HIP_OK(hipMemsetAsync(ws->d_sw_prev_tiles, 0xff, sizeof(int) * 2 * B, ws->stream));   // -1: W holds no tile of an earlier list
+        ws->w_clean = true;
+        ws->sw_items_buf = -1;
+    }
+    return 0;
+}
+void sweep_state_after(aqc_ws* ws, bool sparse, bool replayed) {   // host-side state a sweep leaves (also after a graph replay)
+    if (sparse) {
+        if (replayed) ws->sw_items_buf = -1;   // the replay rebuilt the list from whatever the support was: rebuild when asked next
+    } else {
+        ws->w_clean = false;
+        ws->ckpt_valid = false;                // the dense route works in place on (W, ZW)
+    }
 }
 
 }  // namespace aqc
@@ -127,7 +262,6 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
     return aqc_ws_grad_from(ws, AQC_BUF_X, block_from, block_to, front_layer);
 }
 
-
 int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer) {
     if (check_buf(ws, x_buf)) return 1;
     if (results_guard(ws)) return 1;
@@ -142,84 +276,67 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
     if (p.v3) {
         if (ensure_umat(ws, p)) return 1;
         const int nsubs = (int)p.h_subs3.size();
-        for (size_t s = 0; s < p.h_stages.size(); ++s) {
-            Stage3Args a;
-            memset(&a, 0, sizeof a);
-            a.stage = p.h_stages[s];
-            a.subs = p.d_subs3;
-            a.umat = p.d_umat;
-            a.nsubs_total = nsubs;
-            a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
-            a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
-            a.out0 = ws->bufs[AQC_BUF_W];
-            a.out1 = ws->bufs[AQC_BUF_ZW];
-            a.lane_stride = ws->lane_elems;
+        const size_t m = p.h_stages.size();
+        const bool sparse = sweep_route_sparse(ws, x_buf, false);
+        if (sparse) {
+            if (!ws->capturing && sweep_sparse_prepare(ws)) return 1;
+            if (!ws->d_sw_items || !ws->w_clean || (m >= 3 && !ws->w2)) return fail("sparse sweep inside a captured graph without its preparation");
+            // tiles of the first stage that hold the lhs state: a device-side list (the support may have been chosen on the device),
+            // rebuilt when the support changed; tiles of the previous list that the new one drops are zeroed in W
+            if (ws->capturing || ws->sw_items_buf != x_buf || ws->sw_items_version != ws->supp_version[x_buf]) {
+                ProfScope ps(ws, AQC_K_MISC);
+                HIP_OK(launch_tile_items(p.h_stages[0], ws->d_combo_prev[x_buf], 2, nullptr, 0, ws->batch, ws->d_sw_items, ws->d_sw_counts,
+                                         ws->d_sw_lane_parts, ws->d_sw_prev_tiles, ws->d_sw_clear, ws->d_sw_counts + 1, ws->stream));
+                HIP_OK(launch_clear_tiles(p.h_stages[0], ws->bufs[AQC_BUF_W], ws->lane_elems, ws->d_sw_clear, ws->d_sw_counts + 1, 2 * ws->batch, ws->stream));
+                ws->sw_items_buf = x_buf;
+                ws->sw_items_version = ws->supp_version[x_buf];
+            }
+        }
+        for (size_t s = 0; s < m; ++s) {
+            Stage3Args a = stage3_args(ws, p, s);
+            if (sparse) {
+                // stage 0: (x, Z) on the listed tiles -> W there; stage 1: (W, checkpoint in ZW) -> the second pair; then in place
+                double2* w2 = m >= 3 ? ws->w2 : nullptr;
+                double2* z2 = m >= 3 ? ws->zw2 : nullptr;
+                a.in0 = s == 0 ? ws->bufs[x_buf] : (s == 1 ? ws->bufs[AQC_BUF_W] : w2);
+                a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : (s == 1 ? ws->bufs[AQC_BUF_ZW] : z2);
+                a.out0 = s == 0 ? ws->bufs[AQC_BUF_W] : w2;
+                a.out1 = s == 0 ? nullptr : z2;
+                a.store_out = s + 1 < m ? (s == 0 ? 1 : 3) : 0;
+                if (s == 0) { a.items = ws->d_sw_items; a.nitems = ws->d_sw_counts; a.max_items = 2 * ws->batch; }
+            } else {
+                a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
+                a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];
+                a.out0 = ws->bufs[AQC_BUF_W];
+                a.out1 = ws->bufs[AQC_BUF_ZW];
+                a.store_out = s + 1 < m ? 3 : 0;
+            }
             a.rpart = p.d_rpart;
-            a.ntiles = p.ntiles;
-            a.batch = ws->batch;
             a.chunk = sweep3_chunk(p.ntiles, ws->batch, p.k);
             a.nparts = sweep3_nparts(p.ntiles, ws->batch, p.k);
-            a.store_out = s + 1 < p.h_stages.size() ? 1 : 0;
             if (a.stage.nsubs > 0) stage3_first_offsets(a, p.h_subs3[a.stage.sub_begin]);
-#ifdef AQC_TUNING   // AQC_STAMPS=1: mean cycles per phase of the sweep workgroups of this launch, on stderr
-            static unsigned long long* d_stamps = nullptr;
+#ifdef AQC_TUNING
             const size_t nwg = (size_t)p.ntiles * ws->batch;
-            const bool stamps = env_int("AQC_STAMPS", 0) != 0;
             a.debug = env_int("AQC_DEBUG_SKIP", 0);
-            if (stamps) {
-                if (!d_stamps) HIP_OK(hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 65536 * kStampSlots));
-                if (nwg <= 65536) { HIP_OK(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * nwg * kStampSlots, ws->stream)); a.stamps = d_stamps; }
-            }
+            if (stamps_begin(ws, a, nwg)) return 1;
 #endif
             {
                 ProfScope ps(ws, AQC_K_SWEEP);
                 HIP_OK(launch_sweep3(p.ntiles, ws->batch, p.k, ws->stream, a));
             }
 #ifdef AQC_TUNING
-            if (a.stamps) {
-                std::vector<unsigned long long> h(nwg * kStampSlots);
-                HIP_OK(hipStreamSynchronize(ws->stream));
-                HIP_OK(hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-                const int ns = p.h_stages[s].nsubs;
-                // the 2^12 sweep is persistent: a workgroup's per-sub-stage stamps are those of its LAST item, slot S-4 its end,
-                // slots S-6 / S-5 bracket its last hand-over to a prefetched tile
-                double load = 0, store = 0, total = 0, mf = 0, bar = 0, red = 0, top = 0, turn = 0;
-                size_t live = 0;
-                unsigned long long first_start = ~0ull, last_start = 0, first_end = ~0ull, last_end = 0, wg_min = ~0ull, wg_max = 0;
-                for (size_t w = 0; w < nwg; ++w) {
-                    const unsigned long long* t = h.data() + w * kStampSlots;
-                    if (t[kStampSlots - 4] == 0) continue;   // no workgroup with this index (persistent grid)
-                    ++live;
-                    first_start = std::min(first_start, t[0]); last_start = std::max(last_start, t[0]);
-                    first_end = std::min(first_end, t[kStampSlots - 4]); last_end = std::max(last_end, t[kStampSlots - 4]);
-                    wg_min = std::min(wg_min, t[kStampSlots - 4] - t[0]); wg_max = std::max(wg_max, t[kStampSlots - 4] - t[0]);
-                    load += (double)(t[1] - t[0]);
-                    store += (double)(t[kStampSlots - 1] - t[kStampSlots - 2]);
-                    total += (double)(t[kStampSlots - 4] - t[0]);
-                    if (t[kStampSlots - 5]) turn += (double)(t[kStampSlots - 5] - t[kStampSlots - 6]);
-                    for (int i = 0; i < ns && 5 + 4 * i < kStampSlots - 6; ++i) {
-                        if (i) top += (double)(t[2 + 4 * i] - t[5 + 4 * (i - 1)]);
-                        mf += (double)(t[3 + 4 * i] - t[2 + 4 * i]);
-                        bar += (double)(t[4 + 4 * i] - t[3 + 4 * i]);
-                        red += (double)(t[5 + 4 * i] - t[4 + 4 * i]);
-                    }
-                }
-                const double n = (double)std::max<size_t>(live, 1), items = (double)nwg / n;
-                fprintf(stderr, "aqc_hip stamps: stage %zu (%d sub-stages, %zu workgroups x %.1f items): total %.0f cycles per item = first load %.0f/items + "
-                        "per sub-stage [top %.0f + mfma loop %.0f + scratch/barrier %.0f + reduce %.0f] + store %.0f + hand-over %.0f\n", s, ns, live, items,
-                        total / n / items, load / n, top / n / std::max(ns - 1, 1), mf / n / ns, bar / n / ns, red / n / ns, store / n, turn / n);
-                fprintf(stderr, "aqc_hip stamps: stage %zu workgroup lifetimes (s_memtime ticks): min %llu max %llu; starts spread over %llu, ends over %llu; "
-                        "first start -> last end %llu\n", s, wg_min, wg_max, last_start - first_start, last_end - first_end, last_end - first_start);
-            }
+            if (stamps_sweep(ws, a, s, nwg)) return 1;
 #endif
         }
+        sweep_state_after(ws, sparse, false);
         ProfScope ps(ws, AQC_K_FINALIZE);
         HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
                             ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream,
                             ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads, ws->mirror_grads,
                             ws->gather_rides ? GatherJob{ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->d_small, ws->mirror_small}
                                              : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},
-                            sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k)));
+                            sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k),
+                            sparse ? p.h_stages[0].nsubs : 0, sparse ? ws->d_sw_lane_parts : nullptr));
 #ifdef AQC_TUNING
         if (env_int("AQC_STAMPS", 0) != 0) { HIP_OK(hipStreamSynchronize(ws->stream)); rgrad_print_stamps(nsubs); }
 #endif
@@ -228,6 +345,8 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                                    1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
         return 0;
     }
+    touch_buf(ws, AQC_BUF_W);
+    touch_buf(ws, AQC_BUF_ZW);
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
         StageArgs a;
         memset(&a, 0, sizeof a);
@@ -322,9 +441,13 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     };
     if (thetas) memcpy(pin_th, thetas, sizeof(double) * nth);
     static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
+    // route of the sweep (decided before anything is enqueued: new thetas invalidate the checkpoint, a V^H in this call renews it)
+    const bool sparse = grads && (do_vdag ? sweep_route_sparse(ws, x_buf, true) : (!thetas && sweep_route_sparse(ws, x_buf, false)));
+    if (sparse && sweep_sparse_prepare(ws)) return 1;
     if (thetas && graphs_on && !ws->profile) {
         const std::vector<long long> key = {do_vdag, gathered ? 1 : 0, grads ? 1 : 0, x_buf, block_from, block_to, front_layer,
-                                            (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin};
+                                            (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin,
+                                            sparse ? 1 : 0, (long long)(size_t)ws->d_combo_prev[x_buf]};
         auto it = ws->graphs.find(key);
         if (it == ws->graphs.end()) {
             hipGraph_t graph = nullptr;
@@ -347,6 +470,9 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
         ws->coef_valid = true;
         ws->fwd.u_valid = false;
         ws->inv.u_valid = ws->sweep.u_valid = (do_vdag || grads) && ws->inv.v3 && ws->sweep.v3;
+        ws->ckpt_valid = false;
+        if (do_vdag) apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+        if (grads) sweep_state_after(ws, sparse, true);
         HIP_OK(hipGraphLaunch(it->second, ws->stream));
     } else if (enqueue()) {
         return 1;

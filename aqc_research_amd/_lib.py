@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQC_HIP_LIB", os.path.join(_HERE, "libaqc_hip.so"))
 
 BUF_Y, BUF_Z, BUF_X, BUF_W, BUF_ZW, BUF_X2 = range(6)
-K_APPLY, K_SWEEP, K_COEF, K_FINALIZE, K_MISC = range(5)
+K_APPLY, K_SWEEP, K_COEF, K_FINALIZE, K_MISC, K_SWEEP_LIST, K_APPLY_LIST = range(7)
 ENTANGLERS = {"cx": 0, "cz": 1, "cp": 2}
 
 _P = c_void_p
@@ -102,12 +102,16 @@ SIGNATURES = {
     "aqc_ws_vdot_launch": (c_int, [_P, c_int, c_int]),
     "aqc_ws_vdot_fetch": (c_int, [_P, _D]),
     "aqc_ws_results_async": (c_int, [_P]),
+    "aqc_ws_objective_launch": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "aqc_ws_results_fetch": (c_int, [_P, _D, _D]),
     "aqc_ws_timer_start": (c_int, [_P]),
     "aqc_ws_timer_stop": (c_int, [_P, POINTER(c_float)]),
     "aqc_ws_profile_enable": (c_int, [_P, c_int]),
     "aqc_ws_profile_get": (c_int, [_P, c_int, POINTER(c_int64), POINTER(c_double)]),
     "aqc_ws_profile_reset": (c_int, [_P]),
+    "aqc_ws_profile_log": (c_int, [_P, POINTER(c_int32), _D, c_int, POINTER(c_int)]),
+    "aqc_ws_plan_stage": (c_int, [_P, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "aqc_ws_sparse_counts": (c_int, [_P, POINTER(c_int64)]),
     "aqc_ws_plan_info": (c_int, [_P, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "aqc_ws_kernel_family": (c_int, [_P, c_int]),
     "aqc_ws_plan_substages": (c_int, [_P, c_int]),

@@ -305,6 +305,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     }
     ws->sparse_enabled = env_int("AQC_SPARSE_SWEEP", 1) != 0;
     ws->sparse_min_items = env_int("AQC_SPARSE_MIN_ITEMS", 512);
+    ws->lazy_z_enabled = env_int("AQC_LAZY_Z", 1) != 0;
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
@@ -411,7 +412,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->bufs[b]) (void)hipFree(ws->bufs[b]);
     for (int b = 0; b < AQC_NUM_BUFS; ++b) if (ws->d_combo_prev[b]) (void)hipFree(ws->d_combo_prev[b]);
     for (void* q : {(void*)ws->d_sw_items, (void*)ws->d_sw_clear, (void*)ws->d_sw_counts, (void*)ws->d_sw_lane_parts, (void*)ws->d_sw_prev_tiles,
-                    (void*)ws->w2, (void*)ws->zw2})
+                    (void*)ws->w2, (void*)ws->zw2, (void*)ws->d_vd_items})
         if (q) (void)hipFree(q);
     if (ws->d_sur) (void)hipFree(ws->d_sur);
     if (ws->d_sur_real) (void)hipFree(ws->d_sur_real);
@@ -457,6 +458,7 @@ int aqc_ws_upload(aqc_ws* ws, int buf, const double* src) {
 
 int aqc_ws_upload_lane(aqc_ws* ws, int buf, int lane, const double* src) {
     if (check_buf(ws, buf)) return 1;
+    if (buf == AQC_BUF_Z && ensure_z_full(ws, false)) return 1;
     ws->combo_valid[buf] = false;
     touch_buf(ws, buf);
     if (!src) return fail("null source");
@@ -485,6 +487,8 @@ int aqc_ws_copy_lane(aqc_ws* dst_ws, int dst_buf, int dst_lane, aqc_ws* src_ws, 
     if (dst_ws->device != src_ws->device) return fail("copy_lane: the two workspaces live on different devices");
     if (dst_ws->lane_elems != src_ws->lane_elems) return fail("copy_lane: lane sizes differ");
     if (dst_lane < 0 || dst_lane >= dst_ws->batch || src_lane < 0 || src_lane >= src_ws->batch) return fail("lane out of range");
+    if (src_buf == AQC_BUF_Z && ensure_z_full(src_ws, true)) return 1;
+    if (dst_buf == AQC_BUF_Z && ensure_z_full(dst_ws, false)) return 1;
     HIP_OK(hipSetDevice(dst_ws->device));
     dst_ws->combo_valid[dst_buf] = false;
     touch_buf(dst_ws, dst_buf);
@@ -498,6 +502,7 @@ int aqc_ws_download(aqc_ws* ws, int buf, double* dst) {
     if (check_buf(ws, buf)) return 1;
     if (!dst) return fail("null destination");
     HIP_OK(hipSetDevice(ws->device));
+    if (buf == AQC_BUF_Z && ensure_z_full(ws, true)) return 1;
     return copy_out(ws, dst, ws->bufs[buf], (size_t)ws->batch << ws->ctx->prog.n);
 }
 
@@ -506,6 +511,7 @@ int aqc_ws_download_lane(aqc_ws* ws, int buf, int lane, double* dst) {
     if (!dst) return fail("null destination");
     if (lane < 0 || lane >= ws->batch) return fail("lane out of range");
     HIP_OK(hipSetDevice(ws->device));
+    if (buf == AQC_BUF_Z && ensure_z_full(ws, true)) return 1;
     return copy_out(ws, dst, ws->bufs[buf] + (size_t)lane * ws->lane_elems, (size_t)1 << ws->ctx->prog.n);
 }
 
@@ -605,6 +611,7 @@ int aqc_ws_gather(aqc_ws* ws, int buf, const int64_t* index, int count, double* 
     if (check_buf(ws, buf)) return 1;
     if (!index || !out || count < 1) return fail("invalid gather arguments");
     HIP_OK(hipSetDevice(ws->device));
+    if (buf == AQC_BUF_Z && ensure_z_full(ws, true)) return 1;
     const int64_t dim = (int64_t)1 << ws->ctx->prog.n;
     std::vector<long long> elem(count);
     for (int i = 0; i < count; ++i) {
@@ -628,6 +635,7 @@ int aqc_ws_vdot(aqc_ws* ws, int buf_a, int buf_b, double* out) {
     if (check_buf(ws, buf_a) || check_buf(ws, buf_b)) return 1;
     if (!out) return fail("null output");
     HIP_OK(hipSetDevice(ws->device));
+    if ((buf_a == AQC_BUF_Z || buf_b == AQC_BUF_Z) && ensure_z_full(ws, true)) return 1;
     HIP_OK(hipStreamSynchronize(ws->stream));
     if (ensure_tmp(ws, 0, ws->batch)) return 1;
     {
@@ -688,6 +696,7 @@ int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count) {
     HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     ws->gather_count = count;
+    ++ws->gather_gen;
     return 0;
 }
 
@@ -696,6 +705,8 @@ int aqc_ws_gather_launch(aqc_ws* ws, int buf) {
     if (ws->gather_count < 1) return fail("aqc_ws_gather_setup has not been called");
     HIP_OK(hipSetDevice(ws->device));
     if (results_guard(ws)) return 1;
+    if (buf == AQC_BUF_Z && !ws->z_full && ws->z_gather_gen != ws->gather_gen && ensure_z_full(ws, true)) return 1;   // a partial Z covers the
+                                                                                                                    // set it was computed for
     ProfScope ps(ws, AQC_K_MISC);
     HIP_OK(launch_gather(ws->bufs[buf], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream, ws->mirror_small));
     return 0;
@@ -712,6 +723,7 @@ int aqc_ws_gather_fetch(aqc_ws* ws, double* out) {
 int aqc_ws_vdot_launch(aqc_ws* ws, int buf_a, int buf_b) {
     if (check_buf(ws, buf_a) || check_buf(ws, buf_b)) return 1;
     HIP_OK(hipSetDevice(ws->device));
+    if ((buf_a == AQC_BUF_Z || buf_b == AQC_BUF_Z) && ensure_z_full(ws, true)) return 1;
     if (!ws->d_vdot_out) HIP_OK(hipMalloc((void**)&ws->d_vdot_out, sizeof(double2) * ws->batch));
     if (results_guard(ws)) return 1;
     ProfScope ps(ws, AQC_K_MISC);
@@ -809,6 +821,38 @@ int aqc_ws_profile_get(aqc_ws* ws, int kind, int64_t* launches, double* total_ms
 int aqc_ws_profile_reset(aqc_ws* ws) {
     if (!ws) return fail("null workspace");
     for (int i = 0; i < AQC_NUM_KINDS; ++i) { ws->prof_count[i] = 0; ws->prof_ms[i] = 0.0; }
+    ws->prof_log.clear();
+    return 0;
+}
+
+int aqc_ws_profile_log(aqc_ws* ws, int32_t* kinds, double* ms, int cap, int* count) {
+    if (!ws || !count || cap < 0 || (cap > 0 && (!kinds || !ms))) return fail("invalid argument");
+    *count = (int)ws->prof_log.size();
+    for (int i = 0; i < cap && i < *count; ++i) { kinds[i] = ws->prof_log[i].first; ms[i] = ws->prof_log[i].second; }
+    return 0;
+}
+
+int aqc_ws_plan_stage(aqc_ws* ws, int which, int stage, int* num_subs, int* num_groups, int* bits_out) {
+    if (!ws) return fail("null workspace");
+    const DevPlan& p = which == 0 ? ws->inv : (which == 1 ? ws->sweep : ws->fwd);
+    if (stage < 0 || stage >= (int)p.plan.stages.size()) return fail("stage index out of range");
+    const Stage& st = p.plan.stages[stage];
+    if (num_subs) *num_subs = (int)st.subs.size();
+    if (num_groups) *num_groups = (int)st.ops.size();
+    if (bits_out) for (size_t i = 0; i < st.bits.size(); ++i) bits_out[i] = st.bits[i];
+    return 0;
+}
+
+int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts) {
+    if (!ws || !counts) return fail("null argument");
+    counts[0] = counts[1] = counts[2] = -1;
+    if (!ws->d_sw_counts) return 0;
+    HIP_OK(hipSetDevice(ws->device));
+    int h[4] = {0, 0, 0, 0};
+    HIP_OK(hipStreamSynchronize(ws->stream));
+    HIP_OK(hipMemcpy(h, ws->d_sw_counts, sizeof h, hipMemcpyDeviceToHost));
+    if (ws->sw_lists_built & 1) { counts[0] = h[0]; counts[1] = h[1]; }
+    if (ws->sw_lists_built & 2) counts[2] = h[2];
     return 0;
 }
 

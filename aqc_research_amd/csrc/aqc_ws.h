@@ -177,13 +177,25 @@ struct aqc_ws {
     int* d_sw_counts = nullptr;             // [0] items, [1] tiles to clear
     int* d_sw_lane_parts = nullptr;         // items (= partial-R slots in use) per lane
     int* d_sw_prev_tiles = nullptr;         // [batch][2] tiles of W written by the list in use
+    int sw_lists_built = 0;                 // bit 0: the sweep's list has been built at least once, bit 1: V^H's
     int sw_items_buf = -1;                  // the list in d_sw_items belongs to this lhs buffer ...
     unsigned long long sw_items_version = 0;   // ... at this version of its support
     double2* w2 = nullptr;                  // second scratch pair of the sparse route (plans of >= 3 stages)
     double2* zw2 = nullptr;
+    // "objective" V^H: the last stage of the mirrored V^H runs only over the tiles its readers touch -- the registered gather
+    // indices and the support of the lhs state -- and Z is completed on demand (ensure_z_full) while the checkpoint is valid
+    bool lazy_z_enabled = true;             // AQC_LAZY_Z=0: V^H always writes all of Z
+    bool z_full = true;                     // Z holds V^H y everywhere (false: on the tiles of d_vd_items only)
+    aqc::TileItem* d_vd_items = nullptr;    // [batch][2 + gather_count]
+    size_t vd_items_cap = 0;
+    unsigned long long gather_gen = 0;      // bumped by aqc_ws_gather_setup
+    unsigned long long z_gather_gen = 0;    // what the tiles of a partial Z were chosen for: the gather set ...
+    int z_x_buf = -1;                       // ... and the support of this lhs buffer at this version
+    unsigned long long z_x_version = 0;
     bool profile = false;
-    int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
-    double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0};
+    int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0, 0, 0};
+    double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<std::pair<int, float>> prof_log;   // (kind, ms) of every profiled launch, in order (bounded)
 };
 
 namespace aqc {
@@ -201,6 +213,7 @@ struct ProfScope {  // brackets one launch with events when profiling is on
             hipEventElapsedTime(&ms, ws->pev0, ws->pev1) == hipSuccess) {
             ws->prof_count[kind] += 1;
             ws->prof_ms[kind] += ms;
+            if (ws->prof_log.size() < 100000) ws->prof_log.emplace_back(kind, ms);
         }
     }
 };
@@ -215,7 +228,12 @@ int copy_in(aqc_ws* ws, double2* dst, const double* src, size_t rows);
 int copy_out(aqc_ws* ws, double* dst, const double2* src, size_t rows);
 int results_guard(aqc_ws* ws);
 // aqc_ws_sweep.cpp
-void touch_buf(aqc_ws* ws, int buf);   // somebody other than the V^H / sweep pair writes the buffer
+void touch_buf(aqc_ws* ws, int buf);   // somebody other than the V^H / sweep pair is about to write the whole buffer
+int ensure_z_full(aqc_ws* ws, bool reader);   // before anybody reads Z (or writes a part of it): complete a partial V^H y
+bool vdag_route_restricted(const aqc_ws* ws, int x_buf);
+int run_vdag_restricted(aqc_ws* ws, int x_buf);
+void vdag_restricted_state_after(aqc_ws* ws, int x_buf);
+int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer, bool support_in_gather_set);
 bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag);
 int sweep_sparse_prepare(aqc_ws* ws);
 void apply_state_after(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);

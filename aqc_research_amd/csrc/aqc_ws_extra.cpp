@@ -317,6 +317,7 @@ int aqc_ws_mps_to_vec(aqc_ws* ws, int slot, int buf, int lane) {
     }
     // n == 1: the state is the site tensor itself, [b][1][1]
     ws->combo_valid[buf] = false;
+    if (buf == AQC_BUF_Z && ensure_z_full(ws, false)) return 1;
     touch_buf(ws, buf);
     ProfScope ps(ws, AQC_K_MISC);
     HIP_OK(hipMemcpyAsync(ws->bufs[buf] + (size_t)lane * ws->lane_elems, ws->mps[slot].d_t, sizeof(double2) * 2, hipMemcpyDeviceToDevice, ws->stream));
@@ -371,6 +372,7 @@ static int mps_to_vec_batch_uniform(aqc_ws* ws, int count, const int32_t* slots,
     const std::vector<int>& dims = ws->mps[slots[0]].dims;
     const std::vector<size_t>& off = ws->mps[slots[0]].offset;
     ws->combo_valid[buf] = false;
+    if (buf == AQC_BUF_Z && ensure_z_full(ws, false)) return 1;   // (lanes of Z are rewritten, not all of it)
     touch_buf(ws, buf);
     std::vector<const void*> tabs;
     auto table = [&](auto fn) { const size_t at = tabs.size(); for (int i = 0; i < count; ++i) tabs.push_back(fn(i)); return at; };

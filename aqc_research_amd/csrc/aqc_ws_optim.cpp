@@ -95,11 +95,14 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
     auto evaluate = [&](int update, double* f_o, double* g_o, double2* raw_hs, double2* raw_g) -> int {
         ws->d_thetas = ws->d_thetas_own;
         if (run_coef(ws)) return 1;
-        if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        const bool sparse = sweep_route_sparse(ws, AQC_BUF_X2, true);
+        if (sparse && sweep_sparse_prepare(ws)) return 1;
+        if (sparse && vdag_route_restricted(ws, AQC_BUF_X2)) { if (run_vdag_restricted(ws, AQC_BUF_X2)) return 1; }   // V^H where the gather and
+        else if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;                                                   // the sweep read it
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         HIP_OK(lb_prepare(L, ws->d_small, update, f_o, raw_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
         ++ws->supp_version[AQC_BUF_X2];   // (the leading flip state is chosen on the device: the support may have moved)
-        if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
+        if (grad_from_impl(ws, AQC_BUF_X2, block_from, block_to, front_layer, true)) return 1;
         HIP_OK(lb_take(L, ws->d_grads, g_o, raw_g, st_));
         ++nfev;
         return 0;
@@ -221,6 +224,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
     }
     const bool sparse = sweep_route_sparse(ws, AQC_BUF_X2, true);   // (decided here: part of the captured graph's key)
     if (sparse && sweep_sparse_prepare(ws)) return 1;
+    const bool lazy = sparse && vdag_route_restricted(ws, AQC_BUF_X2);
     const bool real_only = !zero_copy && !grads_out;
     if (real_only && ws->sur_real_cap < nth) {
         HIP_OK(hipStreamSynchronize(st));
@@ -237,7 +241,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         if (!direct_thetas) HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
         if (run_coef(ws)) return 1;
         ws->theta_host = direct_thetas ? pin_th : nullptr;   // the U builder reads the pinned thetas and stores them to HBM
-        if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        if (lazy ? run_vdag_restricted(ws, AQC_BUF_X2) : run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         {
             ProfScope ps(ws, AQC_K_MISC);
@@ -246,7 +250,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
             ++ws->supp_version[AQC_BUF_X2];
         }
         // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
-        if (aqc_ws_grad_from(ws, AQC_BUF_X2, block_from, block_to, front_layer)) return 1;
+        if (grad_from_impl(ws, AQC_BUF_X2, block_from, block_to, front_layer, true)) return 1;
         ws->theta_host = nullptr;
         if (!zero_copy) {
             if (real_only) {   // the surrogate's gradient is the real part: half the bytes over the bus, no pass over them on the host
@@ -264,7 +268,8 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         const std::vector<long long> key = {1000 + update_state + (zero_copy ? 10 : 0) + (real_only ? 20 : 0), block_from, block_to, front_layer,
                                             (long long)S, (long long)(size_t)ws->d_sur_real,
                                             (long long)(size_t)ws->d_sur, (long long)(size_t)ws->h_sur, (long long)(size_t)ws->h_pin,
-                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2], sparse ? 1 : 0};
+                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2], (sparse ? 1 : 0) + (lazy ? 2 : 0),
+                                            (long long)(size_t)ws->d_vd_items};
         auto it = ws->graphs.find(key);
         if (it == ws->graphs.end()) {
             hipGraph_t graph = nullptr;
@@ -288,7 +293,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         ws->fwd.u_valid = false;
         ws->inv.u_valid = ws->sweep.u_valid = ws->inv.v3 && ws->sweep.v3;
         ws->ckpt_valid = false;
-        apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+        if (lazy) vdag_restricted_state_after(ws, AQC_BUF_X2); else apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
         ++ws->supp_version[AQC_BUF_X2];
         sweep_state_after(ws, sparse, true);
         HIP_OK(hipGraphLaunch(it->second, st));

@@ -53,9 +53,11 @@ int run_coef(aqc_ws* ws) {
     return 0;
 }
 
-// somebody other than the V^H / sweep pair below writes buffer `buf`
+// somebody other than the V^H / sweep pair below is about to write ALL of buffer `buf`
 void touch_buf(aqc_ws* ws, int buf) {
+    if (buf == AQC_BUF_ZW && !ws->z_full) (void)ensure_z_full(ws, false);   // the checkpoint goes away: complete Z while it is there
     if (buf == AQC_BUF_Z || buf == AQC_BUF_ZW) ws->ckpt_valid = false;
+    if (buf == AQC_BUF_Z) ws->z_full = true;
     if (buf == AQC_BUF_W) ws->w_clean = false;
 }
 
@@ -153,6 +155,7 @@ void apply_state_after(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {   /
 int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
     DevPlan& p = inverse ? ws->inv : ws->fwd;
     const Program& prog = ws->ctx->prog;
+    if (src_buf == AQC_BUF_Z && ensure_z_full(ws, true)) return 1;
     if (p.v3) {
         if (ensure_umat(ws, p)) return 1;
         const bool keep = keeps_checkpoint(ws, inverse, src_buf, dst_buf);
@@ -198,6 +201,74 @@ int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf) {
     return 0;
 }
 
+// ---- V^H where the objective reads it ------------------------------------------------------------------------------
+// An objective+gradient evaluation reads Z = V^H y in two places: the amplitudes <state_i|V^H y> of the registered gather set
+// (objective_lhs_sur_max.py:99-106) and -- sparse route -- the first-stage tiles of the sweep that hold the lhs state.  The
+// last stage of the mirrored V^H therefore runs over those tiles only (at the headline 5 of 16 per lane: the tile of |0> and
+// of its four flips on qubits 12..15); everything before it is needed in full (it is the second sweep stage's z).  Z is
+// completed on demand -- the checkpoint in ZW is all it takes -- as long as the thetas have not changed.
+bool vdag_route_restricted(const aqc_ws* ws, int x_buf) {
+    return ws->lazy_z_enabled && sweep_route_sparse(ws, x_buf, true) && 2 + ws->gather_count <= kMaxTileCands;
+}
+static Stage3Args last_vdag_stage(aqc_ws* ws) {
+    DevPlan& p = ws->inv;
+    Stage3Args a = stage3_args(ws, p, p.h_stages.size() - 1);
+    a.in0 = ws->bufs[AQC_BUF_ZW];
+    a.out0 = ws->bufs[AQC_BUF_Z];
+    return a;
+}
+int run_vdag_restricted(aqc_ws* ws, int x_buf) {   // Y -> Z; the caller has asked vdag_route_restricted and sweep_sparse_prepare
+    DevPlan& p = ws->inv;
+    if (ensure_umat(ws, p)) return 1;
+    const size_t m = p.h_stages.size();
+    const size_t per_lane = 2 + (size_t)ws->gather_count;
+    if (!ws->d_vd_items || ws->vd_items_cap < per_lane * ws->batch) return fail("objective V^H inside a captured graph without its preparation");
+    for (size_t s = 0; s + 1 < m; ++s) {
+        Stage3Args a = stage3_args(ws, p, s);
+        a.in0 = s == 0 ? ws->bufs[AQC_BUF_Y] : ws->bufs[AQC_BUF_ZW];
+        a.out0 = ws->bufs[AQC_BUF_ZW];
+        ProfScope ps(ws, AQC_K_APPLY);
+        HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+    }
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_tile_items(p.h_stages[m - 1], ws->d_combo_prev[x_buf], 2, ws->gather_count > 0 ? ws->d_index : nullptr, ws->gather_count,
+                                 ws->batch, ws->d_vd_items, ws->d_sw_counts + 2, nullptr, nullptr, nullptr, nullptr, ws->stream));
+    }
+    Stage3Args a = last_vdag_stage(ws);
+    a.items = ws->d_vd_items;
+    a.nitems = ws->d_sw_counts + 2;
+    a.max_items = (int)(per_lane * ws->batch);
+    ws->sw_lists_built |= 2;
+    {
+        ProfScope ps(ws, AQC_K_APPLY_LIST);
+        HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+    }
+    vdag_restricted_state_after(ws, x_buf);
+    return 0;
+}
+void vdag_restricted_state_after(aqc_ws* ws, int x_buf) {
+    apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+    ws->z_full = false;
+    ws->z_gather_gen = ws->gather_gen;
+    ws->z_x_buf = x_buf;
+    ws->z_x_version = ws->supp_version[x_buf];
+}
+int ensure_z_full(aqc_ws* ws, bool reader) {
+    if (ws->z_full) return 0;
+    if (ws->capturing) return fail("BUF_Z is partial inside a captured graph");
+    if (ws->ckpt_valid && ws->inv.u_valid) {   // the last stage once more, over every tile (its inputs are all in ZW)
+        Stage3Args a = last_vdag_stage(ws);
+        ProfScope ps(ws, AQC_K_APPLY);
+        HIP_OK(launch_apply3(ws->inv.ntiles, ws->batch, ws->inv.k, ws->stream, a));
+        ws->z_full = true;
+        return 0;
+    }
+    if (!reader) { ws->z_full = true; return 0; }   // a writer of parts of Z takes the buffer over
+    return fail("BUF_Z holds V^H y only on the tiles the last one-call evaluation read, and the thetas (or ZW) have changed since: "
+                "run aqc_ws_apply(inverse) for the whole vector");
+}
+
 void drop_graphs(aqc_ws* ws) {
     for (auto& kv : ws->graphs) (void)hipGraphExecDestroy(kv.second);
     ws->graphs.clear();
@@ -221,6 +292,7 @@ int sweep_sparse_prepare(aqc_ws* ws) {
         HIP_OK(hipMalloc((void**)&ws->d_sw_items, sizeof(TileItem) * 2 * B));
         HIP_OK(hipMalloc((void**)&ws->d_sw_clear, sizeof(TileItem) * 2 * B));
         HIP_OK(hipMalloc((void**)&ws->d_sw_counts, sizeof(int) * 4));
+        HIP_OK(hipMemsetAsync(ws->d_sw_counts, 0, sizeof(int) * 4, ws->stream));
         HIP_OK(hipMalloc((void**)&ws->d_sw_lane_parts, sizeof(int) * B));
         HIP_OK(hipMalloc((void**)&ws->d_sw_prev_tiles, sizeof(int) * 2 * B));
         ws->w_clean = false;
@@ -228,6 +300,14 @@ int sweep_sparse_prepare(aqc_ws* ws) {
     if (p.h_stages.size() >= 3 && !ws->w2) {   // stages from the second one on work on their own pair: W stays zero outside the listed
         HIP_OK(hipMalloc((void**)&ws->w2, sizeof(double2) * (size_t)B * ws->lane_elems));   // tiles, ZW keeps the checkpoint
         HIP_OK(hipMalloc((void**)&ws->zw2, sizeof(double2) * (size_t)B * ws->lane_elems));
+    }
+    const size_t vd_need = (2 + (size_t)ws->gather_count) * B;
+    if (ws->lazy_z_enabled && ws->vd_items_cap < vd_need) {
+        HIP_OK(hipStreamSynchronize(ws->stream));
+        if (ws->d_vd_items) HIP_OK(hipFree(ws->d_vd_items));
+        ws->d_vd_items = nullptr; ws->vd_items_cap = 0;
+        HIP_OK(hipMalloc((void**)&ws->d_vd_items, sizeof(TileItem) * vd_need));
+        ws->vd_items_cap = vd_need;
     }
     if (!ws->w_clean) {
         HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_W], 0, sizeof(double2) * (size_t)B * ws->lane_elems, ws->stream));
@@ -263,6 +343,15 @@ int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
 }
 
 int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer) {
+    return grad_from_impl(ws, x_buf, block_from, block_to, front_layer, false);
+}
+
+}  // extern "C"
+
+namespace aqc {
+
+// support_in_gather_set: the lhs state was chosen on the device among the registered gather indices (surrogate objective)
+int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer, bool support_in_gather_set) {
     if (check_buf(ws, x_buf)) return 1;
     if (results_guard(ws)) return 1;
     if (x_buf == AQC_BUF_W || x_buf == AQC_BUF_ZW || x_buf == AQC_BUF_Z) return fail("lhs buffer must not be Z, W or ZW");
@@ -278,6 +367,11 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
         const int nsubs = (int)p.h_subs3.size();
         const size_t m = p.h_stages.size();
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
+        // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
+        // state was picked from); anything else reads all of Z
+        if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||
+                                        (ws->z_x_buf == x_buf && ws->z_x_version == ws->supp_version[x_buf]))) && ensure_z_full(ws, true))
+            return 1;
         if (sparse) {
             if (!ws->capturing && sweep_sparse_prepare(ws)) return 1;
             if (!ws->d_sw_items || !ws->w_clean || (m >= 3 && !ws->w2)) return fail("sparse sweep inside a captured graph without its preparation");
@@ -290,6 +384,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                 HIP_OK(launch_clear_tiles(p.h_stages[0], ws->bufs[AQC_BUF_W], ws->lane_elems, ws->d_sw_clear, ws->d_sw_counts + 1, 2 * ws->batch, ws->stream));
                 ws->sw_items_buf = x_buf;
                 ws->sw_items_version = ws->supp_version[x_buf];
+                ws->sw_lists_built |= 1;
             }
         }
         for (size_t s = 0; s < m; ++s) {
@@ -321,7 +416,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
             if (stamps_begin(ws, a, nwg)) return 1;
 #endif
             {
-                ProfScope ps(ws, AQC_K_SWEEP);
+                ProfScope ps(ws, a.items ? AQC_K_SWEEP_LIST : AQC_K_SWEEP);
                 HIP_OK(launch_sweep3(p.ntiles, ws->batch, p.k, ws->stream, a));
             }
 #ifdef AQC_TUNING
@@ -345,6 +440,7 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
                                    1, prog.n, prog.tpb, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->mirror_grads));
         return 0;
     }
+    if (ensure_z_full(ws, true)) return 1;
     touch_buf(ws, AQC_BUF_W);
     touch_buf(ws, AQC_BUF_ZW);
     for (size_t s = 0; s < p.h_stages.size(); ++s) {
@@ -380,6 +476,27 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
     return 0;
 }
 
+}  // namespace aqc
+
+extern "C" {
+
+// Z = V^H Y where the objective reads it, the registered gather (if any), the sweep from x_buf: enqueued, not waited for.
+// What a driver that keeps its thetas on the device (aqc_ws_use_theta_set) calls per evaluation, followed by
+// aqc_ws_results_async.  Equivalent to aqc_ws_apply(1, Y, Z); aqc_ws_gather_launch(Z); aqc_ws_grad_from(x_buf, ...), except that
+// Z may be left partial (completed on demand, see ensure_z_full).
+int aqc_ws_objective_launch(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer) {
+    if (check_buf(ws, x_buf)) return 1;
+    if (x_buf == AQC_BUF_W || x_buf == AQC_BUF_ZW || x_buf == AQC_BUF_Z || x_buf == AQC_BUF_Y) return fail("lhs buffer must be X or X2");
+    if (ensure_coef(ws)) return 1;
+    HIP_OK(hipSetDevice(ws->device));
+    const bool sparse = sweep_route_sparse(ws, x_buf, true);
+    if (sparse && sweep_sparse_prepare(ws)) return 1;
+    if (sparse && vdag_route_restricted(ws, x_buf)) { if (run_vdag_restricted(ws, x_buf)) return 1; }
+    else if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+    if (ws->gather_count > 0 && aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+    return grad_from_impl(ws, x_buf, block_from, block_to, front_layer, false);
+}
+
 int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered, int x_buf, int block_from, int block_to,
                 int front_layer, double* grads) {
     if (!ws) return fail("null workspace");
@@ -411,6 +528,10 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
             w->mirror_grads = nullptr; w->mirror_small = nullptr; w->theta_host = nullptr; w->gather_rides = false;
         }
     } mirror_scope(ws, zero_copy ? pin_gr : nullptr, zero_copy ? pin_sm : nullptr);
+    // route of the sweep (decided before anything is enqueued: new thetas invalidate the checkpoint, a V^H in this call renews it)
+    const bool sparse = grads && (do_vdag ? sweep_route_sparse(ws, x_buf, true) : (!thetas && sweep_route_sparse(ws, x_buf, false)));
+    if (sparse && sweep_sparse_prepare(ws)) return 1;
+    const bool lazy = sparse && do_vdag && vdag_route_restricted(ws, x_buf);   // V^H only where this call (gather, sweep) reads it
     auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
         if (thetas) {
             ws->d_thetas = ws->d_thetas_own;
@@ -422,7 +543,7 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
             if (run_coef(ws)) return 1;
             ws->theta_host = direct_thetas ? pin_th : nullptr;
         }
-        if (do_vdag && run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        if (do_vdag && (lazy ? run_vdag_restricted(ws, x_buf) : run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z))) return 1;
         // with a gradient in the same call the gather (it only reads Z, which the sweep leaves intact) rides along as one
         // extra workgroup per lane of the gradient-walk kernel: one node less on the single-evaluation critical path
         const bool ride = gathered && grads && zero_copy && ws->sweep.v3;
@@ -441,13 +562,11 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     };
     if (thetas) memcpy(pin_th, thetas, sizeof(double) * nth);
     static const bool graphs_on = env_int("AQC_GRAPH", 1) != 0;
-    // route of the sweep (decided before anything is enqueued: new thetas invalidate the checkpoint, a V^H in this call renews it)
-    const bool sparse = grads && (do_vdag ? sweep_route_sparse(ws, x_buf, true) : (!thetas && sweep_route_sparse(ws, x_buf, false)));
-    if (sparse && sweep_sparse_prepare(ws)) return 1;
     if (thetas && graphs_on && !ws->profile) {
         const std::vector<long long> key = {do_vdag, gathered ? 1 : 0, grads ? 1 : 0, x_buf, block_from, block_to, front_layer,
                                             (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin,
-                                            sparse ? 1 : 0, (long long)(size_t)ws->d_combo_prev[x_buf]};
+                                            (sparse ? 1 : 0) + (lazy ? 2 : 0), (long long)(size_t)ws->d_combo_prev[x_buf],
+                                            (long long)(size_t)ws->d_vd_items};
         auto it = ws->graphs.find(key);
         if (it == ws->graphs.end()) {
             hipGraph_t graph = nullptr;
@@ -471,7 +590,7 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
         ws->fwd.u_valid = false;
         ws->inv.u_valid = ws->sweep.u_valid = (do_vdag || grads) && ws->inv.v3 && ws->sweep.v3;
         ws->ckpt_valid = false;
-        if (do_vdag) apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+        if (do_vdag) { if (lazy) vdag_restricted_state_after(ws, x_buf); else apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z); }
         if (grads) sweep_state_after(ws, sparse, true);
         HIP_OK(hipGraphLaunch(it->second, ws->stream));
     } else if (enqueue()) {

@@ -295,6 +295,12 @@ class Workspace:
         check(self._L.aqc_ws_vdot_fetch(self.handle, dptr(out)))
         return out
 
+    def objective_launch(self, x_buf: int = BUF_X, block_range: Optional[Tuple[int, int]] = None, front_layer: bool = True) -> None:
+        """Z = V^H Y (where the evaluation reads it), the registered gather, the sweep from ``x_buf``: enqueued, not waited for."""
+        self._touch(BUF_Z, BUF_W, BUF_ZW)
+        lo, hi = (-1, -1) if block_range is None else (int(block_range[0]), int(block_range[1]))
+        check(self._L.aqc_ws_objective_launch(self.handle, x_buf, lo, hi, int(bool(front_layer))))
+
     def results_async(self) -> None:
         """Enqueue the copies of this evaluation's gradients and gathered amplitudes (or <A|B>) into pinned host memory."""
         check(self._L.aqc_ws_results_async(self.handle))
@@ -327,6 +333,28 @@ class Workspace:
         n, ms = c_int64(), c_double()
         check(self._L.aqc_ws_profile_get(self.handle, kind, byref(n), byref(ms)))
         return int(n.value), float(ms.value)
+
+    def profile_log(self) -> list:
+        """(kind, ms) of every launch profiled since profile(True), in launch order."""
+        n = c_int()
+        check(self._L.aqc_ws_profile_log(self.handle, None, None, 0, byref(n)))
+        kinds = np.zeros(max(n.value, 1), dtype=np.int32)
+        ms = np.zeros(max(n.value, 1), dtype=np.float64)
+        check(self._L.aqc_ws_profile_log(self.handle, kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), dptr(ms), n.value, byref(n)))
+        return [(int(kinds[i]), float(ms[i])) for i in range(n.value)]
+
+    def plan_stage(self, which: int, stage: int) -> Tuple[int, int, list]:
+        """(sub-stages, gate groups, local address bits) of one stage of plan ``which`` as this workspace runs it."""
+        a, b = c_int(), c_int()
+        bits = (c_int * 32)()
+        check(self._L.aqc_ws_plan_stage(self.handle, which, stage, byref(a), byref(b), bits))
+        return a.value, b.value, list(bits[: self.plan_info(which)[1]])
+
+    def sparse_counts(self) -> Tuple[int, int, int]:
+        """Items of the last sparse evaluation: (sweep first stage, tiles cleared in W, V^H last stage); -1 = never built."""
+        c = (c_int64 * 3)()
+        check(self._L.aqc_ws_sparse_counts(self.handle, c))
+        return int(c[0]), int(c[1]), int(c[2])
 
     def plan_info(self, which: int) -> Tuple[int, int, int]:
         a, b, c = c_int(), c_int(), c_int()

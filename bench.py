@@ -739,6 +739,55 @@ def rank_echo(args):
     dist.destroy_process_group()
 
 
+def stage_launch_table(ws, prof_log, prof_steps, N, B):
+    """Per stage launch of one step (matrix-core path): kernel, plan stage, sub-stages, share of the tiles it ran over, average
+    duration (HIP events around every launch of `prof_steps` steps), EXECUTED MFMA flops (288 per amplitude and sub-stage for
+    the sweep: 9 real 16x16x16 products per 256 amplitudes; 96 for V^H) and their rate.  None off the matrix-core path."""
+    from aqc_research_amd._lib import K_APPLY, K_APPLY_LIST, K_SWEEP, K_SWEEP_LIST
+
+    if ws.kernel_family(1) != 3 or ws.kernel_family(0) != 3 or not prof_log or len(prof_log) % prof_steps:
+        return None
+    per = len(prof_log) // prof_steps
+    kinds = [k for k, _ in prof_log[:per]]
+    if any([k for k, _ in prof_log[i * per:(i + 1) * per]] != kinds for i in range(prof_steps)):
+        return None
+    avg = [sum(prof_log[i * per + j][1] for i in range(prof_steps)) / prof_steps for j in range(per)]
+    sw_items, _, vd_items = ws.sparse_counts()
+    rows, at = [], {0: 0, 1: 0}
+    for j, k in enumerate(kinds):
+        if k not in (K_APPLY, K_APPLY_LIST, K_SWEEP, K_SWEEP_LIST):
+            continue
+        which = 1 if k in (K_SWEEP, K_SWEEP_LIST) else 0
+        stages, tile_bits, ntiles = ws.plan_info(which)
+        st = at[which]
+        at[which] += 1
+        if st >= stages:
+            return None
+        nsub = ws.plan_stage(which, st)[0]
+        frac = 1.0
+        if k == K_SWEEP_LIST:
+            frac = sw_items / float(ntiles * B)
+        elif k == K_APPLY_LIST:
+            frac = vd_items / float(ntiles * B)
+        flops = (288.0 if which else 96.0) * N * B * frac * nsub
+        rows.append({"kernel": ("sweep_mfma_kernel" if which else "apply_mfma_kernel") + f"<{tile_bits}{', tile list' if frac < 1 or k in (K_SWEEP_LIST, K_APPLY_LIST) else ''}>",
+                     "plan": "sweep" if which else "V^H", "stage": st, "substages": nsub, "tiles_frac": frac, "avg_ms": avg[j],
+                     "flops": flops, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
+                     "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0})
+    if not rows:
+        return None
+    executed = sum(r["flops"] for r in rows)
+    dense = (288.0 * ws.plan_substages(1) + 96.0 * ws.plan_substages(0)) * N * B
+    stage_ms = sum(r["avg_ms"] for r in rows)
+    return {"launches": rows, "executed_flops_per_step": executed, "dense_route_flops_per_step": dense,
+            "zero_products_avoided_frac": 1.0 - executed / dense, "stage_launch_ms_per_step": stage_ms,
+            "all_launch_ms_per_step": sum(avg),
+            "stage_launches_frac_of_peak": executed / (stage_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if stage_ms > 0 else 0.0,
+            "note": "dense_route_flops = every stage over every tile (the sweep from a dense lhs state and a full V^H); the sparse-lhs "
+                    "route runs the sweep's first stage over the tiles that hold the lhs basis states and V^H's last stage over the "
+                    "tiles the evaluation reads -- products with exact zeros and amplitudes nobody reads are not executed"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -881,6 +930,7 @@ def measure(workload, args, env, full):
     the short configuration runs of the default line leave them out and use --config-steps steps."""
     comm, comm_note, rank, world, local_rank, n_gpus, ranks_seen = (env.comm, env.comm_note, env.rank, env.world, env.local_rank,
                                                                      env.n_gpus, env.ranks_seen)
+    from aqc_research_amd._lib import K_APPLY_LIST, K_SWEEP_LIST
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, HipContext, Workspace
     from oracle import aqc_oracle as orc
 
@@ -954,12 +1004,17 @@ def measure(workload, args, env, full):
         if mps_targets is not None:   # QiskitMPS operands arrive as host tuples on every evaluation (mps_dot_objective.py:41)
             ws.mps_to_vec_batch(zero_list, BUF_X)
             ws.mps_to_vec_batch(mps_targets[i % len(mps_targets)], BUF_Y)
-        ws.apply(True, BUF_Y, BUF_Z)
-        if ncols == 1:
-            ws.gather_launch(BUF_Z)       # hs = <state_i|V^H|target>
+        if ncols == 1 and mps_targets is None:
+            # Z = V^H Y where the evaluation reads it, hs = <state_i|V^H|target> for the registered flip states, the sweep from x:
+            # one enqueue (the same launches as apply + gather_launch + grad, which the other branches spell out)
+            ws.objective_launch(BUF_X, None, True)
         else:
-            ws.vdot_launch(BUF_X, BUF_Z)  # <X|V^H Y>  (sk_core.py:192)
-        ws.grad(None, True)
+            ws.apply(True, BUF_Y, BUF_Z)
+            if ncols == 1:
+                ws.gather_launch(BUF_Z)       # hs = <state_i|V^H|target>
+            else:
+                ws.vdot_launch(BUF_X, BUF_Z)  # <X|V^H Y>  (sk_core.py:192)
+            ws.grad(None, True)
         ws.results_async()   # gradients + amplitudes of THIS step -> pinned host memory (what an optimizer reads every evaluation)
 
     def barrier():
@@ -1067,9 +1122,12 @@ def measure(workload, args, env, full):
         for i in range(W, W + prof_steps):
             step(i)
         ws.sync()
-        kinds = {"apply": K_APPLY, "sweep": K_SWEEP, "coef": K_COEF, "finalize": K_FINALIZE, "misc": K_MISC}
+        kinds = {"apply": K_APPLY, "sweep": K_SWEEP, "coef": K_COEF, "finalize": K_FINALIZE, "misc": K_MISC,
+                 "sweep_tile_list": K_SWEEP_LIST, "apply_tile_list": K_APPLY_LIST}
         prof = {k: ws.profile_get(v) for k, v in kinds.items()}
+        prof_log = ws.profile_log()
         ws.profile(False)
+        stage_launches = stage_launch_table(ws, prof_log, prof_steps, N, B)
         sweep_launches, sweep_ms = prof["sweep"]
         apply_launches, apply_ms = prof["apply"]
         # algorithmic bytes: one gate group = read+write of each live vector
@@ -1088,6 +1146,10 @@ def measure(workload, args, env, full):
             mfma_tflops = 288.0 * N * B * ws.plan_substages(1) * prof_steps / (sweep_ms * 1e-3) / 1e12
         exec_tflops = mfma_tflops if mfma_tflops is not None else sweep_tflops
         exec_flops_per_launch = (288.0 * N * B * ws.plan_substages(1) * prof_steps / max(sweep_launches, 1)) if mfma_tflops is not None else sweep_flops_per_launch
+        dominant = None
+        if stage_launches:   # matrix-core path: every stage launch on its own (a sweep over a tile list is a different launch from a dense one)
+            dominant = max(stage_launches["launches"], key=lambda r: r["avg_ms"])
+            exec_tflops, exec_flops_per_launch, sweep_avg_ms = dominant["TFLOPs"], dominant["flops"], dominant["avg_ms"]
         stages_inv, k_inv, tiles_inv = ws.plan_info(0)
         stages_sw, k_sw, tiles_sw = ws.plan_info(1)
 
@@ -1195,7 +1257,11 @@ def measure(workload, args, env, full):
             # `algorithmic_*`; it is NOT a bound for a kernel that fuses whole gate groups into one 16 x 16 unitary.
             "roofline": {
                 "bound": "mfma",
-                "kernel": ws.sweep_kernel_name(),
+                "kernel": dominant["kernel"] if dominant else ws.sweep_kernel_name(),
+                "launch": None if not dominant else f"{dominant['plan']} stage {dominant['stage']} ({dominant['substages']} sub-stages, "
+                                                     f"{dominant['tiles_frac']:.4g} of the tiles)",
+                "step": None if not stage_launches else {k: v for k, v in stage_launches.items() if k != "launches"},
+                "launches": None if not stage_launches else stage_launches["launches"],
                 "achieved": exec_tflops,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

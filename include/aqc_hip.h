@@ -36,10 +36,17 @@ typedef struct aqc_ctx aqc_ctx; /* ansatz description + gate program (host only)
 typedef struct aqc_ws aqc_ws;   /* device-resident batch workspace            */
 
 enum { AQC_CX = 0, AQC_CZ = 1, AQC_CP = 2 };
-/* device buffers of a workspace, each [batch][2^n][ncols] complex128 */
+/* device buffers of a workspace, each [batch][2^n][ncols] complex128: Y target, Z = V^H Y, X / X2 lhs states of the sweep,
+ * W / ZW scratch of the sweep.  ZW doubles as the checkpoint of V^H: aqc_ws_apply(inverse, Y -> Z) leaves there the state before
+ * its last stage, which is what the sweep's second stage takes as z when the lhs state is sparse (aqc_ws_set_basis /
+ * aqc_ws_set_combo; grad_of_dot_product, core_operations.py:892-935, copies x into w: a one-hot x leaves w zero outside one tile
+ * during the first stage).  One-call evaluations (aqc_ws_eval, aqc_ws_objective_launch, aqc_ws_surrogate_eval, aqc_ws_lbfgs) may
+ * leave Z computed only on the tiles they read; any reader of AQC_BUF_Z through this interface completes it first. */
 enum { AQC_BUF_Y = 0, AQC_BUF_Z = 1, AQC_BUF_X = 2, AQC_BUF_W = 3, AQC_BUF_ZW = 4, AQC_BUF_X2 = 5, AQC_NUM_BUFS = 6 };
 /* kernel families for aqc_ws_profile_get */
-enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC_K_MISC = 4, AQC_NUM_KINDS = 5 };
+enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC_K_MISC = 4,
+       AQC_K_SWEEP_LIST = 5, AQC_K_APPLY_LIST = 6,   /* stage launches over a subset of the tiles (sparse lhs state / objective V^H) */
+       AQC_NUM_KINDS = 7 };
 
 const char* aqc_version(void);
 const char* aqc_last_error(void);
@@ -139,6 +146,10 @@ int aqc_ws_vdot_fetch(aqc_ws* ws, double* out /* [batch] c128 */);
  * after aqc_ws_vdot_launch) into pinned host memory behind the kernels already on the stream, without synchronising;
  * aqc_ws_results_fetch waits for the stream and hands them out (either pointer may be NULL). */
 int aqc_ws_results_async(aqc_ws* ws);
+/* one evaluation of an objective with the thetas in use, enqueued and not waited for: Z = V^H Y (where the evaluation reads it),
+ * the amplitudes registered with aqc_ws_gather_setup (if any; objective_lhs_sur_max.py:99-106), the sweep from x_buf
+ * (:147-175).  Same results as aqc_ws_apply(1, Y, Z); aqc_ws_gather_launch(Z); aqc_ws_grad_from(x_buf, ...). */
+int aqc_ws_objective_launch(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer);
 int aqc_ws_results_fetch(aqc_ws* ws, double* small_out /* [batch][count] c128 */, double* grads_out /* [batch][T] c128 */);
 
 /* ---- MPS helpers (state-vector workspaces only).  An MPS arrives in the reference's QiskitMPS
@@ -289,6 +300,13 @@ int aqc_ws_timer_stop(aqc_ws* ws, float* elapsed_ms); /* synchronises */
 int aqc_ws_profile_enable(aqc_ws* ws, int on);
 int aqc_ws_profile_get(aqc_ws* ws, int kind, int64_t* launches, double* total_ms);
 int aqc_ws_profile_reset(aqc_ws* ws);
+/* the launches profiled since the last reset, in order: kinds[i], ms[i] for i < min(*count, cap); *count = their number */
+int aqc_ws_profile_log(aqc_ws* ws, int32_t* kinds, double* ms, int cap, int* count);
+/* stage `stage` of plan `which` as this workspace runs it: sub-stages, gate groups, local address bits (bits_out: [tile_bits]) */
+int aqc_ws_plan_stage(aqc_ws* ws, int which, int stage, int* num_subs, int* num_groups, int* bits_out);
+/* item lists of the last sparse evaluation (synchronises): counts[0] first-stage items of the sweep, [1] tiles it cleared in W,
+ * [2] last-stage items of V^H; -1 where that list has never been built */
+int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts);
 /* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
 int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,
                      int* num_stages, int* tile_bits, int* num_tiles);

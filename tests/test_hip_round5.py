@@ -1,0 +1,301 @@
+"""Round 5 (GPU): the sparse-lhs route of the sweep, the mirrored V^H with its checkpoint, V^H where the objective reads it.
+
+Reference behaviour pinned here: grad_of_dot_product copies x into w (core_operations.py:892-935); the objectives sweep from
+one-hot states or from a combination of two (objective_base.py:42-255, objective_lhs_sur_max.py:147-191).  The sparse route
+must give what the dense route gives (same kernels on fewer tiles) and what the oracle gives (1e-10).
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import TOL, maxdiff
+from oracle import aqc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _circ(n, ent="cx", depth=24, layout="spin"):
+    from aqc_research_amd import ParametricCircuit
+    from aqc_research_amd.circuit_structures import create_ansatz_structure
+
+    return ParametricCircuit(n, ent, create_ansatz_structure(n, layout, "full", depth))
+
+
+def _trotter(n, layers):
+    from aqc_research_amd import TrotterAnsatz
+    from aqc_research_amd.circuit_structures import make_trotter_like_circuit
+
+    return TrotterAnsatz(n, make_trotter_like_circuit(n, layers), second_order=True)
+
+
+def _ws(circ, batch, monkeypatch, sparse=True, lazy=True, tile=0, min_items=1):
+    from aqc_research_amd.engine import HipContext, Workspace
+
+    monkeypatch.setenv("AQC_SPARSE_SWEEP", "1" if sparse else "0")
+    monkeypatch.setenv("AQC_LAZY_Z", "1" if lazy else "0")
+    monkeypatch.setenv("AQC_SPARSE_MIN_ITEMS", str(min_items))
+    return Workspace(HipContext(circ), batch=batch, tile_bits_apply=tile, tile_bits_sweep=tile)
+
+
+def _oracle_lane(circ, th, target, idx, coef):
+    vh = orc.v_dagger_mul_vec(circ, th, target)
+    x = np.zeros(1 << circ.num_qubits, complex)
+    for i, c in zip(idx, coef):
+        if i >= 0:
+            x[i] = c
+    return vh, orc.grad_of_dot_product(circ, th, x, vh)
+
+
+@pytest.mark.parametrize("n,tile,ent", [(13, 12, "cx"), (14, 12, "cz"), (13, 10, "cp"), (12, 9, "cx"), (11, 8, "cz"), (14, 11, "cx")])
+def test_sparse_route_equals_dense_route_and_oracle(n, tile, ent, monkeypatch):
+    """set_basis with a different index per lane; separate calls (apply, gather, grad): sparse route vs AQC_SPARSE_SWEEP=0."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(100 + n + tile)
+    circ = _circ(n, ent, depth=3 * n)
+    B = 5
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    idx = rng.integers(0, 1 << n, size=B)
+    idx[0] = 0
+    res = {}
+    for sparse in (True, False):
+        ws = _ws(circ, B, monkeypatch, sparse=sparse, tile=tile)
+        assert ws.plan_info(1)[0] >= 2, "the case must have more than one stage"
+        ws.upload(BUF_Y, tg)
+        ws.set_basis(BUF_X, idx)
+        ws.set_thetas(th)
+        ws.apply(True, BUF_Y, BUF_Z)
+        ws.grad(None, True)
+        g = ws.get_grads()
+        z = ws.download(BUF_Z)
+        counts = ws.sparse_counts()
+        assert (counts[0] == B) if sparse else (counts[0] == -1), counts
+        ws.close()
+        res[sparse] = (g, z)
+    assert maxdiff(res[True][1], res[False][1]) == 0.0            # the same V^H
+    assert maxdiff(res[True][0], res[False][0]) < 1e-13           # z of the later stages comes from the checkpoint: last bits differ
+    for b in range(B):
+        vh, g_ref = _oracle_lane(circ, th[b], tg[b], [int(idx[b])], [1.0])
+        assert maxdiff(res[True][1][b], vh) < TOL
+        assert maxdiff(res[True][0][b], g_ref) < TOL
+
+
+def test_first_stage_alone_is_bit_identical_to_the_dense_route(monkeypatch):
+    """Two stages, block_range confined to the first stage's blocks... every gradient entry that belongs to a group of the first
+    sweep stage must be BIT-identical between the routes (same kernel, same operands, zero tiles contribute exact zeros)."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(5)
+    n = 14
+    circ = _circ(n, "cx", depth=30)
+    B = 3
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    grads = {}
+    first_ops = None
+    for sparse in (True, False):
+        ws = _ws(circ, B, monkeypatch, sparse=sparse, tile=12)
+        nsub, nops, bits = ws.plan_stage(1, 0)
+        ws.upload(BUF_Y, tg)
+        ws.set_basis(BUF_X, [0, 5, (1 << n) - 1])
+        ws.set_thetas(th)
+        ws.apply(True, BUF_Y, BUF_Z)
+        ws.grad(None, True)
+        grads[sparse] = ws.get_grads()
+        # gate groups of the first stage (host-only planner query: the same plan)
+        import ctypes
+        from aqc_research_amd import _lib
+        L = _lib.lib()
+        ns, nb, no = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        ops = (ctypes.c_int * 4096)()
+        L.aqc_plan_query(ws.ctx.handle, 1, 1, 12, -1, 0, ctypes.byref(ns), None, ctypes.byref(nb), ops, ctypes.byref(no))
+        first_ops = sorted(ops[: no.value])
+        ws.close()
+    theta_of = []
+    for gi in first_ops:   # thetas of the groups: front groups 3 each, blocks 4 each (cx)
+        theta_of += list(range(3 * gi, 3 * gi + 3)) if gi < n else list(range(3 * n + 4 * (gi - n), 3 * n + 4 * (gi - n) + 4))
+    assert len(theta_of) > 20
+    assert np.array_equal(grads[True][:, theta_of], grads[False][:, theta_of])
+
+
+def test_combo_support_moves_between_evaluations(monkeypatch):
+    """set_combo with two basis states per lane in different / equal tiles, changed from call to call: tiles of W that the new
+    list drops are cleared, lanes with one tile contribute one partial."""
+    from aqc_research_amd.engine import BUF_X2, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(11)
+    n = 14
+    circ = _circ(n, "cx", depth=28)
+    B = 4
+    ws = _ws(circ, B, monkeypatch, tile=12)
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    ws.upload(BUF_Y, tg)
+    hi = 1 << 12
+    plans = [
+        [(0, hi), (3, -1), (hi + 7, 2 * hi + 1), (9, 10)],          # two tiles / one term / two tiles / same tile
+        [(0, 2 * hi), (3, 3 * hi), (hi + 7, -1), (3 * hi, 3 * hi + 1)],
+        [(5, -1), (6, -1), (7, -1), (8, -1)],
+        [(hi, 3 * hi), (2 * hi, 0), (1, hi + 1), (3 * hi + 5, 2)],
+    ]
+    for step, plan in enumerate(plans):
+        th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+        idx = np.array(plan, dtype=np.int64)
+        coef = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
+        ws.set_thetas(th)
+        ws.apply(True, BUF_Y, BUF_Z)
+        ws.set_combo(BUF_X2, idx, coef)
+        ws.grad_from(BUF_X2)
+        g = ws.get_grads()
+        for b in range(B):
+            _, g_ref = _oracle_lane(circ, th[b], tg[b], idx[b], coef[b])
+            assert maxdiff(g[b], g_ref) < TOL, (step, b)
+        want = sum(1 if (j < 0 or (i >> 12) == (j >> 12)) else 2 for i, j in plan)
+        assert ws.sparse_counts()[0] == want
+    ws.close()
+
+
+@pytest.mark.parametrize("n,tile,layers", [(13, 9, 2), (14, 10, 3)])
+def test_three_or_more_stages_second_scratch_pair(n, tile, layers, monkeypatch):
+    """Plans of >= 3 stages: the later stages work on their own scratch pair, W stays clean, two evaluations in a row agree with
+    the oracle (2nd-order Trotter ansatz: thetas that collect two slots)."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y
+
+    rng = np.random.default_rng(21 + n)
+    circ = _trotter(n, layers)
+    B = 3
+    ws = _ws(circ, B, monkeypatch, tile=tile)
+    assert ws.plan_info(1)[0] >= 3
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    ws.upload(BUF_Y, tg)
+    neel = int("01" * (n // 2) + ("0" if n % 2 else ""), 2) & ((1 << n) - 1)
+    ws.set_basis(BUF_X, neel)
+    ws.gather_setup([neel] + [neel ^ (1 << q) for q in range(n)])
+    for _ in range(2):
+        th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+        ws.set_thetas(th)
+        ws.objective_launch(BUF_X)
+        hs = ws.gather_fetch()
+        g = ws.get_grads()
+        for b in range(B):
+            vh, g_ref = _oracle_lane(circ, th[b], tg[b], [neel], [1.0])
+            assert abs(hs[b, 0] - vh[neel]) < TOL and abs(hs[b, n] - vh[neel ^ (1 << (n - 1))]) < TOL
+            assert maxdiff(g[b], g_ref) < TOL
+    ws.close()
+
+
+def test_objective_launch_leaves_partial_z_that_readers_complete(monkeypatch):
+    """V^H where the evaluation reads it: amplitudes and gradients as usual; download / gather / vdot / a second sweep from another
+    lhs state complete Z first; once the thetas have changed a reader fails loudly, a whole-buffer writer takes Z over."""
+    from aqc_research_amd.engine import BUF_X, BUF_X2, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(31)
+    n = 14
+    circ = _circ(n, "cx", depth=26)
+    B = 4
+    ws = _ws(circ, B, monkeypatch, tile=12)
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    ws.upload(BUF_Y, tg)
+    ws.set_basis(BUF_X, 0)
+    flips = [0] + [1 << q for q in range(n)]
+    ws.gather_setup(flips)
+    ws.set_thetas(th)
+    ws.objective_launch(BUF_X)
+    hs = ws.gather_fetch()
+    g = ws.get_grads()
+    sw, _, vd = ws.sparse_counts()
+    assert sw == B and vd == B * 3            # tile 0 and the tiles of the flips on qubits 12, 13
+    vhs = []
+    for b in range(B):
+        vh, g_ref = _oracle_lane(circ, th[b], tg[b], [0], [1.0])
+        vhs.append(vh)
+        assert maxdiff(hs[b], vh[flips]) < TOL and maxdiff(g[b], g_ref) < TOL
+    # an index outside the computed tiles: the reader completes Z
+    far = (3 << 12) + 77
+    got = ws.gather(BUF_Z, [far])
+    assert max(abs(got[b, 0] - vhs[b][far]) for b in range(B)) < TOL
+    ws.objective_launch(BUF_X)
+    assert maxdiff(ws.download(BUF_Z), np.stack(vhs)) < TOL
+    ws.objective_launch(BUF_X)
+    ws.set_basis(BUF_X2, far)                 # a sweep from a state the partial Z was not computed for
+    ws.grad_from(BUF_X2)
+    g2 = ws.get_grads()
+    for b in range(B):
+        _, g_ref = _oracle_lane(circ, th[b], tg[b], [far], [1.0])
+        assert maxdiff(g2[b], g_ref) < TOL
+    # thetas changed while Z is partial: a reader refuses, aqc_ws_apply makes Z whole again
+    ws.objective_launch(BUF_X)
+    ws.set_thetas(th[::-1].copy())
+    with pytest.raises(RuntimeError, match="BUF_Z holds"):
+        ws.download(BUF_Z)
+    ws.apply(True, BUF_Y, BUF_Z)
+    z = ws.download(BUF_Z)
+    for b in range(B):
+        assert maxdiff(z[b], orc.v_dagger_mul_vec(circ, th[B - 1 - b], tg[b])) < TOL
+    ws.close()
+
+
+def test_one_call_evaluations_on_the_sparse_route(monkeypatch):
+    """aqc_ws_eval (captured graph, replayed) and aqc_ws_surrogate_eval with the sparse route forced on a small problem: values
+    equal the dense-route workspace's; the leading flip state moves between tiles from call to call."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y
+
+    rng = np.random.default_rng(41)
+    n = 13
+    circ = _circ(n, "cx", depth=20)
+    B = 6
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    flips = [0] + [1 << q for q in range(n)]
+    ths = [np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)]) for _ in range(4)]
+    out = {}
+    for sparse in (True, False):
+        ws = _ws(circ, B, monkeypatch, sparse=sparse, tile=10)
+        ws.upload(BUF_Y, tg)
+        ws.set_basis(BUF_X, 0)
+        ws.gather_setup(flips)
+        rec = []
+        for th in ths:
+            hs, g = ws.eval(th, vdag=True, gather=True, grad=True)
+            rec.append((hs.copy(), g.copy()))
+        w = np.ones(B)
+        m = np.zeros(B, dtype=np.int64)
+        for th in ths:
+            f, fid, hs, g = ws.surrogate_eval(th, w, m, update_state=True)
+            rec.append((f.copy(), g.copy(), m.copy()))
+        out[sparse] = rec
+        ws.close()
+    for a, b in zip(out[True], out[False]):
+        for u, v in zip(a, b):
+            assert maxdiff(u, v) < 1e-12
+    assert len({tuple(r[2]) for r in out[True][4:]}) > 1 or max(out[True][-1][2]) > 0   # some lane is led by a flip state
+    for k, th in enumerate(ths):
+        for b in range(B):
+            vh, g_ref = _oracle_lane(circ, th[b], tg[b], [0], [1.0])
+            assert maxdiff(out[True][k][0][b], vh[flips]) < TOL and maxdiff(out[True][k][1][b], g_ref) < TOL
+
+
+def test_device_lbfgs_on_the_sparse_route(monkeypatch):
+    """aqc_ws_lbfgs with the sparse route forced: every lane reaches what the dense-route run reaches."""
+    from aqc_research_amd.batched_optimizer import BatchedSurrogateObjective
+
+    rng = np.random.default_rng(51)
+    n = 13
+    circ = _trotter(n, 1)
+    B = 4
+    targets = np.stack([orc.v_mul_vec(circ, 0.3 * orc.rand_thetas(circ.num_thetas, rng), np.eye(1 << n)[0].astype(complex)) for _ in range(B)])
+    x0 = 0.05 * np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    fids = {}
+    for sparse in (True, False):
+        monkeypatch.setenv("AQC_SPARSE_SWEEP", "1" if sparse else "0")
+        monkeypatch.setenv("AQC_SPARSE_MIN_ITEMS", "1")
+        monkeypatch.setenv("AQC_TILE_BITS_APPLY", "10")
+        monkeypatch.setenv("AQC_TILE_BITS_SWEEP", "10")
+        obj = BatchedSurrogateObjective(circ, targets)
+        res = obj.minimize_on_device(x0.copy(), maxiter=25)
+        fids[sparse] = (np.asarray(res["fun"]), np.asarray(res["fidelity"]), np.asarray(res["x"]))
+        obj.close() if hasattr(obj, "close") else None
+    # the same optimisation: the routes differ in the last bits of z, the trajectories stay together over 25 iterations
+    assert np.allclose(fids[True][0], fids[False][0], rtol=1e-6, atol=1e-9)
+    assert np.allclose(fids[True][1], fids[False][1], rtol=1e-6, atol=1e-9)
+    assert maxdiff(fids[True][2], fids[False][2]) < 1e-6
+    assert np.all(fids[True][0] < 1.0)

@@ -129,10 +129,13 @@ def use(communicator: Optional[Communicator]) -> None:
 
 
 def launch_tag() -> str:
-    """Names one launch: all ranks share the launcher as parent process and its rendezvous port; a restarted attempt of an
-    elastic launcher (same agent, same port) gets a new name through its restart count / run id."""
+    """Names one launch from values EVERY rank of it sees alike, on any node: the rendezvous address and port, the launcher's run
+    id / restart count (a restarted attempt of an elastic launcher gets a new name), ``AQC_COMM_TAG`` (``bench.launch_ranks``
+    sets a fresh one per launch).  This is the nonce written behind the id bytes: with ``AQC_COMM_FILE`` on a shared file
+    system the ranks of other nodes must arrive at the same string (the parent pid, which differs from node to node, is only
+    part of the DEFAULT file name, which is node-local anyway)."""
     env = os.environ
-    return "_".join([env.get("MASTER_PORT", "0"), str(os.getppid()), env.get("AQC_COMM_TAG", "0"),
+    return "_".join([env.get("MASTER_ADDR", "local"), env.get("MASTER_PORT", "0"), env.get("AQC_COMM_TAG", "0"),
                      env.get("TORCHELASTIC_RUN_ID", "0"), env.get("TORCHELASTIC_RESTART_COUNT", "0")])
 
 
@@ -145,7 +148,7 @@ def from_environment() -> Communicator:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-        id_file = os.environ.get("AQC_COMM_FILE", os.path.join(tempfile.gettempdir(), f"aqc_comm_id_{launch_tag()}"))
+        id_file = os.environ.get("AQC_COMM_FILE", os.path.join(tempfile.gettempdir(), f"aqc_comm_id_{launch_tag()}_{os.getppid()}"))
         _current = RcclCommunicator(rank, world, local % max(1, _lib.lib().aqc_device_count()), id_file)
     else:
         _current = Communicator()

@@ -404,8 +404,11 @@ hipError_t launch_cd_persistent(const void* prog, int nsegs, int nbits, int col_
                                 int T, double* fobj, int nsweeps, int max_steps, int batch, hipStream_t s) {
     const size_t lds = cd_persistent_lds_bytes(nbits, T);
     const bool big = ((size_t)1 << nbits) / 4 > 256;    // more than one 4-element group per thread (6 qubits: 4)
-    static size_t granted[2] = {0, 0};
-    if (lds > granted[big]) {
+    static size_t granted_all[64][2] = {};   // hipFuncSetAttribute applies to the current device: one record per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    size_t (&granted)[2] = granted_all[dev];
+    if (lds > granted[big] || dev == 0) {   // (device 0 doubles as the catch-all slot: always set there -- the call is cheap)
         hipError_t e = big ? hipFuncSetAttribute(reinterpret_cast<const void*>(cd_persistent_kernel_g4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                            : hipFuncSetAttribute(reinterpret_cast<const void*>(cd_persistent_kernel_g1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -312,12 +312,14 @@ hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, const LaneOp1*
 }
 hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, const LaneOp2* ops, int nops, const LaneOp2& one, const double* thetas, int T,
                               double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per device: hipFuncSetAttribute applies to the current one
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev] || dev == 0) {   // (slot 0 is also the catch-all: always set there)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lanes_gate2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * kSmallMax * kSmallMax * (int)sizeof(cplx));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int h = std::min(kLaneCap, std::max(2, bond_hint));
     const unsigned lds_elems = 2u * (2 * h) * (2 * h);

@@ -175,10 +175,10 @@ int aqc_ws_cd_sweep(aqc_ws* ws, double* thetas_io, double* fobj) {
     if (!ws || !thetas_io || !fobj) return fail("null argument");
     if (cd_checks(ws)) return 1;
     const char* chain = getenv("AQC_CD_CHAIN");   // "1": the launch chain below even where one launch would do (cross-check, timing)
+    if (ws->batch != 1) return fail("aqc_ws_cd_sweep takes thetas_io[T] and one objective value: a single-lane workspace (aqc_ws_cd_sweeps serves lanes)");
     if (aqc_ws_cd_fits_one_launch(ws) && !(chain && chain[0] == '1')) return aqc_ws_cd_sweeps(ws, thetas_io, fobj, 1, -1);
     const Program& prog = ws->ctx->prog;
     const int dim = 1 << prog.n;
-    if (ws->batch != 1) return fail("the launch-chain coordinate descent (operands beyond one workgroup's LDS) runs one lane");
     HIP_OK(hipSetDevice(ws->device));
     const int T = prog.num_thetas();
     if (aqc_ws_set_thetas(ws, thetas_io)) return 1;                  // theta_in = d_thetas_own

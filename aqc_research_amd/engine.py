@@ -431,20 +431,35 @@ _MPS_SLOTS = 64          # AQC_MPS_SLOTS of include/aqc_hip.h
 _MPS_FIRST_CACHED = 4    # slots 0..3 stay with the explicit mps_upload / mps_to_vec / mps_dot calls
 
 
+_DIGEST_FULL_BYTES = 512 * 1024   # tuples up to this size are digested completely on every call
+_DIGEST_WINDOW = 1024             # larger ones: three windows of this many bytes per tensor (first, middle, last) + all Schmidt vectors
+
+
 def _mps_fingerprint(mps) -> tuple:
-    """Cheap content check of a QiskitMPS tuple: shapes and three entries of every tensor; identity (id) of the tuple is the
-    primary key.  It is a tripwire, not a proof: what keeps a resident copy valid is that ``mps_slot_for`` makes the arrays
-    of a cached tuple read-only."""
+    """Content check of a QiskitMPS tuple, taken on EVERY call (identity of the tuple is only the cache key): shapes plus an
+    xxh3 digest of the tensors -- all bytes for tuples up to 512 KiB (a 16-qubit target of bond 16 is 128 KiB), three 1 KiB
+    windows per tensor and every Schmidt vector beyond (a bond-64 target is 2 MiB: a full pass per call and lane would cost more
+    than the evaluation).  The caller's arrays are never touched: an in-place edit between two calls changes the digest and the
+    resident copy is uploaded again, which is what the reference's reload on every call amounts to (mps_dot_objective.py:100-101).
+    Residual hazard, stated: an edit of a few entries of a LARGE tensor outside the windows goes unseen -- pass new arrays (or
+    call ``Workspace.mps_forget``) for such edits; whole-tensor edits (rescaling, truncation) always land in the windows."""
+    import xxhash
+
     gam, lam = mps
-    out = []
-    for g0, g1 in gam:
-        a0, a1 = np.asarray(g0), np.asarray(g1)
-        f0, f1 = a0.reshape(-1), a1.reshape(-1)
-        out.append((a0.shape, complex(f0[0]), complex(f0[-1]), complex(f1[f1.size // 2])))
-    for l in lam:
-        fl = np.asarray(l).reshape(-1)
-        out.append((fl.size, float(fl[0]), float(fl[-1])))
-    return tuple(out)
+    arrays = [np.asarray(g) for pair in gam for g in pair]
+    lams = [np.asarray(l) for l in lam]
+    total = sum(a.nbytes for a in arrays)
+    h = xxhash.xxh3_64()
+    for a in arrays:
+        b = memoryview(a if a.flags.c_contiguous else np.ascontiguousarray(a)).cast("B")
+        if total <= _DIGEST_FULL_BYTES or len(b) <= 3 * _DIGEST_WINDOW:
+            h.update(b)
+        else:
+            mid = (len(b) // 2) & ~15
+            h.update(b[:_DIGEST_WINDOW]); h.update(b[mid:mid + _DIGEST_WINDOW]); h.update(b[-_DIGEST_WINDOW:])
+    for l in lams:
+        h.update(memoryview(l if l.flags.c_contiguous else np.ascontiguousarray(l)).cast("B"))
+    return (tuple(a.shape for a in arrays), h.intdigest())
 
 
 def _mps_bond_dims(mps) -> tuple:
@@ -477,7 +492,7 @@ def _pad_mps(mps, bonds):
 
 def _ws_mps_slot_for(self, mps, bonds=None) -> int:
     """Slot holding a device-resident copy of `mps`: uploaded on first sight, found again by the tuple's identity plus a
-    cheap fingerprint of its tensors (mps_dot_objective.py:41 receives the same target tuple on every call of an
+    digest of its tensors (mps_dot_objective.py:41 receives the same target tuple on every call of an
     optimisation; the reference re-loads it into the simulator each time, :100-101).  Least recently used slot is recycled.
     ``bonds``: bond dimensions the resident copy is zero-padded to (``_pad_mps``; None: as they are)."""
     cache = self.__dict__.setdefault("_mps_cache", {})        # id(mps) -> [slot, fingerprint, tick, keep-alive reference]
@@ -496,17 +511,14 @@ def _ws_mps_slot_for(self, mps, bonds=None) -> int:
         slot = cache.pop(victim)[0]
     self.mps_upload(slot, mps if fp[1] is None else _pad_mps(mps, fp[1]))
     cache[id(mps)] = [slot, fp, self._mps_tick, mps]
-    # the fingerprint only samples the tensors: the resident copy is kept honest by making the cached arrays read-only --
-    # an in-place edit now raises instead of silently evaluating against the stale device copy (pass new arrays to change a
-    # target; arrays that are views of a writable base are the caller's to leave alone)
-    for g0, g1 in mps[0]:
-        for a in (g0, g1):
-            if isinstance(a, np.ndarray):
-                a.flags.writeable = False
-    for l in mps[1]:
-        if isinstance(l, np.ndarray):
-            l.flags.writeable = False
     return slot
+
+
+def _ws_mps_forget(self, mps) -> None:
+    """Drop the resident copy of ``mps`` (after an in-place edit that the windowed digest of a large tuple may not see)."""
+    ent = self.__dict__.setdefault("_mps_cache", {}).get(id(mps))
+    if ent is not None:
+        ent[1] = None   # (the slot stays with the tuple: the next call uploads into it again)
 
 
 def _ws_mps_to_vec_batch(self, mps_list, buf: int, lanes=None) -> None:
@@ -539,6 +551,7 @@ Workspace.mps_upload = _ws_mps_upload
 Workspace.mps_to_vec = _ws_mps_to_vec
 Workspace.mps_dot = _ws_mps_dot
 Workspace.mps_slot_for = _ws_mps_slot_for
+Workspace.mps_forget = _ws_mps_forget
 Workspace.mps_to_vec_batch = _ws_mps_to_vec_batch
 
 

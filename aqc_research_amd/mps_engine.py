@@ -322,11 +322,7 @@ def _apply_on_a_lane(circ, thetas, mps: DeviceMPS, inverse: bool, trunc_thr: flo
 
     dev = int(_lib.lib().aqc_mps_device(mps.handle))
     key = (dev, n, 1, "apply", threading.get_ident())   # (a lane of its own per host thread: the thread lanes of evaluate_lanes call in parallel)
-    ls = _LOCKSTEP_CACHE.get(key)
-    if ls is None:
-        if len(_LOCKSTEP_CACHE) >= 6:
-            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)))   # (freed when its last user lets go: another thread may be inside a call on it)
-        ls = _LOCKSTEP_CACHE[key] = LockstepLanes(n, 1, dev)
+    ls = _lockstep_cached(key, 6, lambda: LockstepLanes(n, 1, dev))
     try:
         ls.set_targets(mps)
         ls.apply_circuit(circ, np.asarray(thetas, dtype=np.float64)[None, :], inverse=inverse, trunc_thr=trunc_thr, max_bond=max_bond)
@@ -394,11 +390,7 @@ def fast_dot_gradient_mps(circ, thetas, lvec: DeviceMPS, vh_phi: DeviceMPS, *, t
 
         dev = int(_lib.lib().aqc_mps_device(vh_phi.handle))   # one lockstep lane: the walk is a chain of fused steps instead of ~10 launches per gate
         key = (dev, n, 1, "gradient", threading.get_ident())
-        ls = _LOCKSTEP_CACHE.get(key)
-        if ls is None:
-            if len(_LOCKSTEP_CACHE) >= 6:
-                _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)))   # (freed when its last user lets go: another thread may be inside a call on it)
-            ls = _LOCKSTEP_CACHE[key] = LockstepLanes(n, 1, dev)
+        ls = _lockstep_cached(key, 6, lambda: LockstepLanes(n, 1, dev))
         try:
             ls.set_targets(vh_phi).set_lhs(lvec)
             check(_lib.lib().aqc_mpsb_gradient_of(ls.handle, byref(desc), dptr(th), float(trunc_thr), int(max_bond), lo, hi, int(bool(front_layer)),
@@ -623,15 +615,24 @@ class LockstepLanes:
 
 
 _LOCKSTEP_CACHE: dict = {}   # (device, qubits, lanes) -> LockstepLanes; the batches of a running optimisation come back every iteration
+_LOCKSTEP_LOCK = __import__("threading").Lock()
+
+
+def _lockstep_cached(key, cap: int, make):
+    """Look up / create an entry of the shared cache under its lock (the host-thread lanes of ``evaluate_lanes`` arrive here
+    together); the evicted object is freed when its last user lets go of it."""
+    with _LOCKSTEP_LOCK:
+        ls = _LOCKSTEP_CACHE.get(key)
+        if ls is None:
+            while len(_LOCKSTEP_CACHE) >= cap:
+                _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)), None)
+            ls = _LOCKSTEP_CACHE[key] = make()
+        return ls
 
 
 def _lockstep_for(num_qubits: int, lanes: int, device: int, targets, lhs) -> LockstepLanes:
     key = (device, num_qubits, lanes)
-    ls = _LOCKSTEP_CACHE.get(key)
-    if ls is None:
-        if len(_LOCKSTEP_CACHE) >= 4:
-            _LOCKSTEP_CACHE.pop(next(iter(_LOCKSTEP_CACHE)))   # (freed when its last user lets go: another thread may be inside a call on it)
-        ls = _LOCKSTEP_CACHE[key] = LockstepLanes(num_qubits, lanes, device)
+    ls = _lockstep_cached(key, 4, lambda: LockstepLanes(num_qubits, lanes, device))
     # the operands are copied into the lanes; the copies are refreshed when a state was replaced or edited in place (DeviceMPS.version)
     ls.set_targets(targets)
     ls.set_lhs(lhs)
@@ -659,13 +660,16 @@ def evaluate_lanes(circ, thetas: np.ndarray, targets, lhs, *, trunc_thr: float =
         raise ValueError("one target and one lhs state per lane (or one for all)")
 
     if method != "threads":   # (a single lane as well: its walk is 5x shorter on the lockstep kernels than on the single-lane engine's launch chain)
-        distinct = {id(m): m for m in tg + lh}.values()
+        distinct = list({id(m): m for m in tg + lh}.values())
         fits = circ.num_qubits >= 2 and max_bond <= LOCKSTEP_MAX_BOND and all(int(m.bond_dims.max()) <= LOCKSTEP_MAX_BOND for m in distinct)
         if fits or method == "lockstep":
             try:
                 shared_t = targets if not isinstance(targets, (list, tuple)) else tg
                 shared_l = lhs if not isinstance(lhs, (list, tuple)) else lh
-                ls = _lockstep_for(circ.num_qubits, lanes, _default_device(), shared_t, shared_l)
+                devs = {int(_lib.lib().aqc_mps_device(m.handle)) for m in distinct}   # the lanes live where the operands live
+                if len(devs) != 1:
+                    raise ValueError(f"the operands of evaluate_lanes live on different devices: {sorted(devs)}")
+                ls = _lockstep_for(circ.num_qubits, lanes, devs.pop(), shared_t, shared_l)
                 return ls.evaluate(circ, th, trunc_thr=trunc_thr, max_bond=max_bond, block_range=block_range, front_layer=front_layer)
             except RuntimeError as err:
                 if method == "lockstep" or "lockstep lanes" not in str(err):

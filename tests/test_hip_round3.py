@@ -452,10 +452,8 @@ def test_mps_batched_contraction_and_slot_cache():
     got = ws.download(BUF_Y)
     for i, m in enumerate(mixed):
         assert maxdiff(got[i], orc.mps_to_vector(m)) < 1e-12
-    with pytest.raises(ValueError):                     # arrays of a cached tuple are read-only: an in-place edit raises
-        a[0][3][0][0, 1] += 0.25                        # instead of evaluating against the stale resident copy
-    a[0][3][0].flags.writeable = True                   # the owner insists: same tuple, new contents (a sampled entry)
-    a[0][3][0][0, 0] += 0.25
+    assert all(g.flags.writeable for pair in a[0] for g in pair)   # the caller's arrays are left as they came
+    a[0][3][0][0, 1] += 0.25                            # same tuple, new contents (any entry: the digest covers small tuples completely)
     ws.mps_to_vec_batch([a] * B, BUF_Y, lanes=np.arange(B)[::-1])
     assert maxdiff(ws.download(BUF_Y)[0], orc.mps_to_vector(a)) < 1e-12
     many = [orc.random_mps(n, 2, rng) for _ in range(70)]   # more than the 60 cached slots

@@ -79,6 +79,7 @@ SIGNATURES = {
     "aqc_mps_fast_dot_gradient": (c_int, [_P, _P, _P, _D, c_double, c_int, c_int, c_int, c_int, _D]),
     "aqc_mpsb_create": (c_int, [c_int, c_int, c_int, POINTER(_P)]),
     "aqc_mpsb_destroy": (c_int, [_P]),
+    "aqc_mpsb_gate2_stats": (c_int, [_P, c_int, _D, c_int]),
     "aqc_mpsb_set_targets": (c_int, [_P, POINTER(_P), c_int]),
     "aqc_mpsb_set_lhs": (c_int, [_P, POINTER(_P), c_int]),
     "aqc_mpsb_eval": (c_int, [_P, _P, _D, c_double, c_int, c_int, c_int, c_int, _D, _D, _D, POINTER(c_int32)]),

@@ -224,8 +224,12 @@ struct LaneOp2 { int q, pad; LaneGate2 g; };   // a 2-qubit gate on the sites (q
 // b / m2 (may be null): a second state that takes the same gates.
 hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, const LaneOp1* ops, int nops, const LaneOp1& one, const double* thetas, int T, int lanes,
                               int bond_hint, hipStream_t s);
+// jstats (may be null): [0] += fp64 flops of the Jacobi rotations actually run (per column pair and sweep: 3 inner products and the
+// rotation of the pair over the rows of the work matrix, 36 flop a row, + the rotation of V, 20 flop a row), [1] += SVDs,
+// [2] += sweeps, [3] += rotations
 hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, const LaneOp2* ops, int nops, const LaneOp2& one, const double* thetas, int T,
-                              double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s);
+                              double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s,
+                              unsigned long long* jstats = nullptr);
 hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,
                                  const double* gh8, int lanes, hipStream_t s);
 hipError_t launch_lanes_env_right(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride, int lanes,

@@ -88,6 +88,15 @@ struct aqc_mpsb {
     int cur_T = 0, cur_max_bond = 0;   // what the last aqc_mpsb_vh / eval ran with (the gradient phase continues from it)
     double cur_trunc = 0.0;
     bool vh_ready = false;
+    // statistics of the truncated 2-qubit gates (aqc_mpsb_gate2_stats): work of the Jacobi sweeps on the device, and -- while
+    // profiling is on -- the duration of every lanes_gate2 launch from a pool of event pairs (read back when the pool is full
+    // and when the figures are asked for)
+    unsigned long long* jstats = nullptr;   // device [4]
+    bool prof = false;
+    std::vector<hipEvent_t> ev;             // pairs
+    size_t ev_used = 0;
+    double gate2_ms = 0.0;
+    long long gate2_launches = 0;
     uint8_t* bits = nullptr;     // basis-state patterns of aqc_mpsb_set_lhs_basis and their pinned staging
     uint8_t* h_bits = nullptr;
     size_t bits_cap = 0;
@@ -101,8 +110,10 @@ void destroy(aqc_mpsb* b) {
     if (b->st) (void)hipStreamSynchronize(b->st);
     for (Lanes* s : {&b->target, &b->lhs, &b->vh, &b->w, &b->z}) s->release();
     for (auto& kv : b->schedules) { if (kv.second.ops1) (void)hipFree(kv.second.ops1); if (kv.second.ops2) (void)hipFree(kv.second.ops2); }
-    for (void* p : {(void*)b->thetas, (void*)b->status, (void*)b->env_l, (void*)b->env_r, (void*)b->e0, (void*)b->e1, (void*)b->vals, (void*)b->bits})
+    for (void* p : {(void*)b->thetas, (void*)b->status, (void*)b->env_l, (void*)b->env_r, (void*)b->e0, (void*)b->e1, (void*)b->vals, (void*)b->bits,
+                    (void*)b->jstats})
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     for (void* p : {(void*)b->h_thetas, (void*)b->h_out, (void*)b->h_bits})
         if (p) (void)hipHostFree(p);
     if (b->st) (void)hipStreamDestroy(b->st);
@@ -123,9 +134,35 @@ int gate1_all(aqc_mpsb* b, Lanes& s, int q, const LaneGate1& g, int T, Lanes* s2
     return 0;
 }
 
+int gate2_events_flush(aqc_mpsb* b) {   // sums the recorded pairs (waits for the stream)
+    if (b->ev_used == 0) return 0;
+    HIP_OK(hipStreamSynchronize(b->st));
+    for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
+        b->gate2_ms += ms;
+        b->gate2_launches += 1;
+    }
+    b->ev_used = 0;
+    return 0;
+}
+struct Gate2Scope {   // brackets one lanes_gate2 launch with an event pair while profiling is on
+    aqc_mpsb* b;
+    bool on;
+    explicit Gate2Scope(aqc_mpsb* b_) : b(b_), on(b_->prof) {
+        if (!on) return;
+        if (b->ev_used + 2 > b->ev.size() && gate2_events_flush(b)) { on = false; return; }
+        if (hipEventRecord(b->ev[b->ev_used], b->st) != hipSuccess) on = false;
+    }
+    ~Gate2Scope() {
+        if (on && hipEventRecord(b->ev[b->ev_used + 1], b->st) == hipSuccess) b->ev_used += 2;
+    }
+};
+
 int gate_adjacent_all(aqc_mpsb* b, Lanes& s, Lanes* s2, int q, const LaneGate2& g, int T, double trunc_thr, int max_bond) {
+    Gate2Scope scope(b);
     HIP_OK(launch_lanes_gate2(s.dev, s2 ? &s2->dev : nullptr, nullptr, 1, LaneOp2{q, 0, g}, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L,
-                              b->active, b->hint, b->st));
+                              b->active, b->hint, b->st, b->jstats));
     return 0;
 }
 
@@ -259,9 +296,11 @@ int apply_circuit_all(aqc_mpsb* b, Lanes& s, const aqc_circuit* c, int T, bool i
     for (const Level& lv : sch.levels) {
         if (lv.n1)
             HIP_OK(launch_lanes_gate1(s.dev, nullptr, sch.ops1 + lv.off1, lv.n1, LaneOp1{}, b->thetas, T, b->active, b->hint, b->st));
-        if (lv.n2)
+        if (lv.n2) {
+            Gate2Scope scope(b);
             HIP_OK(launch_lanes_gate2(s.dev, nullptr, sch.ops2 + lv.off2, lv.n2, LaneOp2{}, b->thetas, T, trunc_thr, max_bond, b->status, b->status + b->L,
-                                      b->active, b->hint, b->st));
+                                      b->active, b->hint, b->st, b->jstats));
+        }
     }
     return 0;
 }
@@ -604,6 +643,39 @@ int aqc_mpsb_create(int device, int num_qubits, int lanes, aqc_mpsb** out) {
 
 int aqc_mpsb_destroy(aqc_mpsb* b) {
     destroy(b);
+    return 0;
+}
+
+/* Work and time of the truncated 2-qubit gates since the last reset.  enable: 1 starts counting (Jacobi work on the device; every
+ * lanes_gate2 launch bracketed by an event pair), 0 stops, -1 leaves the switch alone.  out (may be null): [0] fp64 flops of the
+ * Jacobi rotations that ran, [1] SVDs, [2] sweeps, [3] rotations, [4] lanes_gate2 launches timed, [5] their total duration in ms.
+ * reset != 0 clears the figures after reading them. */
+int aqc_mpsb_gate2_stats(aqc_mpsb* b, int enable, double* out, int reset) {
+    if (!b) return failf("null batch");
+    HIP_OK(hipSetDevice(b->device));
+    if (!b->jstats) {
+        HIP_OK(hipMalloc((void**)&b->jstats, 4 * sizeof(unsigned long long)));
+        HIP_OK(hipMemset(b->jstats, 0, 4 * sizeof(unsigned long long)));
+    }
+    if (gate2_events_flush(b)) return 1;
+    if (enable == 1 && b->ev.empty()) {
+        b->ev.resize(2048);
+        for (hipEvent_t& e : b->ev) HIP_OK(hipEventCreate(&e));
+    }
+    if (enable >= 0) b->prof = enable != 0;
+    if (out) {
+        unsigned long long h[4];
+        HIP_OK(hipStreamSynchronize(b->st));
+        HIP_OK(hipMemcpy(h, b->jstats, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i) out[i] = (double)h[i];
+        out[4] = (double)b->gate2_launches;
+        out[5] = b->gate2_ms;
+    }
+    if (reset) {
+        HIP_OK(hipMemset(b->jstats, 0, 4 * sizeof(unsigned long long)));
+        b->gate2_ms = 0.0;
+        b->gate2_launches = 0;
+    }
     return 0;
 }
 

@@ -69,7 +69,8 @@ __device__ unsigned long long g_gate2_stamps[16];
 // lane's own values), new site tensors, Schmidt values and bond dimension.
 __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m1, int lanes, const LaneOp2* __restrict__ ops, LaneOp2 one,
                                                            const double* __restrict__ thetas, int T, double trunc_thr, int max_bond, double tol, int max_sweeps,
-                                                           int* __restrict__ status, int* __restrict__ peak, unsigned lds_elems) {
+                                                           int* __restrict__ status, int* __restrict__ peak, unsigned lds_elems,
+                                                           unsigned long long* __restrict__ jstats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ cplx gm[16];
     __shared__ double sig[2 * kLaneCap];
@@ -133,6 +134,13 @@ __global__ __launch_bounds__(1024) void lanes_gate2_kernel(LaneMps m0, LaneMps m
     G2_STAMP(3);
     const int sweeps = jacobi_lds_core(sw, sv, wr, wc, tol, max_sweeps, fro2);
     G2_STAMP(4);
+    if (jstats && tid == 0) {   // work of the sweeps that ran (bench.py: roofline of the lockstep lanes)
+        const unsigned long long rot = (unsigned long long)sweeps * (unsigned long long)(wc * (wc - 1) / 2);
+        atomicAdd(&jstats[0], rot * (unsigned long long)(36 * wr + 20 * wc));
+        atomicAdd(&jstats[1], 1ull);
+        atomicAdd(&jstats[2], (unsigned long long)sweeps);
+        atomicAdd(&jstats[3], rot);
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { G2_COUNT(8, sweeps); G2_COUNT(9, wc); G2_COUNT(10, wr); G2_COUNT(12, sweeps * (wc + (wc & 1) - 1)); }
     for (int c = tid; c < wc; c += blockDim.x) sig[c] = lds_column_norm(sw, wr, c);
     __syncthreads();
@@ -311,7 +319,8 @@ hipError_t launch_lanes_gate1(const LaneMps& a, const LaneMps* b, const LaneOp1*
     return hipGetLastError();
 }
 hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, const LaneOp2* ops, int nops, const LaneOp2& one, const double* thetas, int T,
-                              double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s) {
+                              double trunc_thr, int max_bond, int* status, int* peak, int lanes, int bond_hint, hipStream_t s,
+                              unsigned long long* jstats) {
     static bool attr_set[64] = {};   // per device: hipFuncSetAttribute applies to the current one
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -330,7 +339,7 @@ hipError_t launch_lanes_gate2(const LaneMps& m, const LaneMps* m2, const LaneOp2
     const int per_bond = groups * gates > 512 ? 16 : 32;
     const int threads = std::min(1024, std::max(64, (per_bond * h + 63) & ~63));
     lanes_gate2_kernel<<<dim3(groups, gates), threads, lds_elems * sizeof(cplx), s>>>(m, m2 ? *m2 : m, lanes, ops, one, thetas, T, trunc_thr, max_bond, 1e-15, 60,
-                                                                                      status, peak, lds_elems);
+                                                                                      status, peak, lds_elems, jstats);
     return hipGetLastError();
 }
 hipError_t launch_lanes_env_left(const LaneMps& w, const LaneMps& z, int p, const void* in, size_t in_stride, void* out, size_t out_stride,

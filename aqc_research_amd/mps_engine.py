@@ -496,6 +496,14 @@ class LockstepLanes:
         self.handle, self.num_qubits, self.lanes = h, int(num_qubits), int(lanes)
         self._targets = self._lhs = None
 
+    def gate2_stats(self, enable: Optional[bool] = None, reset: bool = False) -> dict:
+        """Work and time of the truncated 2-qubit gates (``aqc_mpsb_gate2_stats``): fp64 flops of the Jacobi rotations that ran, SVDs,
+        sweeps, rotations; ``lanes_gate2`` launches timed and their total duration while ``enable`` is on."""
+        out = np.zeros(6)
+        check(_lib.lib().aqc_mpsb_gate2_stats(self.handle, -1 if enable is None else int(bool(enable)), dptr(out), int(bool(reset))))
+        return {"jacobi_flops": float(out[0]), "svds": int(out[1]), "sweeps": int(out[2]), "rotations": int(out[3]),
+                "launches_timed": int(out[4]), "launch_ms": float(out[5])}
+
     def _handles(self, states):
         lst = list(states) if isinstance(states, (list, tuple)) else [states]
         if len(lst) not in (1, self.lanes):

@@ -49,6 +49,10 @@ WORKLOADS = {
     # h), 10 objective+gradient pairs per job -- sharded over the ranks by run_jobs (job j on rank j % world), results
     # gathered as fixed-size records.  One step = the whole mix.
     "cfg4_jobs": dict(n=20, kind="jobs", seeds=64, horizons=8, evals=10, desc="20-qubit ASP job mix: 64 seeds x 8 horizons (2nd-order Trotter ansatz, 2h layers), 10 objective+gradient pairs per job, sharded by run_jobs"),
+    # config 4 as the reference's driver runs it (time_evol_best_init.py:221-382, job_executor.py:96-161): per horizon the
+    # ground-truth / reference Trotter targets synthesised on the device, 64 random restarts of the 2h-layer ansatz optimised by
+    # L-BFGS under the fidelity threshold, the reference's result record; horizons are the jobs of run_jobs.  One step = the run.
+    "cfg4_driver": dict(n=20, kind="driver", seeds=64, horizons=8, maxiter=40, desc="20-qubit ASP run of the horizon driver: time_evol.run_simulation(UserOptions(num_qubits=20, num_horizons=8, num_seeds=64, objective='sur_max', vectorised_lbfgs=True)) -- Trotter targets synthesised on the device, 64 restarts per horizon as lanes of one batched surrogate objective, L-BFGS (maxiter 40) under the fidelity threshold, horizons sharded by run_jobs"),
     "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=16 (a different one per lane every step), contracted to dense on the device every evaluation"),
     "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=64 (a different one per lane every step), contracted to dense on the device every evaluation"),
     # the same front door at the threshold the reference's own driver hands over (user_options.py:55: trunc_thr = 1e-6): the targets
@@ -100,6 +104,37 @@ def host_cores():
     return min(n, 16)
 
 
+def all_host_cores():
+    """(logical CPUs, physical cores) this process may run on: the affinity mask, cut by the cgroup CPU quota when there is
+    one; physical = distinct (package, core) pairs of /proc/cpuinfo inside the mask."""
+    mask = os.sched_getaffinity(0)
+    logical = len(mask)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            logical = min(logical, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    phys = set()
+    try:
+        cpu = pkg = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu, pkg, core = int(line.split(":")[1]), None, None
+            elif line.startswith("physical id"):
+                pkg = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip() and cpu is not None:
+                if cpu in mask:
+                    phys.add((pkg, core if core is not None else cpu))
+                cpu = None
+    except (OSError, ValueError):
+        phys = set()
+    physical = min(len(phys) or logical, logical)
+    return logical, physical
+
+
 def cpu_baseline(circ, ncols=1, seconds=8.0):
     """The reference algorithm (one pass per gate, one per inner product) timed on the host cores of
     this box on a bounded sample of the same workload: `value` is the compiled C restatement
@@ -142,7 +177,11 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
                 return threads
             return run
 
+        logical, physical = all_host_cores()
+        share = cores                                   # the per-GPU CPU share of the box (16)
+        cores = max(physical, share)                    # the headline figure: one evaluation per physical core the process may use
         n_all, t_all = timed(c_batch(cores), seconds)
+        n_share, t_share = (n_all, t_all) if share == cores else timed(c_batch(share), seconds / 2)
         n_one, t_one = timed(c_batch(1), seconds / 4)
     else:
         u = np.linalg.qr(rng.standard_normal((a.dim, ncols)) + 1j * rng.standard_normal((a.dim, ncols)))[0]
@@ -157,9 +196,11 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
             cref.grad_of_matrix_dot_product(a, th, eye, cref.v_dagger_mul_mat(a, th, u))
             return 1
 
-        cores = 1
+        cores = share = 1
+        logical, physical = all_host_cores()
         n_all, t_all = timed(c_one, seconds)
         n_one, t_one = n_all, t_all
+        n_share, t_share = n_all, t_all
     n_np, t_np = timed(numpy_one, seconds / 2, cap=200)
     if limiter is not None:
         limiter.restore_original_limits()
@@ -170,6 +211,9 @@ def cpu_baseline(circ, ncols=1, seconds=8.0):
         "kind": "port",
         "sample": f"{n_all} objective+gradient evaluations of the same ansatz in {t_all:.1f} s: C restatement of the "
                   f"reference algorithm, {cores} thread(s), one evaluation per thread",
+        "per_gpu_share_16": {"value": n_share / t_share, "cores": share,
+                             "note": "the same on the box's per-GPU CPU share (what an 8-GPU node leaves each rank)"},
+        "affinity": {"logical_cpus": logical, "physical_cores": physical},
         "c_1thread_evals_per_s": n_one / t_one,
         "numpy_1thread_evals_per_s": n_np / t_np,
         "host": {"cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "blas_threads": 1},
@@ -305,6 +349,70 @@ def run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=None):
                    "sharding": "run_jobs: entry j = (horizon j // chunks, seed chunk j % chunks) on rank j % world; chunks = world, so "
                                "every rank holds every horizon; the seeds of an entry are the lanes of one batched objective",
                    "evaluation": "V^H + flip-state amplitudes + ONE sweep from the combined lhs state per lane (aqc_ws_set_combo)"},
+    }
+
+
+def run_driver(args, w, env, full):
+    """--workload cfg4_driver: the horizon driver itself (model_sp_lhs/time_evol.run_simulation), horizons sharded by run_jobs.
+    Short form (configs of the default line): 2 horizons.  After the run one restart is replayed against the C oracle: the
+    objective's amplitude and gradient at the optimised thetas of horizon 1, recomputed on the device AND by the oracle."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, HipContext, Workspace
+    from aqc_research_amd.model_sp_lhs import time_evol
+    from aqc_research_amd.model_sp_lhs.trotter import trotter_ansatz
+    from oracle import aqc_ref as cref
+
+    comm, rank, local_rank, n_gpus = env.comm, env.rank, env.local_rank, env.n_gpus
+    H = w["horizons"] if full else 2
+    mode = os.environ.get("AQC_BENCH_DRIVER_LBFGS", "vectorised")   # vectorised (host L-BFGS over (B, T) arrays) | device (aqc_ws_lbfgs)
+    opts = time_evol.UserOptions(num_qubits=w["n"], num_horizons=H, num_seeds=w["seeds"], objective="sur_max", vectorised_lbfgs=True,
+                                 device_lbfgs=(mode == "device"), maxiter=w["maxiter"], device=local_rank, seed=0x696969)
+    warm = time_evol.UserOptions(num_qubits=w["n"], num_horizons=1, num_seeds=w["seeds"], objective="sur_max", vectorised_lbfgs=True,
+                                 device_lbfgs=(mode == "device"), maxiter=2, device=local_rank, seed=1)
+    time_evol.run_simulation(warm)     # library load, first launches (untimed)
+    comm.barrier()
+    t0 = time.perf_counter()
+    recs = time_evol.run_simulation(opts)
+    comm.barrier()
+    wall = time.perf_counter() - t0
+    if comm.size > 1:
+        wall = float(comm.allreduce(np.array([wall]), "max")[0])
+    evals = int(sum(r["num_fun_ev"] for r in recs))
+    # parity replay of one restart (rank 0): horizon 1, the best restart's thetas
+    parity = None
+    if rank == 0:
+        r1 = min(recs, key=lambda r: r["horizon"])
+        circ = trotter_ansatz(w["n"], int(r1["num_layers"]), True)
+        tgt = time_evol.generate_target(opts, int(r1["horizon"]) - 1).t1_gt
+        th = np.asarray(r1["thetas"], dtype=np.float64)
+        ini = opts.ini_state_index()
+        ws = Workspace(HipContext.of(circ), batch=1, device=local_rank)
+        ws.upload(BUF_Y, tgt)
+        ws.set_basis(BUF_X, ini)
+        ws.gather_setup([ini])
+        hs, g = ws.eval(th, vdag=True, gather=True, grad=True)
+        ws.close()
+        h_ref, g_ref = cref.eval_batch(circ, th[None, :], tgt, ini, min(16, host_cores()))
+        parity = max(abs(hs[0, 0] - h_ref[0]), float(np.abs(g[0] - g_ref[0]).max()))
+        fid_gap = abs(abs(h_ref[0]) ** 2 - float(r1["fidelity"]))   # the record's fidelity against the oracle's at the record's thetas
+        if not parity < PARITY_TOL:
+            print(f"bench.py: cfg4_driver: the replayed restart deviates from the oracle by {parity:g}", file=sys.stderr)
+            os._exit(3)
+    return {
+        "metric": "objective+gradient evals/sec", "value": evals / wall, "unit": "evals/s", "n_gpus": n_gpus, "steps": 1, "warmup": 1,
+        "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "parity_maxerr": parity, "parity_lanes_checked": 1, "record_fidelity_vs_oracle": fid_gap if rank == 0 else None,
+        "parity_note": "horizon 1, best restart: amplitude <ini|V^H|t1_gt>, complex gradient and the record's fidelity at the optimised "
+                       "thetas, device vs C oracle (target = the driver's own ground-truth state)",
+        "config": {"workload": w["desc"], "n_qubits": w["n"], "horizons": H, "restarts_per_horizon": w["seeds"], "lbfgs": mode,
+                   "lbfgs_maxiter": w["maxiter"], "horizons_per_s": H / wall, "optimisations_per_s": H * w["seeds"] / wall,
+                   "evaluations": evals, "lanes_per_entry": w["seeds"],
+                   "fidelity_best_per_horizon": [float(r["fidelity"]) for r in sorted(recs, key=lambda r: r["horizon"])],
+                   "fidelity_threshold_per_horizon": [float(r["fidelity_thr"]) for r in sorted(recs, key=lambda r: r["horizon"])],
+                   "fidelity_min_over_restarts": [float(min(r["fidelities"])) for r in sorted(recs, key=lambda r: r["horizon"])],
+                   "num_thetas_per_horizon": [int(r["num_thetas"]) for r in sorted(recs, key=lambda r: r["horizon"])],
+                   "transport": comm.transport if env.comm_note is None else env.comm_note, "ranks_seen": env.ranks_seen,
+                   "includes": "target synthesis (ground truth with 10x the Trotter steps + reference state) per horizon, initial "
+                               "points, optimisation of all restarts, result records; contexts and plans are built inside the timed run"},
     }
 
 
@@ -490,6 +598,46 @@ def run_mps_engine(args, w, env, full):
     wall = time.perf_counter() - t0
     if env.comm.size > 1:
         wall = float(env.comm.allreduce(np.array([wall]), "max")[0])
+    # roofline of the dominant kernel (lanes_gate2_kernel: a truncated 2-qubit gate = one-sided Jacobi SVD per lane in LDS): fp64 flops of
+    # the rotations that really ran (counted on the device) / the summed duration of its launches (event pairs around each), two more steps
+    roof = None
+    ls = me._lockstep_for(n, B, env.local_rank, targets, basis)
+    ls.gate2_stats(enable=True, reset=True)
+    for i in range(2):
+        me.evaluate_lanes(circ, thetas(30 + i), targets, basis, trunc_thr=thr, method="lockstep")
+    st = ls.gate2_stats(enable=False)
+    if st["launches_timed"] > 0 and st["launch_ms"] > 0:
+        tfl = st["jacobi_flops"] / (st["launch_ms"] * 1e-3) / 1e12
+        roof = {"bound": "valu fp64 (latency-bound in practice)", "kernel": "lanes_gate2_kernel", "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tfl / FP64_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": st["launch_ms"] / st["launches_timed"],
+                "flops_per_launch": st["jacobi_flops"] / st["launches_timed"],
+                "flop_convention": "Jacobi rotations that ran: per column pair and sweep 36 flop per row of the work matrix (three inner products, "
+                                   "rotation of the pair) + 20 per row of V; counted by the kernel",
+                "svds_per_step": st["svds"] / 2, "sweeps_per_svd": st["sweeps"] / max(st["svds"], 1), "rotations_per_svd": st["rotations"] / max(st["svds"], 1),
+                "share_of_step": (st["launch_ms"] / 2) / (wall / K * 1e3)}
+    # pinned check: the same lanes at trunc_thr -> 0 on a register the C oracle reaches and whose bonds cannot outgrow the lanes (10 qubits, same ansatz family): amplitude and
+    # complex gradient of 4 lanes against the dense restatement of the reference
+    from oracle import aqc_ref as cref
+    from oracle.aqc_oracle import mps_to_vector as orc_mps_to_vector
+
+    n_small = 10   # (no bond of a 10-qubit register exceeds the lanes' 32: nothing is truncated at trunc_thr -> 0)
+    circ_s = TrotterAnsatz(n_small, make_trotter_like_circuit(n_small, layers), second_order=True)
+    ths = init_ansatz_to_trotter(circ_s, np.zeros(circ_s.num_thetas), evol_time=evol, delta=1.0)[None, :] + \
+        0.02 * np.random.default_rng(7).standard_normal((4, circ_s.num_thetas))
+    tcirc_s = TrotterAnsatz(n_small, make_trotter_like_circuit(n_small, 3 * layers), second_order=True)
+    neel_s = neel_state_index(n_small)
+    basis_s = me.DeviceMPS.basis_state(n_small, neel_s, device=env.local_rank)
+    tgt_s = me.v_mul_mps(tcirc_s, init_ansatz_to_trotter(tcirc_s, np.zeros(tcirc_s.num_thetas), evol_time=evol, delta=1.0), basis_s, trunc_thr=1e-30)
+    hs4, gs4 = me.evaluate_lanes(circ_s, ths, tgt_s, basis_s, trunc_thr=1e-30, method="lockstep")
+    dense_t = orc_mps_to_vector(tgt_s.to_qiskit())
+    parity = 0.0
+    for b in range(4):
+        h_ref, g_ref = cref.eval_batch(circ_s, ths[b][None, :], dense_t, neel_s, 1)
+        parity = max(parity, abs(hs4[b] - h_ref[0]), float(np.abs(gs4[b] - g_ref[0]).max()))
+    tgt_s.close(); basis_s.close()
+    if not parity < PARITY_TOL:
+        print(f"bench.py: {w['desc'][:40]}: lockstep lanes at trunc_thr -> 0 deviate from the oracle by {parity:g}", file=sys.stderr)
+        os._exit(3)
     me.evaluate_lanes(circ, thetas(49)[:1], targets[:1], basis, trunc_thr=thr)   # (sizes the one-lane batch's launches)
     t1 = time.perf_counter()
     me.evaluate_lanes(circ, thetas(50)[:1], targets[:1], basis, trunc_thr=thr)
@@ -527,9 +675,11 @@ def run_mps_engine(args, w, env, full):
         "config": {"workload": w["desc"], "n_qubits": n, "num_thetas": T, "batch_per_gpu": B, "path": "MPS front door (mps_dot_objective), native MPS engine",
                    "mps_trunc_thr": thr, "target_max_bond": bonds, "mean_fidelity_term": float(np.mean(np.abs(h) ** 2)), "ranks_seen": env.ranks_seen,
                    "lanes": "lockstep, device-resident (aqc_mpsb_eval): one launch per step of the gate walk for all lanes, rank decisions on the device, bonds <= 32"},
-        "roofline": None,
-        "parity_maxerr": None, "parity_lanes_checked": 0,
-        "parity_note": "truncated MPS arithmetic is parity-unpinned (qiskit-aer absent); value / gradient consistency of the engine: "
+        "roofline": roof,
+        "parity_maxerr": parity, "parity_lanes_checked": 4,
+        "parity_note": "parity_maxerr: the lockstep lanes at trunc_thr -> 0 on the 10-qubit member of the same ansatz family against the C oracle "
+                       "(amplitude + complex gradient, 4 lanes); the TRUNCATED arithmetic of the timed 32-qubit workload stays parity-unpinned "
+                       "(qiskit-aer absent); value / gradient consistency of the engine there: "
                        f"|central difference - analytic| = {consistency:.2e} on one parameter",
         "value_gradient_consistency": consistency,
         "lockstep_vs_single_lane_maxerr": lane_err, "lockstep_lanes_checked": nchk,
@@ -902,7 +1052,7 @@ def main():
 # the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
 # MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
 CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "mat10_l40_k16", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
-               "sv20_trotter2", "cfg4_jobs", "mat10_l40", "mps32_trotter2_engine", "mps32_trotter2_opt"]
+               "sv20_trotter2", "cfg4_jobs", "cfg4_driver", "mat10_l40", "mps32_trotter2_engine", "mps32_trotter2_opt"]
 
 
 def brief(o):
@@ -915,7 +1065,8 @@ def brief(o):
          "sweep_avg_launch_ms": r.get("avg_launch_ms"), "parity_maxerr": o.get("parity_maxerr"),
          "parity_lanes_checked": o.get("parity_lanes_checked")}
     for k in ("front_door_single_lane", "jobs_per_s", "mean_fidelity", "single_lane", "host_thread_lanes", "lockstep_vs_single_lane_maxerr", "optimisations_per_s",
-              "fidelity_start_mean", "fidelity_end_mean", "lbfgs_maxiter",
+              "fidelity_start_mean", "fidelity_end_mean", "lbfgs_maxiter", "horizons_per_s", "horizons", "evaluations", "fidelity_best_per_horizon",
+              "fidelity_threshold_per_horizon", "lbfgs",
               "value_gradient_consistency", "parity_note"):
         if k in o:
             b[k] = o[k]
@@ -941,6 +1092,8 @@ def measure(workload, args, env, full):
         return run_mps_engine(args, w, env, full)
     if w["kind"] == "mps_opt":
         return run_mps_opt(args, w, env, full)
+    if w["kind"] == "driver":
+        return run_driver(args, w, env, full)
     if w["kind"] == "jobs":
         out = run_job_mix(args, w, comm, rank, local_rank, n_gpus, comm_note, steps=(args.steps if full else 1))
         out["config"]["ranks_seen"] = ranks_seen

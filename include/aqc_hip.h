@@ -243,6 +243,9 @@ int aqc_mps_fast_dot_gradient(const aqc_circuit* circ, const aqc_mps* lvec, cons
 typedef struct aqc_mpsb aqc_mpsb;
 int aqc_mpsb_create(int device, int num_qubits, int lanes, aqc_mpsb** out);
 int aqc_mpsb_destroy(aqc_mpsb* b);
+/* work and time of the truncated 2-qubit gates of the lanes (the SVDs that qiskit-aer runs per gate, mps_operations.py:252-257):
+ * enable 1 / 0 / -1 (leave); out[6] = fp64 flops of the Jacobi rotations that ran, SVDs, sweeps, rotations, launches timed, their ms */
+int aqc_mpsb_gate2_stats(aqc_mpsb* b, int enable, double* out, int reset);
 /* |phi_l> of every lane (the objective's target, objective_base.py:112 set_target) and <lhs_l| (its left-hand state |0> or the
  * surrogate's low-entangled state, objective_lhs_sur_fast_mps_trotter.py:99); shared != 0: handles[0] serves every lane */
 int aqc_mpsb_set_targets(aqc_mpsb* b, aqc_mps* const* handles, int shared);

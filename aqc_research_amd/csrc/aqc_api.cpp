@@ -543,6 +543,9 @@ int aqc_ws_set_basis(aqc_ws* ws, int buf, const int64_t* index) {
     HIP_OK(hipMemcpyAsync(ws->d_combo_prev[buf], supp.data(), sizeof(long long) * supp.size(), hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     ws->combo_valid[buf] = true;
+    ws->combo_last_elem[buf] = supp;
+    ws->combo_last_coef[buf].assign(4 * (size_t)ws->batch, 0.0);
+    for (int b = 0; b < ws->batch; ++b) ws->combo_last_coef[buf][4 * (size_t)b] = 1.0;
     ++ws->supp_version[buf];
     return 0;
 }
@@ -580,6 +583,9 @@ int aqc_ws_set_combo(aqc_ws* ws, int buf, const int64_t* index, const double* co
         elem[2 * b] = (long long)i0 << ws->col_bits;
         elem[2 * b + 1] = i1 < 0 ? -1 : (long long)i1 << ws->col_bits;
     }
+    // the same combination as the buffer already holds (an objective hands the same lhs state in on every call): nothing to do
+    std::vector<double> cf(coef, coef + 4 * (size_t)B);
+    if (ws->combo_valid[buf] && ws->combo_last_elem[buf] == elem && ws->combo_last_coef[buf] == cf) return 0;
     if (!ws->d_combo_index) HIP_OK(hipMalloc((void**)&ws->d_combo_index, sizeof(long long) * 2 * B));
     if (!ws->d_combo_coef) HIP_OK(hipMalloc((void**)&ws->d_combo_coef, sizeof(double2) * 2 * B));
     if (!ws->d_combo_prev[buf]) { HIP_OK(hipMalloc((void**)&ws->d_combo_prev[buf], sizeof(long long) * 2 * B)); ws->combo_valid[buf] = false; }
@@ -593,6 +599,8 @@ int aqc_ws_set_combo(aqc_ws* ws, int buf, const int64_t* index, const double* co
     ProfScope ps(ws, AQC_K_MISC);
     HIP_OK(launch_scatter_two(ws->bufs[buf], ws->lane_elems, B, ws->d_combo_index, ws->d_combo_coef, ws->d_combo_prev[buf], ws->stream));
     ws->combo_valid[buf] = true;
+    ws->combo_last_elem[buf] = elem;
+    ws->combo_last_coef[buf].swap(cf);
     ++ws->supp_version[buf];
     touch_buf(ws, buf);
     return 0;

@@ -115,6 +115,8 @@ struct aqc_ws {
     long long* d_basis_index = nullptr;   // [batch], set_basis only (keeps the gather set-up intact)
     long long* d_combo_prev[AQC_NUM_BUFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // set_combo: positions written last time
     bool combo_valid[AQC_NUM_BUFS] = {false, false, false, false, false, false};   // buffer holds exactly that sparse pattern
+    std::vector<long long> combo_last_elem[AQC_NUM_BUFS];   // host copy of the pattern (positions, coefficients) the HOST wrote last; device-side
+    std::vector<double> combo_last_coef[AQC_NUM_BUFS];      // writers (lb_prepare) clear it
     // aqc_ws_surrogate_eval: device block [f B | fidelity B | weight B | hs 2 B S | max_no B ints], its pinned mirror
     void* d_sur = nullptr;
     void* h_sur = nullptr;

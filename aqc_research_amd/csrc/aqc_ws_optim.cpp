@@ -81,6 +81,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
         LB_OK(hipMemcpyAsync(L.x, x0, sizeof(double) * BT, hipMemcpyHostToDevice, st_));
         LB_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st_));
         ws->combo_valid[AQC_BUF_X2] = true;   // the buffer holds exactly the pattern its record names (nothing, so far)
+        ws->combo_last_elem[AQC_BUF_X2].clear();
         ++ws->supp_version[AQC_BUF_X2];
         LB_OK(hipStreamSynchronize(st_));
     }
@@ -102,6 +103,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         HIP_OK(lb_prepare(L, ws->d_small, update, f_o, raw_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
         ++ws->supp_version[AQC_BUF_X2];   // (the leading flip state is chosen on the device: the support may have moved)
+        ws->combo_last_elem[AQC_BUF_X2].clear();
         if (grad_from_impl(ws, AQC_BUF_X2, block_from, block_to, front_layer, true)) return 1;
         HIP_OK(lb_take(L, ws->d_grads, g_o, raw_g, st_));
         ++nfev;
@@ -221,6 +223,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_X2], 0, sizeof(double2) * (size_t)B * ws->lane_elems, st));
         HIP_OK(hipMemsetAsync(ws->d_combo_prev[AQC_BUF_X2], 0xff, sizeof(long long) * 2 * B, st));   // -1: nothing to clear
         ws->combo_valid[AQC_BUF_X2] = true;   // the buffer holds exactly the pattern its record names
+        ws->combo_last_elem[AQC_BUF_X2].clear();
     }
     const bool sparse = sweep_route_sparse(ws, AQC_BUF_X2, true);   // (decided here: part of the captured graph's key)
     if (sparse && sweep_sparse_prepare(ws)) return 1;
@@ -248,6 +251,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
             HIP_OK(lb_prepare(L, ws->d_small, update_state, d_f, d_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index,
                               ws->d_combo_prev[AQC_BUF_X2], st));
             ++ws->supp_version[AQC_BUF_X2];
+            ws->combo_last_elem[AQC_BUF_X2].clear();
         }
         // (update_state == 0 leaves weight / max_no / fidelity as they came in; fidelity is only written by an update)
         if (grad_from_impl(ws, AQC_BUF_X2, block_from, block_to, front_layer, true)) return 1;
@@ -295,6 +299,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         ws->ckpt_valid = false;
         if (lazy) vdag_restricted_state_after(ws, AQC_BUF_X2); else apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
         ++ws->supp_version[AQC_BUF_X2];
+        ws->combo_last_elem[AQC_BUF_X2].clear();
         sweep_state_after(ws, sparse, true);
         HIP_OK(hipGraphLaunch(it->second, st));
     } else if (enqueue()) {

@@ -521,6 +521,27 @@ def _ws_mps_forget(self, mps) -> None:
         ent[1] = None   # (the slot stays with the tuple: the next call uploads into it again)
 
 
+def _mps_basis_term(mps):
+    """(index, amplitude) when the MPS is a computational-basis state times a scalar -- every bond 1, one of the two tensors of
+    every site exactly zero (the |0> / flip states the objectives hand in as ``lvec``, objective_base.py:345-435) -- else None."""
+    gam, lam = mps
+    index, amp = 0, 1.0 + 0.0j
+    for q, (g0, g1) in enumerate(gam):
+        if np.size(g0) != 1 or np.size(g1) != 1:
+            return None
+        a0, a1 = complex(np.reshape(g0, -1)[0]), complex(np.reshape(g1, -1)[0])
+        if (a0 == 0) == (a1 == 0):
+            return None
+        if a0 == 0:
+            index |= 1 << q
+        amp *= a1 if a0 == 0 else a0
+    for l in lam:
+        if np.size(l) != 1:
+            return None
+        amp *= float(np.reshape(l, -1)[0])
+    return index, amp
+
+
 def _ws_mps_to_vec_batch(self, mps_list, buf: int, lanes=None) -> None:
     """Dense states of `mps_list` (QiskitMPS tuples, one per lane) into lanes `lanes` (default 0..len-1) of `buf`: resident
     copies through the slot cache, lanes that share a tuple share its slot, ONE contraction chain for all lanes (operands of different
@@ -528,6 +549,13 @@ def _ws_mps_to_vec_batch(self, mps_list, buf: int, lanes=None) -> None:
     lanes = np.arange(len(mps_list), dtype=np.int32) if lanes is None else np.ascontiguousarray(lanes, dtype=np.int32)
     if lanes.size != len(mps_list):
         raise ValueError("one lane per MPS")
+    if buf in (BUF_X, BUF_X2) and lanes.size == self.batch and np.array_equal(lanes, np.arange(self.batch)):
+        # lhs states that are basis states (what every objective sweeps from): two amplitudes per lane written in place instead of a
+        # contraction chain -- and the workspace knows the support, so the sweep takes its sparse route (aqc_ws_sweep.cpp)
+        terms = {id(m): _mps_basis_term(m) for m in {id(m): m for m in mps_list}.values()}
+        if all(t is not None for t in terms.values()):
+            self.set_combo(buf, [[terms[id(m)][0], -1] for m in mps_list], [[terms[id(m)][1], 0.0] for m in mps_list])
+            return
     if len({id(m) for m in mps_list}) > _MPS_SLOTS - _MPS_FIRST_CACHED:
         raise ValueError(f"at most {_MPS_SLOTS - _MPS_FIRST_CACHED} distinct MPS per batched contraction")
     # Truncated canonical tensors (the reference's trunc_thr = 1e-6) differ from target to target by a few bond entries, and the native

@@ -920,7 +920,7 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B):
         elif k == K_APPLY_LIST:
             frac = vd_items / float(ntiles * B)
         flops = (288.0 if which else 96.0) * N * B * frac * nsub
-        rows.append({"kernel": ("sweep_mfma_kernel" if which else "apply_mfma_kernel") + f"<{tile_bits}{', tile list' if frac < 1 or k in (K_SWEEP_LIST, K_APPLY_LIST) else ''}>",
+        rows.append({"kernel": ("sweep_mfma_kernel" if which else "apply_mfma_kernel") + f"<{tile_bits}, {'true' if k in (K_SWEEP_LIST, K_APPLY_LIST) else 'false'}>",   # (true: over a tile list)
                      "plan": "sweep" if which else "V^H", "stage": st, "substages": nsub, "tiles_frac": frac, "avg_ms": avg[j],
                      "flops": flops, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
                      "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0})
@@ -1339,10 +1339,11 @@ def measure(workload, args, env, full):
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pj.get("workload") == workload and pj.get("batch_per_gpu") == B:
+                want = dominant["kernel"] if dominant else "sweep_mfma_kernel"
                 for kname, kv in pj["kernels"].items():
-                    if "sweep_stage_kernel" in kname or "sweep_mfma_kernel" in kname:
+                    if want in kname or (not dominant and "sweep_stage_kernel" in kname):
                         traffic = kv["hbm_bytes_per_launch"]
-                        traffic_source = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_run3.py, "
+                        traffic_source = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_run5.py, "
                                           f"committed as profiles/pmc_traffic.json ({pj.get('date', 'undated')}, {pj.get('source', 'builder-run')})")
         except Exception:
             traffic, traffic_source = None, None

@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <map>
+#include <mutex>
 
 namespace aqc {
 
@@ -177,7 +179,29 @@ namespace {
 // `r` register bits (for long stages: only those containing the bits of the first pending group), executing everything
 // it can reach in program order.  Returns the chosen register-bit masks, or an empty vector when the stage is too
 // large for the search.
+std::vector<uint64_t> beam_substages_search(const std::vector<uint64_t>& op_bits, int k, int r, int width);
+
+// The search only sees the stage's groups as bit masks over its local positions, and the stages of a layered ansatz repeat
+// (a 240-step Trotter circuit at 20 qubits has 182 stages and a dozen distinct patterns; the V plan and the sweep plan of a
+// workspace share all of them): results are remembered per pattern for the life of the process.
 std::vector<uint64_t> beam_substages(const std::vector<uint64_t>& op_bits, int k, int r, int width) {
+    static std::mutex mu;
+    static std::map<std::vector<uint64_t>, std::vector<uint64_t>> memo;
+    std::vector<uint64_t> key = op_bits;
+    key.push_back(((uint64_t)k << 32) | ((uint64_t)r << 16) | (uint64_t)width);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+    }
+    std::vector<uint64_t> out = beam_substages_search(op_bits, k, r, width);
+    std::lock_guard<std::mutex> lock(mu);
+    if (memo.size() > 4096) memo.clear();
+    memo.emplace(std::move(key), out);
+    return out;
+}
+
+std::vector<uint64_t> beam_substages_search(const std::vector<uint64_t>& op_bits, int k, int r, int width) {
     const int nops = (int)op_bits.size();
     if (nops == 0 || k <= r || k > 16 || (long long)nops * nops > 4000000) return {};
     std::vector<uint64_t> masks;

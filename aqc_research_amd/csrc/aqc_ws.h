@@ -191,6 +191,7 @@ struct aqc_ws {
     aqc::TileItem* d_vd_items = nullptr;    // [batch][2 + gather_count]
     size_t vd_items_cap = 0;
     unsigned long long gather_gen = 0;      // bumped by aqc_ws_gather_setup
+    unsigned long long vd_key[3] = {~0ull, ~0ull, ~0ull};   // what d_vd_items was built from: lhs buffer (or -1: gather set alone), its support version, gather_gen
     unsigned long long z_gather_gen = 0;    // what the tiles of a partial Z were chosen for: the gather set ...
     int z_x_buf = -1;                       // ... and the support of this lhs buffer at this version
     unsigned long long z_x_version = 0;
@@ -233,7 +234,7 @@ int results_guard(aqc_ws* ws);
 void touch_buf(aqc_ws* ws, int buf);   // somebody other than the V^H / sweep pair is about to write the whole buffer
 int ensure_z_full(aqc_ws* ws, bool reader);   // before anybody reads Z (or writes a part of it): complete a partial V^H y
 bool vdag_route_restricted(const aqc_ws* ws, int x_buf);
-int run_vdag_restricted(aqc_ws* ws, int x_buf);
+int run_vdag_restricted(aqc_ws* ws, int x_buf, bool support_in_gather_set = false);
 void vdag_restricted_state_after(aqc_ws* ws, int x_buf);
 int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer, bool support_in_gather_set);
 bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag);

@@ -98,7 +98,7 @@ int aqc_ws_lbfgs(aqc_ws* ws, const double* x0, int maxiter, int memory, double g
         if (run_coef(ws)) return 1;
         const bool sparse = sweep_route_sparse(ws, AQC_BUF_X2, true);
         if (sparse && sweep_sparse_prepare(ws)) return 1;
-        if (sparse && vdag_route_restricted(ws, AQC_BUF_X2)) { if (run_vdag_restricted(ws, AQC_BUF_X2)) return 1; }   // V^H where the gather and
+        if (sparse && vdag_route_restricted(ws, AQC_BUF_X2)) { if (run_vdag_restricted(ws, AQC_BUF_X2, true)) return 1; }   // V^H where the gather and
         else if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;                                                   // the sweep read it
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         HIP_OK(lb_prepare(L, ws->d_small, update, f_o, raw_hs, ws->bufs[AQC_BUF_X2], ws->lane_elems, ws->d_index, d_prev, st_));
@@ -244,7 +244,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         if (!direct_thetas) HIP_OK(hipMemcpyAsync(ws->d_thetas, pin_th, sizeof(double) * nth, hipMemcpyHostToDevice, st));
         if (run_coef(ws)) return 1;
         ws->theta_host = direct_thetas ? pin_th : nullptr;   // the U builder reads the pinned thetas and stores them to HBM
-        if (lazy ? run_vdag_restricted(ws, AQC_BUF_X2) : run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
+        if (lazy ? run_vdag_restricted(ws, AQC_BUF_X2, true) : run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
         if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
         {
             ProfScope ps(ws, AQC_K_MISC);

@@ -217,7 +217,9 @@ static Stage3Args last_vdag_stage(aqc_ws* ws) {
     a.out0 = ws->bufs[AQC_BUF_Z];
     return a;
 }
-int run_vdag_restricted(aqc_ws* ws, int x_buf) {   // Y -> Z; the caller has asked vdag_route_restricted and sweep_sparse_prepare
+// support_in_gather_set: the lhs state is picked among the registered gather indices (surrogate objective: |state_0> and the
+// leading flip state) -- the gather set alone names the tiles, and the list only changes when that set does
+int run_vdag_restricted(aqc_ws* ws, int x_buf, bool support_in_gather_set) {   // Y -> Z; the caller has asked vdag_route_restricted and sweep_sparse_prepare
     DevPlan& p = ws->inv;
     if (ensure_umat(ws, p)) return 1;
     const size_t m = p.h_stages.size();
@@ -230,10 +232,13 @@ int run_vdag_restricted(aqc_ws* ws, int x_buf) {   // Y -> Z; the caller has ask
         ProfScope ps(ws, AQC_K_APPLY);
         HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
     }
-    {
+    const bool gather_only = support_in_gather_set && ws->gather_count > 0;
+    const unsigned long long key[3] = {gather_only ? ~0ull - 1 : (unsigned long long)x_buf, gather_only ? 0ull : ws->supp_version[x_buf], ws->gather_gen};
+    if (ws->capturing || key[0] != ws->vd_key[0] || key[1] != ws->vd_key[1] || key[2] != ws->vd_key[2]) {   // (a static list is built once)
         ProfScope ps(ws, AQC_K_MISC);
-        HIP_OK(launch_tile_items(p.h_stages[m - 1], ws->d_combo_prev[x_buf], 2, ws->gather_count > 0 ? ws->d_index : nullptr, ws->gather_count,
-                                 ws->batch, ws->d_vd_items, ws->d_sw_counts + 2, nullptr, nullptr, nullptr, nullptr, ws->stream));
+        HIP_OK(launch_tile_items(p.h_stages[m - 1], gather_only ? nullptr : ws->d_combo_prev[x_buf], 2, ws->gather_count > 0 ? ws->d_index : nullptr,
+                                 ws->gather_count, ws->batch, ws->d_vd_items, ws->d_sw_counts + 2, nullptr, nullptr, nullptr, nullptr, ws->stream));
+        for (int i = 0; i < 3; ++i) ws->vd_key[i] = ws->capturing ? ~0ull : key[i];   // (a captured graph rebuilds it on every replay)
     }
     Stage3Args a = last_vdag_stage(ws);
     a.items = ws->d_vd_items;
@@ -308,6 +313,7 @@ int sweep_sparse_prepare(aqc_ws* ws) {
         ws->d_vd_items = nullptr; ws->vd_items_cap = 0;
         HIP_OK(hipMalloc((void**)&ws->d_vd_items, sizeof(TileItem) * vd_need));
         ws->vd_items_cap = vd_need;
+        ws->vd_key[0] = ws->vd_key[1] = ws->vd_key[2] = ~0ull;
     }
     if (!ws->w_clean) {
         HIP_OK(hipMemsetAsync(ws->bufs[AQC_BUF_W], 0, sizeof(double2) * (size_t)B * ws->lane_elems, ws->stream));

@@ -37,7 +37,8 @@ struct DevStage {
     int32_t nub;          // number of non-local bits
     int32_t sub_begin;    // first DevSub (register-blocked kernels)
     int32_t nsubs;
-    int32_t pad;
+    uint32_t fresh_nonlocal;   // sweep plans: element-offset mask of the non-local address bits that no EARLIER stage had local ("fresh":
+                               // a sweep from basis states leaves w zero wherever such a bit differs from the basis index)
     int32_t ubits[32];    // non-local address bits, ascending
     uint32_t dlo[64];     // element offset of local index low 6 bits
     uint32_t dhi[256];    // element offset of local index bits 6..13
@@ -97,6 +98,13 @@ struct DevSub3 {
     // a few scalar loads instead of 16 loads, 13 readfirstlanes and ~70 scalar operations):
     uint32_t lane12[64];    // per lane: low half = L1 slot (dep_clo[l % 16] ^ dep_a[l / 16]), high half = L2 slot
     uint32_t kk[16][8];     // per group g: [s] = (dep_a[4 s] ^ dep_chi[g]) << 4 (L1, K-step s), [4 + r] = (dep_clo[4 r] ^ dep_chi[g]) << 4
+    // Sweep from basis states (sparse lhs): which index bits of this sub-stage are still FRESH -- local bits that neither an earlier
+    // stage nor an earlier sub-stage of this stage has mixed -- so that w is zero wherever they differ from the basis index:
+    //   bits 0..3   fresh bits of the GROUP index (group g = high chunk bits, dep_chi)      -> whole groups of 16 chunks with w = 0
+    //   bits 4..7   fresh bits of the AMPLITUDE index (register bits); bits 6, 7 select the K-step of the W product
+    //   bits 8..23  local bit position (4 bits each) behind group-index bit 0..3;  bits 24..31: behind amplitude bits 2, 3
+    uint32_t skipinfo;
+    uint32_t pad3[3];
 };
 
 constexpr int kMaxMopsPerSub = 64;   // 8 gate groups x (7 micro-ops + 1 reduction)

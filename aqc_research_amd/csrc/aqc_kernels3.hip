@@ -400,7 +400,37 @@ __device__ __forceinline__ void wait_prefetched(dbl2_t (&pw)[N], dbl2_t (&pz)[N]
 }
 __device__ __forceinline__ unsigned tile_offset3(const DevStage& st, unsigned local) { return st.dlo[local & 63u] | st.dhi[local >> 6]; }
 template <int K> struct SweepShape : TileShape<K, true> {};   // (no comma inside the __launch_bounds__ macro arguments)
-template <int K, bool LIST = false>
+// SKIPW (sweep from basis states, Stage3Args::supp): per item and sub-stage two wave-uniform masks say which of the wave's groups
+// can hold a non-zero w at all and which K-steps of the W product can (see skip_masks); the W product of the other groups / K-steps
+// and the R product of the other groups are not issued -- they would multiply exact zeros.
+__device__ __forceinline__ unsigned elem_bit(const DevStage& st, long long e, unsigned local_pos) {   // local bit `local_pos` of element e
+    const unsigned m = local_pos < 6 ? st.dlo[1u << local_pos] : st.dhi[1u << (local_pos - 6)];
+    return ((unsigned long long)e & m) ? 1u : 0u;
+}
+template <int GPW, int NW>
+__device__ __forceinline__ void skip_masks(const DevStage& st, unsigned info, long long e0, long long e1, int wave, unsigned& nzmask, unsigned& kneed) {
+    nzmask = 0; kneed = 0;
+    const unsigned gfresh = info & 15u, kfresh = (info >> 6) & 3u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const long long e = k ? e1 : e0;
+        if (e < 0) continue;
+        unsigned gb = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (gfresh >> i & 1) gb |= elem_bit(st, e, (info >> (8 + 4 * i)) & 15u) << i;
+        unsigned kb = 0;
+        if (kfresh & 1) kb |= elem_bit(st, e, (info >> 24) & 15u);
+        if (kfresh & 2) kb |= elem_bit(st, e, (info >> 28) & 15u) << 1;
+#pragma unroll
+        for (int j = 0; j < GPW; ++j)
+            if ((((unsigned)(wave + j * NW) ^ gb) & gfresh) == 0) nzmask |= 1u << j;
+#pragma unroll
+        for (unsigned s2 = 0; s2 < 4; ++s2)
+            if (((s2 ^ kb) & kfresh) == 0) kneed |= 1u << s2;
+    }
+}
+template <int K, bool LIST = false, bool SKIPW = false>
 __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void sweep_mfma_kernel(const Stage3Args a) {
     using TS = TileShape<K, true>;
     constexpr int kSlots = TS::kWaves > 4 ? 4 : TS::kWaves;   // scratch slots; 8 waves reduce in pairs first
@@ -487,6 +517,16 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     for (;;) {
     const int bl = it.bl, tile = it.tile;
     const size_t lane_off = item_off;
+    long long se0 = -1, se1 = -1;   // SKIPW: the lane's basis elements that can reach this tile (fresh non-local bits agree with the tile's)
+    if (SKIPW) {
+        const unsigned long long toff = (unsigned long long)tile_base3(st, tile);
+        const long long c0 = a.supp[2 * (size_t)bl], c1 = a.supp[2 * (size_t)bl + 1];
+        const unsigned lo0 = __builtin_amdgcn_readfirstlane((unsigned)c0), hi0 = __builtin_amdgcn_readfirstlane((unsigned)(c0 >> 32));
+        const unsigned lo1 = __builtin_amdgcn_readfirstlane((unsigned)c1), hi1 = __builtin_amdgcn_readfirstlane((unsigned)(c1 >> 32));
+        const long long u0 = (long long)(((unsigned long long)hi0 << 32) | lo0), u1 = (long long)(((unsigned long long)hi1 << 32) | lo1);
+        if (u0 >= 0 && (((unsigned long long)u0 ^ toff) & st.fresh_nonlocal) == 0) se0 = u0;
+        if (u1 >= 0 && (((unsigned long long)u1 ^ toff) & st.fresh_nonlocal) == 0) se1 = u1;
+    }
     const double* umat = a.umat + (size_t)bl * a.nsubs_total * 12 * 64;
     // slot of this item's partial: its tile (one partial per tile), or its segment = number of workgroups that hold earlier
     // tiles of the lane
@@ -524,6 +564,12 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
     };
     for (int si = 0; si < st.nsubs; ++si) {
         const bool from_regs = reg_first && si == 0;
+        unsigned nzmask = ~0u, kneed = 15u;
+        if (SKIPW) {
+            const unsigned info = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
+                (const __attribute__((address_space(4))) void*)(const void*)&a.subs[st.sub_begin + si].skipinfo);
+            skip_masks<TS::kGpw, NW>(st, info, se0, se1, wave, nzmask, kneed);
+        }
         AQC_STAMP(2 + 4 * si);
         if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
         else if (more) fetch_sub<TS::kGpw>(nxt, a.subs, a.umat + (size_t)nbl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
@@ -600,17 +646,26 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             __builtin_amdgcn_sched_barrier(0);
             if (j < TS::kGpw) {
                 aw.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; aw.k2 = aw.k1; aw.k3 = aw.k1; az.k1 = aw.k1; az.k2 = aw.k1; az.k3 = aw.k1;
+                if (!SKIPW) {
 #pragma unroll
-                for (int s = 0; s < (AQC_DBG_TEST(a.debug & 8) ? 0 : 4); ++s) {
-                    aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
-                    aw.k2 = mfma(vw[j & 1][s].x, cur.u1[s], aw.k2);
-                    aw.k3 = mfma(vw[j & 1][s].y, cur.u2[s], aw.k3);
-                    az.k1 = mfma(sz[s], cur.u0[s], az.k1);
-                    az.k2 = mfma(vz[j & 1][s].x, cur.u1[s], az.k2);
-                    az.k3 = mfma(vz[j & 1][s].y, cur.u2[s], az.k3);
+                    for (int s = 0; s < (AQC_DBG_TEST(a.debug & 8) ? 0 : 4); ++s) {
+                        aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
+                        aw.k2 = mfma(vw[j & 1][s].x, cur.u1[s], aw.k2);
+                        aw.k3 = mfma(vw[j & 1][s].y, cur.u2[s], aw.k3);
+                        az.k1 = mfma(sz[s], cur.u0[s], az.k1);
+                        az.k2 = mfma(vz[j & 1][s].x, cur.u1[s], az.k2);
+                        az.k3 = mfma(vz[j & 1][s].y, cur.u2[s], az.k3);
+                    }
+                } else {   // U z always (the LDS writes of group j - 1 ride in this run); U w below, where w can be non-zero
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        az.k1 = mfma(sz[s], cur.u0[s], az.k1);
+                        az.k2 = mfma(vz[j & 1][s].x, cur.u1[s], az.k2);
+                        az.k3 = mfma(vz[j & 1][s].y, cur.u2[s], az.k3);
+                    }
                 }
             }
-            if (j > 0 AQC_DBG_AND(!(a.debug & 4))) {
+            if (!SKIPW && j > 0 AQC_DBG_AND(!(a.debug & 4))) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {   // R += Z' W'^H over the 4 chunks of K-step r
                     t1 = mfma(oz[r].x, ow[r].x, t1);
@@ -622,7 +677,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             // issued between two MFMAs costs ~1.5 cycles (tools/ubench/mfma_f64_shadow.hip), while the same writes bunched
             // after the run -- all four waves at once -- run into the 64-79 B/clk the CU accepts for 128-bit stores
             // (1.7k cycles per sub-stage).  Measured at the headline: sweep launch pair 1.215 -> 1.092 ms.
-            if (j > 0 AQC_DBG_AND(!(a.debug & 1))) {
+            if (j > 0 && !(SKIPW && j == TS::kGpw) AQC_DBG_AND(!(a.debug & 1))) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
 #pragma unroll
@@ -632,6 +687,47 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (SKIPW && j == TS::kGpw) {   // last iteration: no U z run left -- the last group's writes ride in its R run when there is one
+                if (nzmask >> (j - 1) & 1u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        t1 = mfma(oz[r].x, ow[r].x, t1);
+                        t2 = mfma(oz[r].y, ow[r].y, t2);
+                        t3 = mfma(zs[r], wd[r], t3);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, kSweepSpread, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else
+            if (SKIPW) {   // wave-uniform branches around the products that can be non-zero (scalar masks, compile-time j)
+                if (j < TS::kGpw && (nzmask >> j & 1u)) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (kneed >> s & 1u) {
+                            aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
+                            aw.k2 = mfma(vw[j & 1][s].x, cur.u1[s], aw.k2);
+                            aw.k3 = mfma(vw[j & 1][s].y, cur.u2[s], aw.k3);
+                        }
+                }
+                if (j > 0 && (nzmask >> (j - 1) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        t1 = mfma(oz[r].x, ow[r].x, t1);
+                        t2 = mfma(oz[r].y, ow[r].y, t2);
+                        t3 = mfma(zs[r], wd[r], t3);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         AQC_STAMP(3 + 4 * si);
         if (kPersist && more && st.nsubs == 1) {
@@ -1125,6 +1221,9 @@ hipError_t init_kernels3() {
     AQC_TRY(big_lds((apply_mfma_kernel<11, true>))); AQC_TRY(big_lds((apply_mfma_kernel<12, true>)));
     AQC_TRY(big_lds((sweep_mfma_kernel<8, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<10, true>)));
     AQC_TRY(big_lds((sweep_mfma_kernel<11, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<12, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<8, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<10, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<11, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<12, false, true>)));
 #undef AQC_TRY
     return hipSuccess;
 }
@@ -1196,7 +1295,10 @@ hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stag
     const dim3 grid((unsigned)(k >= 12 ? (list ? std::min<long>(nwork, persistent_sweep_grid()) : (nwork + a.chunk - 1) / a.chunk) : nwork));
     const int t = mfma_threads(k, true);
     const size_t l = sweep3_lds_bytes(k);
-#define AQC_LAUNCH(KK) case KK: if (list) sweep_mfma_kernel<KK, true><<<grid, t, l, s>>>(a); else sweep_mfma_kernel<KK, false><<<grid, t, l, s>>>(a); break
+    const bool skipw = !list && a.supp != nullptr;
+#define AQC_LAUNCH(KK) case KK: if (list) sweep_mfma_kernel<KK, true, false><<<grid, t, l, s>>>(a); \
+                                else if (skipw) sweep_mfma_kernel<KK, false, true><<<grid, t, l, s>>>(a); \
+                                else sweep_mfma_kernel<KK, false, false><<<grid, t, l, s>>>(a); break
     switch (k) {
         AQC_LAUNCH(8); AQC_LAUNCH(9); AQC_LAUNCH(10); AQC_LAUNCH(11); AQC_LAUNCH(12);
         default: return hipErrorInvalidValue;

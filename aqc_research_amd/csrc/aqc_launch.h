@@ -70,6 +70,9 @@ struct Stage3Args {
     int chunk, nparts;       // sweep: items per persistent workgroup (0: one item per workgroup) and partial-R slots per
                              // (lane, sub-stage) -- sweep3_chunk / sweep3_nparts
     int store_out;           // sweep: bit 0 store w, bit 1 store z; 0 for the last stage (its w and z are never read again)
+    const long long* supp;   // sweep from basis states: supp[lane][2] = element index of the lane's (<= 2) basis states (-1: none), or null.
+                             // The kernel then skips the W and R products of 16-chunk groups (and K-steps of the W product) where w is
+                             // zero by construction (DevSub3::skipinfo, DevStage::fresh_nonlocal) -- exact zeros, so the results do not change
     const TileItem* items;   // launch over a subset of the (tile, lane) pairs: device table + its length on the device (null: all pairs);
     const int* nitems;       // the grid is sized for max_items, the kernels read the actual length
     int max_items;

@@ -172,6 +172,7 @@ struct aqc_ws {
     bool ckpt_valid = false;       // ... and ZW holds it for the thetas in use and the present contents of Z
     bool w_clean = true;           // W is zero outside the tiles named in d_sw_prev_tiles
     bool sparse_enabled = true;    // AQC_SPARSE_SWEEP=0: always the dense route
+    bool skipw_enabled = true;     // AQC_SKIP_ZERO_W=0: never skip zero groups / K-steps of w inside a stage
     long sparse_min_items = 512;   // the sparse route pays from this many (tile, lane) items per stage launch (AQC_SPARSE_MIN_ITEMS)
     unsigned long long supp_version[AQC_NUM_BUFS] = {0, 0, 0, 0, 0, 0};   // bumped whenever d_combo_prev[buf] (the support of a sparse lhs) changes
     aqc::TileItem* d_sw_items = nullptr;    // first-stage items of the sparse sweep [2 batch], and the tiles to clear in W
@@ -238,6 +239,7 @@ int run_vdag_restricted(aqc_ws* ws, int x_buf, bool support_in_gather_set = fals
 void vdag_restricted_state_after(aqc_ws* ws, int x_buf);
 int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer, bool support_in_gather_set);
 bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag);
+bool sweep_skips_zero_w(const aqc_ws* ws, int x_buf);   // the lhs state is a combination of basis states the device knows: zero groups of w are skipped
 int sweep_sparse_prepare(aqc_ws* ws);
 void apply_state_after(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);
 void sweep_state_after(aqc_ws* ws, bool sparse, bool replayed);

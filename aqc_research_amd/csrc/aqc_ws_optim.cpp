@@ -272,7 +272,7 @@ int aqc_ws_surrogate_eval(aqc_ws* ws, const double* thetas, int update_state, do
         const std::vector<long long> key = {1000 + update_state + (zero_copy ? 10 : 0) + (real_only ? 20 : 0), block_from, block_to, front_layer,
                                             (long long)S, (long long)(size_t)ws->d_sur_real,
                                             (long long)(size_t)ws->d_sur, (long long)(size_t)ws->h_sur, (long long)(size_t)ws->h_pin,
-                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2], (sparse ? 1 : 0) + (lazy ? 2 : 0),
+                                            (long long)(size_t)ws->d_small, (long long)(size_t)ws->d_combo_prev[AQC_BUF_X2], (sparse ? 1 : 0) + (lazy ? 2 : 0) + (sweep_skips_zero_w(ws, AQC_BUF_X2) ? 4 : 0),
                                             (long long)(size_t)ws->d_vd_items};
         auto it = ws->graphs.find(key);
         if (it == ws->graphs.end()) {

@@ -97,6 +97,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
     }
     out.k = (int)plan.stages.front().bits.size();
     out.ntiles = 1 << (plan.nbits - out.k);
+    uint64_t touched_global = 0;   // address bits some earlier stage had local (sparse-lhs bookkeeping, see DevSub3::skipinfo)
     for (const Stage& st : out.plan.stages) {
         DevStage ds;
         memset(&ds, 0, sizeof ds);
@@ -107,7 +108,11 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
         std::vector<int> local_of(plan.nbits, -1);
         for (int j = 0; j < ds.k; ++j) local_of[st.bits[j]] = j;
         for (int b = 0; b < plan.nbits; ++b)
-            if (local_of[b] < 0) ds.ubits[ds.nub++] = b;
+            if (local_of[b] < 0) {
+                ds.ubits[ds.nub++] = b;
+                if (!(touched_global >> b & 1)) ds.fresh_nonlocal |= 1u << b;
+            }
+        uint32_t touched_local = 0;   // local positions an earlier sub-stage of this stage had as register bits
         for (unsigned i = 0; i < 64; ++i) {
             uint32_t off = 0;
             for (int j = 0; j < 6 && j < ds.k; ++j)
@@ -187,11 +192,26 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
                             d3.kk[g][s] = (uint32_t)(d3.dep_a[4 * s] ^ d3.dep_chi[g]) << 4;
                             d3.kk[g][4 + s] = (uint32_t)(d3.dep_clo[4 * s] ^ d3.dep_chi[g]) << 4;
                         }
+                    {   // fresh bits of this sub-stage (see DevSub3::skipinfo)
+                        auto fresh = [&](int local_pos) { return !(touched_global >> st.bits[local_pos] & 1) && !(touched_local >> local_pos & 1); };
+                        uint32_t info = 0;
+                        for (int i = 0; i < 4 && 4 + i < nc; ++i) {   // group-index bit i <-> chunk bit 4 + i
+                            if (fresh(cbits[4 + i])) info |= 1u << i;
+                            info |= (uint32_t)cbits[4 + i] << (8 + 4 * i);
+                        }
+                        for (int i = 0; i < dsub.nbits && i < 4; ++i)
+                            if (fresh(dsub.bits[i])) info |= 1u << (4 + i);
+                        if (dsub.nbits == 4) info |= (uint32_t)dsub.bits[2] << 24 | (uint32_t)dsub.bits[3] << 28;
+                        else info &= ~0xC0u;   // (fewer than 4 register bits: no K-step selection)
+                        d3.skipinfo = info;
+                        for (int i = 0; i < dsub.nbits; ++i) touched_local |= 1u << dsub.bits[i];
+                    }
                     out.h_subs3.push_back(d3);
                 }
             }
         }
         out.h_stages.push_back(ds);
+        for (int b : st.bits) touched_global |= 1ull << b;
     }
 }
 

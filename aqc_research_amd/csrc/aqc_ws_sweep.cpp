@@ -289,6 +289,10 @@ bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag) {
     if (!(will_vdag ? keeps_checkpoint(ws, true, AQC_BUF_Y, AQC_BUF_Z) : ws->ckpt_valid)) return false;   // z of stage 1 available in ZW
     return (long)p.ntiles * ws->batch >= ws->sparse_min_items;   // (fewer items than CUs: a stage takes one item's time either way)
 }
+// Inside a stage the same knowledge goes further (any number of stages, either route): see sweep_mfma_kernel<K, false, true>.
+bool sweep_skips_zero_w(const aqc_ws* ws, int x_buf) {
+    return ws->skipw_enabled && ws->sweep.v3 && ws->combo_valid[x_buf] && ws->d_combo_prev[x_buf] != nullptr;
+}
 // Allocations and one-off clears of the sparse route: everything that must not sit inside a captured graph.
 int sweep_sparse_prepare(aqc_ws* ws) {
     const DevPlan& p = ws->sweep;
@@ -373,6 +377,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         const int nsubs = (int)p.h_subs3.size();
         const size_t m = p.h_stages.size();
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
+        const bool skipw = sweep_skips_zero_w(ws, x_buf);
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||
@@ -412,6 +417,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
                 a.out1 = ws->bufs[AQC_BUF_ZW];
                 a.store_out = s + 1 < m ? 3 : 0;
             }
+            if (skipw && !a.items) a.supp = ws->d_combo_prev[x_buf];
             a.rpart = p.d_rpart;
             a.chunk = sweep3_chunk(p.ntiles, ws->batch, p.k);
             a.nparts = sweep3_nparts(p.ntiles, ws->batch, p.k);
@@ -571,7 +577,8 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     if (thetas && graphs_on && !ws->profile) {
         const std::vector<long long> key = {do_vdag, gathered ? 1 : 0, grads ? 1 : 0, x_buf, block_from, block_to, front_layer,
                                             (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin,
-                                            (sparse ? 1 : 0) + (lazy ? 2 : 0), (long long)(size_t)ws->d_combo_prev[x_buf],
+                                            (sparse ? 1 : 0) + (lazy ? 2 : 0) + (grads && sweep_skips_zero_w(ws, x_buf) ? 4 : 0),
+                                            (long long)(size_t)ws->d_combo_prev[x_buf],
                                             (long long)(size_t)ws->d_vd_items};
         auto it = ws->graphs.find(key);
         if (it == ws->graphs.end()) {

@@ -299,3 +299,39 @@ def test_device_lbfgs_on_the_sparse_route(monkeypatch):
     assert np.allclose(fids[True][1], fids[False][1], rtol=1e-6, atol=1e-9)
     assert maxdiff(fids[True][2], fids[False][2]) < 1e-6
     assert np.all(fids[True][0] < 1.0)
+
+
+@pytest.mark.parametrize("n,tile,ent,trot", [(12, 12, "cx", 2), (10, 10, "cz", 0), (9, 9, "cp", 0), (8, 8, "cx", 0), (14, 12, "cx", 0), (13, 11, "cx", 1),
+                                             (13, 9, "cz", 0)])
+def test_zero_groups_of_w_are_skipped_without_changing_a_bit(n, tile, ent, trot, monkeypatch):
+    """Inside a stage the kernel leaves out the W / R products of 16-chunk groups (and K-steps of the W product) where w is zero
+    because bits no gate has mixed yet differ from the basis index (AQC_SKIP_ZERO_W): the products would multiply exact zeros, so
+    every gradient entry keeps its value bit for bit -- single-stage plans, several stages, both routes, one and two basis states
+    per lane, every tile size."""
+    from aqc_research_amd.engine import BUF_X2, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(300 + n + tile)
+    circ = _trotter(n, trot) if trot else _circ(n, ent, depth=3 * n)
+    B = 4
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    hi = 1 << (n - 1)
+    idx = np.array([[0, -1], [5, hi + 5], [hi | 3, 3 ^ (1 << (n - 2))], [(1 << n) - 1, 1]], dtype=np.int64)
+    coef = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
+    res = {}
+    for skip in ("1", "0"):
+        for sparse in (True, False):
+            monkeypatch.setenv("AQC_SKIP_ZERO_W", skip)
+            ws = _ws(circ, B, monkeypatch, sparse=sparse, tile=tile)
+            ws.upload(BUF_Y, tg)
+            ws.set_thetas(th)
+            ws.apply(True, BUF_Y, BUF_Z)
+            ws.set_combo(BUF_X2, idx, coef)
+            ws.grad_from(BUF_X2)
+            res[(skip, sparse)] = ws.get_grads()
+            ws.close()
+    assert np.array_equal(res[("1", True)], res[("0", True)])
+    assert np.array_equal(res[("1", False)], res[("0", False)])
+    for b in range(B):
+        _, g_ref = _oracle_lane(circ, th[b], tg[b], idx[b], coef[b])
+        assert maxdiff(res[("1", True)][b], g_ref) < TOL

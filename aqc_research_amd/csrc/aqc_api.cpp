@@ -852,6 +852,19 @@ int aqc_ws_plan_stage(aqc_ws* ws, int which, int stage, int* num_subs, int* num_
     return 0;
 }
 
+int aqc_ws_plan_skips(aqc_ws* ws, int which, int stage, int* out, int max_subs) {
+    if (!ws || !out) return fail("null argument");
+    const DevPlan& p = which == 0 ? ws->inv : (which == 1 ? ws->sweep : ws->fwd);
+    if (stage < 0 || stage >= (int)p.h_stages.size()) return fail("stage index out of range");
+    const DevStage& ds = p.h_stages[stage];
+    for (int i = 0; i < ds.nsubs && i < max_subs; ++i) {
+        const uint32_t info = p.v3 && ws->skipw_enabled ? p.h_subs3[ds.sub_begin + i].skipinfo : 0u;
+        out[2 * i] = -__builtin_popcount(info & 15u);
+        out[2 * i + 1] = -__builtin_popcount((info >> 6) & 3u);
+    }
+    return 0;
+}
+
 int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts) {
     if (!ws || !counts) return fail("null argument");
     counts[0] = counts[1] = counts[2] = -1;

@@ -350,6 +350,13 @@ class Workspace:
         check(self._L.aqc_ws_plan_stage(self.handle, which, stage, byref(a), byref(b), bits))
         return a.value, b.value, list(bits[: self.plan_info(which)[1]])
 
+    def plan_skips(self, which: int, stage: int) -> list:
+        """Per sub-stage of a stage: (log2 share of groups, log2 share of W K-steps) a sweep from one basis state per lane issues."""
+        nsub = self.plan_stage(which, stage)[0]
+        out = (c_int * (2 * max(nsub, 1)))()
+        check(self._L.aqc_ws_plan_skips(self.handle, which, stage, out, nsub))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(nsub)]
+
     def sparse_counts(self) -> Tuple[int, int, int]:
         """Items of the last sparse evaluation: (sweep first stage, tiles cleared in W, V^H last stage); -1 = never built."""
         c = (c_int64 * 3)()

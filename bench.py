@@ -889,7 +889,7 @@ def rank_echo(args):
     dist.destroy_process_group()
 
 
-def stage_launch_table(ws, prof_log, prof_steps, N, B):
+def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
     """Per stage launch of one step (matrix-core path): kernel, plan stage, sub-stages, share of the tiles it ran over, average
     duration (HIP events around every launch of `prof_steps` steps), EXECUTED MFMA flops (288 per amplitude and sub-stage for
     the sweep: 9 real 16x16x16 products per 256 amplitudes; 96 for V^H) and their rate.  None off the matrix-core path."""
@@ -920,9 +920,14 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B):
         elif k == K_APPLY_LIST:
             frac = vd_items / float(ntiles * B)
         flops = (288.0 if which else 96.0) * N * B * frac * nsub
+        skipped = 0.0
+        if which and sparse_lhs and k == K_SWEEP:   # dense launch of a sweep from basis states: zero groups / K-steps of w are not issued
+            per_sub = [96.0 + 96.0 * 2.0 ** (g + kk) + 96.0 * 2.0 ** g for g, kk in ws.plan_skips(1, st)]
+            skipped = flops - N * B * frac * sum(per_sub)
+            flops -= skipped
         rows.append({"kernel": ("sweep_mfma_kernel" if which else "apply_mfma_kernel") + f"<{tile_bits}, {'true' if k in (K_SWEEP_LIST, K_APPLY_LIST) else 'false'}>",   # (true: over a tile list)
                      "plan": "sweep" if which else "V^H", "stage": st, "substages": nsub, "tiles_frac": frac, "avg_ms": avg[j],
-                     "flops": flops, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
+                     "flops": flops, "flops_not_issued_zero_w": skipped, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
                      "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0})
     if not rows:
         return None
@@ -1280,7 +1285,7 @@ def measure(workload, args, env, full):
         prof = {k: ws.profile_get(v) for k, v in kinds.items()}
         prof_log = ws.profile_log()
         ws.profile(False)
-        stage_launches = stage_launch_table(ws, prof_log, prof_steps, N, B)
+        stage_launches = stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=(ncols == 1 and mps_targets is None) or (ncols == 1 and chi))
         sweep_launches, sweep_ms = prof["sweep"]
         apply_launches, apply_ms = prof["apply"]
         # algorithmic bytes: one gate group = read+write of each live vector

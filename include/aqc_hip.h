@@ -307,6 +307,9 @@ int aqc_ws_profile_reset(aqc_ws* ws);
 int aqc_ws_profile_log(aqc_ws* ws, int32_t* kinds, double* ms, int cap, int* count);
 /* stage `stage` of plan `which` as this workspace runs it: sub-stages, gate groups, local address bits (bits_out: [tile_bits]) */
 int aqc_ws_plan_stage(aqc_ws* ws, int which, int stage, int* num_subs, int* num_groups, int* bits_out);
+/* per sub-stage of that stage, what a sweep from ONE basis state per lane leaves out (out[sub][2]): log2 of the share of 16-chunk
+ * groups whose W and R products are issued, log2 of the share of K-steps of the W product (both <= 0); zeros when nothing is skipped */
+int aqc_ws_plan_skips(aqc_ws* ws, int which, int stage, int* out, int max_subs);
 /* item lists of the last sparse evaluation (synchronises): counts[0] first-stage items of the sweep, [1] tiles it cleared in W,
  * [2] last-stage items of V^H; -1 where that list has never been built */
 int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts);

@@ -24,6 +24,8 @@
 // fixed-order sum over waves and tiles): run-to-run identical, no float atomics.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "aqc_device.h"
 #include "aqc_launch.h"
 #include "aqc_math.h"
@@ -103,6 +105,7 @@ constexpr int kApplySkip = AQC_EXP_APPLY_SKIP;
 #define AQC_EXP_SWEEP_SKIP 0
 #endif
 constexpr int kSweepSkip = AQC_EXP_SWEEP_SKIP;
+
 constexpr int kSweepSpread = AQC_SWEEP_SPREAD, kApplySpread = AQC_APPLY_SPREAD;   // MFMAs between two LDS writes inside a matrix run (sweep / V, V^H)
 template <int K, bool SWEEP = false> struct TileShape {   // compile-time shape of a 2^K-amplitude tile
     // 4 waves from 2^10 amplitudes up.  (8 waves on the sweep's 2^12 tiles -- two per SIMD -- were measured: the matrix
@@ -400,6 +403,11 @@ __device__ __forceinline__ void wait_prefetched(dbl2_t (&pw)[N], dbl2_t (&pz)[N]
 }
 __device__ __forceinline__ unsigned tile_offset3(const DevStage& st, unsigned local) { return st.dlo[local & 63u] | st.dhi[local >> 6]; }
 template <int K> struct SweepShape : TileShape<K, true> {};   // (no comma inside the __launch_bounds__ macro arguments)
+// MEASURED SLOWER, hence opt-in (AQC_SKIP_ZERO_W=1): the branches cut the 36-MFMA runs of a group iteration into three and keep the
+// compiler from giving the first sub-stage of an item its own copy of the loop; at the headline the last sweep stage takes 1.54 ms
+// with the skips (19 % fewer MFMAs) against 1.46 ms without, 12-qubit 2-layer Trotter 0.164 against 0.161 ms, 12 layers 0.81 against
+// 0.70 (gpurun_out/r5g).  Kept because it is exact (bit-identical gradients, tests/test_hip_round5.py) and states what a faster
+// formulation has to beat: a static z pass over all groups plus a run-time loop over the non-zero groups only.
 // SKIPW (sweep from basis states, Stage3Args::supp): per item and sub-stage two wave-uniform masks say which of the wave's groups
 // can hold a non-zero w at all and which K-steps of the W product can (see skip_masks); the W product of the other groups / K-steps
 // and the R product of the other groups are not issued -- they would multiply exact zeros.
@@ -595,11 +603,17 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
         }
         const unsigned a1z = ad.a1 | ZOFF, a2z = ad.a2 | ZOFF;
+        // (A lambda: hand-made copies of this loop -- one per operand source, or a fused and a branching one -- were tried for the SKIPW
+        // kernel and dropped: two inlined copies push the 2^12 kernel past its registers (300-400 bytes of scratch per lane, and the
+        // allocator then moves the asynchronously loaded prefetch registers while their loads are in flight: wrong results).)
+        auto group_loop = [&]() __attribute__((always_inline)) {
+        constexpr bool SK = SKIPW;
+        const bool from_regs_here = from_regs;
         Acc3 aw, az;               // products of group j - 1 until they are combined, then of group j
 #pragma unroll
         for (int j = 0; j <= TS::kGpw; ++j) {
             if (j + 1 < TS::kGpw AQC_DBG_AND(!(a.debug & 2))) {
-                if (kPersist && from_regs) {
+                if (kPersist && from_regs_here) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         vw[(j + 1) & 1][s] = make_double2(pw[4 * (j + 1) + s].x, pw[4 * (j + 1) + s].y);
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             __builtin_amdgcn_sched_barrier(0);
             if (j < TS::kGpw) {
                 aw.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; aw.k2 = aw.k1; aw.k3 = aw.k1; az.k1 = aw.k1; az.k2 = aw.k1; az.k3 = aw.k1;
-                if (!SKIPW) {
+                if (!SK) {
 #pragma unroll
                     for (int s = 0; s < (AQC_DBG_TEST(a.debug & 8) ? 0 : 4); ++s) {
                         aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                     }
                 }
             }
-            if (!SKIPW && j > 0 AQC_DBG_AND(!(a.debug & 4))) {
+            if (!SK && j > 0 AQC_DBG_AND(!(a.debug & 4))) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {   // R += Z' W'^H over the 4 chunks of K-step r
                     t1 = mfma(oz[r].x, ow[r].x, t1);
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             // issued between two MFMAs costs ~1.5 cycles (tools/ubench/mfma_f64_shadow.hip), while the same writes bunched
             // after the run -- all four waves at once -- run into the 64-79 B/clk the CU accepts for 128-bit stores
             // (1.7k cycles per sub-stage).  Measured at the headline: sweep launch pair 1.215 -> 1.092 ms.
-            if (j > 0 && !(SKIPW && j == TS::kGpw) AQC_DBG_AND(!(a.debug & 1))) {
+            if (j > 0 && !(SK && j == TS::kGpw) AQC_DBG_AND(!(a.debug & 1))) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
 #pragma unroll
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (SKIPW && j == TS::kGpw) {   // last iteration: no U z run left -- the last group's writes ride in its R run when there is one
+            if (SK && j == TS::kGpw) {   // last iteration: no U z run left -- the last group's writes ride in its R run when there is one
                 if (nzmask >> (j - 1) & 1u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else
-            if (SKIPW) {   // wave-uniform branches around the products that can be non-zero (scalar masks, compile-time j)
+            if (SK) {   // wave-uniform branches around the products that can be non-zero (scalar masks, compile-time j)
                 if (j < TS::kGpw && (nzmask >> j & 1u)) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
@@ -729,6 +743,8 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        };
+        group_loop();
         AQC_STAMP(3 + 4 * si);
         if (kPersist && more && st.nsubs == 1) {
 #pragma unroll

@@ -172,7 +172,7 @@ struct aqc_ws {
     bool ckpt_valid = false;       // ... and ZW holds it for the thetas in use and the present contents of Z
     bool w_clean = true;           // W is zero outside the tiles named in d_sw_prev_tiles
     bool sparse_enabled = true;    // AQC_SPARSE_SWEEP=0: always the dense route
-    bool skipw_enabled = true;     // AQC_SKIP_ZERO_W=0: never skip zero groups / K-steps of w inside a stage
+    bool skipw_enabled = false;    // AQC_SKIP_ZERO_W=1: skip zero groups / K-steps of w inside a stage (exact; measured slower, off by default)
     long sparse_min_items = 512;   // the sparse route pays from this many (tile, lane) items per stage launch (AQC_SPARSE_MIN_ITEMS)
     unsigned long long supp_version[AQC_NUM_BUFS] = {0, 0, 0, 0, 0, 0};   // bumped whenever d_combo_prev[buf] (the support of a sparse lhs) changes
     aqc::TileItem* d_sw_items = nullptr;    // first-stage items of the sparse sweep [2 batch], and the tiles to clear in W

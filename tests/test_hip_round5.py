@@ -304,7 +304,7 @@ def test_device_lbfgs_on_the_sparse_route(monkeypatch):
 @pytest.mark.parametrize("n,tile,ent,trot", [(12, 12, "cx", 2), (10, 10, "cz", 0), (9, 9, "cp", 0), (8, 8, "cx", 0), (14, 12, "cx", 0), (13, 11, "cx", 1),
                                              (13, 9, "cz", 0)])
 def test_zero_groups_of_w_are_skipped_without_changing_a_bit(n, tile, ent, trot, monkeypatch):
-    """Inside a stage the kernel leaves out the W / R products of 16-chunk groups (and K-steps of the W product) where w is zero
+    """(Opt-in variant, AQC_SKIP_ZERO_W=1.)  Inside a stage the kernel leaves out the W / R products of 16-chunk groups (and K-steps of the W product) where w is zero
     because bits no gate has mixed yet differ from the basis index (AQC_SKIP_ZERO_W): the products would multiply exact zeros, so
     every gradient entry keeps its value bit for bit -- single-stage plans, several stages, both routes, one and two basis states
     per lane, every tile size."""

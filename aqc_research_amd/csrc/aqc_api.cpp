@@ -153,7 +153,11 @@ int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bi
     const int col_bits = ceil_log2(ncols);
     if (tile_bits <= 0) tile_bits = which == 1 ? 12 : 13;
     if (low_bits < 0) low_bits = 3;
-    const Plan plan = make_plan(ctx->prog, col_bits, tile_bits, low_bits, which == 0);
+    Plan plan = make_plan(ctx->prog, col_bits, tile_bits, low_bits, which == 0);
+    if (which == 3) {   // V^H as the matrix-core workspaces run it: the sweep's plan (sub-stages included) walked backwards
+        split_substages(ctx->prog, plan, 4, 1 << 20);
+        plan = mirror_plan(plan);
+    }
     const std::string err = check_plan(ctx->prog, plan);
     if (!err.empty()) return fail("planner produced an invalid plan: %s", err.c_str());
     if (num_stages) *num_stages = (int)plan.stages.size();
@@ -178,6 +182,7 @@ int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int lo
     if (low_bits < 0) low_bits = 3;
     Plan plan = make_plan(ctx->prog, col_bits, tile_bits, low_bits, which == 0);
     split_substages(ctx->prog, plan, 4, 1 << 20);
+    if (which == 3) plan = mirror_plan(plan);
     const std::string err = check_plan(ctx->prog, plan);
     if (!err.empty()) return fail("planner produced an invalid plan: %s", err.c_str());
     if (stage < 0 || stage >= (int)plan.stages.size()) return fail("stage index out of range");

@@ -320,7 +320,8 @@ int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-f
 int aqc_ws_plan_substages(aqc_ws* ws, int which);
 /* kernel family that runs plan `which`: 1 per-gate-group (VALU), 2 register-blocked (VALU), 3 matrix-core (MFMA) */
 int aqc_ws_kernel_family(aqc_ws* ws, int which);
-/* host-only planner introspection (no GPU needed): stage s of plan `which` for the given tiling;
+/* host-only planner introspection (no GPU needed): stage s of plan `which` for the given tiling (which: 0 V^H planned on its
+ * own, 1 sweep, 2 V, 3 V^H as the sweep's plan walked backwards -- what matrix-core workspaces run, see AQC_BUF_ZW above);
  * ops_out receives gate-group indices (forward program order), bits_out the local address bits */
 int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage,
                    int* num_stages, int* bits_out, int* num_bits, int* ops_out, int* num_ops);

@@ -49,6 +49,27 @@ def test_planner_valid_plans(n, depth):
                             assert bits[:low] == list(range(low))
 
 
+@pytest.mark.parametrize("n,depth,trot", [(9, 20, 0), (13, 40, 0), (16, 40, 0), (20, 40, 0), (12, 0, 3), (14, 0, 2), (20, 0, 2)])
+def test_mirrored_vdag_plan_walks_the_sweep_backwards(n, depth, trot):
+    """V^H of the matrix-core workspaces = the sweep's plan (sub-stages included) walked backwards (mirror_plan): the library
+    validates it as a plan of the INVERSE program (check_plan: every group once, per-qubit order of the inverse, local and
+    register bits), stage j of it has the local bits and the groups of the sweep's stage m - 1 - j, in reverse order -- which is
+    what makes the state before its last stage the sweep's z after its first one."""
+    from aqc_research_amd.engine import HipContext
+
+    blocks = orc.trotter_blocks(n, trot) if trot else orc.spin_blocks(n, depth)
+    ctx = HipContext.of(_circ(n, "cx", blocks.astype(np.int64), bool(trot), bool(trot)))
+    for k in (8, 10, 12):
+        for low in (2, 3):
+            sweep = ctx.plan(1, 1, k, low)
+            mirror = ctx.plan(3, 1, k, low)      # raises if check_plan rejects it
+            assert len(mirror) == len(sweep)
+            for j, (bits, ops) in enumerate(mirror):
+                sbits, sops = sweep[len(sweep) - 1 - j]
+                assert bits == sbits and sorted(ops) == sorted(sops)
+            assert sorted(g for _, o in mirror for g in o) == list(range(ctx.num_gate_groups))
+
+
 def test_planner_matrix_and_trotter():
     from aqc_research_amd.engine import HipContext
 

@@ -1164,7 +1164,7 @@ def measure(workload, args, env, full):
         if mps_targets is not None:   # QiskitMPS operands arrive as host tuples on every evaluation (mps_dot_objective.py:41)
             ws.mps_to_vec_batch(zero_list, BUF_X)
             ws.mps_to_vec_batch(mps_targets[i % len(mps_targets)], BUF_Y)
-        if ncols == 1 and mps_targets is None:
+        if ncols == 1:   # (the MPS front door too: its operands have just been contracted into X and Y)
             # Z = V^H Y where the evaluation reads it, hs = <state_i|V^H|target> for the registered flip states, the sweep from x:
             # one enqueue (the same launches as apply + gather_launch + grad, which the other branches spell out)
             ws.objective_launch(BUF_X, None, True)

@@ -196,20 +196,21 @@ hipError_t launch_mps_product(const void* const* t_tab, void* const* out_tab, in
 __global__ __launch_bounds__(256) void mps_head_kernel(const cplx* const* __restrict__ t_tab, cplx* const* __restrict__ left_out,
                                                        cplx* const* __restrict__ right_out, const MpsHead hd) {
     extern __shared__ __attribute__((aligned(16))) char head_smem[];
-    cplx* buf[2] = {reinterpret_cast<cplx*>(head_smem), reinterpret_cast<cplx*>(head_smem) + kMpsHeadCap};
+    cplx* const buf0 = reinterpret_cast<cplx*>(head_smem);
+    auto bufsel = [&](int k) { return buf0 + (size_t)k * kMpsHeadCap; };
     const int lane = blockIdx.x, side = blockIdx.y, tid = threadIdx.x, n = hd.n;
     const cplx* t = t_tab[lane];
     if (side == 0) {
         if (hd.pl < 2) return;
         const int n1 = hd.dims[1];
-        for (int i = tid; i < 2 * n1; i += 256) buf[0][i] = t[hd.off[0] + i];   // L_0[b][c] = site 0 as stored ([2][1][dims[1]])
+        for (int i = tid; i < 2 * n1; i += 256) bufsel(0)[i] = t[hd.off[0] + i];   // L_0[b][c] = site 0 as stored ([2][1][dims[1]])
         __syncthreads();
         int cur = 0;
         for (int q = 1; q < hd.pl; ++q) {   // L_q[(b << q) + r][c'] = sum_c L_{q-1}[r][c] T_q[b][c][c']
             const int K = hd.dims[q], N = hd.dims[q + 1], rows = 1 << q;
             const cplx* tq = t + hd.off[q];
-            const cplx* in = buf[cur];
-            cplx* out = buf[cur ^ 1];
+            const cplx* in = bufsel(cur);
+            cplx* out = bufsel(cur ^ 1);
             for (int o = tid; o < 2 * rows * N; o += 256) {
                 const int row = o / N, c2 = o - row * N, b = row >> q, r = row & (rows - 1);
                 double re = 0.0, im = 0.0;
@@ -224,18 +225,18 @@ __global__ __launch_bounds__(256) void mps_head_kernel(const cplx* const* __rest
         }
         cplx* dst = left_out[lane];
         const int total = (1 << hd.pl) * hd.dims[hd.pl];
-        for (int i = tid; i < total; i += 256) dst[i] = buf[cur][i];
+        for (int i = tid; i < total; i += 256) dst[i] = bufsel(cur)[i];
     } else {
         if (hd.pr < 2) return;
         const int c0 = hd.dims[n - 1];
-        for (int i = tid; i < 2 * c0; i += 256) buf[0][i] = t[hd.off[n - 1] + i];   // Rt_0[r][chi] = the last site as stored ([2][chi][1])
+        for (int i = tid; i < 2 * c0; i += 256) bufsel(0)[i] = t[hd.off[n - 1] + i];   // Rt_0[r][chi] = the last site as stored ([2][chi][1])
         __syncthreads();
         int cur = 0;
         for (int j = 1; j < hd.pr; ++j) {   // Rt_j[2 c + b][x] = sum_y Rt_{j-1}[c][y] T_q[b][x][y],  q = n - 1 - j
             const int q = n - 1 - j, chil = hd.dims[q], chir = hd.dims[q + 1], rows = 1 << j;
             const cplx* tq = t + hd.off[q];
-            const cplx* in = buf[cur];
-            cplx* out = buf[cur ^ 1];
+            const cplx* in = bufsel(cur);
+            cplx* out = bufsel(cur ^ 1);
             for (int o = tid; o < 2 * rows * chil; o += 256) {
                 const int row = o / chil, x = o - row * chil, b = row & 1, c = row >> 1;
                 double re = 0.0, im = 0.0;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void mps_head_kernel(const cplx* const* __rest
         }
         cplx* dst = right_out[lane];
         const int total = (1 << hd.pr) * hd.dims[n - hd.pr];
-        for (int i = tid; i < total; i += 256) dst[i] = buf[cur][i];
+        for (int i = tid; i < total; i += 256) dst[i] = bufsel(cur)[i];
     }
 }
 hipError_t launch_mps_head(const void* const* t_tab, void* const* left_out, void* const* right_out, const MpsHead& hd, int count, hipStream_t s) {

@@ -159,13 +159,6 @@ hipError_t launch_zgemm_batched(bool conj_t, bool accum, int M, int N, int K, co
 hipError_t launch_zgemm_tables(int M, int N, int K, const void* const* a_tab, int lda, const void* const* b_tab, int ldb, void* const* c_tab, int ldc,
                                size_t stride_a, size_t stride_b, size_t stride_c, int outer, int inner, hipStream_t s, int b_transposed = 0);
 hipError_t launch_mps_product(const void* const* t_tab, void* const* out_tab, int n, int count, hipStream_t s);
-constexpr int kMpsHeadCap = 4096;   // complex elements of a block the head kernel keeps in LDS (two of them: 128 KiB)
-struct MpsHead {            // shapes of one MPS (the same for every lane of a batched contraction), by value in the kernel arguments
-    int n, pl, pr;          // sites absorbed by the head on the left (block of 2^pl rows x dims[pl]) and on the right (2^pr rows x dims[n - pr])
-    int dims[66];           // bond dimensions, dims[0] = dims[n] = 1
-    unsigned long long off[65];   // element offset of site q inside the packed tensors
-};
-hipError_t launch_mps_head(const void* const* t_tab, void* const* left_out, void* const* right_out, const MpsHead& hd, int count, hipStream_t s);
 struct MpsSites {            // site table of one MPS (by value in the kernel arguments)
     int n;
     size_t total;            // complex elements of all site tensors

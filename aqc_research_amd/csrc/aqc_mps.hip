@@ -188,87 +188,6 @@ hipError_t launch_mps_product(const void* const* t_tab, void* const* out_tab, in
     return hipGetLastError();
 }
 
-// Head of the MPS -> dense contraction (aqc_ws_mps_to_vec_batch): the first steps of both chains -- the left block growing from
-// site 0 (every new site the next HIGHER row bit), the transposed right block growing from site n - 1 (every new site the LOWEST
-// row bit) -- are tiny products (2 x 2, 4 x 4, ... rows x bond) that cost a launch each when they go through the zgemm kernel:
-// one workgroup per (lane, side) does them all in LDS (two buffers of kMpsHeadCap elements, plain complex multiply-adds in the
-// order of the summed bond index, so products with exact 0 / 1 stay exact) and hands the block over in the chain's scratch.
-__global__ __launch_bounds__(256) void mps_head_kernel(const cplx* const* __restrict__ t_tab, cplx* const* __restrict__ left_out,
-                                                       cplx* const* __restrict__ right_out, const MpsHead hd) {
-    extern __shared__ __attribute__((aligned(16))) char head_smem[];
-    cplx* const buf0 = reinterpret_cast<cplx*>(head_smem);
-    auto bufsel = [&](int k) { return buf0 + (size_t)k * kMpsHeadCap; };
-    const int lane = blockIdx.x, side = blockIdx.y, tid = threadIdx.x, n = hd.n;
-    const cplx* t = t_tab[lane];
-    if (side == 0) {
-        if (hd.pl < 2) return;
-        const int n1 = hd.dims[1];
-        for (int i = tid; i < 2 * n1; i += 256) bufsel(0)[i] = t[hd.off[0] + i];   // L_0[b][c] = site 0 as stored ([2][1][dims[1]])
-        __syncthreads();
-        int cur = 0;
-        for (int q = 1; q < hd.pl; ++q) {   // L_q[(b << q) + r][c'] = sum_c L_{q-1}[r][c] T_q[b][c][c']
-            const int K = hd.dims[q], N = hd.dims[q + 1], rows = 1 << q;
-            const cplx* tq = t + hd.off[q];
-            const cplx* in = bufsel(cur);
-            cplx* out = bufsel(cur ^ 1);
-            for (int o = tid; o < 2 * rows * N; o += 256) {
-                const int row = o / N, c2 = o - row * N, b = row >> q, r = row & (rows - 1);
-                double re = 0.0, im = 0.0;
-                for (int c = 0; c < K; ++c) {
-                    const cplx a = in[r * K + c], m = tq[((size_t)b * K + c) * N + c2];
-                    re += a.x * m.x - a.y * m.y; im += a.x * m.y + a.y * m.x;
-                }
-                out[o] = make_double2(re, im);
-            }
-            __syncthreads();
-            cur ^= 1;
-        }
-        cplx* dst = left_out[lane];
-        const int total = (1 << hd.pl) * hd.dims[hd.pl];
-        for (int i = tid; i < total; i += 256) dst[i] = bufsel(cur)[i];
-    } else {
-        if (hd.pr < 2) return;
-        const int c0 = hd.dims[n - 1];
-        for (int i = tid; i < 2 * c0; i += 256) bufsel(0)[i] = t[hd.off[n - 1] + i];   // Rt_0[r][chi] = the last site as stored ([2][chi][1])
-        __syncthreads();
-        int cur = 0;
-        for (int j = 1; j < hd.pr; ++j) {   // Rt_j[2 c + b][x] = sum_y Rt_{j-1}[c][y] T_q[b][x][y],  q = n - 1 - j
-            const int q = n - 1 - j, chil = hd.dims[q], chir = hd.dims[q + 1], rows = 1 << j;
-            const cplx* tq = t + hd.off[q];
-            const cplx* in = bufsel(cur);
-            cplx* out = bufsel(cur ^ 1);
-            for (int o = tid; o < 2 * rows * chil; o += 256) {
-                const int row = o / chil, x = o - row * chil, b = row & 1, c = row >> 1;
-                double re = 0.0, im = 0.0;
-                for (int y = 0; y < chir; ++y) {
-                    const cplx a = in[c * chir + y], m = tq[((size_t)b * chil + x) * chir + y];
-                    re += a.x * m.x - a.y * m.y; im += a.x * m.y + a.y * m.x;
-                }
-                out[o] = make_double2(re, im);
-            }
-            __syncthreads();
-            cur ^= 1;
-        }
-        cplx* dst = right_out[lane];
-        const int total = (1 << hd.pr) * hd.dims[n - hd.pr];
-        for (int i = tid; i < total; i += 256) dst[i] = bufsel(cur)[i];
-    }
-}
-hipError_t launch_mps_head(const void* const* t_tab, void* const* left_out, void* const* right_out, const MpsHead& hd, int count, hipStream_t s) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    const int lds = 2 * kMpsHeadCap * (int)sizeof(cplx);
-    if (!attr_set[dev] || dev == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mps_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set[dev] = true;
-    }
-    mps_head_kernel<<<dim3(count, 2), 256, lds, s>>>(reinterpret_cast<const cplx* const*>(t_tab), reinterpret_cast<cplx* const*>(left_out),
-                                                     reinterpret_cast<cplx* const*>(right_out), hd);
-    return hipGetLastError();
-}
-
 // out = sum_i e[i] conj(rc[i]): closes an inner product between a left environment and a (conjugated) right one;
 // one workgroup, fixed-order reduction
 __global__ __launch_bounds__(256) void mps_env_dot_kernel(const cplx* __restrict__ e, const cplx* __restrict__ rc, size_t count, cplx* __restrict__ out) {

@@ -422,26 +422,10 @@ static int mps_to_vec_batch_uniform(aqc_ws* ws, int count, const int32_t* slots,
     if (mps_scratch(ws, per * (size_t)count)) return 1;
     struct Step { int kind, q; size_t a, b, c; };   // offsets (in pointers) of the three tables inside the upload
     std::vector<Step> steps;
-    // the first steps of both chains in ONE launch (mps_head_kernel) while the blocks fit its LDS buffers
-    int pl = 1, pr = 1;
-    static const bool head_on = env_int("AQC_MPS_HEAD", 1) != 0;
-    if (head_on && n <= 64) {
-        while (pl < h && ((size_t)2 << pl) * dims[pl + 1] <= (size_t)kMpsHeadCap) ++pl;          // step q = pl writes 2^(pl+1) x dims[pl+1]
-        while (pr < mh && ((size_t)2 << pr) * dims[n - 1 - pr] <= (size_t)kMpsHeadCap) ++pr;    // step j = pr writes 2^(pr+1) x dims[n-1-pr]
-        if (2 * (size_t)dims[1] > (size_t)kMpsHeadCap) pl = 1;
-        if (2 * (size_t)dims[n - 1] > (size_t)kMpsHeadCap) pr = 1;
-    }
-    const bool head = pl >= 2 || pr >= 2;
     auto lb = [&](int i, int k) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + need_l * (size_t)k); };
     auto rb = [&](int i, int k) { return (const void*)(ws->d_mps_scratch + per * (size_t)i + 2 * need_l + need_r * (size_t)k); };
     auto site = [&](int i, int q) { return (const void*)(ws->mps[slots[i]].d_t + off[q]); };
-    size_t head_t = 0, head_l = 0, head_r = 0;
-    if (head) {
-        head_t = table([&](int i) { return (const void*)ws->mps[slots[i]].d_t; });
-        head_l = table([&](int i) { return lb(i, (pl - 1) & 1); });
-        head_r = table([&](int i) { return rb(i, (pr - 1) & 1); });
-    }
-    for (int q = std::max(1, pl >= 2 ? pl : 1); q < h; ++q) {       // left part: L_q = L_{q-1} T_q, both values of the site's bit (inner = 2)
+    for (int q = 1; q < h; ++q) {       // left part: L_q = L_{q-1} T_q, both values of the site's bit (inner = 2)
         Step st{0, q, 0, 0, 0};
         st.a = q == 1 ? table([&](int i) { return site(i, 0); }) : table([&](int i) { return lb(i, (q - 1) & 1); });
         st.b = table([&](int i) { return site(i, q); });
@@ -451,7 +435,6 @@ static int mps_to_vec_batch_uniform(aqc_ws* ws, int count, const int32_t* slots,
     // right part: Rt_0 = the last site as it is stored ([2][chi][1] = [r][chi]); Rt_j[2 c + b] = Rt_{j-1}[c] T_q[b]^T
     for (int q = n - 2; q >= h; --q) {
         const int j = n - 1 - q;
-        if (pr >= 2 && j < pr) continue;   // done by the head kernel
         Step st{2, q, 0, 0, 0};
         st.a = j == 1 ? table([&](int i) { return site(i, n - 1); }) : table([&](int i) { return rb(i, (j - 1) & 1); });
         st.b = table([&](int i) { return site(i, q); });
@@ -467,14 +450,6 @@ static int mps_to_vec_batch_uniform(aqc_ws* ws, int count, const int32_t* slots,
     ProfScope ps(ws, AQC_K_MISC);
     // the two halves are independent chains of small launches (latency-bound at small bond dimensions): the right half runs
     // on a second stream, forked after everything queued so far and joined before the last product
-    if (head) {   // (before the fork: both chains start from its blocks)
-        MpsHead hd;
-        memset(&hd, 0, sizeof hd);
-        hd.n = n; hd.pl = pl; hd.pr = pr;
-        for (int q = 0; q <= n; ++q) hd.dims[q] = dims[q];
-        for (int q = 0; q < n; ++q) hd.off[q] = off[q];
-        HIP_OK(launch_mps_head(T + head_t, (void* const*)(T + head_l), (void* const*)(T + head_r), hd, count, ws->stream));
-    }
     const bool fork = !ws->profile && !ws->capturing && h > 1 && mh > 1;
     if (fork) {
         if (!ws->mps_stream) {

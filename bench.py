@@ -1253,9 +1253,11 @@ def measure(workload, args, env, full):
     from oracle import aqc_ref as cref
 
     if ncols == 1:
-        for b in check_lanes:
+        for b in check_lanes:   # EVERY delivered output of the lane: all gathered flip-state amplitudes <state_i|V^H|target> and the full gradient
             h_ref, g_ref = cref.eval_batch(circ, last_th[b][None, :], targets[b], 0, 1)
-            parity = max(parity, abs(hs[b, 0] - h_ref[0]), float(np.abs(grads[b] - g_ref[0]).max()))
+            vh_ref = cref.v_dagger_mul_vec(circ, last_th[b], targets[b])
+            parity = max(parity, abs(hs[b, 0] - h_ref[0]), float(np.abs(hs[b] - vh_ref[np.asarray(flip_idx)]).max()),
+                         float(np.abs(grads[b] - g_ref[0]).max()))
     else:
         eye = np.eye(1 << n, ncols, dtype=complex)
         for b in check_lanes[:1]:

@@ -116,6 +116,95 @@ class DenseStateHandler:
         return self._states[state_no]
 
 
+def _circuit_gate_matrix(name: str, params) -> np.ndarray:
+    """Matrix of a gate of the small standard set ``GenericStateHandler`` simulates (Qiskit's conventions; 2-qubit matrices
+    are indexed 2 * bit(first qubit) + bit(second qubit), the first qubit of cx / cy / cz / cp being the control)."""
+    p = [float(v) for v in params]
+    c, sn = (np.cos(0.5 * p[0]), np.sin(0.5 * p[0])) if p else (1.0, 0.0)
+    one = {
+        "x": [[0, 1], [1, 0]], "y": [[0, -1j], [1j, 0]], "z": [[1, 0], [0, -1]], "h": np.array([[1, 1], [1, -1]]) / np.sqrt(2.0),
+        "s": [[1, 0], [0, 1j]], "sdg": [[1, 0], [0, -1j]], "t": [[1, 0], [0, np.exp(0.25j * np.pi)]],
+        "tdg": [[1, 0], [0, np.exp(-0.25j * np.pi)]], "sx": 0.5 * np.array([[1 + 1j, 1 - 1j], [1 - 1j, 1 + 1j]]),
+        "rx": [[c, -1j * sn], [-1j * sn, c]], "ry": [[c, -sn], [sn, c]],
+    }
+    if name in one:
+        return np.asarray(one[name], dtype=np.complex128)
+    if name == "rz":
+        return np.diag([np.exp(-0.5j * p[0]), np.exp(0.5j * p[0])]).astype(np.complex128)
+    if name in ("p", "u1"):
+        return np.diag([1.0, np.exp(1j * p[0])]).astype(np.complex128)
+    if name in ("u", "u3"):
+        th, ph, lam = p
+        return np.array([[np.cos(0.5 * th), -np.exp(1j * lam) * np.sin(0.5 * th)],
+                         [np.exp(1j * ph) * np.sin(0.5 * th), np.exp(1j * (ph + lam)) * np.cos(0.5 * th)]], dtype=np.complex128)
+    two = np.eye(4, dtype=np.complex128)
+    if name == "cx":
+        two[2:, 2:] = [[0, 1], [1, 0]]
+    elif name == "cy":
+        two[2:, 2:] = [[0, -1j], [1j, 0]]
+    elif name == "cz":
+        two[3, 3] = -1
+    elif name in ("cp", "cu1"):
+        two[3, 3] = np.exp(1j * p[0])
+    elif name == "swap":
+        two = two[[0, 2, 1, 3]]
+    else:
+        raise NotImplementedError(
+            f"state_prep_func returned a circuit with a '{name}' gate: GenericStateHandler simulates x, y, z, h, s, sdg, t, tdg, sx, "
+            "rx, ry, rz, p, u, cx, cy, cz, cp, swap (pass a dense (num_states, 2^n) array of prepared states for anything else)")
+    return two
+
+
+class GenericStateHandler(DenseStateHandler):
+    """The reference's ``GenericStateHandler`` (objective_base.py:258-342): the states ``S|0>`` and ``S X_i|0>`` of a GENERAL
+    state-preparation circuit S, built explicitly.  Qiskit is absent here, so S is any duck-typed circuit -- ``num_qubits``
+    and ``data`` with entries ``.operation.name / .operation.params / .qubits`` (a real ``QuantumCircuit`` has exactly these) --
+    over a small standard gate set, simulated gate by gate on the device for all num_qubits + 1 states at once (they are the
+    columns of one 2^n x (n + 1) matrix: one ``aqc_gate_1q`` / ``aqc_gate_2q`` pass per gate).  X_i is applied BEFORE S (:298-303)."""
+
+    def __init__(self, num_qubits: int, max_flips: int, state_prep_func=None, verbose: bool = False):
+        from .. import gates
+
+        if max_flips > 1:
+            raise ValueError("expects 'max_flips <= 1' to save memory")          # objective_base.py:294-295
+        n = int(num_qubits)
+        nstates = n + 1 if max_flips == 1 else 1
+        cols = np.zeros((1 << n, nstates), dtype=np.complex128)
+        cols[0, 0] = 1.0
+        for i in range(1, nstates):
+            cols[1 << (i - 1), i] = 1.0
+        qc = state_prep_func(n) if callable(state_prep_func) else state_prep_func
+        if qc is not None:
+            if getattr(qc, "num_qubits", n) != n:
+                raise ValueError("state_prep_func returned a circuit on a different number of qubits")
+            for ins in qc.data:
+                op, qubits = getattr(ins, "operation", None), getattr(ins, "qubits", None)
+                if op is None:
+                    op, qubits = ins[0], ins[1]
+                name = str(getattr(op, "name", "")).lower()
+                if name in ("id", "i", "barrier", "delay"):
+                    continue
+                idx = []
+                for q in qubits:
+                    if not isinstance(q, (int, np.integer)):
+                        find = getattr(qc, "find_bit", None)
+                        q = find(q).index if find is not None else getattr(q, "index", getattr(q, "_index", None))
+                    if q is None or not 0 <= int(q) < n:
+                        raise ValueError("state_prep_func: cannot resolve a qubit index of the circuit")
+                    idx.append(int(q))
+                g = _circuit_gate_matrix(name, getattr(op, "params", ()))
+                if g.shape == (2, 2) and len(idx) == 1:
+                    gates.apply_1q(g, idx[0], cols, cols)
+                elif g.shape == (4, 4) and len(idx) == 2:
+                    gates.apply_2q(g, idx[0], idx[1], cols, cols)
+                else:
+                    raise ValueError(f"gate '{name}' on {len(idx)} qubit(s)")
+            phase = float(getattr(qc, "global_phase", 0.0) or 0.0)
+            if phase:
+                cols *= np.exp(1j * phase)
+        super().__init__(np.ascontiguousarray(cols.T))
+
+
 class SpService:
     """Counters, statistics and early-termination hooks (objective_base.py:437-622).
     Stoppers are duck-typed (TimeoutChecker / EarlyStopper of the reference's optimizer.py
@@ -191,8 +280,8 @@ class SpLHSObjectiveBase:
 
     ``state_prep_func(num_qubits)`` may return an ``int`` (bit mask of a computational-basis
     preparation, e.g. the Neel state), a circuit that only flips qubits (the reference's ``neel_init_state`` & co.,
-    duck-typed: ``basis_mask_of_circuit``) or a dense (num_states, 2^n) array of prepared states; other Qiskit circuits
-    are outside this path and raise."""
+    duck-typed: ``basis_mask_of_circuit``), a dense (num_states, 2^n) array of prepared states, or a general (duck-typed)
+    circuit over the gate set of ``GenericStateHandler``, whose states are then built explicitly on the device."""
 
     def __init__(self, user_parameters: dict, circuit: ParametricCircuit, use_mps: bool = False, verbose: bool = False):
         if not isinstance(user_parameters, dict):
@@ -213,8 +302,11 @@ class SpLHSObjectiveBase:
             self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=int(prepared))
         elif isinstance(prepared, np.ndarray):
             self._state_handler = DenseStateHandler(prepared)
-        elif hasattr(prepared, "data") and hasattr(prepared, "num_qubits"):   # a (duck-typed) circuit of X gates
-            self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=basis_mask_of_circuit(prepared, n))
+        elif hasattr(prepared, "data") and hasattr(prepared, "num_qubits"):   # a (duck-typed) circuit
+            try:            # X gates only: the flip states stay one-hot (ThinStateHandler, objective_base.py:42-255)
+                self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=basis_mask_of_circuit(prepared, n))
+            except NotImplementedError:   # a general preparation: explicit states (GenericStateHandler, :258-342)
+                self._state_handler = GenericStateHandler(n, max_flips, prepared, verbose)
         else:
             raise NotImplementedError(
                 "state_prep_func must return a basis-state bit mask (int) or a dense array of states; "

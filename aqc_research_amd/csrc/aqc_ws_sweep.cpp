@@ -544,6 +544,8 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     const bool sparse = grads && (do_vdag ? sweep_route_sparse(ws, x_buf, true) : (!thetas && sweep_route_sparse(ws, x_buf, false)));
     if (sparse && sweep_sparse_prepare(ws)) return 1;
     const bool lazy = sparse && do_vdag && vdag_route_restricted(ws, x_buf);   // V^H only where this call (gather, sweep) reads it
+    if (!do_vdag && (gathered || grads) && ensure_z_full(ws, true)) return 1;  // a partial Z left by an earlier call is completed here,
+                                                                              // outside whatever graph is captured below
     auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
         if (thetas) {
             ws->d_thetas = ws->d_thetas_own;

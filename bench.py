@@ -53,6 +53,9 @@ WORKLOADS = {
     # ground-truth / reference Trotter targets synthesised on the device, 64 random restarts of the 2h-layer ansatz optimised by
     # L-BFGS under the fidelity threshold, the reference's result record; horizons are the jobs of run_jobs.  One step = the run.
     "cfg4_driver": dict(n=20, kind="driver", seeds=64, horizons=8, maxiter=40, desc="20-qubit ASP run of the horizon driver: time_evol.run_simulation(UserOptions(num_qubits=20, num_horizons=8, num_seeds=64, objective='sur_max', vectorised_lbfgs=True)) -- Trotter targets synthesised on the device, 64 restarts per horizon as lanes of one batched surrogate objective, L-BFGS (maxiter 40) under the fidelity threshold, horizons sharded by run_jobs"),
+    # config 2 as the reference's launcher runs it (run_time_evol.py defaults = user_options.py:25-129): 12 qubits, six horizons of
+    # 2 .. 12 ansatz layers, ONE optimisation per horizon from the Trotter point (scipy L-BFGS under AqcOptimizer, maxiter 40)
+    "cfg2_driver": dict(n=12, kind="driver", seeds=1, horizons=6, maxiter=40, desc="12-qubit ASP run of the horizon driver at the reference's defaults: time_evol.run_simulation(UserOptions(num_qubits=12, objective='sur_max')) -- six horizons (2..12 layers), one L-BFGS optimisation each (AqcOptimizer on SpSurrogateObjectiveMax, maxiter 40) under the fidelity threshold, Trotter targets synthesised on the device"),
     "mps16_l40_chi16": dict(n=16, blocks=40, kind="generic", chi=16, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=16 (a different one per lane every step), contracted to dense on the device every evaluation"),
     "mps16_l40_chi64": dict(n=16, blocks=40, kind="generic", chi=64, desc="16-qubit, 40-block cx spin ansatz, MPS-dot objective+gradient: QiskitMPS targets chi=64 (a different one per lane every step), contracted to dense on the device every evaluation"),
     # the same front door at the threshold the reference's own driver hands over (user_options.py:55: trunc_thr = 1e-6): the targets
@@ -362,7 +365,7 @@ def run_driver(args, w, env, full):
     from oracle import aqc_ref as cref
 
     comm, rank, local_rank, n_gpus = env.comm, env.rank, env.local_rank, env.n_gpus
-    H = w["horizons"] if full else 2
+    H = w["horizons"] if full or w["seeds"] == 1 else 2
     mode = os.environ.get("AQC_BENCH_DRIVER_LBFGS", "vectorised")   # vectorised (host L-BFGS over (B, T) arrays) | device (aqc_ws_lbfgs)
     opts = time_evol.UserOptions(num_qubits=w["n"], num_horizons=H, num_seeds=w["seeds"], objective="sur_max", vectorised_lbfgs=True,
                                  device_lbfgs=(mode == "device"), maxiter=w["maxiter"], device=local_rank, seed=0x696969)
@@ -408,7 +411,7 @@ def run_driver(args, w, env, full):
                    "evaluations": evals, "lanes_per_entry": w["seeds"],
                    "fidelity_best_per_horizon": [float(r["fidelity"]) for r in sorted(recs, key=lambda r: r["horizon"])],
                    "fidelity_threshold_per_horizon": [float(r["fidelity_thr"]) for r in sorted(recs, key=lambda r: r["horizon"])],
-                   "fidelity_min_over_restarts": [float(min(r["fidelities"])) for r in sorted(recs, key=lambda r: r["horizon"])],
+                   "fidelity_min_over_restarts": [float(min(r.get("fidelities", [r["fidelity"]]))) for r in sorted(recs, key=lambda r: r["horizon"])],
                    "num_thetas_per_horizon": [int(r["num_thetas"]) for r in sorted(recs, key=lambda r: r["horizon"])],
                    "transport": comm.transport if env.comm_note is None else env.comm_note, "ranks_seen": env.ranks_seen,
                    "includes": "target synthesis (ground truth with 10x the Trotter steps + reference state) per horizon, initial "
@@ -1059,7 +1062,7 @@ def main():
 # the short configuration runs of the default invocation, in BASELINE.json's order (cfg 1, 2 first / last horizon, 3 through the
 # MPS front door at the no-truncation and at the reference's default threshold, 4 sizes + job mix, 5)
 CONFIG_RUNS = ["mat5_cyc180", "cd5_cyc180", "mat10_l40_k16", "sv12_trotter2", "sv12_trotter12", "mps16_l40_chi64", "mps16_l40_chi64_thr1e-6", "sv20_l40",
-               "sv20_trotter2", "cfg4_jobs", "cfg4_driver", "mat10_l40", "mps32_trotter2_engine", "mps32_trotter2_opt"]
+               "cfg2_driver", "sv20_trotter2", "cfg4_jobs", "cfg4_driver", "mat10_l40", "mps32_trotter2_engine", "mps32_trotter2_opt"]
 
 
 def brief(o):

@@ -406,7 +406,7 @@ def run_driver(args, w, env, full):
         "parity_maxerr": parity, "parity_lanes_checked": 1, "record_fidelity_vs_oracle": fid_gap if rank == 0 else None,
         "parity_note": "horizon 1, best restart: amplitude <ini|V^H|t1_gt>, complex gradient and the record's fidelity at the optimised "
                        "thetas, device vs C oracle (target = the driver's own ground-truth state)",
-        "config": {"workload": w["desc"], "n_qubits": w["n"], "horizons": H, "restarts_per_horizon": w["seeds"], "lbfgs": mode,
+        "config": {"workload": w["desc"], "n_qubits": w["n"], "horizons": H, "restarts_per_horizon": w["seeds"], "lbfgs": mode if w["seeds"] > 1 else "scipy L-BFGS-B under AqcOptimizer (one objective object per horizon)",
                    "lbfgs_maxiter": w["maxiter"], "horizons_per_s": H / wall, "optimisations_per_s": H * w["seeds"] / wall,
                    "evaluations": evals, "lanes_per_entry": w["seeds"],
                    "fidelity_best_per_horizon": [float(r["fidelity"]) for r in sorted(recs, key=lambda r: r["horizon"])],

@@ -363,11 +363,19 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep})
         if (p->v3) WS_HIP(hipMalloc((void**)&p->d_umat, sizeof(double) * (size_t)batch * std::max<size_t>(p->h_subs3.size(), 1) * 12 * 64));
     {
+        // [V^H | sweep | V]; with the mirrored V^H plan the sweep's jobs write V^H's operands as well (sub-stage s of the sweep is
+        // sub-stage nsubs - 1 - s of V^H, conjugate-transposed) and V^H gets no jobs of its own
         std::vector<UJob> jobs;
+        const int nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
+        ws->ujobs_mirror = ws->inv_mirrored && ws->inv.v3 && (int)ws->inv.h_subs3.size() == nsw && env_int("AQC_UBUILD_MIRROR", 1) != 0;
         for (DevPlan* p : {&ws->inv, &ws->sweep, &ws->fwd})
             if (p->v3)
-                for (size_t i = 0; i < p->h_subs3.size(); ++i)
-                    jobs.push_back({p->d_subs3 + i, p->d_grps, p->d_umat, (int)i, (int)p->h_subs3.size(), p->plan.inverse ? 1 : 0, prog.entangler});
+                for (size_t i = 0; i < p->h_subs3.size(); ++i) {
+                    if (p == &ws->inv && ws->ujobs_mirror) continue;
+                    UJob j{p->d_subs3 + i, p->d_grps, p->d_umat, (int)i, (int)p->h_subs3.size(), p->plan.inverse ? 1 : 0, prog.entangler, nullptr, 0, 0};
+                    if (p == &ws->sweep && ws->ujobs_mirror) { j.umat_mirror = ws->inv.d_umat; j.mirror_index = nsw - 1 - (int)i; j.mirror_nsubs = nsw; }
+                    jobs.push_back(j);
+                }
         if (!jobs.empty()) {
             WS_HIP(hipMalloc((void**)&ws->d_ujobs, sizeof(UJob) * jobs.size()));
             WS_HIP(hipMemcpy(ws->d_ujobs, jobs.data(), sizeof(UJob) * jobs.size(), hipMemcpyHostToDevice));

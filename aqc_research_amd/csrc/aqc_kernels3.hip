@@ -993,6 +993,17 @@ __global__ __launch_bounds__(64) void ubuild_kernel(const UJob* jobs, const doub
         out[(1 * 4 + s) * 64 + lane] = v.y - v.x;   // u1 = Im U - Re U
         out[(2 * 4 + s) * 64 + lane] = v.x + v.y;   // u2 = Re U + Im U
     }
+    if (job.umat_mirror) {   // the mirrored V^H plan runs this sub-stage's U^H: the same matrix conjugate-transposed, no second chain
+        double* om = job.umat_mirror + ((size_t)b * job.mirror_nsubs + job.mirror_index) * 12 * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const cplx t = u[(4 * s + (lane >> 4)) * 16 + (lane & 15)];
+            const double re = t.x, im = -t.y;       // U^H[l % 16][4 s + l / 16] = conj(U[4 s + l / 16][l % 16])
+            om[(0 * 4 + s) * 64 + lane] = re;
+            om[(1 * 4 + s) * 64 + lane] = im - re;
+            om[(2 * 4 + s) * 64 + lane] = re + im;
+        }
+    }
 }
 
 // rho <- G^H rho G for a rotation G (kind, c, s) on local bit LB of a 4 x 4 matrix rho[a * 4 + b] (a: z side, b: w side)

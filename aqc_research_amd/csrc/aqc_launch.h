@@ -97,6 +97,8 @@ struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` o
     double* umat;            // the plan's operand buffer [batch][nsubs][12][64]
     int index, nsubs;
     int inverse, entangler;  // V^H plans apply every group conjugate-transposed; 0 cx, 1 cz, 2 cp
+    double* umat_mirror;     // mirrored V^H plan (or null): this sub-stage's U^H is sub-stage `mirror_index` of that plan's operand buffer
+    int mirror_index, mirror_nsubs;
 };
 hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int T, int batch, hipStream_t s, double* thetas_copy = nullptr);
 struct GatherJob {           // optional passenger of the gradient walk: out[lane][i] = buf[lane][elem[i]] (+ pinned host copy)

@@ -137,7 +137,8 @@ struct aqc_ws {
     // D2H copies) captured once per call signature and replayed -- one launch instead of ~11 host calls per evaluation
     std::map<std::vector<long long>, hipGraphExec_t> graphs;
     bool capturing = false;
-    UJob* d_ujobs = nullptr;          // family 3: [V^H subs | sweep subs | V subs]
+    UJob* d_ujobs = nullptr;          // family 3: [V^H subs | sweep subs | V subs]; ujobs_mirror: no V^H jobs, the sweep's write both operand sets
+    bool ujobs_mirror = false;
     struct MpsSlot {
         std::vector<int> dims;          // n + 1 bond dimensions
         std::vector<size_t> offset;     // element offset of site q inside d_t

@@ -26,7 +26,7 @@ namespace aqc {
 int ensure_umat(aqc_ws* ws, DevPlan& p) {
     if (!p.v3 || p.u_valid) return 0;
     const int T = ws->ctx->prog.num_thetas();
-    const int ninv = ws->inv.v3 ? (int)ws->inv.h_subs3.size() : 0, nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
+    const int ninv = ws->inv.v3 && !ws->ujobs_mirror ? (int)ws->inv.h_subs3.size() : 0, nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
     const int nfwd = ws->fwd.v3 ? (int)ws->fwd.h_subs3.size() : 0;
     ProfScope ps(ws, AQC_K_COEF);
     if (&p == &ws->fwd) {

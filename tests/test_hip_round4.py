@@ -168,7 +168,7 @@ def test_horizon_driver_follows_the_reference_logic(objective):
 
 def test_state_prep_func_returning_a_circuit():
     """objective_base.py:298-303: a reference caller hands ``neel_init_state`` (a circuit of X gates) as ``state_prep_func``;
-    the objective must behave exactly as with the equivalent bit mask, and refuse circuits that are not basis preparations."""
+    the objective must behave exactly as with the equivalent bit mask, and refuse circuits with gates it does not know."""
     from aqc_research_amd import TrotterAnsatz
     from aqc_research_amd.circuit_structures import make_trotter_like_circuit
     from aqc_research_amd.model_sp_lhs.objective_lhs_sur_max import SpSurrogateObjectiveMax
@@ -188,17 +188,18 @@ def test_state_prep_func_returning_a_circuit():
     ref = orc.SurMaxOracle(circ, target, 1, None, True, base_index=neel_state_index(n))
     assert abs(vals[0][0] - ref.objective(th)) < TOL and maxdiff(vals[0][1], ref.gradient(th)) < TOL
 
-    class Had:   # a circuit with a gate that is not a basis preparation
-        num_qubits = n
+    class Odd:   # a circuit with a gate outside the set the state handlers know (round 5: general preparations such as H go through
+        num_qubits = n   # GenericStateHandler, tests/test_hip_round5.py; only unknown gates are refused)
 
         class _I:
             class operation:
-                name = "h"
-            qubits = (0,)
+                name = "ccx"
+                params = ()
+            qubits = (0, 1, 2)
         data = [_I()]
 
     with pytest.raises(NotImplementedError):
-        SpSurrogateObjectiveMax(user_parameters=dict(num_qubits=n, max_flips=1, state_prep_func=lambda k: Had()), circ=circ)
+        SpSurrogateObjectiveMax(user_parameters=dict(num_qubits=n, max_flips=1, state_prep_func=lambda k: Odd()), circ=circ)
 
 
 def test_rccl_init_is_bounded_when_a_rank_never_joins():

@@ -306,6 +306,13 @@ class SpLHSObjectiveBase:
             try:            # X gates only: the flip states stay one-hot (ThinStateHandler, objective_base.py:42-255)
                 self._state_handler = ThinStateHandler(n, max_flips, verbose, base_index=basis_mask_of_circuit(prepared, n))
             except NotImplementedError:   # a general preparation: explicit states (GenericStateHandler, :258-342)
+                if self._use_mps:
+                    from ..mps_dot_objective import use_dense
+
+                    if not use_dense(n, float(user_parameters.get("trunc_thr", 1e-16))):
+                        raise NotImplementedError(
+                            "a general state-preparation circuit on the native MPS route (registers beyond dense reach: the reference's "
+                            "MpsStateHandler, objective_base.py:345-435) is not built; circuits of X gates (basis preparations) are")
                 self._state_handler = GenericStateHandler(n, max_flips, prepared, verbose)
         else:
             raise NotImplementedError(

@@ -3,8 +3,6 @@
 // small complex GEMMs; one LDS-tiled fp64 MFMA zgemm kernel serves them.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "aqc_launch.h"
 
 namespace aqc {
@@ -41,15 +39,12 @@ __global__ void mps_scale_all_kernel(cplx* t, const double* lam, MpsSites sites)
 // are split (re / im) while the tiles are staged into LDS so that every operand read is one b64.
 // Workgroup = 4 waves, 64 x 64 outputs; wave w owns rows [16w, 16w+16) and all four 16-column tiles.
 typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int TM = 64, kTN = 64, kTK = 16, kSmallTN = 16, kSmallTK = 64;
+constexpr int TM = 64, TN = 64, TK = 16;
 // Batching: product z = blockIdx.z uses operand pointers advanced by z * stride; with pointer tables (ZTables, device
 // arrays) product z = outer * inner + i takes its bases from entry `outer` of each table and advances them by i * stride --
 // the lanes of a batched MPS contraction live in unrelated allocations.
 struct ZTables { const cplx* const* a; const cplx* const* b; cplx* const* c; int inner; };
-// TN / TK are template parameters: the default 64 x 64 outputs per workgroup in K steps of 16 serves large products; the steps
-// of the batched MPS -> dense chain are small and latency-bound (<= 64 rows, bond <= 64, a launch each, one after the other), and
-// take 16 output columns per workgroup with the whole K range staged at once: four times the workgroups, one load round trip.
-template <bool CONJ_T, bool ACCUM, int TN, int TK>
+template <bool CONJ_T, bool ACCUM>
 __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const cplx* __restrict__ A, int lda,
                                                     const cplx* __restrict__ B, int ldb, cplx* __restrict__ C, int ldc,
                                                     size_t stride_a, size_t stride_b, size_t stride_c, int b_herm, ZTables tab) {
@@ -64,9 +59,9 @@ __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    double4_t cre[TN / 16], cim[TN / 16];
+    double4_t cre[4], cim[4];
 #pragma unroll
-    for (int t = 0; t < TN / 16; ++t) { cre[t] = double4_t{0, 0, 0, 0}; cim[t] = double4_t{0, 0, 0, 0}; }
+    for (int t = 0; t < 4; ++t) { cre[t] = double4_t{0, 0, 0, 0}; cim[t] = double4_t{0, 0, 0, 0}; }
     for (int k0 = 0; k0 < K; k0 += TK) {
         for (int e = threadIdx.x; e < TK * TM; e += 256) {
             int kk, mm;
@@ -96,7 +91,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const c
             const double ar = sar[ks + lk][16 * wave + li];
             const double ai = sai[ks + lk][16 * wave + li];
 #pragma unroll
-            for (int t = 0; t < TN / 16; ++t) {
+            for (int t = 0; t < 4; ++t) {
                 const double br = sbr[ks + lk][16 * t + li];
                 const double bi = sbi[ks + lk][16 * t + li];
                 cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[t], 0, 0, 0);
@@ -108,7 +103,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(int M, int N, int K, const c
         __syncthreads();
     }
 #pragma unroll
-    for (int t = 0; t < TN / 16; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gm = m0 + 16 * wave + 4 * r + lk, gn = n0 + 16 * t + li;
@@ -134,24 +129,16 @@ namespace {
 hipError_t zgemm_launch(bool conj_t, bool accum, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, size_t sa,
                         size_t sb, size_t sc, int nbatch, int b_herm, hipStream_t s, ZTables tab = ZTables{nullptr, nullptr, nullptr, 0}) {
     if (M <= 0 || N <= 0 || nbatch <= 0) return hipSuccess;
+    const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch);
     const cplx* a = static_cast<const cplx*>(A);
     const cplx* b = static_cast<const cplx*>(B);
     cplx* c = static_cast<cplx*>(C);
-    // the small variant: table launches (the MPS -> dense chain) whose workgroups would not fill the chip with 64-column tiles
-    static const bool small_on = []() { const char* e = getenv("AQC_ZGEMM_SMALL"); return !(e && e[0] == '0'); }();
-    const long wgs64 = (long)((N + kTN - 1) / kTN) * ((M + TM - 1) / TM) * nbatch;
-    if (small_on && tab.inner > 0 && !conj_t && !accum && K <= kSmallTK && wgs64 < 1024) {
-        const dim3 grid((N + kSmallTN - 1) / kSmallTN, (M + TM - 1) / TM, nbatch);
-        zgemm_kernel<false, false, kSmallTN, kSmallTK><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
-        return hipGetLastError();
-    }
-    const dim3 grid((N + kTN - 1) / kTN, (M + TM - 1) / TM, nbatch);
     if (conj_t) {
-        if (accum) zgemm_kernel<true, true, kTN, kTK><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
-        else zgemm_kernel<true, false, kTN, kTK><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
+        if (accum) zgemm_kernel<true, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
+        else zgemm_kernel<true, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
     } else {
-        if (accum) zgemm_kernel<false, true, kTN, kTK><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
-        else zgemm_kernel<false, false, kTN, kTK><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
+        if (accum) zgemm_kernel<false, true><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
+        else zgemm_kernel<false, false><<<grid, 256, 0, s>>>(M, N, K, a, lda, b, ldb, c, ldc, sa, sb, sc, b_herm, tab);
     }
     return hipGetLastError();
 }

@@ -85,6 +85,9 @@ def _canonical_verdict(qiskit_mps) -> bool:
     return verdict
 
 
+_SERIALS = __import__("itertools").count(1)
+
+
 class DeviceMPS:
     """One MPS resident on the GPU."""
 
@@ -92,6 +95,7 @@ class DeviceMPS:
         self.handle = handle
         self._L = _lib.lib()
         self.version = 0   # counts the in-place changes of the state (copies held elsewhere, e.g. by LockstepLanes, go stale)
+        self.serial = next(_SERIALS)   # never reused (unlike id()): what holders of copies remember instead of a reference to the state
 
     @classmethod
     def from_qiskit(cls, qiskit_mps, device: Optional[int] = None, trunc_thr: float = 0.0, assume_canonical: bool = False) -> "DeviceMPS":
@@ -515,8 +519,8 @@ class LockstepLanes:
         """Copies |phi_l> of every lane into the lanes (one state per lane, or one for all).  A call with the very states of the
         previous one, unchanged since (``DeviceMPS.version``), is free: the batches of an optimisation come back every iteration."""
         lst, arr, shared = self._handles(targets)
-        stamp = [(m, m.version) for m in lst]   # (holds the states: their identities stay unique)
-        if self._targets is None or len(stamp) != len(self._targets) or any(a is not b or va != vb for (a, va), (b, vb) in zip(stamp, self._targets)):
+        stamp = [(m.serial, m.version) for m in lst]   # (no reference to the states: a closed one is not kept alive by its copy)
+        if self._targets != stamp:
             check(_lib.lib().aqc_mpsb_set_targets(self.handle, arr, shared))
             self._targets = stamp
         return self
@@ -524,8 +528,8 @@ class LockstepLanes:
     def set_lhs(self, lhs) -> "LockstepLanes":
         """The same for the left-hand states <lhs_l|."""
         lst, arr, shared = self._handles(lhs)
-        stamp = [(m, m.version) for m in lst]
-        if self._lhs is None or len(stamp) != len(self._lhs) or any(a is not b or va != vb for (a, va), (b, vb) in zip(stamp, self._lhs)):
+        stamp = [(m.serial, m.version) for m in lst]
+        if self._lhs != stamp:
             check(_lib.lib().aqc_mpsb_set_lhs(self.handle, arr, shared))
             self._lhs = stamp
         return self

@@ -570,8 +570,13 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(flo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
             }
     };
-    for (int si = 0; si < st.nsubs; ++si) {
-        const bool from_regs = reg_first && si == 0;
+    // One sub-stage, as a lambda with a compile-time tag: the R-only form of the very last sub-stage (see below) is instantiated ONCE,
+    // behind the loop, so that the loop body itself stays free of it (with the extra branch inside, the compiler stops giving the
+    // register-fed first sub-stage of an item its own copy of the loop: +6 % on every dense launch)
+    const int nmain = a.r_only_last && st.nsubs >= 1 && !(kPersist && st.nsubs == 1) ? st.nsubs - 1 : st.nsubs;
+    auto substage = [&](const int si, auto tail_tag, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool kROnly = decltype(tail_tag)::value;
+        const bool from_regs = decltype(first_tag)::value && reg_first;   // (the item's first sub-stage has its own copy: its operands sit in registers)
         unsigned nzmask = ~0u, kneed = 15u;
         if (SKIPW) {
             const unsigned info = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
@@ -744,7 +749,38 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
             }
         }
         };
-        group_loop();
+        // LAST sub-stage of the LAST stage: nothing reads its w' and z' -- only R = Z' W'^H = U (Z W^H) U^H is wanted, and Z W^H comes
+        // from the sub-stage's INPUTS: one real-product triple per group (12 MFMAs instead of 36), no U products, no LDS write-back;
+        // rgrad_kernel conjugates the summed 16 x 16 matrix by U (Stage3Args::r_only_last, launch_rgrad's conj_sub).  The operands are
+        // read in the layout product 2 consumes ("L2": amplitude l % 16 of chunk 4 r + l / 16), which the LDS tile serves as well as L1.
+        if (kROnly) {
+            cplx rw[2][4], rz[2][4];   // (the early L1 reads of group 0 issued behind the previous barrier are simply not used)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { rw[0][r] = lds_get(ad.a2 ^ ad.k2[0][r]); rz[0][r] = lds_get(a2z ^ ad.k2[0][r]); }
+#pragma unroll
+            for (int j = 0; j < TS::kGpw; ++j) {
+                if (j + 1 < TS::kGpw) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { rw[(j + 1) & 1][r] = lds_get(ad.a2 ^ ad.k2[j + 1][r]); rz[(j + 1) & 1][r] = lds_get(a2z ^ ad.k2[j + 1][r]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double zs2[4], wd2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { zs2[r] = rz[j & 1][r].x + rz[j & 1][r].y; wd2[r] = rw[j & 1][r].x - rw[j & 1][r].y; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { asm volatile("" : "+v"(zs2[r])); asm volatile("" : "+v"(wd2[r])); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    t1 = mfma(rz[j & 1][r].x, rw[j & 1][r].x, t1);
+                    t2 = mfma(rz[j & 1][r].y, rw[j & 1][r].y, t2);
+                    t3 = mfma(zs2[r], wd2[r], t3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            group_loop();
+        }
         AQC_STAMP(3 + 4 * si);
         if (kPersist && more && st.nsubs == 1) {
 #pragma unroll
@@ -815,7 +851,10 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
         }
         AQC_STAMP(5 + 4 * si);
         if (!go_on && more) cur = nxt;
-    }
+    };
+    if (nmain > 0) substage(0, std::false_type{}, std::true_type{});
+    for (int si = 1; si < nmain; ++si) substage(si, std::false_type{}, std::false_type{});
+    if (nmain < st.nsubs) substage(nmain, std::true_type{}, std::false_type{});
     AQC_STAMP(kStampSlots - 2);
     // The next item's operands are waited for BEFORE this item's stores are issued: vmcnt counts stores as well, and a wait
     // placed after them would sit out their whole write latency; the loads went out sub-stages ago.  (The loads are inline
@@ -1064,7 +1103,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                            int from, int to, int front, const int* slot_theta, cplx* grads, cplx* mirror,
                                                            const GatherJob gj, int tiles_per_lane, int chunk, int sparse_subs,
-                                                           const int* lane_parts) {   // ntiles: partial slots per (lane, sub-stage)
+                                                           const int* lane_parts, int conj_sub, const double* umat) {   // ntiles: partial slots per (lane, sub-stage)
     if ((int)blockIdx.x == nsubs_total) {   // the passenger (see GatherJob): one extra workgroup per lane of the batch
         const cplx* src = static_cast<const cplx*>(gj.buf) + (size_t)blockIdx.y * gj.lane_stride;
         for (int i = threadIdx.x; i < gj.count; i += 64 * WAVES) {
@@ -1122,6 +1161,41 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // MFMA D layout: entry 64 r + l is R[4 r + l / 16][l % 16]
             R[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[r];
+    }
+    if (si == conj_sub) {   // this sub-stage's R was taken from its INPUTS (sweep_mfma_kernel, r_only): R_end = U R U^H with the sub-stage's U,
+                            // read back from the operand planes the stage kernels use (u0 = Re U, u1 = Im U - Re U; entry [s][l] = U[l % 16][4 s + l / 16])
+        __shared__ cplx Us[16 * 17], Ts[16 * 17];
+        const double* up = umat + ((size_t)b * nsubs_total + si) * 12 * 64;
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const double re = up[(0 * 4 + s2) * 64 + lane], im = up[(1 * 4 + s2) * 64 + lane] + re;
+            Us[(lane & 15) * 17 + 4 * s2 + (lane >> 4)] = make_double2(re, im);
+        }
+        __syncthreads();
+        const int i0 = lane & 15, j0 = lane >> 4;   // this lane: entries (j0 + 4 m, i0)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {               // T = U R
+            const int j = j0 + 4 * m;
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < 16; ++k) {
+                const cplx u = Us[j * 17 + k], r = R[k * 17 + i0];
+                re += u.x * r.x - u.y * r.y; im += u.x * r.y + u.y * r.x;
+            }
+            Ts[j * 17 + i0] = make_double2(re, im);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {               // R = T U^H
+            const int j = j0 + 4 * m;
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < 16; ++k) {
+                const cplx t = Ts[j * 17 + k], u = Us[i0 * 17 + k];
+                re += t.x * u.x + t.y * u.y; im += t.y * u.x - t.x * u.y;
+            }
+            R[j * 17 + i0] = make_double2(re, im);
+        }
+        __syncthreads();
     }
     RG_STAMP(1);
     cplx* out = partial + (size_t)b * nslots;
@@ -1428,7 +1502,7 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
                         const int* slot_theta, void* grads, void* mirror, GatherJob gather, int nparts, int chunk, int sparse_subs,
-                        const int* lane_parts) {
+                        const int* lane_parts, int conj_sub, const double* umat) {
     if (nsubs_total < 1) return hipSuccess;
     const int extra = gather.count > 0 && gather.buf ? 1 : 0;
     const int tiles_per_lane = ntiles;
@@ -1437,11 +1511,11 @@ hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, 
     if (nparts >= 32)
         rgrad_kernel<4><<<dim3(nsubs_total + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                   nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts);
+                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat);
     else
         rgrad_kernel<1><<<dim3(nsubs_total + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts);
+                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat);
     return hipGetLastError();
 }
 

@@ -70,6 +70,8 @@ struct Stage3Args {
     int chunk, nparts;       // sweep: items per persistent workgroup (0: one item per workgroup) and partial-R slots per
                              // (lane, sub-stage) -- sweep3_chunk / sweep3_nparts
     int store_out;           // sweep: bit 0 store w, bit 1 store z; 0 for the last stage (its w and z are never read again)
+    int r_only_last;         // sweep, last stage: its last sub-stage computes R from its INPUTS alone (no U products); the gradient walk
+                             // conjugates that R by the sub-stage's U (launch_rgrad: conj_sub)
     const long long* supp;   // sweep from basis states: supp[lane][2] = element index of the lane's (<= 2) basis states (-1: none), or null.
                              // The kernel then skips the W and R products of 16-chunk groups (and K-steps of the W product) where w is
                              // zero by construction (DevSub3::skipinfo, DevStage::fresh_nonlocal) -- exact zeros, so the results do not change
@@ -109,7 +111,8 @@ hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, 
                         const int* slot_theta = nullptr, void* grads = nullptr, void* mirror = nullptr,
                         GatherJob gather = GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},   // slot_theta: direct mode, see rgrad_kernel
                         int nparts = 0, int chunk = 0,   // partial-R slots per (lane, sub-stage) and the persistent sweep's chunk
-                        int sparse_subs = 0, const int* lane_parts = nullptr);   // the first sparse_subs sub-stages hold lane_parts[lane] partials (item-list launch)
+                        int sparse_subs = 0, const int* lane_parts = nullptr,   // the first sparse_subs sub-stages hold lane_parts[lane] partials (item-list launch)
+                        int conj_sub = -1, const double* umat = nullptr);       // sub-stage whose R arrives as Z W^H of its INPUTS: R <- U R U^H first (umat: the plan's operands)
 // Tile lists on the device (aqc_ws_sweep.cpp).  Per lane, the tiles of `stage` that hold the elements supp[lane][0 .. per_lane)
 // (the support of the lane's sparse lhs state; -1 = none; may be null) and extra[0 .. nextra) (the same for every lane: the
 // registered gather set; may be null), each tile once, in that order -> item list (lane-major, slot = position inside the lane),

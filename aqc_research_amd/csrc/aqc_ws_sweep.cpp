@@ -378,6 +378,10 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         const size_t m = p.h_stages.size();
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
         const bool skipw = sweep_skips_zero_w(ws, x_buf);
+        // the last sub-stage of the last stage is taken from its inputs alone (R = U (Z W^H) U^H, see sweep_mfma_kernel) unless it is also the
+        // FIRST sub-stage of a persistent stage, whose operands sit in the prefetch registers in the other layout
+        const DevStage& last = p.h_stages[m - 1];
+        const int r_only_sub = ws->r_only_enabled && last.nsubs >= 1 && !(p.k >= 12 && last.nsubs == 1) ? last.sub_begin + last.nsubs - 1 : -1;
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||
@@ -418,6 +422,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
                 a.store_out = s + 1 < m ? 3 : 0;
             }
             if (skipw && !a.items) a.supp = ws->d_combo_prev[x_buf];
+            if (s + 1 == m && r_only_sub >= 0) a.r_only_last = 1;
             a.rpart = p.d_rpart;
             a.chunk = sweep3_chunk(p.ntiles, ws->batch, p.k);
             a.nparts = sweep3_nparts(p.ntiles, ws->batch, p.k);
@@ -443,7 +448,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
                             ws->gather_rides ? GatherJob{ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->d_small, ws->mirror_small}
                                              : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},
                             sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k),
-                            sparse ? p.h_stages[0].nsubs : 0, sparse ? ws->d_sw_lane_parts : nullptr));
+                            sparse ? p.h_stages[0].nsubs : 0, sparse ? ws->d_sw_lane_parts : nullptr, r_only_sub, p.d_umat));
 #ifdef AQC_TUNING
         if (env_int("AQC_STAMPS", 0) != 0) { HIP_OK(hipStreamSynchronize(ws->stream)); rgrad_print_stamps(nsubs); }
 #endif

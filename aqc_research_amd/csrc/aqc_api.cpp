@@ -312,6 +312,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     ws->sparse_min_items = env_int("AQC_SPARSE_MIN_ITEMS", 512);
     ws->lazy_z_enabled = env_int("AQC_LAZY_Z", 1) != 0;
     ws->r_only_enabled = env_int("AQC_R_ONLY_LAST", 1) != 0;
+    ws->r_only_max_subs = env_int("AQC_R_ONLY_MAX_SUBS", 12);
     ws->skipw_enabled = env_int("AQC_SKIP_ZERO_W", 0) != 0;   // (measured slower than multiplying the zeros: opt-in, see sweep_mfma_kernel)
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);

@@ -438,7 +438,9 @@ __device__ __forceinline__ void skip_masks(const DevStage& st, unsigned info, lo
             if (((s2 ^ kb) & kfresh) == 0) kneed |= 1u << s2;
     }
 }
-template <int K, bool LIST = false, bool SKIPW = false>
+// RLAST: the launch of the LAST stage when its last sub-stage is taken from its inputs alone (Stage3Args::r_only_last); a variant of
+// its own because the explicit copies it needs cost the plain loop 3 % (see `substage` below).
+template <int K, bool LIST = false, bool SKIPW = false, bool RLAST = false>
 __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void sweep_mfma_kernel(const Stage3Args a) {
     using TS = TileShape<K, true>;
     constexpr int kSlots = TS::kWaves > 4 ? 4 : TS::kWaves;   // scratch slots; 8 waves reduce in pairs first
@@ -570,291 +572,42 @@ __global__ __launch_bounds__(SweepShape<K>::kWaves * 64, K >= 12 ? 1 : 2) void s
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(pz[i]) : "v"(flo16), "s"(uniform_ptr(a.in1 + ub)) : "memory");
             }
     };
-    // One sub-stage, as a lambda with a compile-time tag: the R-only form of the very last sub-stage (see below) is instantiated ONCE,
-    // behind the loop, so that the loop body itself stays free of it (with the extra branch inside, the compiler stops giving the
-    // register-fed first sub-stage of an item its own copy of the loop: +6 % on every dense launch)
-    const int nmain = a.r_only_last && st.nsubs >= 1 && !(kPersist && st.nsubs == 1) ? st.nsubs - 1 : st.nsubs;
-    auto substage = [&](const int si, auto tail_tag, auto first_tag) __attribute__((always_inline)) {
-        constexpr bool kROnly = decltype(tail_tag)::value;
-        const bool from_regs = decltype(first_tag)::value && reg_first;   // (the item's first sub-stage has its own copy: its operands sit in registers)
-        unsigned nzmask = ~0u, kneed = 15u;
-        if (SKIPW) {
-            const unsigned info = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
-                (const __attribute__((address_space(4))) void*)(const void*)&a.subs[st.sub_begin + si].skipinfo);
-            skip_masks<TS::kGpw, NW>(st, info, se0, se1, wave, nzmask, kneed);
+    // The sub-stage body lives in aqc_sweep_substage.inc (see there).  RLAST: the very last sub-stage is taken from its inputs alone
+    // (R = U (Z W^H) U^H), which needs explicit copies: first sub-stage of an item / the others / the R-only one.
+    const int nmain = RLAST && a.r_only_last && st.nsubs >= 1 && !(kPersist && st.nsubs == 1) ? st.nsubs - 1 : st.nsubs;
+    if (!RLAST) {
+        for (int si = 0; si < st.nsubs; ++si) {
+#define AQC_SS_FROM_REGS (reg_first && si == 0)
+#define AQC_SS_RONLY false
+#include "aqc_sweep_substage.inc"
+#undef AQC_SS_FROM_REGS
+#undef AQC_SS_RONLY
         }
-        AQC_STAMP(2 + 4 * si);
-        if (si + 1 < st.nsubs) fetch_sub<TS::kGpw>(nxt, a.subs, umat, st.sub_begin + si + 1, lane, wave, NW);
-        else if (more) fetch_sub<TS::kGpw>(nxt, a.subs, a.umat + (size_t)nbl * a.nsubs_total * 12 * 64, st.sub_begin, lane, wave, NW);
-        // a quarter of the next item's operands, issued BEHIND the operand fetch (loads retire in order): chunk c at the top of
-        // sub-stage min(1 + c, nsubs - 1) -- sub-stage 0 still reads the registers (a single sub-stage: below the group loop)
-        if (kPersist && more && si > 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (si == (1 + c < st.nsubs ? 1 + c : st.nsubs - 1)) prefetch(c);
+    } else {
+        if (nmain > 0) {
+            const int si = 0;
+#define AQC_SS_FROM_REGS reg_first
+#define AQC_SS_RONLY false
+#include "aqc_sweep_substage.inc"
+#undef AQC_SS_FROM_REGS
+#undef AQC_SS_RONLY
         }
-        if (kPersist && !seg_first)
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=a"(racc) : "v"(e16), "s"(uniform_ptr(rpart + (size_t)si * a.nparts * 256)) : "memory");
-        double4_t t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
-        // Software pipeline over the wave's groups, written as CLUSTERS that the compiler may not interleave
-        // (sched_barrier): on gfx950 an fp64 MFMA and vector-ALU instructions of the same SIMD do not overlap, and every
-        // switch between the two costs a few cycles, so the fastest stream is long runs of back-to-back MFMAs with all
-        // the fp64 adds bunched between them.  Per iteration j:  LDS reads of group j + 1 (issue only) | adds: operand
-        // sums of group j, complex results of group j - 1 | 36 MFMAs: U w and U z of group j, then Z' W'^H of group
-        // j - 1 | LDS writes of group j - 1.
-        if (!kEarly) {
-            sub_addr(ad, cur, lds_base);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
+        for (int si = 1; si < nmain; ++si) {
+#define AQC_SS_FROM_REGS false
+#define AQC_SS_RONLY false
+#include "aqc_sweep_substage.inc"
+#undef AQC_SS_FROM_REGS
+#undef AQC_SS_RONLY
         }
-        const unsigned a1z = ad.a1 | ZOFF, a2z = ad.a2 | ZOFF;
-        // (A lambda: hand-made copies of this loop -- one per operand source, or a fused and a branching one -- were tried for the SKIPW
-        // kernel and dropped: two inlined copies push the 2^12 kernel past its registers (300-400 bytes of scratch per lane, and the
-        // allocator then moves the asynchronously loaded prefetch registers while their loads are in flight: wrong results).)
-        auto group_loop = [&]() __attribute__((always_inline)) {
-        constexpr bool SK = SKIPW;
-        const bool from_regs_here = from_regs;
-        Acc3 aw, az;               // products of group j - 1 until they are combined, then of group j
-#pragma unroll
-        for (int j = 0; j <= TS::kGpw; ++j) {
-            if (j + 1 < TS::kGpw AQC_DBG_AND(!(a.debug & 2))) {
-                if (kPersist && from_regs_here) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        vw[(j + 1) & 1][s] = make_double2(pw[4 * (j + 1) + s].x, pw[4 * (j + 1) + s].y);
-                        vz[(j + 1) & 1][s] = make_double2(pz[4 * (j + 1) + s].x, pz[4 * (j + 1) + s].y);
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        vw[(j + 1) & 1][s] = lds_get(ad.a1 ^ ad.k1[j + 1][s]);
-                        vz[(j + 1) & 1][s] = lds_get(a1z ^ ad.k1[j + 1][s]);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            double sw[4], sz[4], zs[4], wd[4];
-            cplx ow[4], oz[4];
-            if (j < TS::kGpw) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { sw[s] = vw[j & 1][s].x + vw[j & 1][s].y; sz[s] = vz[j & 1][s].x + vz[j & 1][s].y; }
-            }
-            if (j > 0) {
-                u_combine(aw, ow);
-                u_combine(az, oz);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { zs[r] = oz[r].x + oz[r].y; wd[r] = ow[r].x - ow[r].y; }
-            }
-            // the sums are pinned HERE (IR-level sinking otherwise moves them in between the MFMAs of the cluster below)
-            if (j < TS::kGpw) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { asm volatile("" : "+v"(sw[s])); asm volatile("" : "+v"(sz[s])); }
-            }
-            if (j > 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { asm volatile("" : "+v"(zs[r])); asm volatile("" : "+v"(wd[r])); }
-            }
-            unsigned wa[4], za[4];   // LDS write addresses of group j - 1, taken in the vector-ALU bunch
-            if (j > 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    wa[r] = ad.a2 ^ ad.k2[j - 1][r]; za[r] = a2z ^ ad.k2[j - 1][r];
-                    asm volatile("" : "+v"(wa[r])); asm volatile("" : "+v"(za[r]));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (j < TS::kGpw) {
-                aw.k1 = double4_t{0.0, 0.0, 0.0, 0.0}; aw.k2 = aw.k1; aw.k3 = aw.k1; az.k1 = aw.k1; az.k2 = aw.k1; az.k3 = aw.k1;
-                if (!SK) {
-#pragma unroll
-                    for (int s = 0; s < (AQC_DBG_TEST(a.debug & 8) ? 0 : 4); ++s) {
-                        aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
-                        aw.k2 = mfma(vw[j & 1][s].x, cur.u1[s], aw.k2);
-                        aw.k3 = mfma(vw[j & 1][s].y, cur.u2[s], aw.k3);
-                        az.k1 = mfma(sz[s], cur.u0[s], az.k1);
-                        az.k2 = mfma(vz[j & 1][s].x, cur.u1[s], az.k2);
-                        az.k3 = mfma(vz[j & 1][s].y, cur.u2[s], az.k3);
-                    }
-                } else {   // U z always (the LDS writes of group j - 1 ride in this run); U w below, where w can be non-zero
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        az.k1 = mfma(sz[s], cur.u0[s], az.k1);
-                        az.k2 = mfma(vz[j & 1][s].x, cur.u1[s], az.k2);
-                        az.k3 = mfma(vz[j & 1][s].y, cur.u2[s], az.k3);
-                    }
-                }
-            }
-            if (!SK && j > 0 AQC_DBG_AND(!(a.debug & 4))) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {   // R += Z' W'^H over the 4 chunks of K-step r
-                    t1 = mfma(oz[r].x, ow[r].x, t1);
-                    t2 = mfma(oz[r].y, ow[r].y, t2);
-                    t3 = mfma(zs[r], wd[r], t3);
-                }
-            }
-            // The 8 LDS writes of group j - 1 ride INSIDE the MFMA run, one after every kSweepSpread MFMAs: an LDS write
-            // issued between two MFMAs costs ~1.5 cycles (tools/ubench/mfma_f64_shadow.hip), while the same writes bunched
-            // after the run -- all four waves at once -- run into the 64-79 B/clk the CU accepts for 128-bit stores
-            // (1.7k cycles per sub-stage).  Measured at the headline: sweep launch pair 1.215 -> 1.092 ms.
-            if (j > 0 && !(SK && j == TS::kGpw) AQC_DBG_AND(!(a.debug & 1))) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, kSweepSpread, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // DS write
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (SK && j == TS::kGpw) {   // last iteration: no U z run left -- the last group's writes ride in its R run when there is one
-                if (nzmask >> (j - 1) & 1u) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        t1 = mfma(oz[r].x, ow[r].x, t1);
-                        t2 = mfma(oz[r].y, ow[r].y, t2);
-                        t3 = mfma(zs[r], wd[r], t3);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, kSweepSpread, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { lds_put(wa[r], ow[r]); lds_put(za[r], oz[r]); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else
-            if (SK) {   // wave-uniform branches around the products that can be non-zero (scalar masks, compile-time j)
-                if (j < TS::kGpw && (nzmask >> j & 1u)) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        if (kneed >> s & 1u) {
-                            aw.k1 = mfma(sw[s], cur.u0[s], aw.k1);
-                            aw.k2 = mfma(vw[j & 1][s].x, cur.u1[s], aw.k2);
-                            aw.k3 = mfma(vw[j & 1][s].y, cur.u2[s], aw.k3);
-                        }
-                }
-                if (j > 0 && (nzmask >> (j - 1) & 1u)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        t1 = mfma(oz[r].x, ow[r].x, t1);
-                        t2 = mfma(oz[r].y, ow[r].y, t2);
-                        t3 = mfma(zs[r], wd[r], t3);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        if (nmain < st.nsubs) {
+            const int si = nmain;
+#define AQC_SS_FROM_REGS false
+#define AQC_SS_RONLY true
+#include "aqc_sweep_substage.inc"
+#undef AQC_SS_FROM_REGS
+#undef AQC_SS_RONLY
         }
-        };
-        // LAST sub-stage of the LAST stage: nothing reads its w' and z' -- only R = Z' W'^H = U (Z W^H) U^H is wanted, and Z W^H comes
-        // from the sub-stage's INPUTS: one real-product triple per group (12 MFMAs instead of 36), no U products, no LDS write-back;
-        // rgrad_kernel conjugates the summed 16 x 16 matrix by U (Stage3Args::r_only_last, launch_rgrad's conj_sub).  The operands are
-        // read in the layout product 2 consumes ("L2": amplitude l % 16 of chunk 4 r + l / 16), which the LDS tile serves as well as L1.
-        if (kROnly) {
-            cplx rw[2][4], rz[2][4];   // (the early L1 reads of group 0 issued behind the previous barrier are simply not used)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { rw[0][r] = lds_get(ad.a2 ^ ad.k2[0][r]); rz[0][r] = lds_get(a2z ^ ad.k2[0][r]); }
-#pragma unroll
-            for (int j = 0; j < TS::kGpw; ++j) {
-                if (j + 1 < TS::kGpw) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { rw[(j + 1) & 1][r] = lds_get(ad.a2 ^ ad.k2[j + 1][r]); rz[(j + 1) & 1][r] = lds_get(a2z ^ ad.k2[j + 1][r]); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                double zs2[4], wd2[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { zs2[r] = rz[j & 1][r].x + rz[j & 1][r].y; wd2[r] = rw[j & 1][r].x - rw[j & 1][r].y; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { asm volatile("" : "+v"(zs2[r])); asm volatile("" : "+v"(wd2[r])); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    t1 = mfma(rz[j & 1][r].x, rw[j & 1][r].x, t1);
-                    t2 = mfma(rz[j & 1][r].y, rw[j & 1][r].y, t2);
-                    t3 = mfma(zs2[r], wd2[r], t3);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            group_loop();
-        }
-        AQC_STAMP(3 + 4 * si);
-        if (kPersist && more && st.nsubs == 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) prefetch(c);
-        }
-        if (si + 1 < st.nsubs || more) fetch_k<TS::kGpw>(ad, a.subs, si + 1 < st.nsubs ? st.sub_begin + si + 1 : st.sub_begin, wave, NW);
-        cplx rr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rr[r] = make_double2(t1[r] + t2[r], t3[r] - t1[r] + t2[r]);   // Re R = T1 + T2, Im R = T3 - T1 + T2
-        cplx* scr = scratch + (kDouble ? parity * (kSlots * 256) : 0);
-        parity ^= 1u;
-        if (TS::kWaves > 4) {   // 8 waves: wave w + 4 hands its R to wave w through the scratch, wave w publishes the pair's sum
-            if (wave >= 4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) scr[((wave - 4) * 4 + r) * 64 + lane] = rr[r];
-            }
-            __syncthreads();   // the sub-stage's tile updates are visible as well
-            if (wave < 4) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const cplx p = scr[(wave * 4 + r) * 64 + lane];
-                    scr[(wave * 4 + r) * 64 + lane] = make_double2(rr[r].x + p.x, rr[r].y + p.y);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) scr[(wave * 4 + r) * 64 + lane] = rr[r];
-        }
-        __syncthreads();   // the sub-stage's tile updates and every slot of the scratch are visible
-        AQC_STAMP(4 + 4 * si);
-        // fixed-order sum over the slots.  With four waves (one entry per thread) the reads go out first, then -- if the item
-        // goes on -- the next sub-stage's addresses and the LDS reads of its group 0, then the sum: one LDS latency is paid
-        // where three were (scratch, scratch again, operands)
-        const bool go_on = si + 1 < st.nsubs;
-        if (kEarly) {
-            cplx p[kSlots];
-#pragma unroll
-            for (int w = 0; w < kSlots; ++w) p[w] = scr[w * 256 + threadIdx.x];
-            __builtin_amdgcn_sched_barrier(0);
-            if (go_on) {
-                cur = nxt;
-                sub_addr(ad, cur, lds_base);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { vw[0][s] = lds_get(ad.a1 ^ ad.k1[0][s]); vz[0][s] = lds_get((ad.a1 | ZOFF) ^ ad.k1[0][s]); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            double re = p[0].x, im = p[0].y;
-#pragma unroll
-            for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
-            if (kPersist && !seg_first) {   // + what the earlier tiles of the segment left (requested at the top of the sub-stage)
-                asm volatile("s_waitcnt vmcnt(0)" : "+a"(racc) : : "memory");   // the load is not tracked by the compiler; the
-                re += racc.x; im += racc.y;                                      // operand ties every later read of racc to this wait
-            }
-            rpart[(size_t)si * a.nparts * 256 + threadIdx.x] = make_double2(re, im);
-            if (!kDouble) __syncthreads();
-        } else {
-            for (int e = threadIdx.x; e < 256; e += TS::kWaves * 64) {
-                cplx p[kSlots];
-#pragma unroll
-                for (int w = 0; w < kSlots; ++w) p[w] = scr[w * 256 + e];
-                double re = p[0].x, im = p[0].y;
-#pragma unroll
-                for (int w = 1; w < kSlots; ++w) { re += p[w].x; im += p[w].y; }
-                rpart[(size_t)si * a.nparts * 256 + e] = make_double2(re, im);
-            }
-            if (!kDouble) __syncthreads();
-            if (go_on) cur = nxt;
-        }
-        AQC_STAMP(5 + 4 * si);
-        if (!go_on && more) cur = nxt;
-    };
-    if (nmain > 0) substage(0, std::false_type{}, std::true_type{});
-    for (int si = 1; si < nmain; ++si) substage(si, std::false_type{}, std::false_type{});
-    if (nmain < st.nsubs) substage(nmain, std::true_type{}, std::false_type{});
+    }
     AQC_STAMP(kStampSlots - 2);
     // The next item's operands are waited for BEFORE this item's stores are issued: vmcnt counts stores as well, and a wait
     // placed after them would sit out their whole write latency; the loads went out sub-stages ago.  (The loads are inline
@@ -1325,6 +1078,9 @@ hipError_t init_kernels3() {
     AQC_TRY(big_lds((sweep_mfma_kernel<8, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, false, true>)));
     AQC_TRY(big_lds((sweep_mfma_kernel<10, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<11, false, true>)));
     AQC_TRY(big_lds((sweep_mfma_kernel<12, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<8, false, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, false, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<10, false, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<11, false, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<12, false, false, true>)));
 #undef AQC_TRY
     return hipSuccess;
 }
@@ -1397,8 +1153,10 @@ hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stag
     const int t = mfma_threads(k, true);
     const size_t l = sweep3_lds_bytes(k);
     const bool skipw = !list && a.supp != nullptr;
+    const bool rlast = !list && !skipw && a.r_only_last != 0;
 #define AQC_LAUNCH(KK) case KK: if (list) sweep_mfma_kernel<KK, true, false><<<grid, t, l, s>>>(a); \
                                 else if (skipw) sweep_mfma_kernel<KK, false, true><<<grid, t, l, s>>>(a); \
+                                else if (rlast) sweep_mfma_kernel<KK, false, false, true><<<grid, t, l, s>>>(a); \
                                 else sweep_mfma_kernel<KK, false, false><<<grid, t, l, s>>>(a); break
     switch (k) {
         AQC_LAUNCH(8); AQC_LAUNCH(9); AQC_LAUNCH(10); AQC_LAUNCH(11); AQC_LAUNCH(12);

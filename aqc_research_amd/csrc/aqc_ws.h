@@ -174,6 +174,7 @@ struct aqc_ws {
     bool w_clean = true;           // W is zero outside the tiles named in d_sw_prev_tiles
     bool sparse_enabled = true;    // AQC_SPARSE_SWEEP=0: always the dense route
     bool r_only_enabled = true;    // AQC_R_ONLY_LAST=0: the sweep's very last sub-stage runs its U products like every other
+    int r_only_max_subs = 12;      // ... and so it does when the last stage has more sub-stages than this (AQC_R_ONLY_MAX_SUBS)
     bool skipw_enabled = false;    // AQC_SKIP_ZERO_W=1: skip zero groups / K-steps of w inside a stage (exact; measured slower, off by default)
     long sparse_min_items = 512;   // the sparse route pays from this many (tile, lane) items per stage launch (AQC_SPARSE_MIN_ITEMS)
     unsigned long long supp_version[AQC_NUM_BUFS] = {0, 0, 0, 0, 0, 0};   // bumped whenever d_combo_prev[buf] (the support of a sparse lhs) changes

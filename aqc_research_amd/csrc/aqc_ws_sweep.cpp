@@ -381,7 +381,10 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         // the last sub-stage of the last stage is taken from its inputs alone (R = U (Z W^H) U^H, see sweep_mfma_kernel) unless it is also the
         // FIRST sub-stage of a persistent stage, whose operands sit in the prefetch registers in the other layout
         const DevStage& last = p.h_stages[m - 1];
-        const int r_only_sub = ws->r_only_enabled && last.nsubs >= 1 && !(p.k >= 12 && last.nsubs == 1) ? last.sub_begin + last.nsubs - 1 : -1;
+        // ... and unless the stage is long: the variant of the kernel that does it (explicit copies of the sub-stage loop) runs the other
+        // sub-stages 3 % slower, the saving is 2/3 of ONE sub-stage
+        const int r_only_sub = ws->r_only_enabled && last.nsubs >= 1 && last.nsubs <= ws->r_only_max_subs && !(p.k >= 12 && last.nsubs == 1)
+                                   ? last.sub_begin + last.nsubs - 1 : -1;
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||

@@ -310,6 +310,9 @@ int aqc_ws_plan_stage(aqc_ws* ws, int which, int stage, int* num_subs, int* num_
 /* per sub-stage of that stage, what a sweep from ONE basis state per lane leaves out (out[sub][2]): log2 of the share of 16-chunk
  * groups whose W and R products are issued, log2 of the share of K-steps of the W product (both <= 0); zeros when nothing is skipped */
 int aqc_ws_plan_skips(aqc_ws* ws, int which, int stage, int* out, int max_subs);
+/* index (over all stages) of the sweep's sub-stage that is taken from its inputs alone -- the last one of the last stage,
+ * R = U (Z W^H) U^H: a third of a sub-stage's matrix work -- or -1 when the sweep runs it like the others */
+int aqc_ws_sweep_r_only_sub(aqc_ws* ws);
 /* item lists of the last sparse evaluation (synchronises): counts[0] first-stage items of the sweep, [1] tiles it cleared in W,
  * [2] last-stage items of V^H; -1 where that list has never been built */
 int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts);

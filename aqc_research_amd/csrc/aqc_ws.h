@@ -242,7 +242,8 @@ int run_vdag_restricted(aqc_ws* ws, int x_buf, bool support_in_gather_set = fals
 void vdag_restricted_state_after(aqc_ws* ws, int x_buf);
 int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer, bool support_in_gather_set);
 bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag);
-bool sweep_skips_zero_w(const aqc_ws* ws, int x_buf);   // the lhs state is a combination of basis states the device knows: zero groups of w are skipped
+bool sweep_skips_zero_w(const aqc_ws* ws, int x_buf);
+int sweep_r_only_sub(const aqc_ws* ws);   // the lhs state is a combination of basis states the device knows: zero groups of w are skipped
 int sweep_sparse_prepare(aqc_ws* ws);
 void apply_state_after(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);
 void sweep_state_after(aqc_ws* ws, bool sparse, bool replayed);

@@ -289,6 +289,17 @@ bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag) {
     if (!(will_vdag ? keeps_checkpoint(ws, true, AQC_BUF_Y, AQC_BUF_Z) : ws->ckpt_valid)) return false;   // z of stage 1 available in ZW
     return (long)p.ntiles * ws->batch >= ws->sparse_min_items;   // (fewer items than CUs: a stage takes one item's time either way)
 }
+// The last sub-stage of the last stage is taken from its inputs alone (R = U (Z W^H) U^H, see sweep_mfma_kernel) unless it is also the
+// FIRST sub-stage of a persistent stage, whose operands sit in the prefetch registers in the other layout, and unless the stage is
+// long: the variant of the kernel that does it (explicit copies of the sub-stage loop) runs the other sub-stages 3 % slower, the
+// saving is 2/3 of ONE sub-stage.  Returns the sub-stage's index over all stages, or -1.
+int sweep_r_only_sub(const aqc_ws* ws) {
+    const DevPlan& p = ws->sweep;
+    if (!p.v3 || !ws->r_only_enabled || p.h_stages.empty()) return -1;
+    const DevStage& last = p.h_stages.back();
+    if (last.nsubs < 1 || last.nsubs > ws->r_only_max_subs || (p.k >= 12 && last.nsubs == 1)) return -1;
+    return last.sub_begin + last.nsubs - 1;
+}
 // Inside a stage the same knowledge goes further (any number of stages, either route): see sweep_mfma_kernel<K, false, true>.
 bool sweep_skips_zero_w(const aqc_ws* ws, int x_buf) {
     return ws->skipw_enabled && ws->sweep.v3 && ws->combo_valid[x_buf] && ws->d_combo_prev[x_buf] != nullptr;
@@ -348,6 +359,8 @@ int aqc_ws_apply(aqc_ws* ws, int inverse, int src_buf, int dst_buf) {
     return run_apply(ws, inverse != 0, src_buf, dst_buf);
 }
 
+int aqc_ws_sweep_r_only_sub(aqc_ws* ws) { return ws ? sweep_r_only_sub(ws) : -1; }
+
 int aqc_ws_grad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
     return aqc_ws_grad_from(ws, AQC_BUF_X, block_from, block_to, front_layer);
 }
@@ -378,13 +391,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         const size_t m = p.h_stages.size();
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
         const bool skipw = sweep_skips_zero_w(ws, x_buf);
-        // the last sub-stage of the last stage is taken from its inputs alone (R = U (Z W^H) U^H, see sweep_mfma_kernel) unless it is also the
-        // FIRST sub-stage of a persistent stage, whose operands sit in the prefetch registers in the other layout
-        const DevStage& last = p.h_stages[m - 1];
-        // ... and unless the stage is long: the variant of the kernel that does it (explicit copies of the sub-stage loop) runs the other
-        // sub-stages 3 % slower, the saving is 2/3 of ONE sub-stage
-        const int r_only_sub = ws->r_only_enabled && last.nsubs >= 1 && last.nsubs <= ws->r_only_max_subs && !(p.k >= 12 && last.nsubs == 1)
-                                   ? last.sub_begin + last.nsubs - 1 : -1;
+        const int r_only_sub = sweep_r_only_sub(ws);
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||

@@ -357,6 +357,10 @@ class Workspace:
         check(self._L.aqc_ws_plan_skips(self.handle, which, stage, out, nsub))
         return [(out[2 * i], out[2 * i + 1]) for i in range(nsub)]
 
+    def sweep_r_only_sub(self) -> int:
+        """Index (over all stages) of the sweep's sub-stage that is taken from its inputs alone (R-only), or -1."""
+        return int(self._L.aqc_ws_sweep_r_only_sub(self.handle))
+
     def sparse_counts(self) -> Tuple[int, int, int]:
         """Items of the last sparse evaluation: (sweep first stage, tiles cleared in W, V^H last stage); -1 = never built."""
         c = (c_int64 * 3)()

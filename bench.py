@@ -923,15 +923,18 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
         elif k == K_APPLY_LIST:
             frac = vd_items / float(ntiles * B)
         flops = (288.0 if which else 96.0) * N * B * frac * nsub
+        r_only = bool(which) and st == stages - 1 and ws.sweep_r_only_sub() >= 0   # its last sub-stage: R from the inputs, 12 of 36 MFMAs per group
+        if r_only:
+            flops -= 192.0 * N * B * frac
         skipped = 0.0
         if which and sparse_lhs and k == K_SWEEP:   # dense launch of a sweep from basis states: zero groups / K-steps of w are not issued
             per_sub = [96.0 + 96.0 * 2.0 ** (g + kk) + 96.0 * 2.0 ** g for g, kk in ws.plan_skips(1, st)]
             skipped = flops - N * B * frac * sum(per_sub)
             flops -= skipped
         over_list = "true" if k in (K_SWEEP_LIST, K_APPLY_LIST) else "false"   # the names rocprofv3 shows: <tile bits, over a tile list[, zero-w skips]>
-        rows.append({"kernel": (f"sweep_mfma_kernel<{tile_bits}, {over_list}, {'true' if which and sparse_lhs and k == K_SWEEP and any(g or kk for g, kk in ws.plan_skips(1, st)) else 'false'}>"
+        rows.append({"kernel": (f"sweep_mfma_kernel<{tile_bits}, {over_list}, {'true' if which and sparse_lhs and k == K_SWEEP and any(g or kk for g, kk in ws.plan_skips(1, st)) else 'false'}, {'true' if r_only else 'false'}>"
                                 if which else f"apply_mfma_kernel<{tile_bits}, {over_list}>"),
-                     "plan": "sweep" if which else "V^H", "stage": st, "substages": nsub, "tiles_frac": frac, "avg_ms": avg[j],
+                     "plan": "sweep" if which else "V^H", "stage": st, "substages": nsub, "last_substage_r_only": r_only, "tiles_frac": frac, "avg_ms": avg[j],
                      "flops": flops, "flops_not_issued_zero_w": skipped, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
                      "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0})
     if not rows:

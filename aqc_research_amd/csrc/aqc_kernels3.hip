@@ -917,13 +917,14 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     }
     if (si == conj_sub) {   // this sub-stage's R was taken from its INPUTS (sweep_mfma_kernel, r_only): R_end = U R U^H with the sub-stage's U,
                             // read back from the operand planes the stage kernels use (u0 = Re U, u1 = Im U - Re U; entry [s][l] = U[l % 16][4 s + l / 16])
-        __shared__ cplx Us[16 * 17], Ts[16 * 17];
+        cplx* const Us = &rho_s[0][0];   // (16 x 16 each, in arrays the walk has not started to use / the tile sum is done with:
+        cplx* const Ts = &psum[0][0];    // no extra LDS -- a dozen of these workgroups share a CU)
         const double* up = umat + ((size_t)b * nsubs_total + si) * 12 * 64;
         __syncthreads();
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
             const double re = up[(0 * 4 + s2) * 64 + lane], im = up[(1 * 4 + s2) * 64 + lane] + re;
-            Us[(lane & 15) * 17 + 4 * s2 + (lane >> 4)] = make_double2(re, im);
+            Us[(lane & 15) * 16 + 4 * s2 + (lane >> 4)] = make_double2(re, im);
         }
         __syncthreads();
         const int i0 = lane & 15, j0 = lane >> 4;   // this lane: entries (j0 + 4 m, i0)
@@ -932,10 +933,10 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
             const int j = j0 + 4 * m;
             double re = 0.0, im = 0.0;
             for (int k = 0; k < 16; ++k) {
-                const cplx u = Us[j * 17 + k], r = R[k * 17 + i0];
+                const cplx u = Us[j * 16 + k], r = R[k * 17 + i0];
                 re += u.x * r.x - u.y * r.y; im += u.x * r.y + u.y * r.x;
             }
-            Ts[j * 17 + i0] = make_double2(re, im);
+            Ts[j * 16 + i0] = make_double2(re, im);
         }
         __syncthreads();
 #pragma unroll
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
             const int j = j0 + 4 * m;
             double re = 0.0, im = 0.0;
             for (int k = 0; k < 16; ++k) {
-                const cplx t = Ts[j * 17 + k], u = Us[i0 * 17 + k];
+                const cplx t = Ts[j * 16 + k], u = Us[i0 * 16 + k];
                 re += t.x * u.x + t.y * u.y; im += t.y * u.x - t.x * u.y;
             }
             R[j * 17 + i0] = make_double2(re, im);

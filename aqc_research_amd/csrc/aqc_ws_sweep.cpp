@@ -391,7 +391,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         const size_t m = p.h_stages.size();
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
         const bool skipw = sweep_skips_zero_w(ws, x_buf);
-        const int r_only_sub = sweep_r_only_sub(ws);
+        const int r_only_sub = skipw ? -1 : sweep_r_only_sub(ws);   // (the zero-w variant of the kernel has no R-only form)
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||

@@ -319,6 +319,7 @@ def test_zero_groups_of_w_are_skipped_without_changing_a_bit(n, tile, ent, trot,
     idx = np.array([[0, -1], [5, hi + 5], [hi | 3, 3 ^ (1 << (n - 2))], [(1 << n) - 1, 1]], dtype=np.int64)
     coef = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
     res = {}
+    monkeypatch.setenv("AQC_R_ONLY_LAST", "0")   # (the R-only last sub-stage rounds R differently; it has its own test below)
     for skip in ("1", "0"):
         for sparse in (True, False):
             monkeypatch.setenv("AQC_SKIP_ZERO_W", skip)
@@ -335,6 +336,53 @@ def test_zero_groups_of_w_are_skipped_without_changing_a_bit(n, tile, ent, trot,
     for b in range(B):
         _, g_ref = _oracle_lane(circ, th[b], tg[b], idx[b], coef[b])
         assert maxdiff(res[("1", True)][b], g_ref) < TOL
+
+
+@pytest.mark.parametrize("n,tile,ent,trot", [(12, 12, "cx", 2), (12, 12, "cx", 0), (10, 10, "cz", 0), (9, 9, "cp", 0), (8, 8, "cx", 0), (14, 12, "cx", 0),
+                                             (13, 11, "cx", 1), (13, 9, "cz", 0), (16, 12, "cx", 0)])
+def test_r_only_last_substage_equals_full_sweep_and_oracle(n, tile, ent, trot, monkeypatch):
+    """The sweep's last sub-stage forms R = U (Z W^dagger) U^dagger from its inputs instead of updating w and z (nobody reads them
+    afterwards) and the gradient kernel conjugates by U: same gradient as the full form to rounding (AQC_R_ONLY_LAST=0) and as the
+    oracle, on both routes, one and two basis states per lane, one and several stages; the plan says which sub-stage it is."""
+    from aqc_research_amd.engine import BUF_X2, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(500 + n + tile)
+    circ = _trotter(n, trot) if trot else _circ(n, ent, depth=3 * n)
+    B = 4
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    hi = 1 << (n - 1)
+    idx = np.array([[0, -1], [5, hi + 5], [hi | 3, 3 ^ (1 << (n - 2))], [(1 << n) - 1, 1]], dtype=np.int64)
+    coef = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
+    res, used = {}, {}
+    for r_only in ("1", "0"):
+        for sparse in (True, False):
+            monkeypatch.setenv("AQC_R_ONLY_LAST", r_only)
+            monkeypatch.setenv("AQC_R_ONLY_MAX_SUBS", "64")
+            ws = _ws(circ, B, monkeypatch, sparse=sparse, tile=tile)
+            used[(r_only, sparse)] = ws.sweep_r_only_sub()
+            ws.upload(BUF_Y, tg)
+            ws.set_thetas(th)
+            ws.apply(True, BUF_Y, BUF_Z)
+            ws.set_combo(BUF_X2, idx, coef)
+            ws.grad_from(BUF_X2)
+            res[(r_only, sparse)] = ws.get_grads()
+            # a second evaluation with other angles through the same workspace (u planes rebuilt, R-only again)
+            ws.set_thetas(th[::-1].copy())
+            ws.apply(True, BUF_Y, BUF_Z)
+            ws.grad_from(BUF_X2)
+            res[(r_only, sparse, 2)] = ws.get_grads()
+            ws.close()
+    assert used[("0", True)] == -1 and used[("0", False)] == -1
+    for sparse in (True, False):
+        assert maxdiff(res[("1", sparse)], res[("0", sparse)]) < 1e-13
+        assert maxdiff(res[("1", sparse, 2)], res[("0", sparse, 2)]) < 1e-13
+    for b in range(B):
+        _, g_ref = _oracle_lane(circ, th[b], tg[b], idx[b], coef[b])
+        assert maxdiff(res[("1", True)][b], g_ref) < TOL
+        assert maxdiff(res[("1", False)][b], g_ref) < TOL
+        _, g_ref2 = _oracle_lane(circ, th[B - 1 - b], tg[b], idx[b], coef[b])
+        assert maxdiff(res[("1", True, 2)][b], g_ref2) < TOL
 
 
 class _Op:

@@ -318,6 +318,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
         const std::string err = check_plan(prog, p->plan);
         if (!err.empty()) { delete ws; return fail("planner produced an invalid plan: %s", err.c_str()); }
     }
+    proj_plan(ws, low_bits);   // the sweep's later stages on a virtual register, where the plan allows (aqc_ws_project.cpp)
 
     const int T = prog.num_thetas();
     const int G = (int)prog.groups.size();
@@ -354,6 +355,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     WS_HIP(hipEventCreate(&ws->ev0)); WS_HIP(hipEventCreate(&ws->ev1));
     WS_HIP(hipEventCreate(&ws->pev0)); WS_HIP(hipEventCreate(&ws->pev1));
     WS_TRY(upload_plan(ws->fwd)); WS_TRY(upload_plan(ws->inv)); WS_TRY(upload_plan(ws->sweep));
+    WS_TRY(proj_alloc(ws));
     WS_HIP(hipMalloc((void**)&ws->d_thetas_own, sizeof(double) * (size_t)batch * std::max(T, 1)));
     ws->d_thetas = ws->d_thetas_own;
     WS_HIP(hipMalloc((void**)&ws->d_coef, sizeof(double) * (size_t)batch * (prog.n + prog.num_blocks + 1) * kCoefStride));
@@ -365,13 +367,14 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep})
         if (p->v3) WS_HIP(hipMalloc((void**)&p->d_umat, sizeof(double) * (size_t)batch * std::max<size_t>(p->h_subs3.size(), 1) * 12 * 64));
     {
-        // [V^H | sweep | V]; with the mirrored V^H plan the sweep's jobs write V^H's operands as well (sub-stage s of the sweep is
-        // sub-stage nsubs - 1 - s of V^H, conjugate-transposed) and V^H gets no jobs of its own
+        // [V^H | sweep | virtual sweep | V]; with the mirrored V^H plan the sweep's jobs write V^H's operands as well (sub-stage s of the
+        // sweep is sub-stage nsubs - 1 - s of V^H, conjugate-transposed) and V^H gets no jobs of its own
         std::vector<UJob> jobs;
+        DevPlan* vsw = ws->proj.ok ? &ws->proj.vsw : nullptr;
         const int nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
         ws->ujobs_mirror = ws->inv_mirrored && ws->inv.v3 && (int)ws->inv.h_subs3.size() == nsw && env_int("AQC_UBUILD_MIRROR", 1) != 0;
-        for (DevPlan* p : {&ws->inv, &ws->sweep, &ws->fwd})
-            if (p->v3)
+        for (DevPlan* p : {&ws->inv, &ws->sweep, vsw, &ws->fwd})
+            if (p && p->v3)
                 for (size_t i = 0; i < p->h_subs3.size(); ++i) {
                     if (p == &ws->inv && ws->ujobs_mirror) continue;
                     UJob j{p->d_subs3 + i, p->d_grps, p->d_umat, (int)i, (int)p->h_subs3.size(), p->plan.inverse ? 1 : 0, prog.entangler, nullptr, 0, 0};
@@ -412,6 +415,7 @@ int aqc_ws_destroy(aqc_ws* ws) {
     (void)hipSetDevice(ws->device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
     drop_graphs(ws);
+    proj_free(ws);
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         if (p->d_stages) (void)hipFree(p->d_stages);
         if (p->d_ops) (void)hipFree(p->d_ops);
@@ -890,6 +894,16 @@ int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts) {
     HIP_OK(hipMemcpy(h, ws->d_sw_counts, sizeof h, hipMemcpyDeviceToHost));
     if (ws->sw_lists_built & 1) { counts[0] = h[0]; counts[1] = h[1]; }
     if (ws->sw_lists_built & 2) counts[2] = h[2];
+    return 0;
+}
+
+int aqc_ws_projected_info(aqc_ws* ws, int32_t* info) {
+    if (!ws || !info) return fail("null argument");
+    const aqc::ProjRoute& pr = ws->proj;
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    if (!pr.ok) return 0;
+    info[0] = 1; info[1] = pr.nv; info[2] = pr.t; info[3] = pr.cb; info[4] = (int32_t)pr.vsw.h_stages.size();
+    info[5] = (int32_t)pr.vsw.h_subs3.size(); info[6] = pr.kv; info[7] = pr.first_subs;
     return 0;
 }
 

@@ -856,8 +856,8 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                            int from, int to, int front, const int* slot_theta, cplx* grads, cplx* mirror,
                                                            const GatherJob gj, int tiles_per_lane, int chunk, int sparse_subs,
-                                                           const int* lane_parts, int conj_sub, const double* umat) {   // ntiles: partial slots per (lane, sub-stage)
-    if ((int)blockIdx.x == nsubs_total) {   // the passenger (see GatherJob): one extra workgroup per lane of the batch
+                                                           const int* lane_parts, int conj_sub, const double* umat, int nsubs_run) {   // ntiles: partial slots per (lane, sub-stage)
+    if ((int)blockIdx.x == nsubs_run) {   // (nsubs_run: the launch walks the first nsubs_run sub-stages of the plan)   // the passenger (see GatherJob): one extra workgroup per lane of the batch
         const cplx* src = static_cast<const cplx*>(gj.buf) + (size_t)blockIdx.y * gj.lane_stride;
         for (int i = threadIdx.x; i < gj.count; i += 64 * WAVES) {
             const cplx v = src[(size_t)gj.elem[i]];
@@ -1144,7 +1144,7 @@ hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stag
     if (a.ntiles != ntiles || a.batch != batch) return hipErrorInvalidValue;
     const bool list = a.items != nullptr;
     if (list && (!a.nitems || a.max_items < 1)) return hipErrorInvalidValue;
-    if (a.nparts != sweep3_nparts(ntiles, batch, k) || (!list && a.chunk != sweep3_chunk(ntiles, batch, k))) return hipErrorInvalidValue;
+    if (a.nparts < 1 || (!list && (a.nparts != sweep3_nparts(ntiles, batch, k) || a.chunk != sweep3_chunk(ntiles, batch, k)))) return hipErrorInvalidValue;   // (a list names its slots)
     if (k >= 12 && a.stage.nsubs <= 0) return hipErrorInvalidValue;   // the persistent form feeds the first sub-stage from registers
     for (int l = 0; l < 64; ++l)   // the persistent sweep addresses its prefetch with a 32-bit byte offset per lane
         if (k >= 12 && a.stage.dlo[l] >= (1u << 28)) return hipErrorInvalidValue;
@@ -1261,20 +1261,22 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
                         const int* slot_theta, void* grads, void* mirror, GatherJob gather, int nparts, int chunk, int sparse_subs,
-                        const int* lane_parts, int conj_sub, const double* umat) {
+                        const int* lane_parts, int conj_sub, const double* umat, int nsubs_run) {
     if (nsubs_total < 1) return hipSuccess;
+    if (nsubs_run < 0 || nsubs_run > nsubs_total) nsubs_run = nsubs_total;
     const int extra = gather.count > 0 && gather.buf ? 1 : 0;
+    if (nsubs_run + extra < 1) return hipSuccess;
     const int tiles_per_lane = ntiles;
     if (nparts <= 0) nparts = ntiles;
     ntiles = nparts;   // slots per (lane, sub-stage); the kernels derive the number in use from (tiles_per_lane, chunk)
     if (nparts >= 32)
-        rgrad_kernel<4><<<dim3(nsubs_total + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+        rgrad_kernel<4><<<dim3(nsubs_run + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                   nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat);
+                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat, nsubs_run);
     else
-        rgrad_kernel<1><<<dim3(nsubs_total + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
+        rgrad_kernel<1><<<dim3(nsubs_run + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat);
+                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat, nsubs_run);
     return hipGetLastError();
 }
 

@@ -93,6 +93,31 @@ hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stag
 void rgrad_print_stamps(int nsubs);   // tuning builds only
 int sweep3_chunk(int ntiles, int batch, int k);
 int sweep3_nparts(int ntiles, int batch, int k);
+// Projected dense stages of the sparse-lhs sweep (aqc_project.hip, aqc_ws_project.cpp): the state that enters the stages after the
+// first is psi (x) |e> on (first stage's local bits) x (the other bits), and those stages touch the qubits T only, so everything the
+// gradient needs of z there is its projection y0[i_T, c] = sum_u conj(psi[u, c]) z[u, i_T] (u: local bits of the first stage outside T,
+// c: those inside T) -- a register of |T| + |c| virtual qubits per lane instead of n.
+struct ProjArgs {
+    const double2* zin;      // z as it enters the dense stages (the checkpoint of the mirrored V^H), [batch][lane_stride]
+    const double2* w;        // w after the first stage (psi on the listed tiles), same layout
+    size_t lane_stride;
+    const TileItem* items;   // first-stage items of the sparse sweep (lane, tile of the first stage, slot) and their number
+    const int* nitems;
+    const int* lane_parts;   // items per lane
+    int nub0, ubits0[32];    // non-local address bits of the first stage (tile index -> element offset)
+    const unsigned* off_t;   // [2^t]: element offset of the value i of the T bits;  [2^(us-4)]: of block k of 16 values of the summed bits
+    const unsigned* off_usblk;   // (their low four are address bits 0..3: 16 contiguous elements);  [2^cb]: of the value c of the bits in both
+    const unsigned* off_cb;
+    int t, cb, us, nvp, ntiles_v;
+    unsigned ff_mask, cb_mask, tf_mask;   // address bits outside the first stage's local set and outside T (fixed to the item's) / in both / in T only
+    double2* vm;             // [batch][2][2^nvp]: the virtual lhs state (basis vectors) ...
+    double2* vy;             // ... and the projection, index = i_T | c << t
+    TileItem* vitems;        // items of the virtual stage launches: (lane, slot ntiles_v + tile, the same as partial slot)
+    int* vcount;
+    int* vlane_parts;
+    int batch;
+};
+hipError_t launch_project(const ProjArgs& a, hipStream_t s);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
     const DevSub3* sub;
     const DevGrp* grps;      // the plan's gate groups
@@ -112,7 +137,8 @@ hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, 
                         GatherJob gather = GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},   // slot_theta: direct mode, see rgrad_kernel
                         int nparts = 0, int chunk = 0,   // partial-R slots per (lane, sub-stage) and the persistent sweep's chunk
                         int sparse_subs = 0, const int* lane_parts = nullptr,   // the first sparse_subs sub-stages hold lane_parts[lane] partials (item-list launch)
-                        int conj_sub = -1, const double* umat = nullptr);       // sub-stage whose R arrives as Z W^H of its INPUTS: R <- U R U^H first (umat: the plan's operands)
+                        int conj_sub = -1, const double* umat = nullptr,        // sub-stage whose R arrives as Z W^H of its INPUTS: R <- U R U^H first (umat: the plan's operands)
+                        int nsubs_run = -1);                                    // walk the first nsubs_run sub-stages only (-1: all)
 // Tile lists on the device (aqc_ws_sweep.cpp).  Per lane, the tiles of `stage` that hold the elements supp[lane][0 .. per_lane)
 // (the support of the lane's sparse lhs state; -1 = none; may be null) and extra[0 .. nextra) (the same for every lane: the
 // registered gather set; may be null), each tile once, in that order -> item list (lane-major, slot = position inside the lane),

@@ -101,17 +101,20 @@ int popcount64(uint64_t v) { return __builtin_popcountll(v); }
 
 }  // namespace
 
-Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, bool inverse) {
+Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, bool inverse, const std::vector<int>* subset, int nbits) {
     Plan plan;
-    plan.nbits = col_bits + prog.n;
+    plan.nbits = nbits > 0 ? nbits : col_bits + prog.n;
     plan.col_bits = col_bits;
     plan.inverse = inverse;
     const int k = std::min(std::max(tile_bits, 2), plan.nbits);
     plan.tile_bits = k;
     low_bits = std::max(0, std::min(low_bits, k - 2));
 
-    std::vector<int> order(prog.groups.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = inverse ? (int)(order.size() - 1 - i) : (int)i;
+    std::vector<int> order(subset ? subset->size() : prog.groups.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        const size_t j = inverse ? order.size() - 1 - i : i;
+        order[i] = subset ? (*subset)[j] : (int)j;
+    }
 
     const uint64_t forced = low_bits ? ((1ull << low_bits) - 1) : 0;
     while (!order.empty()) {
@@ -326,7 +329,7 @@ void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops)
     }
 }
 
-std::string check_plan(const Program& prog, const Plan& plan) {
+std::string check_plan(const Program& prog, const Plan& plan, const std::vector<int>* subset) {
     const int G = (int)prog.groups.size();
     std::vector<int> seen(G, 0);
     std::vector<int> last_on_bit(plan.nbits, plan.inverse ? G : -1);
@@ -347,8 +350,14 @@ std::string check_plan(const Program& prog, const Plan& plan) {
             }
         }
     }
+    std::vector<int> want(G, subset ? 0 : 1);
+    if (subset)
+        for (int gi : *subset) {
+            if (gi < 0 || gi >= G) return "subset index out of range";
+            want[gi] = 1;
+        }
     for (int i = 0; i < G; ++i)
-        if (seen[i] != 1) return "group not scheduled";
+        if (seen[i] != want[i]) return want[i] ? "group not scheduled" : "group outside the subset scheduled";
     for (const Stage& st : plan.stages) {
         if (st.subs.empty()) continue;
         std::vector<int> local_of(plan.nbits, -1);

@@ -63,7 +63,9 @@ struct Plan {
 // Cuts the program (forward order, or reversed when inverse) into stages of at most
 // tile_bits local bits; the lowest `low_bits` address bits are always local so that
 // every HBM access is a run of 2^low_bits contiguous complex128.
-Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, bool inverse);
+// `subset` (optional): plan only these gate groups (indices in forward program order) -- a sub-circuit.
+// `nbits` (optional): size of the register when it is not col_bits + prog.n (a sub-circuit moved to a register of its own).
+Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, bool inverse, const std::vector<int>* subset = nullptr, int nbits = 0);
 
 // Partitions every stage into sub-stages: each sub-stage touches at most `reg_bits` of the stage's
 // local bits (held in registers by one thread: 2^reg_bits amplitudes) and at most `max_ops` groups.
@@ -71,6 +73,6 @@ void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops)
 
 // Throws nothing; returns "" if the plan executes every group exactly once, in an order
 // compatible with per-qubit program order, using only local bits.
-std::string check_plan(const Program& prog, const Plan& plan);
+std::string check_plan(const Program& prog, const Plan& plan, const std::vector<int>* subset = nullptr);   // subset: exactly these groups are scheduled
 
 }  // namespace aqc

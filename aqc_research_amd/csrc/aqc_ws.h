@@ -67,6 +67,24 @@ struct DevPlan {
     int family() const { return v3 ? 3 : (v2 ? 2 : 1); }
 };
 
+// Projected route of the sparse-lhs sweep (aqc_ws_project.cpp): the dense stages run on a virtual register
+struct ProjRoute {
+    bool ok = false;
+    int t = 0, cb = 0, us = 0, nv = 0, nvp = 0, kv = 0, ntiles_v = 0;
+    int first_subs = 0;            // sub-stages of the real sweep plan that still run on the real register (its first stage)
+    Program vprog;                 // the gate groups of the dense stages on virtual qubits (group indices, thetas, slots: the real ones)
+    std::vector<int> rest;         // their indices, in execution order
+    DevPlan vsw;                   // sweep plan of the virtual register
+    double2* vm = nullptr;         // [batch][2][2^nvp]
+    double2* vy = nullptr;
+    unsigned* d_tab = nullptr;     // off_t | off_usblk | off_cb
+    std::vector<unsigned> h_tab;
+    unsigned ff_mask = 0, cb_mask = 0, tf_mask = 0;
+    TileItem* d_items = nullptr;   // [2 batch ntiles_v]
+    int* d_count = nullptr;
+    int* d_lane_parts = nullptr;   // [batch]
+};
+
 // aqc_ws_plan.cpp
 void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma = false, bool presplit = false);
 int upload_plan(DevPlan& p);
@@ -199,9 +217,10 @@ struct aqc_ws {
     unsigned long long z_gather_gen = 0;    // what the tiles of a partial Z were chosen for: the gather set ...
     int z_x_buf = -1;                       // ... and the support of this lhs buffer at this version
     unsigned long long z_x_version = 0;
+    aqc::ProjRoute proj;                    // dense stages of the sparse route on a virtual register (AQC_PROJECTED=0: off)
     bool profile = false;
-    int64_t prof_count[AQC_NUM_KINDS] = {0, 0, 0, 0, 0, 0, 0};
-    double prof_ms[AQC_NUM_KINDS] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t prof_count[AQC_NUM_KINDS] = {};
+    double prof_ms[AQC_NUM_KINDS] = {};
     std::vector<std::pair<int, float>> prof_log;   // (kind, ms) of every profiled launch, in order (bounded)
 };
 
@@ -251,5 +270,12 @@ int ensure_umat(aqc_ws* ws, DevPlan& p);
 int run_coef(aqc_ws* ws);
 int run_apply(aqc_ws* ws, bool inverse, int src_buf, int dst_buf);
 void drop_graphs(aqc_ws* ws);
+// aqc_ws_project.cpp
+void proj_plan(aqc_ws* ws, int low_bits);   // decides the route and lowers the virtual plan (host only)
+int proj_alloc(aqc_ws* ws);                 // its device side (plan tables, buffers, offset tables)
+void proj_free(aqc_ws* ws);
+bool sweep_route_projected(const aqc_ws* ws, bool sparse);
+int run_projected_stages(aqc_ws* ws);       // projection + the virtual stage launches (after the sweep's first stage)
+int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_layer);
 
 }  // namespace aqc

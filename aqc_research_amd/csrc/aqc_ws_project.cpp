@@ -1,0 +1,204 @@
+// The dense stages of the sparse-lhs sweep on a VIRTUAL register (grad_of_dot_product, core_operations.py:823-1019, for the
+// lhs states every surrogate objective sweeps from: objective_base.py:42-255).
+//
+// After its first stage (local address bits L0) the lhs state of a lane is  w = psi (x) |e>:  psi = the stage's gates applied to the
+// basis index on L0 (one tile of W), e = the basis index on the other bits F.  Let T be the qubits the gates of the LATER stages
+// touch, Cb = T n L0, Us = L0 \ T.  Those gates act on T alone, so for every sub-stage k of theirs
+//     w_k[u, i_T] = sum_c M_k[i_T, c] psi[u, c],        M_k = U_k ... U_1 M_0,   M_0[i_T, c] = [i_T = (c on Cb, e on T n F)]
+// and the 16 x 16 matrix the gradient walk needs,  R_k = sum z_k w_k^H  over everything but the sub-stage's register bits, is
+//     R_k = sum_{rest of i_T, c} Y_k M_k^H,             Y_k = U_k ... U_1 Y_0,   Y_0[i_T, c] = sum_u conj(psi[u, c]) z_0[u, i_T]
+// (z_0: z as it enters those stages = the checkpoint the mirrored V^H keeps in ZW).  M and Y are states of |T| + |Cb| virtual
+// qubits -- T, plus one spectator per qubit of Cb -- and R_k is exactly what the sweep kernels form from a (w, z) pair: the later
+// stages become an ordinary sweep of the gates' sub-circuit on that small register, after ONE pass over z (aqc_project.hip).
+// At the headline (16 qubits, L0 = 0..11, T = 8..15) the register has 12 qubits: 1/16 of the elements, and the second stage of
+// the sweep -- more than half of an evaluation on the sparse route -- becomes one memory-bound pass plus a tile per lane.
+// Exact: the same sums in another order.  Two basis states per lane: one item (M, Y pair) per tile of the first stage they occupy.
+#include "aqc_ws.h"
+
+#include <algorithm>
+
+using namespace aqc;
+
+namespace aqc {
+
+namespace {
+int popc(uint64_t v) { return __builtin_popcountll(v); }
+unsigned deposit_bits(unsigned v, const std::vector<int>& bits) {
+    unsigned o = 0;
+    for (size_t j = 0; j < bits.size(); ++j)
+        if (v >> j & 1) o |= 1u << bits[j];
+    return o;
+}
+}  // namespace
+
+void proj_plan(aqc_ws* ws, int low_bits) {
+    ProjRoute& pr = ws->proj;
+    pr.ok = false;
+    const Program& prog = ws->ctx->prog;
+    const DevPlan& p = ws->sweep;
+    if (env_int("AQC_PROJECTED", 1) == 0 || !ws->sparse_enabled || !ws->inv_mirrored || !p.v3 || ws->col_bits != 0 || ws->ncols != 1 ||
+        p.plan.stages.size() < 2 || prog.n > 30)
+        return;
+    const int n = prog.n;
+    uint64_t L0 = 0, T = 0;
+    for (int b : p.plan.stages[0].bits) L0 |= 1ull << b;
+    pr.rest.clear();
+    for (size_t s = 1; s < p.plan.stages.size(); ++s)
+        for (int gi : p.plan.stages[s].ops) {
+            const GateGroup& g = prog.groups[gi];
+            pr.rest.push_back(gi);
+            T |= 1ull << g.q0;
+            if (g.q1 >= 0) T |= 1ull << g.q1;
+        }
+    if (pr.rest.empty()) return;
+    const uint64_t all = (1ull << n) - 1, F = all & ~L0, Cb = T & L0, Us = L0 & ~T;
+    pr.t = popc(T); pr.cb = popc(Cb); pr.us = popc(Us);
+    pr.nv = pr.t + pr.cb;
+    // the pass over z reads runs of 16 elements (address bits 0..3 among the summed ones); the register must be worth it
+    if ((Us & 15) != 15 || pr.t < 4 || pr.cb > 6 || pr.nv + 2 > n || pr.nv > 20) return;
+    pr.nvp = std::max(pr.nv, 8);
+    pr.kv = std::min(pr.nvp, p.k);
+    pr.ntiles_v = 1 << (pr.nvp - pr.kv);
+    pr.first_subs = p.h_stages[0].nsubs;
+    std::vector<int> tbits, cbits, ubits_hi;
+    std::vector<int> vq(n, -1);
+    for (int b = 0; b < n; ++b) {
+        if (T >> b & 1) { vq[b] = (int)tbits.size(); tbits.push_back(b); }
+        if (Cb >> b & 1) cbits.push_back(b);
+        if ((Us >> b & 1) && b >= 4) ubits_hi.push_back(b);
+    }
+    pr.vprog = prog;   // group indices, thetas and slots stay the real ones; only the qubits move
+    for (int gi : pr.rest) {
+        GateGroup& g = pr.vprog.groups[gi];
+        g.q0 = vq[g.q0];
+        if (g.q1 >= 0) g.q1 = vq[g.q1];
+    }
+    Plan best;
+    for (int lb = std::max(low_bits, 2); lb >= 2; --lb) {
+        Plan cand = make_plan(pr.vprog, 0, pr.kv, lb, false, &pr.rest, pr.nvp);
+        if (best.stages.empty() || cand.stages.size() < best.stages.size()) best = cand;
+    }
+    lower_plan(pr.vprog, best, pr.vsw, 4, true, true);
+    if (!pr.vsw.v3 || !check_plan(pr.vprog, pr.vsw.plan, &pr.rest).empty()) return;
+    for (DevStage& ds : pr.vsw.h_stages) {   // one more non-local bit: the item (first or second tile of the lane's lhs state)
+        if (ds.nub >= 32) return;
+        ds.ubits[ds.nub++] = pr.nvp;
+        ds.ntiles *= 2;
+    }
+    pr.ff_mask = (unsigned)(F & ~T);
+    pr.cb_mask = (unsigned)Cb;
+    pr.tf_mask = (unsigned)(T & F);
+    pr.h_tab.clear();
+    for (unsigned i = 0; i < (1u << pr.t); ++i) pr.h_tab.push_back(deposit_bits(i, tbits));
+    for (unsigned k = 0; k < (1u << (pr.us - 4)); ++k) pr.h_tab.push_back(deposit_bits(k, ubits_hi));
+    for (unsigned c = 0; c < (1u << pr.cb); ++c) pr.h_tab.push_back(deposit_bits(c, cbits));
+    pr.ok = true;
+    if (env_int("AQC_VERBOSE", 0))
+        fprintf(stderr, "aqc_hip: projected route: the sweep's stages after the first run on %d virtual qubits (%d touched, %d shared with the first "
+                "stage) instead of %d: %zu stage(s) of 2^%d tiles, %zu sub-stages\n", pr.nv, pr.t, pr.cb, n, pr.vsw.h_stages.size(), pr.kv,
+                pr.vsw.h_subs3.size());
+}
+
+int proj_alloc(aqc_ws* ws) {
+    ProjRoute& pr = ws->proj;
+    if (!pr.ok) return 0;
+    const size_t B = (size_t)ws->batch;
+    if (upload_plan(pr.vsw)) return 1;
+    const size_t nsubs = std::max<size_t>(pr.vsw.h_subs3.size(), 1);
+    HIP_OK(hipMalloc((void**)&pr.vsw.d_umat, sizeof(double) * B * nsubs * 12 * 64));
+    HIP_OK(hipMalloc((void**)&pr.vsw.d_rpart, sizeof(double2) * B * nsubs * (2 * (size_t)pr.ntiles_v) * 256));
+    const size_t vbytes = sizeof(double2) * B * (2ull << pr.nvp);
+    HIP_OK(hipMalloc((void**)&pr.vm, vbytes));
+    HIP_OK(hipMalloc((void**)&pr.vy, vbytes));
+    HIP_OK(hipMemsetAsync(pr.vm, 0, vbytes, ws->stream));   // (entries beyond 2^nv -- a register padded to 8 qubits -- stay zero for good)
+    HIP_OK(hipMemsetAsync(pr.vy, 0, vbytes, ws->stream));
+    HIP_OK(hipMalloc((void**)&pr.d_tab, sizeof(unsigned) * pr.h_tab.size()));
+    HIP_OK(hipMemcpy(pr.d_tab, pr.h_tab.data(), sizeof(unsigned) * pr.h_tab.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void**)&pr.d_items, sizeof(TileItem) * 2 * B * pr.ntiles_v));
+    HIP_OK(hipMalloc((void**)&pr.d_count, sizeof(int)));
+    HIP_OK(hipMemsetAsync(pr.d_count, 0, sizeof(int), ws->stream));
+    HIP_OK(hipMalloc((void**)&pr.d_lane_parts, sizeof(int) * B));
+    HIP_OK(hipMemsetAsync(pr.d_lane_parts, 0, sizeof(int) * B, ws->stream));
+    return 0;
+}
+
+void proj_free(aqc_ws* ws) {
+    ProjRoute& pr = ws->proj;
+    DevPlan& v = pr.vsw;
+    for (void* q : {(void*)v.d_stages, (void*)v.d_ops, (void*)v.d_subs, (void*)v.d_mops, (void*)v.d_subs3, (void*)v.d_grps, (void*)v.d_umat,
+                    (void*)v.d_rpart, (void*)pr.vm, (void*)pr.vy, (void*)pr.d_tab, (void*)pr.d_items, (void*)pr.d_count, (void*)pr.d_lane_parts})
+        if (q) (void)hipFree(q);
+    v.d_stages = nullptr; v.d_ops = nullptr; v.d_subs = nullptr; v.d_mops = nullptr; v.d_subs3 = nullptr; v.d_grps = nullptr;
+    v.d_umat = nullptr; v.d_rpart = nullptr;
+    pr.vm = pr.vy = nullptr; pr.d_tab = nullptr; pr.d_items = nullptr; pr.d_count = nullptr; pr.d_lane_parts = nullptr;
+    pr.ok = false;
+}
+
+bool sweep_route_projected(const aqc_ws* ws, bool sparse) { return sparse && ws->proj.ok; }
+
+// after the sweep's first stage (W holds psi on the listed tiles, ZW the checkpoint): the projection, then the virtual stages
+int run_projected_stages(aqc_ws* ws) {
+    ProjRoute& pr = ws->proj;
+    const DevPlan& p = ws->sweep;
+    DevPlan& v = pr.vsw;
+    {
+        ProjArgs a;
+        memset(&a, 0, sizeof a);
+        a.zin = ws->bufs[AQC_BUF_ZW];
+        a.w = ws->bufs[AQC_BUF_W];
+        a.lane_stride = ws->lane_elems;
+        a.items = ws->d_sw_items;
+        a.nitems = ws->d_sw_counts;
+        a.lane_parts = ws->d_sw_lane_parts;
+        const DevStage& s0 = p.h_stages[0];
+        a.nub0 = s0.nub;
+        for (int i = 0; i < s0.nub; ++i) a.ubits0[i] = s0.ubits[i];
+        a.off_t = pr.d_tab;
+        a.off_usblk = pr.d_tab + (1u << pr.t);
+        a.off_cb = a.off_usblk + (1u << (pr.us - 4));
+        a.t = pr.t; a.cb = pr.cb; a.us = pr.us; a.nvp = pr.nvp; a.ntiles_v = pr.ntiles_v;
+        a.ff_mask = pr.ff_mask; a.cb_mask = pr.cb_mask; a.tf_mask = pr.tf_mask;
+        a.vm = pr.vm; a.vy = pr.vy;
+        a.vitems = pr.d_items; a.vcount = pr.d_count; a.vlane_parts = pr.d_lane_parts;
+        a.batch = ws->batch;
+        ProfScope ps(ws, AQC_K_PROJECT);
+        HIP_OK(launch_project(a, ws->stream));
+    }
+    const size_t m = v.h_stages.size();
+    const int ntiles = 2 * pr.ntiles_v;
+    for (size_t s = 0; s < m; ++s) {
+        Stage3Args a;
+        memset(&a, 0, sizeof a);
+        a.stage = v.h_stages[s];
+        a.subs = v.d_subs3;
+        a.umat = v.d_umat;
+        a.nsubs_total = (int)v.h_subs3.size();
+        a.lane_stride = 2ull << pr.nvp;
+        a.ntiles = ntiles;
+        a.batch = ws->batch;
+        a.in0 = pr.vm; a.in1 = pr.vy; a.out0 = pr.vm; a.out1 = pr.vy;
+        a.store_out = s + 1 < m ? 3 : 0;
+        a.items = pr.d_items; a.nitems = pr.d_count; a.max_items = 2 * ws->batch * pr.ntiles_v;
+        a.rpart = v.d_rpart;
+        a.nparts = ntiles;
+        a.chunk = 0;
+        if (a.stage.nsubs > 0) stage3_first_offsets(a, v.h_subs3[a.stage.sub_begin]);
+        ProfScope ps(ws, AQC_K_SWEEP_VIRTUAL);
+        HIP_OK(launch_sweep3(ntiles, ws->batch, pr.kv, ws->stream, a));
+    }
+    return 0;
+}
+
+// the gradient entries of the virtual plan's gate groups (the real plan's walk stops after its first stage)
+int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
+    ProjRoute& pr = ws->proj;
+    const Program& prog = ws->ctx->prog;
+    DevPlan& v = pr.vsw;
+    const int nsubs = (int)v.h_subs3.size(), ntiles = 2 * pr.ntiles_v;
+    HIP_OK(launch_rgrad(v.d_subs3, v.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), v.d_rpart, ntiles, nsubs, ws->d_partial, ws->nslots,
+                        block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads,
+                        ws->mirror_grads, GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr}, ntiles, 0, nsubs, pr.d_lane_parts, -1, v.d_umat));
+    return 0;
+}
+
+}  // namespace aqc

@@ -26,8 +26,11 @@ namespace aqc {
 int ensure_umat(aqc_ws* ws, DevPlan& p) {
     if (!p.v3 || p.u_valid) return 0;
     const int T = ws->ctx->prog.num_thetas();
-    const int ninv = ws->inv.v3 && !ws->ujobs_mirror ? (int)ws->inv.h_subs3.size() : 0, nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
+    const int ninv = ws->inv.v3 && !ws->ujobs_mirror ? (int)ws->inv.h_subs3.size() : 0;
+    int nsw = ws->sweep.v3 ? (int)ws->sweep.h_subs3.size() : 0;
     const int nfwd = ws->fwd.v3 ? (int)ws->fwd.h_subs3.size() : 0;
+    const int nvs = ws->proj.ok ? (int)ws->proj.vsw.h_subs3.size() : 0;   // (the virtual sweep's jobs follow the sweep's: one launch builds both)
+    nsw += nvs;
     ProfScope ps(ws, AQC_K_COEF);
     if (&p == &ws->fwd) {
         HIP_OK(launch_ubuild(ws->d_ujobs + ninv + nsw, nfwd, ws->d_thetas, T, ws->batch, ws->stream));
@@ -317,7 +320,7 @@ int sweep_sparse_prepare(aqc_ws* ws) {
         HIP_OK(hipMalloc((void**)&ws->d_sw_prev_tiles, sizeof(int) * 2 * B));
         ws->w_clean = false;
     }
-    if (p.h_stages.size() >= 3 && !ws->w2) {   // stages from the second one on work on their own pair: W stays zero outside the listed
+    if (p.h_stages.size() >= 3 && !ws->w2 && !ws->proj.ok) {   // (the projected route runs the later stages on its own small register)   // stages from the second one on work on their own pair: W stays zero outside the listed
         HIP_OK(hipMalloc((void**)&ws->w2, sizeof(double2) * (size_t)B * ws->lane_elems));   // tiles, ZW keeps the checkpoint
         HIP_OK(hipMalloc((void**)&ws->zw2, sizeof(double2) * (size_t)B * ws->lane_elems));
     }
@@ -391,7 +394,8 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         const size_t m = p.h_stages.size();
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
         const bool skipw = sweep_skips_zero_w(ws, x_buf);
-        const int r_only_sub = skipw ? -1 : sweep_r_only_sub(ws);   // (the zero-w variant of the kernel has no R-only form)
+        const bool projected = sweep_route_projected(ws, sparse);   // the stages after the first on the virtual register (aqc_ws_project.cpp)
+        const int r_only_sub = skipw || projected ? -1 : sweep_r_only_sub(ws);   // (the zero-w variant of the kernel has no R-only form)
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||
@@ -399,7 +403,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
             return 1;
         if (sparse) {
             if (!ws->capturing && sweep_sparse_prepare(ws)) return 1;
-            if (!ws->d_sw_items || !ws->w_clean || (m >= 3 && !ws->w2)) return fail("sparse sweep inside a captured graph without its preparation");
+            if (!ws->d_sw_items || !ws->w_clean || (m >= 3 && !ws->w2 && !projected)) return fail("sparse sweep inside a captured graph without its preparation");
             // tiles of the first stage that hold the lhs state: a device-side list (the support may have been chosen on the device),
             // rebuilt when the support changed; tiles of the previous list that the new one drops are zeroed in W
             if (ws->capturing || ws->sw_items_buf != x_buf || ws->sw_items_version != ws->supp_version[x_buf]) {
@@ -412,7 +416,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
                 ws->sw_lists_built |= 1;
             }
         }
-        for (size_t s = 0; s < m; ++s) {
+        for (size_t s = 0; s < (projected ? 1 : m); ++s) {
             Stage3Args a = stage3_args(ws, p, s);
             if (sparse) {
                 // stage 0: (x, Z) on the listed tiles -> W there; stage 1: (W, checkpoint in ZW) -> the second pair; then in place
@@ -450,15 +454,18 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
             if (stamps_sweep(ws, a, s, nwg)) return 1;
 #endif
         }
+        if (projected && run_projected_stages(ws)) return 1;
         sweep_state_after(ws, sparse, false);
         ProfScope ps(ws, AQC_K_FINALIZE);
+        if (projected && run_projected_rgrad(ws, block_from, block_to, front_layer)) return 1;
         HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
                             ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream,
                             ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads, ws->mirror_grads,
                             ws->gather_rides ? GatherJob{ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->d_small, ws->mirror_small}
                                              : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},
                             sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k),
-                            sparse ? p.h_stages[0].nsubs : 0, sparse ? ws->d_sw_lane_parts : nullptr, r_only_sub, p.d_umat));
+                            sparse ? p.h_stages[0].nsubs : 0, sparse ? ws->d_sw_lane_parts : nullptr, r_only_sub, p.d_umat,
+                            projected ? p.h_stages[0].nsubs : -1));
 #ifdef AQC_TUNING
         if (env_int("AQC_STAMPS", 0) != 0) { HIP_OK(hipStreamSynchronize(ws->stream)); rgrad_print_stamps(nsubs); }
 #endif

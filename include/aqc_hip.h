@@ -46,7 +46,8 @@ enum { AQC_BUF_Y = 0, AQC_BUF_Z = 1, AQC_BUF_X = 2, AQC_BUF_W = 3, AQC_BUF_ZW = 
 /* kernel families for aqc_ws_profile_get */
 enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC_K_MISC = 4,
        AQC_K_SWEEP_LIST = 5, AQC_K_APPLY_LIST = 6,   /* stage launches over a subset of the tiles (sparse lhs state / objective V^H) */
-       AQC_NUM_KINDS = 7 };
+       AQC_K_PROJECT = 7, AQC_K_SWEEP_VIRTUAL = 8,   /* projected route: the pass over z, the sweep's later stages on the virtual register */
+       AQC_NUM_KINDS = 9 };
 
 const char* aqc_version(void);
 const char* aqc_last_error(void);
@@ -316,6 +317,10 @@ int aqc_ws_sweep_r_only_sub(aqc_ws* ws);
 /* item lists of the last sparse evaluation (synchronises): counts[0] first-stage items of the sweep, [1] tiles it cleared in W,
  * [2] last-stage items of V^H; -1 where that list has never been built */
 int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts);
+/* projected route of the sparse-lhs sweep (the stages after the first on a virtual register, csrc/aqc_ws_project.cpp): info[0] 1 if
+ * the workspace has it, [1] virtual qubits, [2] qubits the later stages touch, [3] of them local to the first stage, [4] stages and
+ * [5] sub-stages of the virtual plan, [6] its tile bits, [7] sub-stages left on the real register */
+int aqc_ws_projected_info(aqc_ws* ws, int32_t* info);
 /* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
 int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,
                      int* num_stages, int* tile_bits, int* num_tiles);

@@ -385,6 +385,90 @@ def test_r_only_last_substage_equals_full_sweep_and_oracle(n, tile, ent, trot, m
         assert maxdiff(res[("1", True, 2)][b], g_ref2) < TOL
 
 
+@pytest.mark.parametrize("n,tile,kind,arg", [(16, 12, "spin", 40), (16, 12, "spin", 20), (14, 12, "spin", 40), (14, 12, "trotter", 2), (16, 12, "trotter", 2),
+                                             (18, 12, "spin", 40), (15, 10, "spin", 30), (14, 9, "spin", 24), (13, 8, "spin", 18), (16, 11, "spin", 36)])
+def test_projected_route_equals_full_size_sweep_and_oracle(n, tile, kind, arg, monkeypatch):
+    """The sweep's stages after the first on the virtual register (AQC_PROJECTED, csrc/aqc_ws_project.cpp): the same gradient as the
+    full-size stages (AQC_PROJECTED=0) to rounding and as the oracle -- one and two basis states per lane (same tile, different tiles),
+    one and several virtual stages, registers padded to 8 virtual qubits, two evaluations per workspace."""
+    from aqc_research_amd.engine import BUF_X2, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(700 + n + tile)
+    circ = _trotter(n, arg) if kind == "trotter" else _circ(n, "cx", depth=arg)
+    B = 5
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    hi = 1 << (n - 1)
+    idx = np.array([[0, -1], [5, hi + 5], [hi | 3, 3 ^ (1 << (n - 2))], [(1 << n) - 1, 1], [(1 << (n - 2)) | 7, -1]], dtype=np.int64)
+    coef = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
+    res, info = {}, {}
+    for proj in ("1", "0"):
+        monkeypatch.setenv("AQC_PROJECTED", proj)
+        ws = _ws(circ, B, monkeypatch, sparse=True, tile=tile)
+        info[proj] = ws.projected_info()
+        ws.upload(BUF_Y, tg)
+        for rep in range(2):
+            ws.set_thetas(th if rep == 0 else th[::-1].copy())
+            ws.apply(True, BUF_Y, BUF_Z)
+            ws.set_combo(BUF_X2, idx, coef)
+            ws.grad_from(BUF_X2)
+            res[(proj, rep)] = ws.get_grads()
+        ws.close()
+    assert info["0"] == {}
+    if not info["1"]:
+        pytest.skip("the plan of this shape has no projected route")
+    assert info["1"]["virtual_qubits"] + 2 <= n
+    for rep in range(2):
+        assert maxdiff(res[("1", rep)], res[("0", rep)]) < 1e-13
+    for b in range(B):
+        _, g_ref = _oracle_lane(circ, th[b], tg[b], idx[b], coef[b])
+        assert maxdiff(res[("1", 0)][b], g_ref) < TOL
+        _, g_ref2 = _oracle_lane(circ, th[B - 1 - b], tg[b], idx[b], coef[b])
+        assert maxdiff(res[("1", 1)][b], g_ref2) < TOL
+
+
+def test_projected_route_through_the_one_call_evaluations(monkeypatch):
+    """aqc_ws_eval (captured graph, replayed) and the surrogate objective's one-call evaluation take the projected route: same
+    amplitudes and gradients as with AQC_PROJECTED=0, three calls each with new thetas."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y
+
+    n = 16
+    rng = np.random.default_rng(811)
+    circ = _circ(n, "cx", depth=40)
+    B = 8
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    ths = [np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)]) for _ in range(3)]
+    flips = np.array([0] + [1 << q for q in range(n)], dtype=np.int64)
+    out = {}
+    for proj in ("1", "0"):
+        monkeypatch.setenv("AQC_PROJECTED", proj)
+        ws = _ws(circ, B, monkeypatch, sparse=True, tile=12)
+        assert bool(ws.projected_info()) == (proj == "1")
+        ws.upload(BUF_Y, tg)
+        ws.set_basis(BUF_X, 0)
+        ws.gather_setup(flips)
+        got = []
+        for th in ths:
+            hs, g = ws.eval(th, vdag=True, gather=True, grad=True, x_buf=BUF_X, block_range=(0, circ.num_blocks), front_layer=True)
+            got.append((hs.copy(), g.copy()))
+        w = np.full(B, 0.3)
+        mx = np.array([0, 1, 13, 16, 0, 5, 14, 2], dtype=np.int64)
+        for th in ths:
+            f, fid, hs, gc = ws.surrogate_eval(th, w.copy(), mx.copy(), 2, (0, circ.num_blocks), True)
+            got.append((np.asarray(hs).copy(), np.asarray(gc).copy(), np.asarray(f).copy()))
+        out[proj] = got
+        ws.close()
+    for a, b in zip(out["1"], out["0"]):
+        for x, y in zip(a, b):
+            assert maxdiff(x, y) < 1e-13
+    for i, th in enumerate(ths):
+        for b in range(0, B, 3):
+            vh = orc.v_dagger_mul_vec(circ, th[b], tg[b])
+            x = np.zeros(1 << n, complex); x[0] = 1.0
+            assert maxdiff(out["1"][i][0][b], vh[flips]) < TOL
+            assert maxdiff(out["1"][i][1][b], orc.grad_of_dot_product(circ, th[b], x, vh)) < TOL
+
+
 class _Op:
     def __init__(self, name, params=()):
         self.name, self.params = name, list(params)

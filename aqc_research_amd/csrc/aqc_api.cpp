@@ -900,10 +900,11 @@ int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts) {
 int aqc_ws_projected_info(aqc_ws* ws, int32_t* info) {
     if (!ws || !info) return fail("null argument");
     const aqc::ProjRoute& pr = ws->proj;
-    for (int i = 0; i < 8; ++i) info[i] = 0;
+    for (int i = 0; i < 16; ++i) info[i] = 0;
     if (!pr.ok) return 0;
     info[0] = 1; info[1] = pr.nv; info[2] = pr.t; info[3] = pr.cb; info[4] = (int32_t)pr.vsw.h_stages.size();
-    info[5] = (int32_t)pr.vsw.h_subs3.size(); info[6] = pr.kv; info[7] = pr.first_subs;
+    info[5] = (int32_t)pr.vsw.h_subs3.size(); info[6] = pr.kv; info[7] = pr.first_subs; info[8] = pr.us; info[9] = pr.nvp;
+    for (size_t s = 0; s < pr.vsw.h_stages.size() && s < 6; ++s) info[10 + s] = pr.vsw.h_stages[s].nsubs;
     return 0;
 }
 

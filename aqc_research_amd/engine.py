@@ -369,12 +369,13 @@ class Workspace:
 
     def projected_info(self) -> dict:
         """The projected route of the sparse-lhs sweep (its stages after the first on a virtual register), or {} without it."""
-        c = (ctypes.c_int32 * 8)()
+        c = (ctypes.c_int32 * 16)()
         check(self._L.aqc_ws_projected_info(self.handle, c))
         if not c[0]:
             return {}
         return {"virtual_qubits": int(c[1]), "touched_qubits": int(c[2]), "shared_with_first_stage": int(c[3]), "stages": int(c[4]),
-                "substages": int(c[5]), "tile_bits": int(c[6]), "substages_on_the_register": int(c[7])}
+                "substages": int(c[5]), "tile_bits": int(c[6]), "substages_on_the_register": int(c[7]), "summed_bits": int(c[8]),
+                "padded_qubits": int(c[9]), "substages_per_stage": [int(c[10 + i]) for i in range(min(int(c[4]), 6))]}
 
     def plan_info(self, which: int) -> Tuple[int, int, int]:
         a, b, c = c_int(), c_int(), c_int()

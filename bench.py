@@ -896,7 +896,7 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
     """Per stage launch of one step (matrix-core path): kernel, plan stage, sub-stages, share of the tiles it ran over, average
     duration (HIP events around every launch of `prof_steps` steps), EXECUTED MFMA flops (288 per amplitude and sub-stage for
     the sweep: 9 real 16x16x16 products per 256 amplitudes; 96 for V^H) and their rate.  None off the matrix-core path."""
-    from aqc_research_amd._lib import K_APPLY, K_APPLY_LIST, K_SWEEP, K_SWEEP_LIST
+    from aqc_research_amd._lib import K_APPLY, K_APPLY_LIST, K_PROJECT, K_SWEEP, K_SWEEP_LIST, K_SWEEP_VIRTUAL
 
     if ws.kernel_family(1) != 3 or ws.kernel_family(0) != 3 or not prof_log or len(prof_log) % prof_steps:
         return None
@@ -907,7 +907,30 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
     avg = [sum(prof_log[i * per + j][1] for i in range(prof_steps)) / prof_steps for j in range(per)]
     sw_items, _, vd_items = ws.sparse_counts()
     rows, at = [], {0: 0, 1: 0}
+    proj = ws.projected_info()   # the sweep's stages after the first on a virtual register (csrc/aqc_ws_project.cpp), or {}
+    vstage = 0
     for j, k in enumerate(kinds):
+        if k == K_PROJECT and proj:   # one pass over z (the checkpoint of V^H): 2^(touched + summed bits) elements per item, memory-bound
+            cols = 16 * max(1, (1 << proj["shared_with_first_stage"]) // 16)
+            elems = float(sw_items) * 2.0 ** (proj["touched_qubits"] + proj["summed_bits"])
+            flops = 8.0 * elems * cols
+            nbytes = 16.0 * elems
+            rows.append({"kernel": f"project_kernel<{max(1, min(4, cols // 16))}>", "plan": "projection of z onto the lhs subspace", "stage": None, "substages": None,
+                         "last_substage_r_only": False, "tiles_frac": None, "avg_ms": avg[j], "flops": flops, "flops_not_issued_zero_w": 0.0,
+                         "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
+                         "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0,
+                         "bound": "hbm", "bytes_read": nbytes, "GBps": nbytes / (avg[j] * 1e-3) / 1e9 if avg[j] > 0 else 0.0,
+                         "frac_of_hbm_peak": nbytes / (avg[j] * 1e-3) / 1e9 / HBM_PEAK_GBS if avg[j] > 0 else 0.0})
+            continue
+        if k == K_SWEEP_VIRTUAL and proj:
+            nsub = proj["substages_per_stage"][vstage] if vstage < len(proj["substages_per_stage"]) else 0
+            flops = 288.0 * float(sw_items) * 2.0 ** proj["padded_qubits"] * nsub
+            rows.append({"kernel": f"sweep_mfma_kernel<{proj['tile_bits']}, true, false, false>", "plan": f"sweep, stages after the first on {proj['virtual_qubits']} virtual qubits",
+                         "stage": vstage, "substages": nsub, "last_substage_r_only": False, "tiles_frac": None, "avg_ms": avg[j], "flops": flops,
+                         "flops_not_issued_zero_w": 0.0, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
+                         "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0})
+            vstage += 1
+            continue
         if k not in (K_APPLY, K_APPLY_LIST, K_SWEEP, K_SWEEP_LIST):
             continue
         which = 1 if k in (K_SWEEP, K_SWEEP_LIST) else 0
@@ -948,7 +971,10 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
             "stage_launches_frac_of_peak": executed / (stage_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if stage_ms > 0 else 0.0,
             "note": "dense_route_flops = every stage over every tile (the sweep from a dense lhs state and a full V^H); the sparse-lhs "
                     "route runs the sweep's first stage over the tiles that hold the lhs basis states and V^H's last stage over the "
-                    "tiles the evaluation reads -- products with exact zeros and amplitudes nobody reads are not executed"}
+                    "tiles the evaluation reads -- products with exact zeros and amplitudes nobody reads are not executed; with the projected "
+                    "route (projected_route: csrc/aqc_ws_project.cpp) the sweep's stages after the first run on a virtual register of "
+                    "`virtual_qubits` qubits per lane after one pass over z",
+            "projected_route": proj or None}
 
 
 def main():
@@ -1094,7 +1120,7 @@ def measure(workload, args, env, full):
     the short configuration runs of the default line leave them out and use --config-steps steps."""
     comm, comm_note, rank, world, local_rank, n_gpus, ranks_seen = (env.comm, env.comm_note, env.rank, env.world, env.local_rank,
                                                                      env.n_gpus, env.ranks_seen)
-    from aqc_research_amd._lib import K_APPLY_LIST, K_SWEEP_LIST
+    from aqc_research_amd._lib import K_APPLY_LIST, K_PROJECT, K_SWEEP_LIST, K_SWEEP_VIRTUAL
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, HipContext, Workspace
     from oracle import aqc_oracle as orc
 
@@ -1291,7 +1317,7 @@ def measure(workload, args, env, full):
             step(i)
         ws.sync()
         kinds = {"apply": K_APPLY, "sweep": K_SWEEP, "coef": K_COEF, "finalize": K_FINALIZE, "misc": K_MISC,
-                 "sweep_tile_list": K_SWEEP_LIST, "apply_tile_list": K_APPLY_LIST}
+                 "sweep_tile_list": K_SWEEP_LIST, "apply_tile_list": K_APPLY_LIST, "project": K_PROJECT, "sweep_virtual": K_SWEEP_VIRTUAL}
         prof = {k: ws.profile_get(v) for k, v in kinds.items()}
         prof_log = ws.profile_log()
         ws.profile(False)
@@ -1425,16 +1451,18 @@ def measure(workload, args, env, full):
             # SURVEY 8(d)'s gate-by-gate flop count (what the reference's algorithm would spend) rides along as
             # `algorithmic_*`; it is NOT a bound for a kernel that fuses whole gate groups into one 16 x 16 unitary.
             "roofline": {
-                "bound": "mfma",
+                "bound": dominant.get("bound", "mfma") if dominant else "mfma",
                 "kernel": dominant["kernel"] if dominant else ws.sweep_kernel_name(),
-                "launch": None if not dominant else f"{dominant['plan']} stage {dominant['stage']} ({dominant['substages']} sub-stages, "
-                                                     f"{dominant['tiles_frac']:.4g} of the tiles)",
+                "launch": None if not dominant else (dominant["plan"] if dominant["stage"] is None or dominant["tiles_frac"] is None else
+                                                     f"{dominant['plan']} stage {dominant['stage']} ({dominant['substages']} sub-stages, "
+                                                     f"{dominant['tiles_frac']:.4g} of the tiles)"),
                 "step": None if not stage_launches else {k: v for k, v in stage_launches.items() if k != "launches"},
                 "launches": None if not stage_launches else stage_launches["launches"],
-                "achieved": exec_tflops,
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": exec_tflops / FP64_PEAK_TFLOPS,
+                # (a memory-bound dominant launch -- the projected route's pass over z -- is priced in bytes)
+                "achieved": dominant["GBps"] if dominant and dominant.get("bound") == "hbm" else exec_tflops,
+                "peak": HBM_PEAK_GBS if dominant and dominant.get("bound") == "hbm" else FP64_PEAK_TFLOPS,
+                "unit": "GB/s" if dominant and dominant.get("bound") == "hbm" else "TFLOP/s",
+                "frac": dominant["frac_of_hbm_peak"] if dominant and dominant.get("bound") == "hbm" else exec_tflops / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "avg_launch_ms": sweep_avg_ms,

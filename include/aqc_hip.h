@@ -319,7 +319,8 @@ int aqc_ws_sweep_r_only_sub(aqc_ws* ws);
 int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts);
 /* projected route of the sparse-lhs sweep (the stages after the first on a virtual register, csrc/aqc_ws_project.cpp): info[0] 1 if
  * the workspace has it, [1] virtual qubits, [2] qubits the later stages touch, [3] of them local to the first stage, [4] stages and
- * [5] sub-stages of the virtual plan, [6] its tile bits, [7] sub-stages left on the real register */
+ * [5] sub-stages of the virtual plan, [6] its tile bits, [7] sub-stages left on the real register, [8] bits of the first stage the
+ * pass over z sums over, [9] virtual qubits after padding (>= 8), [10..15] sub-stages of the virtual stages; info holds 16 entries */
 int aqc_ws_projected_info(aqc_ws* ws, int32_t* info);
 /* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
 int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,

@@ -415,8 +415,9 @@ def test_projected_route_equals_full_size_sweep_and_oracle(n, tile, kind, arg, m
             res[(proj, rep)] = ws.get_grads()
         ws.close()
     assert info["0"] == {}
-    if not info["1"]:
-        pytest.skip("the plan of this shape has no projected route")
+    if not info["1"]:   # (a shape whose later stages touch too much of the register: both runs took the full-size stages)
+        assert all(np.array_equal(res[("1", rep)], res[("0", rep)]) for rep in range(2))
+        return
     assert info["1"]["virtual_qubits"] + 2 <= n
     for rep in range(2):
         assert maxdiff(res[("1", rep)], res[("0", rep)]) < 1e-13

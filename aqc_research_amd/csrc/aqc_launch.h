@@ -97,26 +97,34 @@ int sweep3_nparts(int ntiles, int batch, int k);
 // first is psi (x) |e> on (first stage's local bits) x (the other bits), and those stages touch the qubits T only, so everything the
 // gradient needs of z there is its projection y0[i_T, c] = sum_u conj(psi[u, c]) z[u, i_T] (u: local bits of the first stage outside T,
 // c: those inside T) -- a register of |T| + |c| virtual qubits per lane instead of n.
+struct ProjMap { const unsigned* tab; int shift; };   // index -> element offset: a table, or the index shifted (virtual register)
 struct ProjArgs {
-    const double2* zin;      // z as it enters the dense stages (the checkpoint of the mirrored V^H), [batch][lane_stride]
-    const double2* w;        // w after the first stage (psi on the listed tiles), same layout
+    // the product  out[keep, c] = sum_k conj(S[k, c]) Y[k, keep]  per item
+    const double2* y;        // full-size operand, [batch][lane_stride]; read at (lane) + (the item's tile bits & ff_mask) + y_keep[keep] + y_k[k]
+    const double2* s;        // small operand: real register (lane + the item's tile + s_k[k] + s_c[c]) or virtual ((2 lane + slot) << nvp + ...)
+    double2* out;            // the same choice
+    int s_virtual, out_virtual;
+    int staged;              // k runs along contiguous memory of y and s (low four bits of k = address bits 0..3): fetch 256-byte runs through LDS
+    int keep_bits, k_bits, cb;
+    ProjMap y_keep, y_k, s_k, s_c, o_keep, o_c;
     size_t lane_stride;
     const TileItem* items;   // first-stage items of the sparse sweep (lane, tile of the first stage, slot) and their number
     const int* nitems;
     const int* lane_parts;   // items per lane
     int nub0, ubits0[32];    // non-local address bits of the first stage (tile index -> element offset)
-    const unsigned* off_t;   // [2^t]: element offset of the value i of the T bits;  [2^(us-4)]: of block k of 16 values of the summed bits
-    const unsigned* off_usblk;   // (their low four are address bits 0..3: 16 contiguous elements);  [2^cb]: of the value c of the bits in both
-    const unsigned* off_cb;
-    int t, cb, us, nvp, ntiles_v;
     unsigned ff_mask, cb_mask, tf_mask;   // address bits outside the first stage's local set and outside T (fixed to the item's) / in both / in T only
-    double2* vm;             // [batch][2][2^nvp]: the virtual lhs state (basis vectors) ...
-    double2* vy;             // ... and the projection, index = i_T | c << t
+    int nvp;
+    // project_init_kernel: the virtual lhs pattern and the bookkeeping of the virtual stage launches
+    const unsigned* off_t;   // [2^t]: element offset of the value i of the T bits;  [2^cb]: of the value c of the bits shared with the first stage
+    const unsigned* off_cb;
+    int t, ntiles_v;
+    double2* vm;             // [batch][2][2^nvp]
     TileItem* vitems;        // items of the virtual stage launches: (lane, slot ntiles_v + tile, the same as partial slot)
     int* vcount;
     int* vlane_parts;
     int batch;
 };
+hipError_t launch_project_init(const ProjArgs& a, hipStream_t s);
 hipError_t launch_project(const ProjArgs& a, hipStream_t s);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
     const DevSub3* sub;

@@ -1,7 +1,10 @@
-// Projection of z onto the subspace the lhs state of the sweep occupies when it enters the stages after the first
-// (host side and the mathematics: aqc_ws_project.cpp).  Per item (lane, tile of the first stage that holds the lhs state):
-//     y0[i_T, c] = sum_u conj(psi[u, c]) z[u, i_T]        m0[i_T, c] = [i_T restricted to the bits of c equals c][its other bits equal the tile's]
-// a (2^cb x 2^us) by (2^us x 2^t) complex product on the fp64 matrix cores -- z is read once, which is what the launch costs.
+// Passes over a full-size state of the projected route (host side and the mathematics: aqc_ws_project.cpp).  One kernel, two uses:
+//     out[keep, c] = sum_k conj(S[k, c]) Y[k, keep]                  per item = (lane, first-stage tile that holds the lhs state)
+//   * Y = z (the checkpoint of V^H) or the target y, k = the first stage's local bits outside T, keep = the bits T, S = psi (w after
+//     the first stage):  the projection of z onto the subspace the lhs state spans when it enters the later stages;
+//   * Y = the target y, k = the bits T, keep = the first stage's local bits outside T, S = the virtual basis pattern after the later
+//     stages' gates:  the tile of (later stages)^H y that the lhs state and the gathered amplitudes live on.
+// A (2^cb x 2^nk) by (2^nk x 2^nkeep) complex product per item on the fp64 matrix cores; Y is read once, which is what a launch costs.
 #include <hip/hip_runtime.h>
 
 #include "aqc_launch.h"
@@ -10,89 +13,223 @@ namespace aqc {
 
 using cplx = double2;
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+// Y is streamed (read once): no reason to keep it in the caches the small operand lives in
+__device__ __forceinline__ cplx pj_stream(const cplx* p) { const double2_t v = __builtin_nontemporal_load(reinterpret_cast<const double2_t*>(p)); return make_double2(v.x, v.y); }
 
 __device__ __forceinline__ double4_t pj_mfma(double a, double b, double4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned pj_off(const ProjMap& m, unsigned i) { return m.tab ? m.tab[i] : (i << m.shift); }
+__device__ __forceinline__ size_t pj_tile_bits(const ProjArgs& a, int tile) {   // element offset of a first-stage tile: the values of its non-local bits
+    size_t e = 0;
+    for (int i = 0; i < a.nub0; ++i) e |= (size_t)((tile >> i) & 1) << a.ubits0[i];
+    return e;
+}
 
-// Workgroup = 4 waves, wave = 16 values of i_T (the B operand's columns; MFMA rows = 16 values of c), K = the summed bits u: per block of
-// 16 values of u a lane loads 4 consecutive elements of its row of z (k-group = lane / 16: u = 16 kb + 4 (lane / 16) + jj) and of
-// its row of psi -- 64 contiguous bytes each, 256 contiguous bytes per row and block.
-template <int NB>
+// Wave = RB blocks of 16 values of `keep` (the B operand's columns; MFMA rows = 16 values of c), K = the summed index: per block of
+// 16 values of k a lane loads the 4 elements k = 16 kb + 4 (lane / 16) + jj of its row(s) of Y and of its row of S.
+template <int RB, int NB>
 __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     const int item = blockIdx.y;
+    if (item >= *a.nitems) return;
+    const TileItem it = a.items[item];
+    const size_t ebits = pj_tile_bits(a, it.tile);
+    const int nkeep = 1 << a.keep_bits, ncb = 1 << a.cb, nkb = 1 << (a.k_bits - 4);
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kg = l >> 4;
+    const int rb0 = (blockIdx.x * 4 + wave) * RB;
+    if (rb0 * 16 >= nkeep) return;
+    const size_t vbase = ((size_t)it.lane * 2 + it.slot) << a.nvp;
+    const size_t real_base = (size_t)it.lane * a.lane_stride;
+    const cplx* ybase = a.y + real_base + (ebits & a.ff_mask);
+    const cplx* sbase = a.s + (a.s_virtual ? vbase : real_base + ebits);
+    cplx* obase = a.out + (a.out_virtual ? vbase : real_base + ebits);
+    const cplx* yrow[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const int keep = (rb0 + q) * 16 + r16;
+        yrow[q] = ybase + (keep < nkeep ? pj_off(a.y_keep, keep) : 0u);
+    }
+    for (int nb0 = 0; nb0 * 16 < ncb; nb0 += NB) {
+        const cplx* srow[NB];
+        bool valid[NB];
+        double4_t re[RB][NB], im[RB][NB];
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int c = (nb0 + p) * 16 + r16;
+            valid[p] = c < ncb;
+            srow[p] = sbase + (valid[p] ? pj_off(a.s_c, c) : 0u);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) { re[q][p] = double4_t{0.0, 0.0, 0.0, 0.0}; im[q][p] = re[q][p]; }
+        }
+        for (int kb = 0; kb < nkb; ++kb) {
+            unsigned yo[4], so[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const unsigned k = (unsigned)(kb * 16 + 4 * kg + jj);
+                yo[jj] = pj_off(a.y_k, k);
+                so[jj] = pj_off(a.s_k, k);
+            }
+            cplx zv[RB][4], pv[NB][4];
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) zv[q][jj] = pj_stream(&yrow[q][yo[jj]]);
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) pv[p][jj] = valid[p] ? srow[p][so[jj]] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int p = 0; p < NB; ++p)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {   // conj(s) y = (sr yr + si yi) + i (sr yi - si yr)
+                        re[q][p] = pj_mfma(pv[p][jj].x, zv[q][jj].x, re[q][p]);
+                        re[q][p] = pj_mfma(pv[p][jj].y, zv[q][jj].y, re[q][p]);
+                        im[q][p] = pj_mfma(pv[p][jj].x, zv[q][jj].y, im[q][p]);
+                        im[q][p] = pj_mfma(-pv[p][jj].y, zv[q][jj].x, im[q][p]);
+                    }
+        }
+        // D[row = lane / 16 + 4 r][col = lane % 16]: row = c within its block, col = keep within its block
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int keep = (rb0 + q) * 16 + r16;
+            if (keep >= nkeep) continue;
+            cplx* orow = obase + pj_off(a.o_keep, keep);
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = (nb0 + p) * 16 + kg + 4 * r;
+                    if (c < ncb) orow[pj_off(a.o_c, c)] = make_double2(re[q][p][r], im[q][p][r]);
+                }
+        }
+    }
+}
+
+// The same product when the summed index k runs along contiguous memory of BOTH operands (the projection: k = the low address bits) and
+// `keep` / c do not: a lane of the matrix-core layout would then fetch 16 bytes of a row of its own -- 64 separate 64-byte sectors per
+// wave instruction, which is what the L1 can look up, not what the memory delivers.  Here a wave fetches its 16 x 16 block of Y and of S
+// as 256-byte runs (lane = 4 rows x 16 consecutive k), hands them through a private LDS tile (rows padded to 17 elements) and reads them
+// back in the operand layout; the next block's loads are in flight while the 16 MFMAs of this one run.  No workgroup barrier.
+constexpr int kPjRow = 17;   // elements per LDS row
+__global__ __launch_bounds__(256) void project_staged_kernel(const ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pj_smem[];
+    const int item = blockIdx.y;
+    if (item >= *a.nitems) return;
+    const TileItem it = a.items[item];
+    const size_t ebits = pj_tile_bits(a, it.tile);
+    const int nkeep = 1 << a.keep_bits, ncb = 1 << a.cb, nkb = 1 << (a.k_bits - 4);
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kg = l >> 4;
+    const int rb = blockIdx.x * 4 + wave;
+    if (rb * 16 >= nkeep) return;
+    cplx* zt = reinterpret_cast<cplx*>(pj_smem) + (size_t)wave * (2 * 16 * kPjRow);
+    cplx* pt = zt + 16 * kPjRow;
+    const size_t vbase = ((size_t)it.lane * 2 + it.slot) << a.nvp;
+    const size_t real_base = (size_t)it.lane * a.lane_stride;
+    const cplx* ybase = a.y + real_base + (ebits & a.ff_mask) + r16;
+    const cplx* sbase = a.s + (a.s_virtual ? vbase : real_base + ebits) + r16;
+    cplx* obase = a.out + (a.out_virtual ? vbase : real_base + ebits);
+    unsigned zoff[4];   // rows 4 j + kg of the wave's block of Y
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zoff[j] = pj_off(a.y_keep, (unsigned)(rb * 16 + 4 * j + kg));
+    for (int nb = 0; nb * 16 < ncb; ++nb) {
+        unsigned poff[4];
+        bool pvalid[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = nb * 16 + 4 * j + kg;
+            pvalid[j] = c < ncb;
+            poff[j] = pvalid[j] ? pj_off(a.s_c, (unsigned)c) : 0u;
+        }
+        double4_t re = {0.0, 0.0, 0.0, 0.0}, im = re;
+        cplx zc[4], pc[4], zn[4], pn[4];
+        {
+            const unsigned yb = pj_off(a.y_k, 0u), sb = pj_off(a.s_k, 0u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { zc[j] = pj_stream(ybase + zoff[j] + yb); pc[j] = pvalid[j] ? sbase[poff[j] + sb] : make_double2(0.0, 0.0); }
+        }
+        for (int kb = 0; kb < nkb; ++kb) {
+            if (kb + 1 < nkb) {
+                const unsigned yb = pj_off(a.y_k, (unsigned)(kb + 1) * 16u), sb = pj_off(a.s_k, (unsigned)(kb + 1) * 16u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { zn[j] = pj_stream(ybase + zoff[j] + yb); pn[j] = pvalid[j] ? sbase[poff[j] + sb] : make_double2(0.0, 0.0); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { zt[(4 * j + kg) * kPjRow + r16] = zc[j]; pt[(4 * j + kg) * kPjRow + r16] = pc[j]; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cplx zv[4], pv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { zv[jj] = zt[r16 * kPjRow + 4 * kg + jj]; pv[jj] = pt[r16 * kPjRow + 4 * kg + jj]; }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {   // conj(s) y = (sr yr + si yi) + i (sr yi - si yr)
+                re = pj_mfma(pv[jj].x, zv[jj].x, re);
+                re = pj_mfma(pv[jj].y, zv[jj].y, re);
+                im = pj_mfma(pv[jj].x, zv[jj].y, im);
+                im = pj_mfma(-pv[jj].y, zv[jj].x, im);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { zc[j] = zn[j]; pc[j] = pn[j]; }
+        }
+        cplx* orow = obase + pj_off(a.o_keep, (unsigned)(rb * 16 + r16));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = nb * 16 + kg + 4 * r;
+            if (c < ncb) orow[pj_off(a.o_c, (unsigned)c)] = make_double2(re[r], im[r]);
+        }
+    }
+}
+
+hipError_t launch_project(const ProjArgs& a, hipStream_t s) {
+    if (a.staged) {   // (the host has checked: the low four bits of k are address bits 0..3 of both operands)
+        if (a.keep_bits < 4 || a.k_bits < 4 || a.cb < 0 || a.cb > 12 || a.batch < 1 || !a.y || !a.s || !a.out) return hipErrorInvalidValue;
+        const int blocks = 1 << (a.keep_bits - 4);
+        project_staged_kernel<<<dim3((unsigned)((blocks + 3) / 4), (unsigned)(2 * a.batch)), 256, 4 * 2 * 16 * kPjRow * sizeof(cplx), s>>>(a);
+        return hipGetLastError();
+    }
+    if (a.keep_bits < 4 || a.k_bits < 4 || a.cb < 0 || a.cb > 12 || a.batch < 1 || !a.y || !a.s || !a.out) return hipErrorInvalidValue;
+    const int blocks = 1 << (a.keep_bits - 4);
+    const bool wide = blocks >= 16;   // four blocks of `keep` per wave: S is fetched once for four columns of Y
+    const dim3 grid((unsigned)((blocks / (wide ? 4 : 1) + 3) / 4), (unsigned)(2 * a.batch));
+    if (wide) {
+        if (a.cb <= 4) project_kernel<4, 1><<<grid, 256, 0, s>>>(a);
+        else project_kernel<4, 2><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (a.cb <= 4) project_kernel<1, 1><<<grid, 256, 0, s>>>(a);
+        else if (a.cb == 5) project_kernel<1, 2><<<grid, 256, 0, s>>>(a);
+        else project_kernel<1, 4><<<grid, 256, 0, s>>>(a);
+    }
+    return hipGetLastError();
+}
+
+// The lhs state of the virtual register, M_0[i_T, c] = [i_T on the shared bits = c][i_T on the other touched bits = the tile's], and
+// the item list of the virtual stage launches (one workgroup per item; workgroup 0 also the counts).
+__global__ __launch_bounds__(256) void project_init_kernel(const ProjArgs a) {
+    const int item = blockIdx.x;
     const int nitems = *a.nitems;
-    if (blockIdx.x == 0 && item == 0) {   // bookkeeping of the virtual stage launches
+    if (item == 0) {
         if (threadIdx.x == 0) *a.vcount = nitems * a.ntiles_v;
         for (int b = threadIdx.x; b < a.batch; b += 256) a.vlane_parts[b] = a.lane_parts[b] * a.ntiles_v;
     }
     if (item >= nitems) return;
     const TileItem it = a.items[item];
-    size_t ebits = 0;   // element offset of the tile: the values of the first stage's non-local bits
-    for (int i = 0; i < a.nub0; ++i) ebits |= (size_t)((it.tile >> i) & 1) << a.ubits0[i];
-    if (blockIdx.x == 0)
-        for (int tt = threadIdx.x; tt < a.ntiles_v; tt += 256)
-            a.vitems[(size_t)item * a.ntiles_v + tt] = TileItem{it.lane, it.slot * a.ntiles_v + tt, it.slot * a.ntiles_v + tt, 0};
-    const int rows = 1 << a.t, ncb = 1 << a.cb, nkb = 1 << (a.us - 4);
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kg = l >> 4;
-    const int rb = blockIdx.x * 4 + wave;
-    if (rb * 16 >= rows) return;
-    const size_t vbase = ((size_t)it.lane * 2 + it.slot) << a.nvp;
-    const unsigned my_t = a.off_t[rb * 16 + r16];
-    const cplx* zrow = a.zin + (size_t)it.lane * a.lane_stride + my_t + (ebits & a.ff_mask) + 4 * kg;
-    for (int nb0 = 0; nb0 * 16 < ncb; nb0 += NB) {
-        const cplx* prow[NB];
-        bool valid[NB];
-        double4_t re[NB], im[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int c = (nb0 + q) * 16 + r16;
-            valid[q] = c < ncb;
-            prow[q] = a.w + (size_t)it.lane * a.lane_stride + ebits + (valid[q] ? a.off_cb[c] : 0u) + 4 * kg;
-            re[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-            im[q] = re[q];
-        }
-        for (int kb = 0; kb < nkb; ++kb) {
-            const unsigned uo = a.off_usblk[kb];
-            cplx zv[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) zv[jj] = zrow[uo + jj];
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                cplx pv[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) pv[jj] = valid[q] ? prow[q][uo + jj] : make_double2(0.0, 0.0);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {   // conj(p) z = (pr zr + pi zi) + i (pr zi - pi zr)
-                    re[q] = pj_mfma(pv[jj].x, zv[jj].x, re[q]);
-                    re[q] = pj_mfma(pv[jj].y, zv[jj].y, re[q]);
-                    im[q] = pj_mfma(pv[jj].x, zv[jj].y, im[q]);
-                    im[q] = pj_mfma(-pv[jj].y, zv[jj].x, im[q]);
-                }
-            }
-        }
-        // D[row = lane / 16 + 4 r][col = lane % 16]: row = c within the block, col = i_T within the wave's 16
-        const int i_t = rb * 16 + r16;
+    const unsigned ebits = (unsigned)pj_tile_bits(a, it.tile);
+    for (int tt = threadIdx.x; tt < a.ntiles_v; tt += 256)
+        a.vitems[(size_t)item * a.ntiles_v + tt] = TileItem{it.lane, it.slot * a.ntiles_v + tt, it.slot * a.ntiles_v + tt, 0};
+    cplx* vm = a.vm + (((size_t)it.lane * 2 + it.slot) << a.nvp);
+    const int nv = a.t + a.cb;
+    for (unsigned v = threadIdx.x; v < (1u << nv); v += 256) {
+        const unsigned i_t = v & ((1u << a.t) - 1), c = v >> a.t;
         const unsigned t_bits = a.off_t[i_t];
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = (nb0 + q) * 16 + kg + 4 * r;
-                if (c >= ncb) continue;
-                const size_t v = vbase + (size_t)i_t + ((size_t)c << a.t);
-                a.vy[v] = make_double2(re[q][r], im[q][r]);
-                const bool one = (t_bits & a.cb_mask) == a.off_cb[c] && (t_bits & a.tf_mask) == ((unsigned)ebits & a.tf_mask);
-                a.vm[v] = make_double2(one ? 1.0 : 0.0, 0.0);
-            }
+        const bool one = (t_bits & a.cb_mask) == a.off_cb[c] && (t_bits & a.tf_mask) == (ebits & a.tf_mask);
+        vm[v] = make_double2(one ? 1.0 : 0.0, 0.0);
     }
 }
-
-hipError_t launch_project(const ProjArgs& a, hipStream_t s) {
-    if (a.t < 4 || a.us < 4 || a.cb < 0 || a.cb > 12 || a.batch < 1) return hipErrorInvalidValue;
-    const int rows = 1 << a.t;
-    const dim3 grid((unsigned)((rows / 16 + 3) / 4), (unsigned)(2 * a.batch));
-    if (a.cb <= 4) project_kernel<1><<<grid, 256, 0, s>>>(a);
-    else if (a.cb == 5) project_kernel<2><<<grid, 256, 0, s>>>(a);
-    else project_kernel<4><<<grid, 256, 0, s>>>(a);
+hipError_t launch_project_init(const ProjArgs& a, hipStream_t s) {
+    if (a.batch < 1 || !a.vm || !a.vitems || !a.vcount || !a.vlane_parts) return hipErrorInvalidValue;
+    project_init_kernel<<<dim3((unsigned)(2 * a.batch)), 256, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -60,12 +60,12 @@ void proj_plan(aqc_ws* ws, int low_bits) {
     pr.kv = std::min(pr.nvp, p.k);
     pr.ntiles_v = 1 << (pr.nvp - pr.kv);
     pr.first_subs = p.h_stages[0].nsubs;
-    std::vector<int> tbits, cbits, ubits_hi;
+    std::vector<int> tbits, cbits, usbits;
     std::vector<int> vq(n, -1);
     for (int b = 0; b < n; ++b) {
         if (T >> b & 1) { vq[b] = (int)tbits.size(); tbits.push_back(b); }
         if (Cb >> b & 1) cbits.push_back(b);
-        if ((Us >> b & 1) && b >= 4) ubits_hi.push_back(b);
+        if (Us >> b & 1) usbits.push_back(b);
     }
     pr.vprog = prog;   // group indices, thetas and slots stay the real ones; only the qubits move
     for (int gi : pr.rest) {
@@ -90,7 +90,7 @@ void proj_plan(aqc_ws* ws, int low_bits) {
     pr.tf_mask = (unsigned)(T & F);
     pr.h_tab.clear();
     for (unsigned i = 0; i < (1u << pr.t); ++i) pr.h_tab.push_back(deposit_bits(i, tbits));
-    for (unsigned k = 0; k < (1u << (pr.us - 4)); ++k) pr.h_tab.push_back(deposit_bits(k, ubits_hi));
+    for (unsigned k = 0; k < (1u << pr.us); ++k) pr.h_tab.push_back(deposit_bits(k, usbits));
     for (unsigned c = 0; c < (1u << pr.cb); ++c) pr.h_tab.push_back(deposit_bits(c, cbits));
     pr.ok = true;
     if (env_int("AQC_VERBOSE", 0))
@@ -136,31 +136,53 @@ void proj_free(aqc_ws* ws) {
 
 bool sweep_route_projected(const aqc_ws* ws, bool sparse) { return sparse && ws->proj.ok; }
 
+// what every launch of the route shares: the first-stage items, the bit masks, the virtual buffers' bookkeeping
+static ProjArgs proj_args(aqc_ws* ws) {
+    ProjRoute& pr = ws->proj;
+    ProjArgs a;
+    memset(&a, 0, sizeof a);
+    a.lane_stride = ws->lane_elems;
+    a.items = ws->d_sw_items;
+    a.nitems = ws->d_sw_counts;
+    a.lane_parts = ws->d_sw_lane_parts;
+    const DevStage& s0 = ws->sweep.h_stages[0];
+    a.nub0 = s0.nub;
+    for (int i = 0; i < s0.nub; ++i) a.ubits0[i] = s0.ubits[i];
+    a.ff_mask = pr.ff_mask; a.cb_mask = pr.cb_mask; a.tf_mask = pr.tf_mask;
+    a.nvp = pr.nvp;
+    a.off_t = pr.d_tab;
+    a.off_cb = pr.d_tab + (1u << pr.t) + (1u << pr.us);
+    a.t = pr.t; a.cb = pr.cb; a.ntiles_v = pr.ntiles_v;
+    a.vm = pr.vm;
+    a.vitems = pr.d_items; a.vcount = pr.d_count; a.vlane_parts = pr.d_lane_parts;
+    a.batch = ws->batch;
+    return a;
+}
+
 // after the sweep's first stage (W holds psi on the listed tiles, ZW the checkpoint): the projection, then the virtual stages
 int run_projected_stages(aqc_ws* ws) {
     ProjRoute& pr = ws->proj;
-    const DevPlan& p = ws->sweep;
     DevPlan& v = pr.vsw;
     {
-        ProjArgs a;
-        memset(&a, 0, sizeof a);
-        a.zin = ws->bufs[AQC_BUF_ZW];
-        a.w = ws->bufs[AQC_BUF_W];
-        a.lane_stride = ws->lane_elems;
-        a.items = ws->d_sw_items;
-        a.nitems = ws->d_sw_counts;
-        a.lane_parts = ws->d_sw_lane_parts;
-        const DevStage& s0 = p.h_stages[0];
-        a.nub0 = s0.nub;
-        for (int i = 0; i < s0.nub; ++i) a.ubits0[i] = s0.ubits[i];
-        a.off_t = pr.d_tab;
-        a.off_usblk = pr.d_tab + (1u << pr.t);
-        a.off_cb = a.off_usblk + (1u << (pr.us - 4));
-        a.t = pr.t; a.cb = pr.cb; a.us = pr.us; a.nvp = pr.nvp; a.ntiles_v = pr.ntiles_v;
-        a.ff_mask = pr.ff_mask; a.cb_mask = pr.cb_mask; a.tf_mask = pr.tf_mask;
-        a.vm = pr.vm; a.vy = pr.vy;
-        a.vitems = pr.d_items; a.vcount = pr.d_count; a.vlane_parts = pr.d_lane_parts;
-        a.batch = ws->batch;
+        ProjArgs a = proj_args(ws);
+        {
+            ProfScope ps(ws, AQC_K_MISC);
+            HIP_OK(launch_project_init(a, ws->stream));
+        }
+        // Y_0[i_T, c] = sum_u conj(psi[u, c]) z[u, i_T]:  Y = the checkpoint, k = u, keep = i_T, S = psi in W, out = the virtual z
+        a.y = ws->bufs[AQC_BUF_ZW];
+        a.s = ws->bufs[AQC_BUF_W];
+        a.out = pr.vy;
+        a.s_virtual = 0; a.out_virtual = 1;
+        a.staged = 1;   // (proj_plan: address bits 0..3 are among the summed ones)
+        a.keep_bits = pr.t; a.k_bits = pr.us;
+        const unsigned* off_us = pr.d_tab + (1u << pr.t);
+        a.y_keep = ProjMap{pr.d_tab, 0};
+        a.y_k = ProjMap{off_us, 0};
+        a.s_k = ProjMap{off_us, 0};
+        a.s_c = ProjMap{a.off_cb, 0};
+        a.o_keep = ProjMap{nullptr, 0};
+        a.o_c = ProjMap{nullptr, pr.t};
         ProfScope ps(ws, AQC_K_PROJECT);
         HIP_OK(launch_project(a, ws->stream));
     }

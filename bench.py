@@ -915,7 +915,9 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
             elems = float(sw_items) * 2.0 ** (proj["touched_qubits"] + proj["summed_bits"])
             flops = 8.0 * elems * cols
             nbytes = 16.0 * elems
-            rows.append({"kernel": f"project_kernel<{max(1, min(4, cols // 16))}>", "plan": "projection of z onto the lhs subspace", "stage": None, "substages": None,
+            wide = proj["touched_qubits"] >= 8
+            nb = 1 if proj["shared_with_first_stage"] <= 4 else (2 if wide or proj["shared_with_first_stage"] == 5 else 4)
+            rows.append({"kernel": "project_staged_kernel", "plan": "projection of z onto the lhs subspace", "stage": None, "substages": None,
                          "last_substage_r_only": False, "tiles_frac": None, "avg_ms": avg[j], "flops": flops, "flops_not_issued_zero_w": 0.0,
                          "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
                          "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0,

@@ -313,6 +313,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     ws->lazy_z_enabled = env_int("AQC_LAZY_Z", 1) != 0;
     ws->r_only_enabled = env_int("AQC_R_ONLY_LAST", 1) != 0;
     ws->r_only_max_subs = env_int("AQC_R_ONLY_MAX_SUBS", 12);
+    ws->proj_vdag_enabled = env_int("AQC_PROJECTED_VDAG", 1) != 0;
     ws->skipw_enabled = env_int("AQC_SKIP_ZERO_W", 0) != 0;   // (measured slower than multiplying the zeros: opt-in, see sweep_mfma_kernel)
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {
         const std::string err = check_plan(prog, p->plan);
@@ -379,6 +380,10 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
                     if (p == &ws->inv && ws->ujobs_mirror) continue;
                     UJob j{p->d_subs3 + i, p->d_grps, p->d_umat, (int)i, (int)p->h_subs3.size(), p->plan.inverse ? 1 : 0, prog.entangler, nullptr, 0, 0};
                     if (p == &ws->sweep && ws->ujobs_mirror) { j.umat_mirror = ws->inv.d_umat; j.mirror_index = nsw - 1 - (int)i; j.mirror_nsubs = nsw; }
+                    if (p == vsw) {   // the virtual plan walked backwards takes its operands from the same jobs
+                        const int nvs = (int)vsw->h_subs3.size();
+                        j.umat_mirror = ws->proj.vinv.d_umat; j.mirror_index = nvs - 1 - (int)i; j.mirror_nsubs = nvs;
+                    }
                     jobs.push_back(j);
                 }
         if (!jobs.empty()) {
@@ -724,6 +729,7 @@ int aqc_ws_gather_setup(aqc_ws* ws, const int64_t* index, int count) {
     HIP_OK(hipMemcpyAsync(ws->d_index, elem.data(), sizeof(long long) * count, hipMemcpyHostToDevice, ws->stream));
     HIP_OK(hipStreamSynchronize(ws->stream));
     ws->gather_count = count;
+    ws->h_gather = elem;
     ++ws->gather_gen;
     return 0;
 }

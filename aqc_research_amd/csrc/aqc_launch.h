@@ -125,6 +125,7 @@ struct ProjArgs {
     int batch;
 };
 hipError_t launch_project_init(const ProjArgs& a, hipStream_t s);
+hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, hipStream_t s);
 hipError_t launch_project(const ProjArgs& a, hipStream_t s);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
     const DevSub3* sub;

@@ -60,14 +60,14 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
 #pragma unroll
             for (int q = 0; q < RB; ++q) { re[q][p] = double4_t{0.0, 0.0, 0.0, 0.0}; im[q][p] = re[q][p]; }
         }
+        unsigned ylow[4], slow[4];   // offset of k = offset of its block of 16 + offset of its low four bits (disjoint address bits, or a shift)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { ylow[jj] = pj_off(a.y_k, (unsigned)(4 * kg + jj)); slow[jj] = pj_off(a.s_k, (unsigned)(4 * kg + jj)); }
         for (int kb = 0; kb < nkb; ++kb) {
+            const unsigned yb = pj_off(a.y_k, (unsigned)kb * 16u), sb = pj_off(a.s_k, (unsigned)kb * 16u);
             unsigned yo[4], so[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const unsigned k = (unsigned)(kb * 16 + 4 * kg + jj);
-                yo[jj] = pj_off(a.y_k, k);
-                so[jj] = pj_off(a.s_k, k);
-            }
+            for (int jj = 0; jj < 4; ++jj) { yo[jj] = yb + ylow[jj]; so[jj] = sb + slow[jj]; }
             cplx zv[RB][4], pv[NB][4];
 #pragma unroll
             for (int q = 0; q < RB; ++q)
@@ -230,6 +230,39 @@ __global__ __launch_bounds__(256) void project_init_kernel(const ProjArgs a) {
 hipError_t launch_project_init(const ProjArgs& a, hipStream_t s) {
     if (a.batch < 1 || !a.vm || !a.vitems || !a.vcount || !a.vlane_parts) return hipErrorInvalidValue;
     project_init_kernel<<<dim3((unsigned)(2 * a.batch)), 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// Amplitudes <g|V^H y> of gather indices g that lie OUTSIDE the lane's first-stage tile but share its index on the first stage's local
+// bits (flip states on the other bits): with the virtual z, Y_0 = (later stages)^H proj(y), of an lhs state that is ONE basis state with
+// coefficient 1,  <g|V^H y> = sum_c Y_0[(c on the shared bits, g on the touched bits outside the first stage), c].
+__global__ __launch_bounds__(64) void project_amps_kernel(const ProjArgs a, const long long* gather, int ngather, const long long* supp, double2* small,
+                                                          const double2* vy) {
+    const int b = blockIdx.x;
+    const long long e = supp[2 * (size_t)b];
+    if (e < 0) return;
+    unsigned fmask = 0;
+    for (int i = 0; i < a.nub0; ++i) fmask |= 1u << a.ubits0[i];
+    const cplx* y0 = vy + (((size_t)b * 2) << a.nvp);
+    const int ncb = 1 << a.cb;
+    for (int i = threadIdx.x; i < ngather; i += 64) {
+        const unsigned g = (unsigned)gather[i];
+        if ((((unsigned)e ^ g) & fmask) == 0) continue;   // inside the lane's tile: the gather has read it from Z
+        double re = 0.0, im = 0.0;
+        for (int c = 0; c < ncb; ++c) {
+            const unsigned want = a.off_cb[c] | (g & a.tf_mask);   // the T bits of the entry: shared ones = c, the others = g's
+            unsigned i_t = 0;
+            for (int j = 0; j < a.t; ++j)
+                if (want & a.off_t[1u << j]) i_t |= 1u << j;
+            const cplx v = y0[i_t + ((size_t)c << a.t)];
+            re += v.x; im += v.y;
+        }
+        small[(size_t)b * ngather + i] = make_double2(re, im);
+    }
+}
+hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, hipStream_t s) {
+    if (!gather || ngather < 1 || !supp || !small || !vy) return hipErrorInvalidValue;
+    project_amps_kernel<<<dim3((unsigned)a.batch), 64, 0, s>>>(a, gather, ngather, supp, static_cast<double2*>(small), static_cast<const double2*>(vy));
     return hipGetLastError();
 }
 

@@ -75,8 +75,11 @@ struct ProjRoute {
     Program vprog;                 // the gate groups of the dense stages on virtual qubits (group indices, thetas, slots: the real ones)
     std::vector<int> rest;         // their indices, in execution order
     DevPlan vsw;                   // sweep plan of the virtual register
-    double2* vm = nullptr;         // [batch][2][2^nvp]
-    double2* vy = nullptr;
+    DevPlan vinv;                  // ... walked backwards (the objective's V^H by projection: Y_0 = (later stages)^H proj(y))
+    double2* vm = nullptr;         // [batch][2][2^nvp]: the virtual lhs pattern M_0 ...
+    double2* vy = nullptr;         // ... the virtual z ...
+    double2* vme = nullptr;        // ... and M after the later stages' gates (objective by projection)
+    unsigned l0_mask = 0;          // address bits local to the first stage
     unsigned* d_tab = nullptr;     // off_t | off_usblk | off_cb
     std::vector<unsigned> h_tab;
     unsigned ff_mask = 0, cb_mask = 0, tf_mask = 0;
@@ -218,6 +221,12 @@ struct aqc_ws {
     int z_x_buf = -1;                       // ... and the support of this lhs buffer at this version
     unsigned long long z_x_version = 0;
     aqc::ProjRoute proj;                    // dense stages of the sparse route on a virtual register (AQC_PROJECTED=0: off)
+    bool proj_vdag_enabled = true;          // AQC_PROJECTED_VDAG=0: V^H of a one-call evaluation always by its stages
+    bool proj_y0_ready = false;             // the virtual z (proj.vy) holds Y_0 for the sweep that follows in the same call (run_vdag_projected)
+    bool z_from_y = false;                  // a partial Z without a checkpoint: completed by a full V^H from Y (thetas and Y unchanged since)
+    std::vector<long long> h_gather;        // host copy of the registered gather indices (elements)
+    unsigned long long projb_key[3] = {~0ull, ~0ull, ~0ull};   // (lhs buffer, its support version, gather_gen) the verdict below was taken for
+    bool projb_ok = false;
     bool profile = false;
     int64_t prof_count[AQC_NUM_KINDS] = {};
     double prof_ms[AQC_NUM_KINDS] = {};
@@ -277,5 +286,9 @@ void proj_free(aqc_ws* ws);
 bool sweep_route_projected(const aqc_ws* ws, bool sparse);
 int run_projected_stages(aqc_ws* ws);       // projection + the virtual stage launches (after the sweep's first stage)
 int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_layer);
+bool vdag_route_projected(aqc_ws* ws, int x_buf);   // the objective's V^H by two passes over y instead of its stages (host-known single basis state)
+int run_vdag_projected(aqc_ws* ws, int x_buf);      // Y -> Z on the lhs tiles, the virtual z for the sweep that follows
+int proj_fix_amplitudes(aqc_ws* ws, int x_buf);     // after the gather: the amplitudes outside the lhs tiles, from the virtual z
+int ensure_sweep_items(aqc_ws* ws, int x_buf);      // aqc_ws_sweep.cpp: the first-stage item list of the sparse sweep, rebuilt when the support changed
 
 }  // namespace aqc

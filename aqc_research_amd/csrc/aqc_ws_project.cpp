@@ -80,11 +80,15 @@ void proj_plan(aqc_ws* ws, int low_bits) {
     }
     lower_plan(pr.vprog, best, pr.vsw, 4, true, true);
     if (!pr.vsw.v3 || !check_plan(pr.vprog, pr.vsw.plan, &pr.rest).empty()) return;
-    for (DevStage& ds : pr.vsw.h_stages) {   // one more non-local bit: the item (first or second tile of the lane's lhs state)
-        if (ds.nub >= 32) return;
-        ds.ubits[ds.nub++] = pr.nvp;
-        ds.ntiles *= 2;
-    }
+    lower_plan(pr.vprog, mirror_plan(pr.vsw.plan), pr.vinv, 4, false, true, true);
+    if (!pr.vinv.v3 || pr.vinv.h_subs3.size() != pr.vsw.h_subs3.size()) return;
+    for (DevPlan* q : {&pr.vsw, &pr.vinv})
+        for (DevStage& ds : q->h_stages) {   // one more non-local bit: the item (first or second tile of the lane's lhs state)
+            if (ds.nub >= 32) return;
+            ds.ubits[ds.nub++] = pr.nvp;
+            ds.ntiles *= 2;
+        }
+    pr.l0_mask = (unsigned)L0;
     pr.ff_mask = (unsigned)(F & ~T);
     pr.cb_mask = (unsigned)Cb;
     pr.tf_mask = (unsigned)(T & F);
@@ -103,15 +107,18 @@ int proj_alloc(aqc_ws* ws) {
     ProjRoute& pr = ws->proj;
     if (!pr.ok) return 0;
     const size_t B = (size_t)ws->batch;
-    if (upload_plan(pr.vsw)) return 1;
+    if (upload_plan(pr.vsw) || upload_plan(pr.vinv)) return 1;
     const size_t nsubs = std::max<size_t>(pr.vsw.h_subs3.size(), 1);
     HIP_OK(hipMalloc((void**)&pr.vsw.d_umat, sizeof(double) * B * nsubs * 12 * 64));
+    HIP_OK(hipMalloc((void**)&pr.vinv.d_umat, sizeof(double) * B * nsubs * 12 * 64));
     HIP_OK(hipMalloc((void**)&pr.vsw.d_rpart, sizeof(double2) * B * nsubs * (2 * (size_t)pr.ntiles_v) * 256));
     const size_t vbytes = sizeof(double2) * B * (2ull << pr.nvp);
     HIP_OK(hipMalloc((void**)&pr.vm, vbytes));
     HIP_OK(hipMalloc((void**)&pr.vy, vbytes));
     HIP_OK(hipMemsetAsync(pr.vm, 0, vbytes, ws->stream));   // (entries beyond 2^nv -- a register padded to 8 qubits -- stay zero for good)
     HIP_OK(hipMemsetAsync(pr.vy, 0, vbytes, ws->stream));
+    HIP_OK(hipMalloc((void**)&pr.vme, vbytes));
+    HIP_OK(hipMemsetAsync(pr.vme, 0, vbytes, ws->stream));
     HIP_OK(hipMalloc((void**)&pr.d_tab, sizeof(unsigned) * pr.h_tab.size()));
     HIP_OK(hipMemcpy(pr.d_tab, pr.h_tab.data(), sizeof(unsigned) * pr.h_tab.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc((void**)&pr.d_items, sizeof(TileItem) * 2 * B * pr.ntiles_v));
@@ -124,13 +131,16 @@ int proj_alloc(aqc_ws* ws) {
 
 void proj_free(aqc_ws* ws) {
     ProjRoute& pr = ws->proj;
-    DevPlan& v = pr.vsw;
-    for (void* q : {(void*)v.d_stages, (void*)v.d_ops, (void*)v.d_subs, (void*)v.d_mops, (void*)v.d_subs3, (void*)v.d_grps, (void*)v.d_umat,
-                    (void*)v.d_rpart, (void*)pr.vm, (void*)pr.vy, (void*)pr.d_tab, (void*)pr.d_items, (void*)pr.d_count, (void*)pr.d_lane_parts})
+    for (DevPlan* vp : {&pr.vsw, &pr.vinv}) {
+        DevPlan& v = *vp;
+        for (void* q : {(void*)v.d_stages, (void*)v.d_ops, (void*)v.d_subs, (void*)v.d_mops, (void*)v.d_subs3, (void*)v.d_grps, (void*)v.d_umat, (void*)v.d_rpart})
+            if (q) (void)hipFree(q);
+        v.d_stages = nullptr; v.d_ops = nullptr; v.d_subs = nullptr; v.d_mops = nullptr; v.d_subs3 = nullptr; v.d_grps = nullptr;
+        v.d_umat = nullptr; v.d_rpart = nullptr;
+    }
+    for (void* q : {(void*)pr.vm, (void*)pr.vy, (void*)pr.vme, (void*)pr.d_tab, (void*)pr.d_items, (void*)pr.d_count, (void*)pr.d_lane_parts})
         if (q) (void)hipFree(q);
-    v.d_stages = nullptr; v.d_ops = nullptr; v.d_subs = nullptr; v.d_mops = nullptr; v.d_subs3 = nullptr; v.d_grps = nullptr;
-    v.d_umat = nullptr; v.d_rpart = nullptr;
-    pr.vm = pr.vy = nullptr; pr.d_tab = nullptr; pr.d_items = nullptr; pr.d_count = nullptr; pr.d_lane_parts = nullptr;
+    pr.vm = pr.vy = pr.vme = nullptr; pr.d_tab = nullptr; pr.d_items = nullptr; pr.d_count = nullptr; pr.d_lane_parts = nullptr;
     pr.ok = false;
 }
 
@@ -163,7 +173,9 @@ static ProjArgs proj_args(aqc_ws* ws) {
 int run_projected_stages(aqc_ws* ws) {
     ProjRoute& pr = ws->proj;
     DevPlan& v = pr.vsw;
-    {
+    if (ws->proj_y0_ready) {   // run_vdag_projected of this call has left M_0 and Y_0 (from the target) on the virtual register
+        ws->proj_y0_ready = false;
+    } else {
         ProjArgs a = proj_args(ws);
         {
             ProfScope ps(ws, AQC_K_MISC);
@@ -220,6 +232,151 @@ int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_laye
     HIP_OK(launch_rgrad(v.d_subs3, v.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), v.d_rpart, ntiles, nsubs, ws->d_partial, ws->nslots,
                         block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads,
                         ws->mirror_grads, GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr}, ntiles, 0, nsubs, pr.d_lane_parts, -1, v.d_umat));
+    return 0;
+}
+
+// ---- the objective's V^H by projection ------------------------------------------------------------------------------------------
+// One-call evaluations whose lhs state is ONE basis state per lane with coefficient 1, known to the host (aqc_ws_set_basis), and
+// whose gather indices lie in the lane's first-stage tile or differ from the basis index only on the other bits (the flip states
+// of the surrogate objectives): nothing of Z = V^H y is read outside the lhs tile, so the stages of V^H are not run at all.
+//     C[tile e][u, c] = sum_{i_T} conj(M_end[i_T, c]) y[u, i_T]      M_end = (later stages' gates) M_0: the tile of (later stages)^H y
+//     Y_end[i_T, c]   = sum_u conj(psi[u, c]) y[u, i_T]              psi = (first stage's gates)|e_L0>:  Y_0 = (later stages)^H Y_end
+// -- two passes over y (the target is read twice, V^H's first stage read and wrote the whole state and ran 4 sub-stages over it) --,
+// then V^H's last stage on the lhs tile alone (Z there), the sweep's first stage as ever, the virtual stages from (M_0, Y_0), and
+// <g|V^H y> = sum_c Y_0[(c, g on T n F), c] for the gather indices outside the tile.
+bool vdag_route_projected(aqc_ws* ws, int x_buf) {
+    ProjRoute& pr = ws->proj;
+    if (!pr.ok || !ws->proj_vdag_enabled || ws->capturing) return false;
+    const unsigned long long key[3] = {(unsigned long long)x_buf, ws->supp_version[x_buf], ws->gather_gen};
+    if (key[0] == ws->projb_key[0] && key[1] == ws->projb_key[1] && key[2] == ws->projb_key[2]) return ws->projb_ok;
+    for (int i = 0; i < 3; ++i) ws->projb_key[i] = key[i];
+    ws->projb_ok = false;
+    const std::vector<long long>& el = ws->combo_last_elem[x_buf];
+    const std::vector<double>& cf = ws->combo_last_coef[x_buf];
+    const size_t B = (size_t)ws->batch;
+    if (el.size() != 2 * B || cf.size() != 4 * B || (ws->gather_count > 0 && ws->h_gather.size() != (size_t)ws->gather_count)) return false;
+    const unsigned fmask = ~pr.l0_mask & (unsigned)((1ull << ws->ctx->prog.n) - 1);
+    for (size_t b = 0; b < B; ++b) {
+        if (el[2 * b] < 0 || el[2 * b + 1] >= 0 || cf[4 * b] != 1.0 || cf[4 * b + 1] != 0.0) return false;
+        const unsigned e = (unsigned)el[2 * b];
+        for (long long gl : ws->h_gather) {
+            const unsigned d = e ^ (unsigned)gl;
+            if ((d & fmask) == 0) continue;                                // inside the lane's tile
+            if ((d & pr.l0_mask) != 0 || (d & pr.ff_mask) != 0) return false;   // another psi, or another slice of y
+        }
+    }
+    ws->projb_ok = true;
+    return true;
+}
+
+static int virtual_apply(aqc_ws* ws, DevPlan& v, const double2* src, double2* dst) {
+    ProjRoute& pr = ws->proj;
+    const size_t m = v.h_stages.size();
+    const int ntiles = 2 * pr.ntiles_v;
+    for (size_t s = 0; s < m; ++s) {
+        Stage3Args a;
+        memset(&a, 0, sizeof a);
+        a.stage = v.h_stages[s];
+        a.subs = v.d_subs3;
+        a.umat = v.d_umat;
+        a.nsubs_total = (int)v.h_subs3.size();
+        a.lane_stride = 2ull << pr.nvp;
+        a.ntiles = ntiles;
+        a.batch = ws->batch;
+        a.in0 = s == 0 ? src : dst;
+        a.out0 = dst;
+        a.items = pr.d_items; a.nitems = pr.d_count; a.max_items = 2 * ws->batch * pr.ntiles_v;
+        ProfScope ps(ws, AQC_K_SWEEP_VIRTUAL);
+        HIP_OK(launch_apply3(ntiles, ws->batch, pr.kv, ws->stream, a));
+    }
+    return 0;
+}
+
+int run_vdag_projected(aqc_ws* ws, int x_buf) {   // the caller has asked vdag_route_projected, sweep_sparse_prepare
+    ProjRoute& pr = ws->proj;
+    DevPlan& p = ws->sweep;
+    if (ensure_umat(ws, ws->inv)) return 1;
+    if (!ws->d_sw_items || !ws->w_clean) return fail("objective by projection without the sparse route's preparation");
+    if (ensure_sweep_items(ws, x_buf)) return 1;
+    {   // psi: the first stage's gates on the basis index, on the listed tiles (x -> W)
+        Stage3Args a;
+        memset(&a, 0, sizeof a);
+        a.stage = p.h_stages[0];
+        a.subs = p.d_subs3;
+        a.umat = p.d_umat;
+        a.nsubs_total = (int)p.h_subs3.size();
+        a.lane_stride = ws->lane_elems;
+        a.ntiles = p.ntiles;
+        a.batch = ws->batch;
+        a.in0 = ws->bufs[x_buf];
+        a.out0 = ws->bufs[AQC_BUF_W];
+        a.items = ws->d_sw_items; a.nitems = ws->d_sw_counts; a.max_items = 2 * ws->batch;
+        ProfScope ps(ws, AQC_K_APPLY_LIST);
+        HIP_OK(launch_apply3(p.ntiles, ws->batch, p.k, ws->stream, a));
+    }
+    ProjArgs a = proj_args(ws);
+    {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_project_init(a, ws->stream));
+    }
+    if (virtual_apply(ws, pr.vsw, pr.vm, pr.vme)) return 1;   // M_end
+    const unsigned* off_us = pr.d_tab + (1u << pr.t);
+    {   // Y_end = proj(y)
+        ProjArgs q = a;
+        q.y = ws->bufs[AQC_BUF_Y]; q.s = ws->bufs[AQC_BUF_W]; q.out = pr.vy;
+        q.s_virtual = 0; q.out_virtual = 1; q.staged = 1;
+        q.keep_bits = pr.t; q.k_bits = pr.us;
+        q.y_keep = ProjMap{pr.d_tab, 0}; q.y_k = ProjMap{off_us, 0};
+        q.s_k = ProjMap{off_us, 0}; q.s_c = ProjMap{a.off_cb, 0};
+        q.o_keep = ProjMap{nullptr, 0}; q.o_c = ProjMap{nullptr, pr.t};
+        ProfScope ps(ws, AQC_K_PROJECT);
+        HIP_OK(launch_project(q, ws->stream));
+    }
+    {   // the lhs tile of (later stages)^H y, into ZW
+        ProjArgs q = a;
+        q.y = ws->bufs[AQC_BUF_Y]; q.s = pr.vme; q.out = ws->bufs[AQC_BUF_ZW];
+        q.s_virtual = 1; q.out_virtual = 0; q.staged = 0;
+        q.keep_bits = pr.us; q.k_bits = pr.t;
+        q.y_keep = ProjMap{off_us, 0}; q.y_k = ProjMap{pr.d_tab, 0};
+        q.s_k = ProjMap{nullptr, 0}; q.s_c = ProjMap{nullptr, pr.t};
+        q.o_keep = ProjMap{off_us, 0}; q.o_c = ProjMap{a.off_cb, 0};
+        ProfScope ps(ws, AQC_K_PROJECT);
+        HIP_OK(launch_project(q, ws->stream));
+    }
+    if (virtual_apply(ws, pr.vinv, pr.vy, pr.vy)) return 1;   // Y_0
+    {   // V^H's last stage on the lhs tiles: ZW -> Z
+        DevPlan& iv = ws->inv;
+        Stage3Args s3;
+        memset(&s3, 0, sizeof s3);
+        s3.stage = iv.h_stages.back();
+        s3.subs = iv.d_subs3;
+        s3.umat = iv.d_umat;
+        s3.nsubs_total = (int)iv.h_subs3.size();
+        s3.lane_stride = ws->lane_elems;
+        s3.ntiles = iv.ntiles;
+        s3.batch = ws->batch;
+        s3.in0 = ws->bufs[AQC_BUF_ZW];
+        s3.out0 = ws->bufs[AQC_BUF_Z];
+        s3.items = ws->d_sw_items; s3.nitems = ws->d_sw_counts; s3.max_items = 2 * ws->batch;
+        ProfScope ps(ws, AQC_K_APPLY_LIST);
+        HIP_OK(launch_apply3(iv.ntiles, ws->batch, iv.k, ws->stream, s3));
+    }
+    vdag_restricted_state_after(ws, x_buf);
+    ws->ckpt_valid = false;         // ZW holds the lhs tiles of the checkpoint only
+    ws->z_gather_gen = ~0ull;       // Z covers the lhs tiles, not the gather set: a later gather completes it first
+    ws->z_from_y = true;
+    ws->proj_y0_ready = true;
+    return 0;
+}
+
+// the registered gather of a Z that run_vdag_projected has left: the indices inside the lhs tiles from Z, the others from the virtual z
+int proj_fix_amplitudes(aqc_ws* ws, int x_buf) {
+    ProjRoute& pr = ws->proj;
+    if (results_guard(ws)) return 1;
+    ProfScope ps(ws, AQC_K_MISC);
+    HIP_OK(launch_gather(ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream, nullptr));
+    ProjArgs a = proj_args(ws);
+    HIP_OK(launch_project_amps(a, ws->d_index, ws->gather_count, ws->d_combo_prev[x_buf], ws->d_small, pr.vy, ws->stream));
     return 0;
 }
 

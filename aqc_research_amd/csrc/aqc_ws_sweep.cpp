@@ -50,6 +50,8 @@ int run_coef(aqc_ws* ws) {
     ws->fwd.u_valid = ws->inv.u_valid = ws->sweep.u_valid = false;
     ws->coef_valid = true;
     ws->ckpt_valid = false;   // ZW (and Z) belong to the previous thetas
+    ws->z_from_y = false;
+    ws->proj_y0_ready = false;
     if (ws->fwd.v3 && ws->inv.v3 && ws->sweep.v3 && !ws->need_coef) return 0;   // the matrix-core path reads the thetas directly
     ProfScope ps(ws, AQC_K_COEF);
     HIP_OK(launch_coef(ws->d_thetas, ws->d_coef, prog.n, prog.num_blocks, prog.tpb, prog.tail_blocks, ws->batch, ws->stream));
@@ -60,6 +62,8 @@ int run_coef(aqc_ws* ws) {
 void touch_buf(aqc_ws* ws, int buf) {
     if (buf == AQC_BUF_ZW && !ws->z_full) (void)ensure_z_full(ws, false);   // the checkpoint goes away: complete Z while it is there
     if (buf == AQC_BUF_Z || buf == AQC_BUF_ZW) ws->ckpt_valid = false;
+    if (buf == AQC_BUF_Y || buf == AQC_BUF_Z) ws->z_from_y = false;
+    ws->proj_y0_ready = false;
     if (buf == AQC_BUF_Z) ws->z_full = true;
     if (buf == AQC_BUF_W) ws->w_clean = false;
 }
@@ -273,6 +277,10 @@ int ensure_z_full(aqc_ws* ws, bool reader) {
         return 0;
     }
     if (!reader) { ws->z_full = true; return 0; }   // a writer of parts of Z takes the buffer over
+    if (ws->z_from_y && ws->inv.u_valid) {   // (objective by projection: no checkpoint -- the whole V^H once more, from Y)
+        ws->z_full = true;
+        return run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+    }
     return fail("BUF_Z holds V^H y only on the tiles the last one-call evaluation read, and the thetas (or ZW) have changed since: "
                 "run aqc_ws_apply(inverse) for the whole vector");
 }
@@ -289,7 +297,7 @@ bool sweep_route_sparse(const aqc_ws* ws, int x_buf, bool will_vdag) {
     const DevPlan& p = ws->sweep;
     if (!ws->sparse_enabled || !p.v3 || !ws->inv_mirrored || p.h_stages.size() < 2) return false;
     if (!ws->combo_valid[x_buf] || !ws->d_combo_prev[x_buf]) return false;          // support of the lhs state known on the device
-    if (!(will_vdag ? keeps_checkpoint(ws, true, AQC_BUF_Y, AQC_BUF_Z) : ws->ckpt_valid)) return false;   // z of stage 1 available in ZW
+    if (!(will_vdag ? keeps_checkpoint(ws, true, AQC_BUF_Y, AQC_BUF_Z) : (ws->ckpt_valid || ws->proj_y0_ready))) return false;   // z of stage 1 available in ZW (or projected already)
     return (long)p.ntiles * ws->batch >= ws->sparse_min_items;   // (fewer items than CUs: a stage takes one item's time either way)
 }
 // The last sub-stage of the last stage is taken from its inputs alone (R = U (Z W^H) U^H, see sweep_mfma_kernel) unless it is also the
@@ -376,6 +384,22 @@ int aqc_ws_grad_from(aqc_ws* ws, int x_buf, int block_from, int block_to, int fr
 
 namespace aqc {
 
+// tiles of the first stage that hold the lhs state: a device-side list (the support may have been chosen on the device),
+// rebuilt when the support changed; tiles of the previous list that the new one drops are zeroed in W
+int ensure_sweep_items(aqc_ws* ws, int x_buf) {
+    const DevPlan& p = ws->sweep;
+    if (ws->capturing || ws->sw_items_buf != x_buf || ws->sw_items_version != ws->supp_version[x_buf]) {
+        ProfScope ps(ws, AQC_K_MISC);
+        HIP_OK(launch_tile_items(p.h_stages[0], ws->d_combo_prev[x_buf], 2, nullptr, 0, ws->batch, ws->d_sw_items, ws->d_sw_counts,
+                                 ws->d_sw_lane_parts, ws->d_sw_prev_tiles, ws->d_sw_clear, ws->d_sw_counts + 1, ws->stream));
+        HIP_OK(launch_clear_tiles(p.h_stages[0], ws->bufs[AQC_BUF_W], ws->lane_elems, ws->d_sw_clear, ws->d_sw_counts + 1, 2 * ws->batch, ws->stream));
+        ws->sw_items_buf = x_buf;
+        ws->sw_items_version = ws->supp_version[x_buf];
+        ws->sw_lists_built |= 1;
+    }
+    return 0;
+}
+
 // support_in_gather_set: the lhs state was chosen on the device among the registered gather indices (surrogate objective)
 int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int front_layer, bool support_in_gather_set) {
     if (check_buf(ws, x_buf)) return 1;
@@ -404,17 +428,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         if (sparse) {
             if (!ws->capturing && sweep_sparse_prepare(ws)) return 1;
             if (!ws->d_sw_items || !ws->w_clean || (m >= 3 && !ws->w2 && !projected)) return fail("sparse sweep inside a captured graph without its preparation");
-            // tiles of the first stage that hold the lhs state: a device-side list (the support may have been chosen on the device),
-            // rebuilt when the support changed; tiles of the previous list that the new one drops are zeroed in W
-            if (ws->capturing || ws->sw_items_buf != x_buf || ws->sw_items_version != ws->supp_version[x_buf]) {
-                ProfScope ps(ws, AQC_K_MISC);
-                HIP_OK(launch_tile_items(p.h_stages[0], ws->d_combo_prev[x_buf], 2, nullptr, 0, ws->batch, ws->d_sw_items, ws->d_sw_counts,
-                                         ws->d_sw_lane_parts, ws->d_sw_prev_tiles, ws->d_sw_clear, ws->d_sw_counts + 1, ws->stream));
-                HIP_OK(launch_clear_tiles(p.h_stages[0], ws->bufs[AQC_BUF_W], ws->lane_elems, ws->d_sw_clear, ws->d_sw_counts + 1, 2 * ws->batch, ws->stream));
-                ws->sw_items_buf = x_buf;
-                ws->sw_items_version = ws->supp_version[x_buf];
-                ws->sw_lists_built |= 1;
-            }
+            if (ensure_sweep_items(ws, x_buf)) return 1;
         }
         for (size_t s = 0; s < (projected ? 1 : m); ++s) {
             Stage3Args a = stage3_args(ws, p, s);
@@ -525,9 +539,12 @@ int aqc_ws_objective_launch(aqc_ws* ws, int x_buf, int block_from, int block_to,
     HIP_OK(hipSetDevice(ws->device));
     const bool sparse = sweep_route_sparse(ws, x_buf, true);
     if (sparse && sweep_sparse_prepare(ws)) return 1;
-    if (sparse && vdag_route_restricted(ws, x_buf)) { if (run_vdag_restricted(ws, x_buf)) return 1; }
+    const bool lazy = sparse && vdag_route_restricted(ws, x_buf);
+    const bool by_projection = lazy && vdag_route_projected(ws, x_buf);
+    if (by_projection) { if (run_vdag_projected(ws, x_buf)) return 1; }
+    else if (lazy) { if (run_vdag_restricted(ws, x_buf)) return 1; }
     else if (run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)) return 1;
-    if (ws->gather_count > 0 && aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+    if (ws->gather_count > 0 && (by_projection ? proj_fix_amplitudes(ws, x_buf) : aqc_ws_gather_launch(ws, AQC_BUF_Z))) return 1;
     return grad_from_impl(ws, x_buf, block_from, block_to, front_layer, false);
 }
 
@@ -566,6 +583,8 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     const bool sparse = grads && (do_vdag ? sweep_route_sparse(ws, x_buf, true) : (!thetas && sweep_route_sparse(ws, x_buf, false)));
     if (sparse && sweep_sparse_prepare(ws)) return 1;
     const bool lazy = sparse && do_vdag && vdag_route_restricted(ws, x_buf);   // V^H only where this call (gather, sweep) reads it
+    // ... and by two passes over y instead of its stages where the lhs state and the gather set allow (never with a riding gather)
+    const bool by_projection = lazy && grads && !(gathered && zero_copy && ws->sweep.v3) && vdag_route_projected(ws, x_buf);
     if (!do_vdag && (gathered || grads) && ensure_z_full(ws, true)) return 1;  // a partial Z left by an earlier call is completed here,
                                                                               // outside whatever graph is captured below
     auto enqueue = [&]() -> int {   // everything between the host copy of the thetas and the final synchronisation
@@ -579,12 +598,12 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
             if (run_coef(ws)) return 1;
             ws->theta_host = direct_thetas ? pin_th : nullptr;
         }
-        if (do_vdag && (lazy ? run_vdag_restricted(ws, x_buf) : run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z))) return 1;
+        if (do_vdag && (by_projection ? run_vdag_projected(ws, x_buf) : (lazy ? run_vdag_restricted(ws, x_buf) : run_apply(ws, true, AQC_BUF_Y, AQC_BUF_Z)))) return 1;
         // with a gradient in the same call the gather (it only reads Z, which the sweep leaves intact) rides along as one
         // extra workgroup per lane of the gradient-walk kernel: one node less on the single-evaluation critical path
         const bool ride = gathered && grads && zero_copy && ws->sweep.v3;
         if (gathered && !ride) {
-            if (aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
+            if (by_projection ? proj_fix_amplitudes(ws, x_buf) : aqc_ws_gather_launch(ws, AQC_BUF_Z)) return 1;
             if (!zero_copy) HIP_OK(hipMemcpyAsync(pin_sm, ws->d_small, sizeof(double2) * nsm, hipMemcpyDeviceToHost, ws->stream));
         }
         ws->gather_rides = ride;
@@ -601,7 +620,7 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
     if (thetas && graphs_on && !ws->profile) {
         const std::vector<long long> key = {do_vdag, gathered ? 1 : 0, grads ? 1 : 0, x_buf, block_from, block_to, front_layer,
                                             (long long)ws->gather_count, (long long)(size_t)ws->d_small, (long long)(size_t)ws->h_pin,
-                                            (sparse ? 1 : 0) + (lazy ? 2 : 0) + (grads && sweep_skips_zero_w(ws, x_buf) ? 4 : 0),
+                                            (sparse ? 1 : 0) + (lazy ? 2 : 0) + (grads && sweep_skips_zero_w(ws, x_buf) ? 4 : 0) + (by_projection ? 8 : 0),
                                             (long long)(size_t)ws->d_combo_prev[x_buf],
                                             (long long)(size_t)ws->d_vd_items};
         auto it = ws->graphs.find(key);
@@ -627,7 +646,10 @@ int aqc_ws_eval(aqc_ws* ws, const double* thetas, int do_vdag, double* gathered,
         ws->fwd.u_valid = false;
         ws->inv.u_valid = ws->sweep.u_valid = (do_vdag || grads) && ws->inv.v3 && ws->sweep.v3;
         ws->ckpt_valid = false;
-        if (do_vdag) { if (lazy) vdag_restricted_state_after(ws, x_buf); else apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z); }
+        if (do_vdag) {
+            if (lazy) vdag_restricted_state_after(ws, x_buf); else apply_state_after(ws, true, AQC_BUF_Y, AQC_BUF_Z);
+            if (by_projection) { ws->ckpt_valid = false; ws->z_from_y = true; ws->z_gather_gen = ~0ull; }   // (what run_vdag_projected leaves)
+        }
         if (grads) sweep_state_after(ws, sparse, true);
         HIP_OK(hipGraphLaunch(it->second, ws->stream));
     } else if (enqueue()) {

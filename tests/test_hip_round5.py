@@ -470,6 +470,67 @@ def test_projected_route_through_the_one_call_evaluations(monkeypatch):
             assert maxdiff(out["1"][i][1][b], orc.grad_of_dot_product(circ, th[b], x, vh)) < TOL
 
 
+@pytest.mark.parametrize("n,depth,case", [(16, 40, "zero"), (16, 40, "shifted"), (14, 40, "zero"), (18, 40, "shifted")])
+def test_objective_by_projection_equals_the_stages_of_vdag(n, depth, case, monkeypatch):
+    """One-call evaluations from ONE basis state per lane (set_basis) whose gather set stays in the lane's first-stage tile or flips
+    bits outside it: V^H's stages are replaced by two passes over the target (AQC_PROJECTED_VDAG, csrc/aqc_ws_project.cpp).  Same
+    amplitudes and gradient as with the stages (AQC_PROJECTED_VDAG=0) and as the oracle, through aqc_ws_objective_launch and
+    aqc_ws_eval (graph replays); Z, partial afterwards, is completed from Y when somebody reads it."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(900 + n)
+    circ = _circ(n, "cx", depth=depth)
+    B = 40
+    T = circ.num_thetas
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    ths = [np.stack([orc.rand_thetas(T, rng) for _ in range(B)]) for _ in range(2)]
+    hi = n - 12
+    if case == "zero":
+        basis = np.zeros(B, dtype=np.int64)
+        gather = np.array([0] + [1 << q for q in range(n)], dtype=np.int64)
+    else:   # the same index on the first stage's bits, different ones above; the gather set moves above only
+        basis = np.array([5 | ((b * 7) % (1 << hi)) << 12 for b in range(B)], dtype=np.int64)
+        gather = np.array([5 | (f << 12) for f in sorted({0, 1, 2, (1 << hi) - 1, 1 << (hi - 1)})] + [5 ^ 1, 5 ^ 8], dtype=np.int64)[:5]
+    from aqc_research_amd._lib import K_PROJECT
+
+    out, passes = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AQC_PROJECTED_VDAG", mode)
+        ws = _ws(circ, B, monkeypatch, sparse=True, tile=12)
+        assert ws.projected_info()
+        ws.upload(BUF_Y, tg)
+        ws.set_basis(BUF_X, basis)
+        ws.gather_setup(gather)
+        got = []
+        for th in ths:   # aqc_ws_eval: thetas in, amplitudes and gradient out
+            hs, g = ws.eval(th, vdag=True, gather=True, grad=True, x_buf=BUF_X, block_range=(0, circ.num_blocks), front_layer=True)
+            got.append((hs.copy(), g.copy()))
+        for th in ths:   # the driver's form: thetas resident, launches only
+            ws.set_thetas(th)
+            ws.objective_launch(BUF_X)
+            got.append((ws.gather_fetch().copy(), ws.get_grads().copy()))
+        z_after = ws.download(BUF_Z)   # (a reader of Z: completed first)
+        ws.profile(True)               # which route ran: passes over a full-size state per evaluation (2 = by projection, 1 = checkpoint only)
+        ws.set_thetas(ths[0])
+        ws.objective_launch(BUF_X)
+        ws.sync()
+        passes[mode] = ws.profile_get(K_PROJECT)[0]
+        ws.profile(False)
+        out[mode] = (got, z_after)
+        ws.close()
+    assert passes == {"1": 2, "0": 1}
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert maxdiff(a[0], b[0]) < 1e-13 and maxdiff(a[1], b[1]) < 1e-13
+    for i, th in enumerate(ths + ths):
+        for b in range(0, B, 9):
+            vh = orc.v_dagger_mul_vec(circ, th[b], tg[b])
+            x = np.zeros(1 << n, complex); x[basis[b]] = 1.0
+            assert maxdiff(out["1"][0][i][0][b], vh[gather]) < TOL
+            assert maxdiff(out["1"][0][i][1][b], orc.grad_of_dot_product(circ, th[b], x, vh)) < TOL
+    for b in (0, B - 1):
+        assert maxdiff(out["1"][1][b], orc.v_dagger_mul_vec(circ, ths[-1][b], tg[b])) < TOL
+
+
 class _Op:
     def __init__(self, name, params=()):
         self.name, self.params = name, list(params)

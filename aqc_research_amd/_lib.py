@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AQC_HIP_LIB", os.path.join(_HERE, "libaqc_hip.so"))
 
 BUF_Y, BUF_Z, BUF_X, BUF_W, BUF_ZW, BUF_X2 = range(6)
-K_APPLY, K_SWEEP, K_COEF, K_FINALIZE, K_MISC, K_SWEEP_LIST, K_APPLY_LIST, K_PROJECT, K_SWEEP_VIRTUAL = range(9)
+K_APPLY, K_SWEEP, K_COEF, K_FINALIZE, K_MISC, K_SWEEP_LIST, K_APPLY_LIST, K_PROJECT, K_SWEEP_VIRTUAL, K_APPLY_VIRTUAL = range(10)
 ENTANGLERS = {"cx": 0, "cz": 1, "cp": 2}
 
 _P = c_void_p

@@ -286,7 +286,7 @@ static int virtual_apply(aqc_ws* ws, DevPlan& v, const double2* src, double2* ds
         a.in0 = s == 0 ? src : dst;
         a.out0 = dst;
         a.items = pr.d_items; a.nitems = pr.d_count; a.max_items = 2 * ws->batch * pr.ntiles_v;
-        ProfScope ps(ws, AQC_K_SWEEP_VIRTUAL);
+        ProfScope ps(ws, AQC_K_APPLY_VIRTUAL);
         HIP_OK(launch_apply3(ntiles, ws->batch, pr.kv, ws->stream, a));
     }
     return 0;

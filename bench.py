@@ -896,7 +896,7 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
     """Per stage launch of one step (matrix-core path): kernel, plan stage, sub-stages, share of the tiles it ran over, average
     duration (HIP events around every launch of `prof_steps` steps), EXECUTED MFMA flops (288 per amplitude and sub-stage for
     the sweep: 9 real 16x16x16 products per 256 amplitudes; 96 for V^H) and their rate.  None off the matrix-core path."""
-    from aqc_research_amd._lib import K_APPLY, K_APPLY_LIST, K_PROJECT, K_SWEEP, K_SWEEP_LIST, K_SWEEP_VIRTUAL
+    from aqc_research_amd._lib import K_APPLY, K_APPLY_LIST, K_APPLY_VIRTUAL, K_PROJECT, K_SWEEP, K_SWEEP_LIST, K_SWEEP_VIRTUAL
 
     if ws.kernel_family(1) != 3 or ws.kernel_family(0) != 3 or not prof_log or len(prof_log) % prof_steps:
         return None
@@ -908,30 +908,53 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
     sw_items, _, vd_items = ws.sparse_counts()
     rows, at = [], {0: 0, 1: 0}
     proj = ws.projected_info()   # the sweep's stages after the first on a virtual register (csrc/aqc_ws_project.cpp), or {}
-    vstage = 0
+    by_projection = bool(proj) and kinds.count(K_PROJECT) == 2   # ... and V^H of the evaluation as two passes over the target (same file)
+    vstage = vapply = nproj = napply_list = 0
+
+    def mfma_row(kernel, plan, stage, nsub, tiles_frac, ms, flops, **extra):
+        row = {"kernel": kernel, "plan": plan, "stage": stage, "substages": nsub, "last_substage_r_only": False, "tiles_frac": tiles_frac, "avg_ms": ms,
+               "flops": flops, "flops_not_issued_zero_w": 0.0, "TFLOPs": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+               "frac_of_peak": flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ms > 0 else 0.0}
+        row.update(extra)
+        return row
+
     for j, k in enumerate(kinds):
-        if k == K_PROJECT and proj:   # one pass over z (the checkpoint of V^H): 2^(touched + summed bits) elements per item, memory-bound
+        if k == K_PROJECT and proj:   # one pass over z (the checkpoint of V^H) or over the target: 2^(touched + summed bits) elements per item, memory-bound
             cols = 16 * max(1, (1 << proj["shared_with_first_stage"]) // 16)
             elems = float(sw_items) * 2.0 ** (proj["touched_qubits"] + proj["summed_bits"])
             flops = 8.0 * elems * cols
             nbytes = 16.0 * elems
-            wide = proj["touched_qubits"] >= 8
-            nb = 1 if proj["shared_with_first_stage"] <= 4 else (2 if wide or proj["shared_with_first_stage"] == 5 else 4)
-            rows.append({"kernel": "project_staged_kernel", "plan": "projection of z onto the lhs subspace", "stage": None, "substages": None,
-                         "last_substage_r_only": False, "tiles_frac": None, "avg_ms": avg[j], "flops": flops, "flops_not_issued_zero_w": 0.0,
-                         "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
-                         "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0,
-                         "bound": "hbm", "bytes_read": nbytes, "GBps": nbytes / (avg[j] * 1e-3) / 1e9 if avg[j] > 0 else 0.0,
-                         "frac_of_hbm_peak": nbytes / (avg[j] * 1e-3) / 1e9 / HBM_PEAK_GBS if avg[j] > 0 else 0.0})
+            second = by_projection and nproj == 1
+            rows.append(mfma_row("project_kernel<4, 1>" if second else "project_staged_kernel",
+                                 ("lhs tile of (later stages)^H y: sum over the touched qubits" if second else
+                                  ("projection of the target onto the lhs subspace" if by_projection else "projection of z onto the lhs subspace")),
+                                 None, None, None, avg[j], flops, bound="hbm", bytes_read=nbytes, GBps=nbytes / (avg[j] * 1e-3) / 1e9 if avg[j] > 0 else 0.0,
+                                 frac_of_hbm_peak=nbytes / (avg[j] * 1e-3) / 1e9 / HBM_PEAK_GBS if avg[j] > 0 else 0.0))
+            nproj += 1
             continue
-        if k == K_SWEEP_VIRTUAL and proj:
-            nsub = proj["substages_per_stage"][vstage] if vstage < len(proj["substages_per_stage"]) else 0
-            flops = 288.0 * float(sw_items) * 2.0 ** proj["padded_qubits"] * nsub
-            rows.append({"kernel": f"sweep_mfma_kernel<{proj['tile_bits']}, true, false, false>", "plan": f"sweep, stages after the first on {proj['virtual_qubits']} virtual qubits",
-                         "stage": vstage, "substages": nsub, "last_substage_r_only": False, "tiles_frac": None, "avg_ms": avg[j], "flops": flops,
-                         "flops_not_issued_zero_w": 0.0, "TFLOPs": flops / (avg[j] * 1e-3) / 1e12 if avg[j] > 0 else 0.0,
-                         "frac_of_peak": flops / (avg[j] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if avg[j] > 0 else 0.0})
-            vstage += 1
+        if k in (K_SWEEP_VIRTUAL, K_APPLY_VIRTUAL) and proj:
+            sweep_kind = k == K_SWEEP_VIRTUAL
+            per = proj["substages_per_stage"]
+            if sweep_kind:
+                st_v = vstage
+                vstage += 1
+            else:   # the virtual plan forwards (M_end), then backwards (Y_0)
+                st_v = vapply if vapply < len(per) else 2 * len(per) - 1 - vapply
+                vapply += 1
+            nsub = per[st_v] if 0 <= st_v < len(per) else 0
+            flops = (288.0 if sweep_kind else 96.0) * float(sw_items) * 2.0 ** proj["padded_qubits"] * nsub
+            name = f"sweep_mfma_kernel<{proj['tile_bits']}, true, false, false>" if sweep_kind else f"apply_mfma_kernel<{proj['tile_bits']}, true>"
+            what = (f"sweep, stages after the first on {proj['virtual_qubits']} virtual qubits" if sweep_kind else
+                    (f"virtual lhs pattern through the later stages' gates" if vapply <= len(per) else "virtual z: (later stages)^H of the projection"))
+            rows.append(mfma_row(name, what, st_v, nsub, None, avg[j], flops))
+            continue
+        if k == K_APPLY_LIST and by_projection:   # first: psi (the sweep's first stage applied to the lhs tiles); second: V^H's last stage on them
+            stages, tile_bits, ntiles = ws.plan_info(1)
+            nsub = ws.plan_stage(1, 0)[0]
+            frac = sw_items / float(ntiles * B)
+            rows.append(mfma_row(f"apply_mfma_kernel<{tile_bits}, true>", "first stage's gates on the lhs tiles (psi)" if napply_list == 0 else "V^H",
+                                 0 if napply_list == 0 else stages - 1, nsub, frac, avg[j], 96.0 * N * B * frac * nsub))
+            napply_list += 1
             continue
         if k not in (K_APPLY, K_APPLY_LIST, K_SWEEP, K_SWEEP_LIST):
             continue
@@ -975,8 +998,9 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
                     "route runs the sweep's first stage over the tiles that hold the lhs basis states and V^H's last stage over the "
                     "tiles the evaluation reads -- products with exact zeros and amplitudes nobody reads are not executed; with the projected "
                     "route (projected_route: csrc/aqc_ws_project.cpp) the sweep's stages after the first run on a virtual register of "
-                    "`virtual_qubits` qubits per lane after one pass over z",
-            "projected_route": proj or None}
+                    "`virtual_qubits` qubits per lane after one pass over z; a one-call evaluation from one basis state replaces the stages of V^H "
+                    "by two passes over the target (objective_by_projection)",
+            "projected_route": proj or None, "objective_by_projection": by_projection}
 
 
 def main():
@@ -1122,7 +1146,7 @@ def measure(workload, args, env, full):
     the short configuration runs of the default line leave them out and use --config-steps steps."""
     comm, comm_note, rank, world, local_rank, n_gpus, ranks_seen = (env.comm, env.comm_note, env.rank, env.world, env.local_rank,
                                                                      env.n_gpus, env.ranks_seen)
-    from aqc_research_amd._lib import K_APPLY_LIST, K_PROJECT, K_SWEEP_LIST, K_SWEEP_VIRTUAL
+    from aqc_research_amd._lib import K_APPLY_LIST, K_APPLY_VIRTUAL, K_PROJECT, K_SWEEP_LIST, K_SWEEP_VIRTUAL
     from aqc_research_amd.engine import BUF_X, BUF_Y, BUF_Z, K_APPLY, K_COEF, K_FINALIZE, K_MISC, K_SWEEP, HipContext, Workspace
     from oracle import aqc_oracle as orc
 
@@ -1319,7 +1343,8 @@ def measure(workload, args, env, full):
             step(i)
         ws.sync()
         kinds = {"apply": K_APPLY, "sweep": K_SWEEP, "coef": K_COEF, "finalize": K_FINALIZE, "misc": K_MISC,
-                 "sweep_tile_list": K_SWEEP_LIST, "apply_tile_list": K_APPLY_LIST, "project": K_PROJECT, "sweep_virtual": K_SWEEP_VIRTUAL}
+                 "sweep_tile_list": K_SWEEP_LIST, "apply_tile_list": K_APPLY_LIST, "project": K_PROJECT, "sweep_virtual": K_SWEEP_VIRTUAL,
+                 "apply_virtual": K_APPLY_VIRTUAL}
         prof = {k: ws.profile_get(v) for k, v in kinds.items()}
         prof_log = ws.profile_log()
         ws.profile(False)

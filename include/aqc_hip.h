@@ -46,8 +46,9 @@ enum { AQC_BUF_Y = 0, AQC_BUF_Z = 1, AQC_BUF_X = 2, AQC_BUF_W = 3, AQC_BUF_ZW = 
 /* kernel families for aqc_ws_profile_get */
 enum { AQC_K_APPLY = 0, AQC_K_SWEEP = 1, AQC_K_COEF = 2, AQC_K_FINALIZE = 3, AQC_K_MISC = 4,
        AQC_K_SWEEP_LIST = 5, AQC_K_APPLY_LIST = 6,   /* stage launches over a subset of the tiles (sparse lhs state / objective V^H) */
-       AQC_K_PROJECT = 7, AQC_K_SWEEP_VIRTUAL = 8,   /* projected route: the pass over z, the sweep's later stages on the virtual register */
-       AQC_NUM_KINDS = 9 };
+       AQC_K_PROJECT = 7, AQC_K_SWEEP_VIRTUAL = 8,   /* projected route: a pass over z / the target, the sweep's later stages on the virtual register, */
+       AQC_K_APPLY_VIRTUAL = 9,                      /* their gates (or the inverses) applied to one virtual state (objective by projection) */
+       AQC_NUM_KINDS = 10 };
 
 const char* aqc_version(void);
 const char* aqc_last_error(void);

@@ -192,6 +192,7 @@ def test_objective_launch_leaves_partial_z_that_readers_complete(monkeypatch):
     n = 14
     circ = _circ(n, "cx", depth=26)
     B = 4
+    monkeypatch.setenv("AQC_PROJECTED_VDAG", "0")   # (V^H by its stages: by projection it is test_objective_by_projection_equals_the_stages_of_vdag)
     ws = _ws(circ, B, monkeypatch, tile=12)
     tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
     th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])

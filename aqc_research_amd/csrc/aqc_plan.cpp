@@ -267,7 +267,7 @@ std::vector<uint64_t> beam_substages_search(const std::vector<uint64_t>& op_bits
 
 }  // namespace
 
-void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops) {
+void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops, int beam_width) {
     for (Stage& st : plan.stages) {
         st.subs.clear();
         const int k = (int)st.bits.size();
@@ -281,7 +281,7 @@ void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops)
             Sim sim{prog, order, plan.col_bits, &local_of};
             std::vector<uint64_t> op_bits;
             for (int gi : order) op_bits.push_back(sim.group_bits(prog.groups[gi]));
-            chosen = beam_substages(op_bits, k, r, 64);
+            chosen = beam_substages(op_bits, k, r, beam_width);
         }
         size_t next_choice = 0;
         while (!order.empty()) {

@@ -69,7 +69,7 @@ Plan make_plan(const Program& prog, int col_bits, int tile_bits, int low_bits, b
 
 // Partitions every stage into sub-stages: each sub-stage touches at most `reg_bits` of the stage's
 // local bits (held in registers by one thread: 2^reg_bits amplitudes) and at most `max_ops` groups.
-void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops);
+void split_substages(const Program& prog, Plan& plan, int reg_bits, int max_ops, int beam_width = 64);   // beam_width: candidates kept per level of the sub-stage search
 
 // Throws nothing; returns "" if the plan executes every group exactly once, in an order
 // compatible with per-qubit program order, using only local bits.

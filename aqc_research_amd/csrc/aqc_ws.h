@@ -89,7 +89,7 @@ struct ProjRoute {
 };
 
 // aqc_ws_plan.cpp
-void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma = false, bool presplit = false);
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma = false, bool presplit = false, int beam_width = 64);
 int upload_plan(DevPlan& p);
 Plan mirror_plan(const Plan& plan);   // the same stages and sub-stages walked backwards: the plan of V^H whose intermediate states are the sweep's
 
@@ -222,6 +222,7 @@ struct aqc_ws {
     unsigned long long z_x_version = 0;
     aqc::ProjRoute proj;                    // dense stages of the sparse route on a virtual register (AQC_PROJECTED=0: off)
     bool proj_vdag_enabled = true;          // AQC_PROJECTED_VDAG=0: V^H of a one-call evaluation always by its stages
+    long long proj_vdag_min_elems = 1ll << 24;   // ... and from this many amplitudes per batch (fewer: its extra launches cost more than V^H's stages; AQC_PROJECTED_VDAG_MIN_ELEMS)
     bool proj_y0_ready = false;             // the virtual z (proj.vy) holds Y_0 for the sweep that follows in the same call (run_vdag_projected)
     bool z_from_y = false;                  // a partial Z without a checkpoint: completed by a full V^H from Y (thetas and Y unchanged since)
     std::vector<long long> h_gather;        // host copy of the registered gather indices (elements)

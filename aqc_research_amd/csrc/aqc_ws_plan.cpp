@@ -77,7 +77,7 @@ void emit_mops(const Program& prog, int gi, int pc, int pt, bool inverse, bool w
 
 }  // namespace
 
-void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma, bool presplit) {
+void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bits, bool with_dots, bool mfma, bool presplit, int beam_width) {
     out.plan = plan;
     out.h_stages.clear();
     out.h_ops.clear();
@@ -89,7 +89,7 @@ void lower_plan(const Program& prog, const Plan& plan, DevPlan& out, int reg_bit
     out.v3 = mfma && reg_bits == 4 && (int)plan.stages.front().bits.size() >= 8;
     out.v2 = !out.v3 && reg_bits > 0 && (int)plan.stages.front().bits.size() >= reg_bits;
     if (out.v3) {
-        if (!presplit) split_substages(prog, out.plan, 4, 1 << 30);   // a sub-stage is one 16 x 16 unitary: any number of groups
+        if (!presplit) split_substages(prog, out.plan, 4, 1 << 30, beam_width);   // a sub-stage is one 16 x 16 unitary: any number of groups
     } else if (out.v2) {
         int max_ops = reg_bits == 4 ? kMaxOpsPerSub : kMaxOpsPerSub / 2;
         if (prog.entangler == 2) max_ops /= 2;   // CP: two reductions per block

@@ -78,7 +78,8 @@ void proj_plan(aqc_ws* ws, int low_bits) {
         Plan cand = make_plan(pr.vprog, 0, pr.kv, lb, false, &pr.rest, pr.nvp);
         if (best.stages.empty() || cand.stages.size() < best.stages.size()) best = cand;
     }
-    lower_plan(pr.vprog, best, pr.vsw, 4, true, true);
+    // (a narrow sub-stage search: the virtual stages are a small share of an evaluation, planning them must not cost what planning the real ones does)
+    lower_plan(pr.vprog, best, pr.vsw, 4, true, true, false, env_int("AQC_PROJECTED_BEAM", 8));
     if (!pr.vsw.v3 || !check_plan(pr.vprog, pr.vsw.plan, &pr.rest).empty()) return;
     lower_plan(pr.vprog, mirror_plan(pr.vsw.plan), pr.vinv, 4, false, true, true);
     if (!pr.vinv.v3 || pr.vinv.h_subs3.size() != pr.vsw.h_subs3.size()) return;
@@ -246,7 +247,7 @@ int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_laye
 // <g|V^H y> = sum_c Y_0[(c, g on T n F), c] for the gather indices outside the tile.
 bool vdag_route_projected(aqc_ws* ws, int x_buf) {
     ProjRoute& pr = ws->proj;
-    if (!pr.ok || !ws->proj_vdag_enabled || ws->capturing) return false;
+    if (!pr.ok || !ws->proj_vdag_enabled || ws->capturing || (long long)ws->lane_elems * ws->batch < ws->proj_vdag_min_elems) return false;
     const unsigned long long key[3] = {(unsigned long long)x_buf, ws->supp_version[x_buf], ws->gather_gen};
     if (key[0] == ws->projb_key[0] && key[1] == ws->projb_key[1] && key[2] == ws->projb_key[2]) return ws->projb_ok;
     for (int i = 0; i < 3; ++i) ws->projb_key[i] = key[i];

@@ -495,6 +495,7 @@ def test_objective_by_projection_equals_the_stages_of_vdag(n, depth, case, monke
     from aqc_research_amd._lib import K_PROJECT
 
     out, passes = {}, {}
+    monkeypatch.setenv("AQC_PROJECTED_VDAG_MIN_ELEMS", "1")
     for mode in ("1", "0"):
         monkeypatch.setenv("AQC_PROJECTED_VDAG", mode)
         ws = _ws(circ, B, monkeypatch, sparse=True, tile=12)

@@ -26,6 +26,8 @@ def copy(src, dst):
 
 names = {"bench_default.json": "r05_sv16_l40_b1024_bench.json", "bench_b64.json": "r05_sv16_l40_b64_bench.json",
          "bench_dense_route.json": "r05_sv16_l40_b1024_bench_dense_route.json",
+         "bench_full_size_stages.json": "r05_sv16_l40_b1024_bench_sparse_route_full_size_stages.json",
+         "bench_vdag_by_stages.json": "r05_sv16_l40_b1024_bench_projected_sweep_vdag_by_stages.json",
          "bench_under_rocprof.json": "r05_sv16_l40_b1024_bench_under_rocprof.json",
          "bench_cfg4_driver.json": "r05_bench_cfg4_driver.json", "bench_cfg4_under_rocprof.json": "r05_cfg4_driver_bench_under_rocprof.json"}
 for name, tag in names.items():
@@ -43,9 +45,11 @@ if have("pmc_f", "f_counter_collection.csv") and have("pmc_w", "w_counter_collec
     d = json.load(open(out))
     d["date"] = today
     d["source"] = ("builder-run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/prof_run5.py (the bench's evaluation: objective_launch on "
-                   "the sparse route), tools/refresh_profiles_r05.sh; at this workload every kernel name is ONE stage launch: apply<12, false> = V^H "
-                   "stage 0 (all tiles), apply<12, true> = V^H stage 1 over the evaluation's tiles, sweep<12, true> = sweep stage 0 over the lhs "
-                   "tiles, sweep<12, false> = sweep stage 1 (all tiles)")
+                   "the sparse route, objective by projection), tools/refresh_profiles_r05.sh; per kernel NAME, mean over its launches: "
+                   "project_staged_kernel = the projection of the target (one launch per evaluation), project_kernel<4, 1> = the lhs tile of "
+                   "(later stages)^H y (one launch), apply<12, true> = four launches (psi, the virtual pattern forwards, the virtual z backwards, "
+                   "V^H's last stage on the lhs tiles), sweep<12, true> = two (first stage on the lhs tiles, virtual stage); AQC_PROJECTED=0 "
+                   "gives the names of the full-size route: apply<12, false> = V^H stage 0, sweep<12, false, false, true> = sweep stage 1")
     json.dump(d, open(out, "w"), indent=1)
     shutil.copyfile(out, os.path.join(DST, "pmc_traffic.json"))
     print("wrote pmc traffic")
@@ -54,7 +58,7 @@ sq = [os.path.join(SRC, d, "s_counter_collection.csv") for d in ("sq1", "sq2", "
 if sq:
     txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_summary.py")] + sq, check=True, capture_output=True, text=True).stdout
     with open(os.path.join(DST, "r05_sq_counters.txt"), "w") as f:
-        f.write("# rocprofv3 --pmc passes of tools/prof_run5.py (16 qubits, 40 blocks, 1024 lanes, sparse route; mean per launch), " + today + "\n")
+        f.write("# rocprofv3 --pmc passes of tools/prof_run5.py (16 qubits, 40 blocks, 1024 lanes, sparse + projected route, objective by projection; mean per launch of a kernel name), " + today + "\n")
         f.write("# SIMD-cycles of a launch = duration x clock x 1024 SIMDs; GRBM_GUI_ACTIVE / 8 XCDs / duration = the clock the launch really ran at\n")
         f.write(txt)
     print("wrote sq counters")

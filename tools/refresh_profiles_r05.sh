@@ -14,6 +14,8 @@ bench)
   python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err     # the driver's command: headline + every config
   python bench.py --batch 64 --no-configs --no-cpu-baseline --no-objective-object > $O/bench_b64.json 2> $O/bench_b64.err
   AQC_SPARSE_SWEEP=0 python bench.py --no-configs --no-cpu-baseline --no-objective-object --no-latency > $O/bench_dense_route.json 2> $O/bench_dense_route.err
+  AQC_PROJECTED=0 python bench.py --no-configs --no-cpu-baseline --no-objective-object --no-latency > $O/bench_full_size_stages.json 2> $O/bench_full_size_stages.err
+  AQC_PROJECTED_VDAG=0 python bench.py --no-configs --no-cpu-baseline --no-objective-object --no-latency > $O/bench_vdag_by_stages.json 2> $O/bench_vdag_by_stages.err
   echo "bench done" ;;
 trace)
   rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --no-configs --no-cpu-baseline --no-latency --no-objective-object --sustain-seconds 0 > $O/bench_under_rocprof.json 2> $O/kt.err

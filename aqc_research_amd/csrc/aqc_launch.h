@@ -117,6 +117,7 @@ struct ProjArgs {
     // project_init_kernel: the virtual lhs pattern and the bookkeeping of the virtual stage launches
     const unsigned* off_t;   // [2^t]: element offset of the value i of the T bits;  [2^cb]: of the value c of the bits shared with the first stage
     const unsigned* off_cb;
+    const unsigned* it_of_c; // [2^cb]: index on the T bits whose shared bits hold c (the others 0)
     int t, ntiles_v;
     double2* vm;             // [batch][2][2^nvp]
     TileItem* vitems;        // items of the virtual stage launches: (lane, slot ntiles_v + tile, the same as partial slot)

@@ -109,21 +109,23 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
 // The same product when the summed index k runs along contiguous memory of BOTH operands (the projection: k = the low address bits) and
 // `keep` / c do not: a lane of the matrix-core layout would then fetch 16 bytes of a row of its own -- 64 separate 64-byte sectors per
 // wave instruction, which is what the L1 can look up, not what the memory delivers.  Here a wave fetches its 16 x 16 block of Y and of S
-// as 256-byte runs (lane = 4 rows x 16 consecutive k), hands them through a private LDS tile (rows padded to 17 elements) and reads them
-// back in the operand layout; the next block's loads are in flight while the 16 MFMAs of this one run.  No workgroup barrier.
+// as 256-byte runs (lane = 4 rows x 16 consecutive k), hands them through LDS tiles (rows padded to 17 elements) and reads them
+// back in the operand layout; the next block's loads are in flight while the 16 MFMAs of this one run.
 constexpr int kPjRow = 17;   // elements per LDS row
+// (S -- the same 16 x 16 block for the four waves of a workgroup -- is fetched once per workgroup, a quarter by each wave, into a
+// shared tile that is double-buffered over the blocks of k: one workgroup barrier per block.)
 __global__ __launch_bounds__(256) void project_staged_kernel(const ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pj_smem[];
     const int item = blockIdx.y;
-    if (item >= *a.nitems) return;
+    if (item >= *a.nitems) return;   // (uniform over the workgroup: before any barrier)
     const TileItem it = a.items[item];
     const size_t ebits = pj_tile_bits(a, it.tile);
     const int nkeep = 1 << a.keep_bits, ncb = 1 << a.cb, nkb = 1 << (a.k_bits - 4);
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kg = l >> 4;
     const int rb = blockIdx.x * 4 + wave;
-    if (rb * 16 >= nkeep) return;
-    cplx* zt = reinterpret_cast<cplx*>(pj_smem) + (size_t)wave * (2 * 16 * kPjRow);
-    cplx* pt = zt + 16 * kPjRow;
+    const bool active = rb * 16 < nkeep;   // (a wave without rows still fetches its quarter of S and meets the barriers)
+    cplx* zt = reinterpret_cast<cplx*>(pj_smem) + (size_t)wave * (16 * kPjRow);
+    cplx* pt = reinterpret_cast<cplx*>(pj_smem) + 4 * (16 * kPjRow);   // [2][16][kPjRow]
     const size_t vbase = ((size_t)it.lane * 2 + it.slot) << a.nvp;
     const size_t real_base = (size_t)it.lane * a.lane_stride;
     const cplx* ybase = a.y + real_base + (ebits & a.ff_mask) + r16;
@@ -131,36 +133,34 @@ __global__ __launch_bounds__(256) void project_staged_kernel(const ProjArgs a) {
     cplx* obase = a.out + (a.out_virtual ? vbase : real_base + ebits);
     unsigned zoff[4];   // rows 4 j + kg of the wave's block of Y
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zoff[j] = pj_off(a.y_keep, (unsigned)(rb * 16 + 4 * j + kg));
+    for (int j = 0; j < 4; ++j) zoff[j] = active ? pj_off(a.y_keep, (unsigned)(rb * 16 + 4 * j + kg)) : 0u;
     for (int nb = 0; nb * 16 < ncb; ++nb) {
-        unsigned poff[4];
-        bool pvalid[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = nb * 16 + 4 * j + kg;
-            pvalid[j] = c < ncb;
-            poff[j] = pvalid[j] ? pj_off(a.s_c, (unsigned)c) : 0u;
-        }
+        const int c_mine = nb * 16 + 4 * wave + kg;   // the row of S this lane fetches
+        const bool pvalid = c_mine < ncb;
+        const unsigned poff = pvalid ? pj_off(a.s_c, (unsigned)c_mine) : 0u;
         double4_t re = {0.0, 0.0, 0.0, 0.0}, im = re;
-        cplx zc[4], pc[4], zn[4], pn[4];
+        cplx zc[4], zn[4], pc, pn;
         {
             const unsigned yb = pj_off(a.y_k, 0u), sb = pj_off(a.s_k, 0u);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { zc[j] = pj_stream(ybase + zoff[j] + yb); pc[j] = pvalid[j] ? sbase[poff[j] + sb] : make_double2(0.0, 0.0); }
+            for (int j = 0; j < 4; ++j) zc[j] = active ? pj_stream(ybase + zoff[j] + yb) : make_double2(0.0, 0.0);
+            pc = pvalid ? sbase[poff + sb] : make_double2(0.0, 0.0);
         }
         for (int kb = 0; kb < nkb; ++kb) {
             if (kb + 1 < nkb) {
                 const unsigned yb = pj_off(a.y_k, (unsigned)(kb + 1) * 16u), sb = pj_off(a.s_k, (unsigned)(kb + 1) * 16u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { zn[j] = pj_stream(ybase + zoff[j] + yb); pn[j] = pvalid[j] ? sbase[poff[j] + sb] : make_double2(0.0, 0.0); }
+                for (int j = 0; j < 4; ++j) zn[j] = active ? pj_stream(ybase + zoff[j] + yb) : make_double2(0.0, 0.0);
+                pn = pvalid ? sbase[poff + sb] : make_double2(0.0, 0.0);
             }
+            cplx* ptb = pt + (kb & 1) * (16 * kPjRow);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { zt[(4 * j + kg) * kPjRow + r16] = zc[j]; pt[(4 * j + kg) * kPjRow + r16] = pc[j]; }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < 4; ++j) zt[(4 * j + kg) * kPjRow + r16] = zc[j];
+            ptb[(4 * wave + kg) * kPjRow + r16] = pc;
+            __syncthreads();   // S of this block is complete (its buffer is written again two blocks on, behind the next barrier)
             cplx zv[4], pv[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { zv[jj] = zt[r16 * kPjRow + 4 * kg + jj]; pv[jj] = pt[r16 * kPjRow + 4 * kg + jj]; }
+            for (int jj = 0; jj < 4; ++jj) { zv[jj] = zt[r16 * kPjRow + 4 * kg + jj]; pv[jj] = ptb[r16 * kPjRow + 4 * kg + jj]; }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {   // conj(s) y = (sr yr + si yi) + i (sr yi - si yr)
                 re = pj_mfma(pv[jj].x, zv[jj].x, re);
@@ -168,16 +168,18 @@ __global__ __launch_bounds__(256) void project_staged_kernel(const ProjArgs a) {
                 im = pj_mfma(pv[jj].x, zv[jj].y, im);
                 im = pj_mfma(-pv[jj].y, zv[jj].x, im);
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { zc[j] = zn[j]; pc[j] = pn[j]; }
+            for (int j = 0; j < 4; ++j) zc[j] = zn[j];
+            pc = pn;
         }
-        cplx* orow = obase + pj_off(a.o_keep, (unsigned)(rb * 16 + r16));
+        __syncthreads();   // (the next block of columns starts with buffer 0 again)
+        if (active) {
+            cplx* orow = obase + pj_off(a.o_keep, (unsigned)(rb * 16 + r16));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = nb * 16 + kg + 4 * r;
-            if (c < ncb) orow[pj_off(a.o_c, (unsigned)c)] = make_double2(re[r], im[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int c = nb * 16 + kg + 4 * r;
+                if (c < ncb) orow[pj_off(a.o_c, (unsigned)c)] = make_double2(re[r], im[r]);
+            }
         }
     }
 }
@@ -186,7 +188,7 @@ hipError_t launch_project(const ProjArgs& a, hipStream_t s) {
     if (a.staged) {   // (the host has checked: the low four bits of k are address bits 0..3 of both operands)
         if (a.keep_bits < 4 || a.k_bits < 4 || a.cb < 0 || a.cb > 12 || a.batch < 1 || !a.y || !a.s || !a.out) return hipErrorInvalidValue;
         const int blocks = 1 << (a.keep_bits - 4);
-        project_staged_kernel<<<dim3((unsigned)((blocks + 3) / 4), (unsigned)(2 * a.batch)), 256, 4 * 2 * 16 * kPjRow * sizeof(cplx), s>>>(a);
+        project_staged_kernel<<<dim3((unsigned)((blocks + 3) / 4), (unsigned)(2 * a.batch)), 256, 6 * 16 * kPjRow * sizeof(cplx), s>>>(a);
         return hipGetLastError();
     }
     if (a.keep_bits < 4 || a.k_bits < 4 || a.cb < 0 || a.cb > 12 || a.batch < 1 || !a.y || !a.s || !a.out) return hipErrorInvalidValue;
@@ -248,13 +250,12 @@ __global__ __launch_bounds__(64) void project_amps_kernel(const ProjArgs a, cons
     for (int i = threadIdx.x; i < ngather; i += 64) {
         const unsigned g = (unsigned)gather[i];
         if ((((unsigned)e ^ g) & fmask) == 0) continue;   // inside the lane's tile: the gather has read it from Z
+        unsigned it_g = 0;   // the entry's index on the touched bits outside the first stage: g's
+        for (int j = 0; j < a.t; ++j)
+            if (g & a.tf_mask & a.off_t[1u << j]) it_g |= 1u << j;
         double re = 0.0, im = 0.0;
-        for (int c = 0; c < ncb; ++c) {
-            const unsigned want = a.off_cb[c] | (g & a.tf_mask);   // the T bits of the entry: shared ones = c, the others = g's
-            unsigned i_t = 0;
-            for (int j = 0; j < a.t; ++j)
-                if (want & a.off_t[1u << j]) i_t |= 1u << j;
-            const cplx v = y0[i_t + ((size_t)c << a.t)];
+        for (int c = 0; c < ncb; ++c) {   // ... and on the shared ones: c (it_of_c: the T index with those bits = c, the others 0)
+            const cplx v = y0[(a.it_of_c[c] | it_g) + ((size_t)c << a.t)];
             re += v.x; im += v.y;
         }
         small[(size_t)b * ngather + i] = make_double2(re, im);

@@ -97,6 +97,13 @@ void proj_plan(aqc_ws* ws, int low_bits) {
     for (unsigned i = 0; i < (1u << pr.t); ++i) pr.h_tab.push_back(deposit_bits(i, tbits));
     for (unsigned k = 0; k < (1u << pr.us); ++k) pr.h_tab.push_back(deposit_bits(k, usbits));
     for (unsigned c = 0; c < (1u << pr.cb); ++c) pr.h_tab.push_back(deposit_bits(c, cbits));
+    for (unsigned c = 0; c < (1u << pr.cb); ++c) {   // the same as an index on the T bits
+        const unsigned addr = deposit_bits(c, cbits);
+        unsigned it = 0;
+        for (size_t j = 0; j < tbits.size(); ++j)
+            if (addr >> tbits[j] & 1) it |= 1u << j;
+        pr.h_tab.push_back(it);
+    }
     pr.ok = true;
     if (env_int("AQC_VERBOSE", 0))
         fprintf(stderr, "aqc_hip: projected route: the sweep's stages after the first run on %d virtual qubits (%d touched, %d shared with the first "
@@ -163,6 +170,7 @@ static ProjArgs proj_args(aqc_ws* ws) {
     a.nvp = pr.nvp;
     a.off_t = pr.d_tab;
     a.off_cb = pr.d_tab + (1u << pr.t) + (1u << pr.us);
+    a.it_of_c = a.off_cb + (1u << pr.cb);
     a.t = pr.t; a.cb = pr.cb; a.ntiles_v = pr.ntiles_v;
     a.vm = pr.vm;
     a.vitems = pr.d_items; a.vcount = pr.d_count; a.vlane_parts = pr.d_lane_parts;

@@ -22,7 +22,7 @@ def main(fetch_csv, write_csv, out_json, workload, batch):
     out = {"workload": workload, "batch_per_gpu": int(batch), "unit": "bytes per launch",
            "correction": "FETCH_SIZE x 2 (gfx950 wide coalesced reads), KiB -> bytes", "kernels": {}}
     for k in f:
-        if "stage_kernel" not in k and "mfma_kernel" not in k:
+        if "stage_kernel" not in k and "mfma_kernel" not in k and "project_" not in k:
             continue
         short = k.split("(")[0].replace("void ", "")
         out["kernels"][short] = {

@@ -118,6 +118,8 @@ struct ProjArgs {
     const unsigned* off_t;   // [2^t]: element offset of the value i of the T bits;  [2^cb]: of the value c of the bits shared with the first stage
     const unsigned* off_cb;
     const unsigned* it_of_c; // [2^cb]: index on the T bits whose shared bits hold c (the others 0)
+    const unsigned* off_us;  // [2^us]: element offset of the value u of the first stage's local bits outside T
+    int us_bits;
     int t, ntiles_v;
     double2* vm;             // [batch][2][2^nvp]
     TileItem* vitems;        // items of the virtual stage launches: (lane, slot ntiles_v + tile, the same as partial slot)
@@ -126,6 +128,7 @@ struct ProjArgs {
     int batch;
 };
 hipError_t launch_project_init(const ProjArgs& a, hipStream_t s);
+hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile, void* yout, hipStream_t s);   // both products of the objective by projection, one fetch of y
 hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, hipStream_t s);
 hipError_t launch_project(const ProjArgs& a, hipStream_t s);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages

@@ -7,6 +7,8 @@
 // A (2^cb x 2^nk) by (2^nk x 2^nkeep) complex product per item on the fp64 matrix cores; Y is read once, which is what a launch costs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "aqc_launch.h"
 
 namespace aqc {
@@ -232,6 +234,177 @@ __global__ __launch_bounds__(256) void project_init_kernel(const ProjArgs a) {
 hipError_t launch_project_init(const ProjArgs& a, hipStream_t s) {
     if (a.batch < 1 || !a.vm || !a.vitems || !a.vcount || !a.vlane_parts) return hipErrorInvalidValue;
     project_init_kernel<<<dim3((unsigned)(2 * a.batch)), 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---- both products of the objective by projection from ONE fetch of the target --------------------------------------------------
+//     C[u, c]   = sum_{i_T} conj(M_end[i_T, c]) y[i_T, u]      (the lhs tile of (later stages)^H y; keeps u, sums over i_T)
+//     Y[i_T, c] = sum_u     conj(psi[u, c])     y[i_T, u]      (the projection; keeps i_T, sums over u)
+// A workgroup = one item, wave w = the 64 values u in [64 w, 64 w + 64) (four blocks of 16), walking over the blocks of 16 values of
+// i_T.  The block of y a lane fetches (lane % 16 = u, 256-byte runs) IS the operand layout of the first product, whose sums complete
+// inside the wave (C accumulates in registers over the walk); for the second product the block is transposed through a wave-private
+// LDS tile, multiplied with the wave's 64 x 16 slice of psi (registers, fetched once), and the four waves' partial sums over u are added
+// in a fixed order through a double-buffered LDS tile -- one workgroup barrier per block of i_T.  Needs 2^us <= 256 and cb <= 4.
+// QB blocks of 16 values of u per wave, 16 / QB waves per workgroup (QB = 2: eight waves, two per SIMD -- the registers of a wave
+// with four blocks leave room for one).  Complex products in the three-multiplication form: with a = conj(s),
+//     re = sr yr + si yi = A1 + A2,   im = sr yi - si yr = A3 + A1 - A2,   A3 = sum (sr + si)(yi - yr)
+// -- three MFMAs per K-step instead of four, the two extra sums are a handful of vector adds per block.
+template <int QB>
+__global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const ProjArgs a, const double2* __restrict__ mend, double2* __restrict__ ctile,
+                                                                          double2* __restrict__ yout) {
+    constexpr int NW = 16 / QB;
+    constexpr int PB = QB >= 2 ? 2 : 1;          // blocks transposed at a time (tiles per wave)
+    constexpr bool kRedDouble = QB >= 2;         // (sixteen waves: one reduction tile and a second barrier -- two would not fit the LDS)
+    extern __shared__ __attribute__((aligned(16))) char pj_smem[];
+    const int item = blockIdx.x;
+    if (item >= *a.nitems) return;   // (uniform over the workgroup: before any barrier)
+    const TileItem it = a.items[item];
+    const size_t ebits = pj_tile_bits(a, it.tile);
+    const int nu = 1 << a.us_bits, ncb = 1 << a.cb, nkb = 1 << (a.t - 4);
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kg = l >> 4;
+    cplx* tile = reinterpret_cast<cplx*>(pj_smem) + (size_t)wave * (PB * 16 * kPjRow);   // transposition tiles of the wave
+    cplx* red = reinterpret_cast<cplx*>(pj_smem) + NW * (PB * 16 * kPjRow);              // [2 (or 1)][NW waves][256]
+    const size_t vbase = ((size_t)it.lane * 2 + it.slot) << a.nvp;
+    const size_t real_base = (size_t)it.lane * a.lane_stride;
+    const cplx* ybase = a.y + real_base + (ebits & a.ff_mask);
+    const cplx* wbase = a.s + real_base + ebits;          // psi: w after the first stage, on the item's tile
+    const cplx* mbase = mend + vbase;                     // M_end, virtual layout: i_T + (c << t)
+    const bool cvalid = r16 < ncb;
+    // this lane's slice of psi: A operand of the second product, rows c = r16, k = u = 16 (QB wave + q) + 4 kg + jj
+    cplx pa[QB][4];
+    double ps[QB][4];
+    unsigned yoff[QB];   // element offset of u = 16 (QB wave + q) + r16: the lane's column of y in block q
+    bool uvalid[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int ub = QB * wave + q;
+        uvalid[q] = ub * 16 < nu;
+        yoff[q] = uvalid[q] ? a.off_us[ub * 16 + r16] : 0u;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            pa[q][jj] = (uvalid[q] && cvalid) ? wbase[a.off_us[ub * 16 + 4 * kg + jj] + a.off_cb[r16]] : make_double2(0.0, 0.0);
+            ps[q][jj] = pa[q][jj].x + pa[q][jj].y;
+        }
+    }
+    double4_t c1[QB], c2[QB], c3[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) { c1[q] = double4_t{0.0, 0.0, 0.0, 0.0}; c2[q] = c1[q]; c3[q] = c1[q]; }
+    unsigned tlow[4];   // rows i_T = 16 kb + 4 kg + jj of y
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) tlow[jj] = a.off_t[4 * kg + jj];
+    cplx yv[QB][4];
+    {
+        const unsigned tb = a.off_t[0];
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) yv[q][jj] = uvalid[q] ? pj_stream(ybase + yoff[q] + tb + tlow[jj]) : make_double2(0.0, 0.0);
+    }
+    for (int kb = 0; kb < nkb; ++kb) {
+        // M_end rows i_T = 16 kb + 4 kg + jj, column c = r16: A operand of the first product
+        cplx ma[4];
+        double ms[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            ma[jj] = cvalid ? mbase[(size_t)(kb * 16 + 4 * kg + jj) + ((size_t)r16 << a.t)] : make_double2(0.0, 0.0);
+            ms[jj] = ma[jj].x + ma[jj].y;
+        }
+        double4_t y1 = {0.0, 0.0, 0.0, 0.0}, y2 = y1, y3 = y1;
+#pragma unroll
+        for (int h0 = 0; h0 < QB; h0 += PB) {
+#pragma unroll
+            for (int qq = 0; qq < PB; ++qq) {   // first product on the fetched layout; the block goes to its transposition tile
+                const int q = h0 + qq;
+                cplx* tq = tile + qq * (16 * kPjRow);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) tq[(4 * kg + jj) * kPjRow + r16] = yv[q][jj];   // [row = i_T in the block][col = u in the block]
+                double yd[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) yd[jj] = yv[q][jj].y - yv[q][jj].x;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    c1[q] = pj_mfma(ma[jj].x, yv[q][jj].x, c1[q]);
+                    c2[q] = pj_mfma(ma[jj].y, yv[q][jj].y, c2[q]);
+                    c3[q] = pj_mfma(ms[jj], yd[jj], c3[q]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (h0 + PB >= QB && kb + 1 < nkb) {   // the fetched block is consumed: the next one is requested under the second product
+                const unsigned tb = a.off_t[(kb + 1) * 16];
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) yv[q][jj] = uvalid[q] ? pj_stream(ybase + yoff[q] + tb + tlow[jj]) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int qq = 0; qq < PB; ++qq) {   // second product: B[k = u][col = i_T] = the tile read across
+                const int q = h0 + qq;
+                const cplx* tq = tile + qq * (16 * kPjRow);
+                cplx tr[4];
+                double td[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { tr[jj] = tq[r16 * kPjRow + 4 * kg + jj]; td[jj] = tr[jj].y - tr[jj].x; }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    y1 = pj_mfma(pa[q][jj].x, tr[jj].x, y1);
+                    y2 = pj_mfma(pa[q][jj].y, tr[jj].y, y2);
+                    y3 = pj_mfma(ps[q][jj], td[jj], y3);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // (the tiles are written again by the next pair of blocks)
+        }
+        // the waves' sums over their values of u, added in wave order: D[row = c = kg + 4 r][col = i_T in the block = r16]
+        cplx* rb = red + (kRedDouble ? (size_t)(kb & 1) * (NW * 256) : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rb[wave * 256 + (kg + 4 * r) * 16 + r16] = make_double2(y1[r] + y2[r], y3[r] + y1[r] - y2[r]);
+        __syncthreads();   // (this buffer is written again two blocks on, behind the next barrier)
+        if (threadIdx.x < 256) {
+            const int c = threadIdx.x >> 4, i_l = threadIdx.x & 15;
+            double re = 0.0, im = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const cplx v = rb[w * 256 + threadIdx.x]; re += v.x; im += v.y; }
+            if (c < ncb) yout[vbase + (size_t)(kb * 16 + i_l) + ((size_t)c << a.t)] = make_double2(re, im);
+        }
+        if (!kRedDouble) __syncthreads();
+    }
+    // C: D[row = c = kg + 4 r][col = u in the block = r16]
+    cplx* obase = ctile + real_base + ebits;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        if (!uvalid[q]) continue;
+        cplx* orow = obase + yoff[q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = kg + 4 * r;
+            if (c < ncb) orow[a.off_cb[c]] = make_double2(c1[q][r] + c2[q][r], c3[q][r] + c1[q][r] - c2[q][r]);
+        }
+    }
+}
+hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile, void* yout, hipStream_t s) {
+    if (a.t < 4 || a.us_bits < 4 || a.us_bits > 8 || a.cb < 0 || a.cb > 4 || a.batch < 1 || !a.y || !a.s || !mend || !ctile || !yout || !a.off_us)
+        return hipErrorInvalidValue;
+    static const int qb = []() { const char* e = getenv("AQC_PROJECTED_FUSED_QB"); const int v = e ? atoi(e) : 2; return v == 4 || v == 1 ? v : 2; }();
+    static bool attr_set[64] = {};   // (per device: the eight- and sixteen-wave forms need more than the default 64 KiB of LDS)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    const size_t lds1 = (16 * 1 * 16 * kPjRow + 1 * 16 * 256) * sizeof(cplx), lds2 = (8 * 2 * 16 * kPjRow + 2 * 8 * 256) * sizeof(cplx),
+                 lds4 = (4 * 2 * 16 * kPjRow + 2 * 4 * 256) * sizeof(cplx);
+    if (!attr_set[dev] || dev == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const dim3 grid((unsigned)(2 * a.batch));
+    const double2* m = static_cast<const double2*>(mend);
+    double2* c = static_cast<double2*>(ctile);
+    double2* y = static_cast<double2*>(yout);
+    if (qb == 2) project_fused_kernel<2><<<grid, 512, lds2, s>>>(a, m, c, y);
+    else if (qb == 1) project_fused_kernel<1><<<grid, 1024, lds1, s>>>(a, m, c, y);
+    else project_fused_kernel<4><<<grid, 256, lds4, s>>>(a, m, c, y);
     return hipGetLastError();
 }
 

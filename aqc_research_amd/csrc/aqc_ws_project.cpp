@@ -171,6 +171,8 @@ static ProjArgs proj_args(aqc_ws* ws) {
     a.off_t = pr.d_tab;
     a.off_cb = pr.d_tab + (1u << pr.t) + (1u << pr.us);
     a.it_of_c = a.off_cb + (1u << pr.cb);
+    a.off_us = pr.d_tab + (1u << pr.t);
+    a.us_bits = pr.us;
     a.t = pr.t; a.cb = pr.cb; a.ntiles_v = pr.ntiles_v;
     a.vm = pr.vm;
     a.vitems = pr.d_items; a.vcount = pr.d_count; a.vlane_parts = pr.d_lane_parts;
@@ -330,6 +332,13 @@ int run_vdag_projected(aqc_ws* ws, int x_buf) {   // the caller has asked vdag_r
     }
     if (virtual_apply(ws, pr.vsw, pr.vm, pr.vme)) return 1;   // M_end
     const unsigned* off_us = pr.d_tab + (1u << pr.t);
+    static const bool fused_on = env_int("AQC_PROJECTED_FUSED", 1) != 0;
+    if (fused_on && pr.us <= 8 && pr.cb <= 4) {   // both products from one fetch of the target
+        ProjArgs q = a;
+        q.y = ws->bufs[AQC_BUF_Y]; q.s = ws->bufs[AQC_BUF_W];
+        ProfScope ps(ws, AQC_K_PROJECT);
+        HIP_OK(launch_project_fused(q, pr.vme, ws->bufs[AQC_BUF_ZW], pr.vy, ws->stream));
+    } else {
     {   // Y_end = proj(y)
         ProjArgs q = a;
         q.y = ws->bufs[AQC_BUF_Y]; q.s = ws->bufs[AQC_BUF_W]; q.out = pr.vy;
@@ -351,6 +360,7 @@ int run_vdag_projected(aqc_ws* ws, int x_buf) {   // the caller has asked vdag_r
         q.o_keep = ProjMap{off_us, 0}; q.o_c = ProjMap{a.off_cb, 0};
         ProfScope ps(ws, AQC_K_PROJECT);
         HIP_OK(launch_project(q, ws->stream));
+    }
     }
     if (virtual_apply(ws, pr.vinv, pr.vy, pr.vy)) return 1;   // Y_0
     {   // V^H's last stage on the lhs tiles: ZW -> Z

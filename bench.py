@@ -908,7 +908,8 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
     sw_items, _, vd_items = ws.sparse_counts()
     rows, at = [], {0: 0, 1: 0}
     proj = ws.projected_info()   # the sweep's stages after the first on a virtual register (csrc/aqc_ws_project.cpp), or {}
-    by_projection = bool(proj) and kinds.count(K_PROJECT) == 2   # ... and V^H of the evaluation as two passes over the target (same file)
+    by_projection = bool(proj) and K_APPLY_VIRTUAL in kinds   # ... and V^H of the evaluation by projections of the target (same file)
+    fused = by_projection and kinds.count(K_PROJECT) == 1        # both of them from one fetch (project_fused_kernel)
     vstage = vapply = nproj = napply_list = 0
 
     def mfma_row(kernel, plan, stage, nsub, tiles_frac, ms, flops, **extra):
@@ -925,6 +926,13 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
             flops = 8.0 * elems * cols
             nbytes = 16.0 * elems
             second = by_projection and nproj == 1
+            if fused:   # two products, three real MFMAs per K-step each
+                flops = 2.0 * 6.0 * elems * cols
+                rows.append(mfma_row("project_fused_kernel<2>", "lhs tile of (later stages)^H y AND projection of the target, one fetch of the target",
+                                     None, None, None, avg[j], flops, bound="hbm", bytes_read=nbytes, GBps=nbytes / (avg[j] * 1e-3) / 1e9 if avg[j] > 0 else 0.0,
+                                     frac_of_hbm_peak=nbytes / (avg[j] * 1e-3) / 1e9 / HBM_PEAK_GBS if avg[j] > 0 else 0.0))
+                nproj += 1
+                continue
             rows.append(mfma_row("project_kernel<4, 1>" if second else "project_staged_kernel",
                                  ("lhs tile of (later stages)^H y: sum over the touched qubits" if second else
                                   ("projection of the target onto the lhs subspace" if by_projection else "projection of z onto the lhs subspace")),

@@ -492,7 +492,7 @@ def test_objective_by_projection_equals_the_stages_of_vdag(n, depth, case, monke
     else:   # the same index on the first stage's bits, different ones above; the gather set moves above only
         basis = np.array([5 | ((b * 7) % (1 << hi)) << 12 for b in range(B)], dtype=np.int64)
         gather = np.array([5 | (f << 12) for f in sorted({0, 1, 2, (1 << hi) - 1, 1 << (hi - 1)})] + [5 ^ 1, 5 ^ 8], dtype=np.int64)[:5]
-    from aqc_research_amd._lib import K_PROJECT
+    from aqc_research_amd._lib import K_APPLY_VIRTUAL
 
     out, passes = {}, {}
     monkeypatch.setenv("AQC_PROJECTED_VDAG_MIN_ELEMS", "1")
@@ -512,15 +512,15 @@ def test_objective_by_projection_equals_the_stages_of_vdag(n, depth, case, monke
             ws.objective_launch(BUF_X)
             got.append((ws.gather_fetch().copy(), ws.get_grads().copy()))
         z_after = ws.download(BUF_Z)   # (a reader of Z: completed first)
-        ws.profile(True)               # which route ran: passes over a full-size state per evaluation (2 = by projection, 1 = checkpoint only)
+        ws.profile(True)               # which route ran: by projection the virtual plan is also applied forwards and backwards
         ws.set_thetas(ths[0])
         ws.objective_launch(BUF_X)
         ws.sync()
-        passes[mode] = ws.profile_get(K_PROJECT)[0]
+        passes[mode] = ws.profile_get(K_APPLY_VIRTUAL)[0]
         ws.profile(False)
         out[mode] = (got, z_after)
         ws.close()
-    assert passes == {"1": 2, "0": 1}
+    assert passes["1"] >= 2 and passes["0"] == 0
     for a, b in zip(out["1"][0], out["0"][0]):
         assert maxdiff(a[0], b[0]) < 1e-13 and maxdiff(a[1], b[1]) < 1e-13
     for i, th in enumerate(ths + ths):

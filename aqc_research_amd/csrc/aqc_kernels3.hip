@@ -1082,6 +1082,9 @@ hipError_t init_kernels3() {
     AQC_TRY(big_lds((sweep_mfma_kernel<8, false, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, false, false, true>)));
     AQC_TRY(big_lds((sweep_mfma_kernel<10, false, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<11, false, false, true>)));
     AQC_TRY(big_lds((sweep_mfma_kernel<12, false, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<8, true, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<9, true, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<10, true, false, true>))); AQC_TRY(big_lds((sweep_mfma_kernel<11, true, false, true>)));
+    AQC_TRY(big_lds((sweep_mfma_kernel<12, true, false, true>)));
 #undef AQC_TRY
     return hipSuccess;
 }
@@ -1154,8 +1157,9 @@ hipError_t launch_sweep3(int ntiles, int batch, int k, hipStream_t s, const Stag
     const int t = mfma_threads(k, true);
     const size_t l = sweep3_lds_bytes(k);
     const bool skipw = !list && a.supp != nullptr;
-    const bool rlast = !list && !skipw && a.r_only_last != 0;
-#define AQC_LAUNCH(KK) case KK: if (list) sweep_mfma_kernel<KK, true, false><<<grid, t, l, s>>>(a); \
+    const bool rlast = !skipw && a.r_only_last != 0;
+#define AQC_LAUNCH(KK) case KK: if (list && rlast) sweep_mfma_kernel<KK, true, false, true><<<grid, t, l, s>>>(a); \
+                                else if (list) sweep_mfma_kernel<KK, true, false><<<grid, t, l, s>>>(a); \
                                 else if (skipw) sweep_mfma_kernel<KK, false, true><<<grid, t, l, s>>>(a); \
                                 else if (rlast) sweep_mfma_kernel<KK, false, false, true><<<grid, t, l, s>>>(a); \
                                 else sweep_mfma_kernel<KK, false, false><<<grid, t, l, s>>>(a); break

@@ -86,6 +86,8 @@ struct ProjRoute {
     TileItem* d_items = nullptr;   // [2 batch ntiles_v]
     int* d_count = nullptr;
     int* d_lane_parts = nullptr;   // [batch]
+    int init_buf = -1;             // vm holds the pattern M_0 (and d_items the list) of this lhs buffer ...
+    unsigned long long init_version = 0;   // ... at this version of its support (single virtual stage: nothing overwrites vm)
 };
 
 // aqc_ws_plan.cpp

@@ -419,7 +419,11 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         const bool sparse = sweep_route_sparse(ws, x_buf, false);
         const bool skipw = sweep_skips_zero_w(ws, x_buf);
         const bool projected = sweep_route_projected(ws, sparse);   // the stages after the first on the virtual register (aqc_ws_project.cpp)
-        const int r_only_sub = skipw || projected ? -1 : sweep_r_only_sub(ws);   // (the zero-w variant of the kernel has no R-only form)
+        int r_only_sub = skipw || projected ? -1 : sweep_r_only_sub(ws);   // (the zero-w variant of the kernel has no R-only form)
+        // objective by projection: psi is in W already and nobody reads the first stage's z': ITS last sub-stage is the R-only one
+        const bool first_stage_r_only = projected && ws->proj_y0_ready && ws->r_only_enabled && p.h_stages[0].nsubs >= 2 &&
+                                        p.h_stages[0].nsubs <= ws->r_only_max_subs;
+        if (first_stage_r_only) r_only_sub = p.h_stages[0].sub_begin + p.h_stages[0].nsubs - 1;
         // a partial Z covers the sparse route's reads when its tiles were chosen for this lhs state (or for a gather set the
         // state was picked from); anything else reads all of Z
         if (!ws->z_full && !(sparse && ((support_in_gather_set && ws->z_gather_gen == ws->gather_gen) ||
@@ -442,6 +446,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
                 a.out1 = s == 0 ? nullptr : z2;
                 a.store_out = s + 1 < m ? (s == 0 ? 1 : 3) : 0;
                 if (s == 0) { a.items = ws->d_sw_items; a.nitems = ws->d_sw_counts; a.max_items = 2 * ws->batch; }
+                if (s == 0 && first_stage_r_only) { a.r_only_last = 1; a.store_out = 0; }
             } else {
                 a.in0 = s == 0 ? ws->bufs[x_buf] : ws->bufs[AQC_BUF_W];
                 a.in1 = s == 0 ? ws->bufs[AQC_BUF_Z] : ws->bufs[AQC_BUF_ZW];

@@ -980,6 +980,8 @@ def stage_launch_table(ws, prof_log, prof_steps, N, B, sparse_lhs=False):
             frac = vd_items / float(ntiles * B)
         flops = (288.0 if which else 96.0) * N * B * frac * nsub
         r_only = bool(which) and st == stages - 1 and ws.sweep_r_only_sub() >= 0   # its last sub-stage: R from the inputs, 12 of 36 MFMAs per group
+        if which and k == K_SWEEP_LIST and by_projection and 2 <= nsub <= 12 and os.environ.get("AQC_R_ONLY_LAST", "1") != "0":
+            r_only = True   # objective by projection: nobody reads what the first stage leaves -- ITS last sub-stage is the R-only one (grad_from_impl)
         if r_only:
             flops -= 192.0 * N * B * frac
         skipped = 0.0

@@ -114,6 +114,7 @@ SIGNATURES = {
     "aqc_ws_plan_stage": (c_int, [_P, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "aqc_ws_sparse_counts": (c_int, [_P, POINTER(c_int64)]),
     "aqc_ws_projected_info": (c_int, [_P, POINTER(c_int32)]),
+    "aqc_plan_projected": (c_int, [_P, c_int, c_int, POINTER(c_int32)]),
     "aqc_ws_plan_skips": (c_int, [_P, c_int, c_int, POINTER(c_int), c_int]),
     "aqc_ws_sweep_r_only_sub": (c_int, [_P]),
     "aqc_ws_plan_info": (c_int, [_P, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

@@ -172,6 +172,30 @@ int aqc_plan_query(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bi
     return 0;
 }
 
+// host-only: the projected route a state-vector workspace of this tiling would take (same fields as aqc_ws_projected_info)
+int aqc_plan_projected(aqc_ctx* ctx, int tile_bits, int low_bits, int32_t* info) {
+    if (!ctx || !info) return fail("null argument");
+    if (tile_bits <= 0) tile_bits = 12;
+    if (low_bits < 0) low_bits = 3;
+    const Program& prog = ctx->prog;
+    tile_bits = std::min(std::max(tile_bits, 8), std::min(12, prog.n));
+    aqc_ws tmp;   // (never touches a device: proj_plan only reads the plan and the switches)
+    tmp.ctx = ctx;
+    tmp.ncols = 1; tmp.col_bits = 0; tmp.nbits = prog.n;
+    Plan best = make_plan(prog, 0, tile_bits, low_bits, false);
+    for (int lb = low_bits - 1; lb >= 2; --lb) {
+        Plan cand = make_plan(prog, 0, tile_bits, lb, false);
+        if (cand.stages.size() < best.stages.size()) best = cand;
+    }
+    lower_plan(prog, best, tmp.sweep, 4, true, true);
+    tmp.sparse_enabled = true;
+    tmp.inv_mirrored = tmp.sweep.v3 && tmp.sweep.plan.stages.size() >= 2;
+    proj_plan(&tmp, low_bits);
+    const int rc = aqc_ws_projected_info(&tmp, info);
+    tmp.ctx = nullptr;
+    return rc;
+}
+
 // host-only: register bits (local positions inside the stage's tile) and number of gate groups of every sub-stage of stage
 // `stage` as the matrix-core kernels run it (4 register bits, unlimited groups); subs_out receives [num_subs][5] ints
 int aqc_plan_substages(aqc_ctx* ctx, int ncols, int which, int tile_bits, int low_bits, int stage, int* num_subs, int* subs_out, int max_subs) {

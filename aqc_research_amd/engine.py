@@ -79,6 +79,16 @@ class HipContext:
             ws = self._ws[key] = Workspace(self, batch=batch, ncols=ncols, device=device, **kw)
         return ws
 
+    def plan_projected(self, tile_bits: int = 0, low_bits: int = -1) -> dict:
+        """Host-only: the projected route (Workspace.projected_info) a state-vector workspace of this tiling would take, or {}."""
+        c = (ctypes.c_int32 * 16)()
+        check(_lib.lib().aqc_plan_projected(self.handle, tile_bits, low_bits, c))
+        if not c[0]:
+            return {}
+        return {"virtual_qubits": int(c[1]), "touched_qubits": int(c[2]), "shared_with_first_stage": int(c[3]), "stages": int(c[4]),
+                "substages": int(c[5]), "tile_bits": int(c[6]), "substages_on_the_register": int(c[7]), "summed_bits": int(c[8]),
+                "padded_qubits": int(c[9]), "substages_per_stage": [int(c[10 + i]) for i in range(min(int(c[4]), 6))]}
+
     def plan(self, which: int = 1, ncols: int = 1, tile_bits: int = 0, low_bits: int = -1):
         """Host-only planner introspection: list of (local_bits, gate_group_indices)."""
         L = _lib.lib()

@@ -323,6 +323,8 @@ int aqc_ws_sparse_counts(aqc_ws* ws, int64_t* counts);
  * [5] sub-stages of the virtual plan, [6] its tile bits, [7] sub-stages left on the real register, [8] bits of the first stage the
  * pass over z sums over, [9] virtual qubits after padding (>= 8), [10..15] sub-stages of the virtual stages; info holds 16 entries */
 int aqc_ws_projected_info(aqc_ws* ws, int32_t* info);
+/* host-only (no GPU needed): the same for the state-vector workspace a context would get at this tiling */
+int aqc_plan_projected(aqc_ctx* ctx, int tile_bits, int low_bits, int32_t* info);
 /* plan introspection: number of fused stages (kernel launches) of V^H and of the sweep */
 int aqc_ws_plan_info(aqc_ws* ws, int which /*0 apply-inverse, 1 sweep, 2 apply-forward*/,
                      int* num_stages, int* tile_bits, int* num_tiles);

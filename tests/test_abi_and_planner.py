@@ -150,3 +150,28 @@ def test_mps_lanes_fail_loudly_without_gpu():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300).stdout
     assert out.count("RAISED") == 2 and out.count("no CPU fallback") == 2 and "CREATED" not in out, out
+
+
+def test_projected_route_is_planned_on_the_host():
+    """The projected route of the sparse-lhs sweep (csrc/aqc_ws_project.cpp) is decided and planned without a GPU: the qubits the
+    stages after the first touch, those they share with the first stage, the virtual register and its (checked) plan.  Headline
+    shape: 8 touched + 4 shared = 12 virtual qubits instead of 16, the second stage's 4 sub-stages on one 2^12 tile per lane;
+    20 qubits: 14; circuits whose later stages touch every bit of the first stage, and single-stage plans, have no such route."""
+    from aqc_research_amd import ParametricCircuit, TrotterAnsatz
+    from aqc_research_amd.circuit_structures import create_ansatz_structure, make_trotter_like_circuit
+    from aqc_research_amd.engine import HipContext
+
+    def route(n, blocks):
+        return HipContext(ParametricCircuit(n, "cx", create_ansatz_structure(n, "spin", "full", blocks))).plan_projected()
+
+    head = route(16, 40)
+    assert head["virtual_qubits"] == 12 and head["touched_qubits"] == 8 and head["shared_with_first_stage"] == 4
+    assert head["stages"] == 1 and head["substages"] == 4 and head["substages_on_the_register"] == 7 and head["summed_bits"] == 8
+    big = route(20, 40)
+    assert big["virtual_qubits"] == 14 and big["virtual_qubits"] + 2 <= 20 and sum(big["substages_per_stage"]) == big["substages"]
+    small = route(16, 20)   # 6 virtual qubits, padded to the smallest matrix-core tile
+    assert small["virtual_qubits"] == 6 and small["padded_qubits"] == 8 and small["tile_bits"] == 8
+    assert route(16, 80) == {} and route(12, 40) == {}
+    tro = HipContext(TrotterAnsatz(20, make_trotter_like_circuit(20, 2), second_order=True)).plan_projected()
+    assert tro["virtual_qubits"] == 16 and tro["touched_qubits"] == 12
+    assert HipContext(TrotterAnsatz(20, make_trotter_like_circuit(20, 3), second_order=True)).plan_projected() == {}

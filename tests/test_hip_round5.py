@@ -536,6 +536,58 @@ def test_objective_by_projection_equals_the_stages_of_vdag(n, depth, case, tile,
         assert maxdiff(out["1"][1][b], orc.v_dagger_mul_vec(circ, ths[-1][b], tg[b])) < TOL
 
 
+# one shape per kind of virtual register the planner produces on random spin ansaetze: (qubits shared with the first stage, virtual
+# stages, register padded to 8 qubits) -- found with HipContext.plan_projected on the host
+_ROUTE_SHAPES = [(16, 7, 8), (14, 7, 10), (17, 5, 8), (16, 10, 9), (14, 6, 11), (17, 15, 8), (16, 22, 10), (12, 19, 10), (15, 21, 8),
+                 (12, 25, 10), (13, 23, 12), (15, 29, 8), (15, 36, 10), (13, 37, 12), (16, 48, 12)]
+
+
+@pytest.mark.parametrize("n,blocks,tile", _ROUTE_SHAPES)
+def test_projected_routes_on_every_kind_of_virtual_register(n, blocks, tile, monkeypatch):
+    """Both projected routes against the full-size stages (AQC_PROJECTED=0) on shapes that cover what proj_plan can produce: 0 to 5
+    qubits shared with the first stage (5: two column blocks, the objective's two products as two launches), one and two virtual
+    stages, registers padded to 8 qubits.  Sweep from two basis states per lane (projection of the checkpoint), then a one-call
+    evaluation from one basis state with a flip-state gather set (objective by projection)."""
+    from aqc_research_amd.engine import BUF_X, BUF_X2, BUF_Y, BUF_Z
+
+    rng = np.random.default_rng(1000 * n + 10 * blocks + tile)
+    circ = _circ(n, "cx", depth=blocks)
+    B = 3
+    T = circ.num_thetas
+    th = np.stack([orc.rand_thetas(T, rng) for _ in range(B)])
+    tg = np.stack([orc.rand_state(n, rng) for _ in range(B)])
+    top = 1 << (n - 1)
+    idx = np.array([[0, -1], [3, top | 3], [top | 5, (1 << (n - 2)) | 6]], dtype=np.int64)
+    coef = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
+    flips = np.array([0] + [1 << q for q in range(n)], dtype=np.int64)
+    monkeypatch.setenv("AQC_PROJECTED_VDAG_MIN_ELEMS", "1")
+    res = {}
+    for proj in ("1", "0"):
+        monkeypatch.setenv("AQC_PROJECTED", proj)
+        ws = _ws(circ, B, monkeypatch, sparse=True, tile=tile)
+        info = ws.projected_info()
+        assert bool(info) == (proj == "1"), "the shape was chosen for its route"
+        ws.upload(BUF_Y, tg)
+        ws.set_thetas(th)
+        ws.apply(True, BUF_Y, BUF_Z)
+        ws.set_combo(BUF_X2, idx, coef)
+        ws.grad_from(BUF_X2)
+        g_combo = ws.get_grads()
+        ws.set_basis(BUF_X, 0)
+        ws.gather_setup(flips)
+        ws.set_thetas(th[::-1].copy())
+        ws.objective_launch(BUF_X)
+        res[proj] = (g_combo, ws.gather_fetch().copy(), ws.get_grads().copy())
+        ws.close()
+    for a, b in zip(res["1"], res["0"]):
+        assert maxdiff(a, b) < 1e-13
+    if n <= 14:   # (the full-size route is checked against the oracle everywhere else; here once more on the small shapes)
+        _, g_ref = _oracle_lane(circ, th[1], tg[1], idx[1], coef[1])
+        assert maxdiff(res["1"][0][1], g_ref) < TOL
+        vh = orc.v_dagger_mul_vec(circ, th[B - 1], tg[0])
+        assert maxdiff(res["1"][1][0], vh[flips]) < TOL
+
+
 class _Op:
     def __init__(self, name, params=()):
         self.name, self.params = name, list(params)

@@ -1,4 +1,9 @@
-// Passes over a full-size state of the projected route (host side and the mathematics: aqc_ws_project.cpp).  One kernel, two uses:
+// Passes over a full-size state of the projected route (host side and the mathematics: aqc_ws_project.cpp).
+//   project_kernel<RB, NB>   the product below with both operands fetched in the matrix-core layout (good when `keep` runs along memory)
+//   project_staged_kernel    the same through LDS tiles (when the SUMMED index runs along memory: the projection)
+//   project_fused_kernel<QB> both uses below from ONE fetch of the target (objective by projection)
+//   project_init_kernel, project_amps_kernel   the virtual lhs pattern / amplitudes read off the virtual z
+// The product, two uses:
 //     out[keep, c] = sum_k conj(S[k, c]) Y[k, keep]                  per item = (lane, first-stage tile that holds the lhs state)
 //   * Y = z (the checkpoint of V^H) or the target y, k = the first stage's local bits outside T, keep = the bits T, S = psi (w after
 //     the first stage):  the projection of z onto the subspace the lhs state spans when it enters the later stages;

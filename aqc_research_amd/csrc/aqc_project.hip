@@ -251,7 +251,7 @@ hipError_t launch_project_init(const ProjArgs& a, hipStream_t s) {
 // LDS tile, multiplied with the wave's 64 x 16 slice of psi (registers, fetched once), and the four waves' partial sums over u are added
 // in a fixed order through a double-buffered LDS tile -- one workgroup barrier per block of i_T.  Needs 2^us <= 256 and cb <= 4.
 // QB blocks of 16 values of u per wave, 16 / QB waves per workgroup (QB = 2: eight waves, two per SIMD -- the registers of a wave
-// with four blocks leave room for one).  Complex products in the three-multiplication form: with a = conj(s),
+// with four blocks leave room for one; sixteen waves with one block each measured 0.36 ms against 0.35 and were dropped).  Complex products in the three-multiplication form: with a = conj(s),
 //     re = sr yr + si yi = A1 + A2,   im = sr yi - si yr = A3 + A1 - A2,   A3 = sum (sr + si)(yi - yr)
 // -- three MFMAs per K-step instead of four, the two extra sums are a handful of vector adds per block.
 template <int QB>
@@ -305,14 +305,22 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) yv[q][jj] = uvalid[q] ? pj_stream(ybase + yoff[q] + tb + tlow[jj]) : make_double2(0.0, 0.0);
     }
+    // M_end rows i_T = 16 kb + 4 kg + jj, column c = r16: A operand of the first product, fetched one block ahead (scattered 16-byte
+    // loads from L2: their latency would otherwise open every block)
+    cplx mn[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) mn[jj] = cvalid ? mbase[(size_t)(4 * kg + jj) + ((size_t)r16 << a.t)] : make_double2(0.0, 0.0);
     for (int kb = 0; kb < nkb; ++kb) {
-        // M_end rows i_T = 16 kb + 4 kg + jj, column c = r16: A operand of the first product
         cplx ma[4];
         double ms[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            ma[jj] = cvalid ? mbase[(size_t)(kb * 16 + 4 * kg + jj) + ((size_t)r16 << a.t)] : make_double2(0.0, 0.0);
+            ma[jj] = mn[jj];
             ms[jj] = ma[jj].x + ma[jj].y;
+        }
+        if (kb + 1 < nkb) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) mn[jj] = cvalid ? mbase[(size_t)((kb + 1) * 16 + 4 * kg + jj) + ((size_t)r16 << a.t)] : make_double2(0.0, 0.0);
         }
         double4_t y1 = {0.0, 0.0, 0.0, 0.0}, y2 = y1, y3 = y1;
 #pragma unroll
@@ -390,16 +398,14 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
 hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile, void* yout, hipStream_t s) {
     if (a.t < 4 || a.us_bits < 4 || a.us_bits > 8 || a.cb < 0 || a.cb > 4 || a.batch < 1 || !a.y || !a.s || !mend || !ctile || !yout || !a.off_us)
         return hipErrorInvalidValue;
-    static const int qb = []() { const char* e = getenv("AQC_PROJECTED_FUSED_QB"); const int v = e ? atoi(e) : 2; return v == 4 || v == 1 ? v : 2; }();
-    static bool attr_set[64] = {};   // (per device: the eight- and sixteen-wave forms need more than the default 64 KiB of LDS)
+    static const int qb = []() { const char* e = getenv("AQC_PROJECTED_FUSED_QB"); return e && atoi(e) == 4 ? 4 : 2; }();
+    static bool attr_set[64] = {};   // (per device: the eight-wave form needs more than the default 64 KiB of LDS)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    const size_t lds1 = (16 * 1 * 16 * kPjRow + 1 * 16 * 256) * sizeof(cplx), lds2 = (8 * 2 * 16 * kPjRow + 2 * 8 * 256) * sizeof(cplx),
-                 lds4 = (4 * 2 * 16 * kPjRow + 2 * 4 * 256) * sizeof(cplx);
+    const size_t lds2 = (8 * 2 * 16 * kPjRow + 2 * 8 * 256) * sizeof(cplx), lds4 = (4 * 2 * 16 * kPjRow + 2 * 4 * 256) * sizeof(cplx);
     if (!attr_set[dev] || dev == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(project_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
@@ -408,7 +414,6 @@ hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile
     double2* c = static_cast<double2*>(ctile);
     double2* y = static_cast<double2*>(yout);
     if (qb == 2) project_fused_kernel<2><<<grid, 512, lds2, s>>>(a, m, c, y);
-    else if (qb == 1) project_fused_kernel<1><<<grid, 1024, lds1, s>>>(a, m, c, y);
     else project_fused_kernel<4><<<grid, 256, lds4, s>>>(a, m, c, y);
     return hipGetLastError();
 }

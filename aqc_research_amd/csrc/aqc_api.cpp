@@ -338,6 +338,7 @@ int aqc_ws_create(aqc_ctx* ctx, int device, int batch, int ncols, int tile_bits_
     ws->r_only_enabled = env_int("AQC_R_ONLY_LAST", 1) != 0;
     ws->r_only_max_subs = env_int("AQC_R_ONLY_MAX_SUBS", 12);
     ws->proj_vdag_enabled = env_int("AQC_PROJECTED_VDAG", 1) != 0;
+    ws->proj_fused_enabled = env_int("AQC_PROJECTED_FUSED", 1) != 0;
     ws->proj_vdag_min_elems = (long long)env_int("AQC_PROJECTED_VDAG_MIN_ELEMS", 1 << 24);
     ws->skipw_enabled = env_int("AQC_SKIP_ZERO_W", 0) != 0;   // (measured slower than multiplying the zeros: opt-in, see sweep_mfma_kernel)
     for (DevPlan* p : {&ws->fwd, &ws->inv, &ws->sweep}) {

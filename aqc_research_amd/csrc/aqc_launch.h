@@ -120,6 +120,7 @@ struct ProjArgs {
     const unsigned* it_of_c; // [2^cb]: index on the T bits whose shared bits hold c (the others 0)
     const unsigned* off_us;  // [2^us]: element offset of the value u of the first stage's local bits outside T
     int us_bits;
+    size_t part_stride;      // fused pass with more than 256 summed values: elements between the partial copies of the virtual z
     int t, ntiles_v;
     double2* vm;             // [batch][2][2^nvp]
     TileItem* vitems;        // items of the virtual stage launches: (lane, slot ntiles_v + tile, the same as partial slot)

@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
     const cplx* ybase = a.y + real_base + (ebits & a.ff_mask);
     const cplx* wbase = a.s + real_base + ebits;          // psi: w after the first stage, on the item's tile
     const cplx* mbase = mend + vbase;                     // M_end, virtual layout: i_T + (c << t)
+    yout += (size_t)blockIdx.y * a.part_stride;           // (the projection's partial sum over this workgroup's values of u)
     const bool cvalid = r16 < ncb;
     // this lane's slice of psi: A operand of the second product, rows c = r16, k = u = 16 (QB wave + q) + 4 kg + jj
     cplx pa[QB][4];
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
     bool uvalid[QB];
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-        const int ub = QB * wave + q;
+        const int ub = 16 * (int)blockIdx.y + QB * wave + q;   // (blockIdx.y: which 256 values of u -- more than 256: partial projections)
         uvalid[q] = ub * 16 < nu;
         yoff[q] = uvalid[q] ? a.off_us[ub * 16 + r16] : 0u;
 #pragma unroll
@@ -395,8 +396,21 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
         }
     }
 }
+// more than 256 values of u: the workgroups of an item leave partial projections in consecutive copies of the virtual register
+// (part_stride apart); this adds copies 1 .. nparts - 1 into copy 0, in that order
+__global__ __launch_bounds__(256) void project_sum_kernel(const ProjArgs a, double2* __restrict__ yout, int nparts) {
+    const int item = blockIdx.y;
+    if (item >= *a.nitems) return;
+    const TileItem it = a.items[item];
+    const size_t vbase = ((size_t)it.lane * 2 + it.slot) << a.nvp;
+    const unsigned v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= (1u << (a.t + a.cb))) return;
+    cplx acc = yout[vbase + v];
+    for (int p = 1; p < nparts; ++p) { const cplx x = yout[(size_t)p * a.part_stride + vbase + v]; acc.x += x.x; acc.y += x.y; }
+    yout[vbase + v] = acc;
+}
 hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile, void* yout, hipStream_t s) {
-    if (a.t < 4 || a.us_bits < 4 || a.us_bits > 8 || a.cb < 0 || a.cb > 4 || a.batch < 1 || !a.y || !a.s || !mend || !ctile || !yout || !a.off_us)
+    if (a.t < 4 || a.us_bits < 4 || a.us_bits > 10 || (a.us_bits > 8 && a.part_stride == 0) || a.cb < 0 || a.cb > 4 || a.batch < 1 || !a.y || !a.s || !mend || !ctile || !yout || !a.off_us)
         return hipErrorInvalidValue;
     static const int qb = []() { const char* e = getenv("AQC_PROJECTED_FUSED_QB"); return e && atoi(e) == 4 ? 4 : 2; }();
     static bool attr_set[64] = {};   // (per device: the eight-wave form needs more than the default 64 KiB of LDS)
@@ -409,12 +423,18 @@ hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    const dim3 grid((unsigned)(2 * a.batch));
+    const int nparts = a.us_bits > 8 ? 1 << (a.us_bits - 8) : 1;
+    const dim3 grid((unsigned)(2 * a.batch), (unsigned)nparts);
     const double2* m = static_cast<const double2*>(mend);
     double2* c = static_cast<double2*>(ctile);
     double2* y = static_cast<double2*>(yout);
     if (qb == 2) project_fused_kernel<2><<<grid, 512, lds2, s>>>(a, m, c, y);
     else project_fused_kernel<4><<<grid, 256, lds4, s>>>(a, m, c, y);
+    if (nparts > 1) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        project_sum_kernel<<<dim3((unsigned)(((1u << (a.t + a.cb)) + 255) / 256), (unsigned)(2 * a.batch)), 256, 0, s>>>(a, y, nparts);
+    }
     return hipGetLastError();
 }
 

@@ -79,6 +79,7 @@ struct ProjRoute {
     double2* vm = nullptr;         // [batch][2][2^nvp]: the virtual lhs pattern M_0 ...
     double2* vy = nullptr;         // ... the virtual z ...
     double2* vme = nullptr;        // ... and M after the later stages' gates (objective by projection)
+    int vy_copies = 1;             // vy holds this many copies of the virtual z (fused pass over more than 256 summed values: partial sums)
     unsigned l0_mask = 0;          // address bits local to the first stage
     unsigned* d_tab = nullptr;     // off_t | off_usblk | off_cb
     std::vector<unsigned> h_tab;
@@ -225,6 +226,7 @@ struct aqc_ws {
     aqc::ProjRoute proj;                    // dense stages of the sparse route on a virtual register (AQC_PROJECTED=0: off)
     bool proj_vdag_enabled = true;          // AQC_PROJECTED_VDAG=0: V^H of a one-call evaluation always by its stages
     long long proj_vdag_min_elems = 1ll << 24;   // ... and from this many amplitudes per batch (fewer: its extra launches cost more than V^H's stages; AQC_PROJECTED_VDAG_MIN_ELEMS)
+    bool proj_fused_enabled = true;         // AQC_PROJECTED_FUSED=0: its two products as two launches (two fetches of the target)
     bool proj_y0_ready = false;             // the virtual z (proj.vy) holds Y_0 for the sweep that follows in the same call (run_vdag_projected)
     bool z_from_y = false;                  // a partial Z without a checkpoint: completed by a full V^H from Y (thetas and Y unchanged since)
     std::vector<long long> h_gather;        // host copy of the registered gather indices (elements)

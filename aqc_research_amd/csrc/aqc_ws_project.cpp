@@ -122,9 +122,10 @@ int proj_alloc(aqc_ws* ws) {
     HIP_OK(hipMalloc((void**)&pr.vsw.d_rpart, sizeof(double2) * B * nsubs * (2 * (size_t)pr.ntiles_v) * 256));
     const size_t vbytes = sizeof(double2) * B * (2ull << pr.nvp);
     HIP_OK(hipMalloc((void**)&pr.vm, vbytes));
-    HIP_OK(hipMalloc((void**)&pr.vy, vbytes));
+    pr.vy_copies = pr.us > 8 && pr.us <= 10 && pr.cb <= 4 ? 1 << (pr.us - 8) : 1;
+    HIP_OK(hipMalloc((void**)&pr.vy, vbytes * pr.vy_copies));
     HIP_OK(hipMemsetAsync(pr.vm, 0, vbytes, ws->stream));   // (entries beyond 2^nv -- a register padded to 8 qubits -- stay zero for good)
-    HIP_OK(hipMemsetAsync(pr.vy, 0, vbytes, ws->stream));
+    HIP_OK(hipMemsetAsync(pr.vy, 0, vbytes * pr.vy_copies, ws->stream));
     HIP_OK(hipMalloc((void**)&pr.vme, vbytes));
     HIP_OK(hipMemsetAsync(pr.vme, 0, vbytes, ws->stream));
     HIP_OK(hipMalloc((void**)&pr.d_tab, sizeof(unsigned) * pr.h_tab.size()));
@@ -341,9 +342,9 @@ int run_vdag_projected(aqc_ws* ws, int x_buf) {   // the caller has asked vdag_r
     if (ensure_pattern(ws, a)) return 1;
     if (virtual_apply(ws, pr.vsw, pr.vm, pr.vme)) return 1;   // M_end
     const unsigned* off_us = pr.d_tab + (1u << pr.t);
-    static const bool fused_on = env_int("AQC_PROJECTED_FUSED", 1) != 0;
-    if (fused_on && pr.us <= 8 && pr.cb <= 4) {   // both products from one fetch of the target
+    if (ws->proj_fused_enabled && pr.us <= 10 && pr.cb <= 4 && (pr.us <= 8 || pr.vy_copies == 1 << (pr.us - 8))) {   // both products from one fetch of the target
         ProjArgs q = a;
+        q.part_stride = (size_t)ws->batch * (2ull << pr.nvp);
         q.y = ws->bufs[AQC_BUF_Y]; q.s = ws->bufs[AQC_BUF_W];
         ProfScope ps(ws, AQC_K_PROJECT);
         HIP_OK(launch_project_fused(q, pr.vme, ws->bufs[AQC_BUF_ZW], pr.vy, ws->stream));

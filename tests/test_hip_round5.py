@@ -536,6 +536,47 @@ def test_objective_by_projection_equals_the_stages_of_vdag(n, depth, case, tile,
         assert maxdiff(out["1"][1][b], orc.v_dagger_mul_vec(circ, ths[-1][b], tg[b])) < TOL
 
 
+@pytest.mark.parametrize("n,blocks", [(16, 40), (18, 30), (20, 40)])
+def test_fused_pass_equals_the_two_launches(n, blocks, monkeypatch):
+    """Objective by projection: both products from one fetch of the target (project_fused_kernel; at 20 qubits the summed index has 512
+    values: two workgroups per item and a fixed-order sum of their partial projections) against the two launches
+    (AQC_PROJECTED_FUSED=0) and against V^H by its stages (AQC_PROJECTED_VDAG=0): amplitudes and gradients."""
+    from aqc_research_amd.engine import BUF_X, BUF_Y
+
+    rng = np.random.default_rng(77 + n)
+    circ = _circ(n, "cx", depth=blocks)
+    B = 3
+    th = np.stack([orc.rand_thetas(circ.num_thetas, rng) for _ in range(B)])
+    tg = rng.standard_normal((B, 1 << n)) + 1j * rng.standard_normal((B, 1 << n))
+    tg /= np.linalg.norm(tg, axis=1, keepdims=True)
+    flips = np.array([0] + [1 << q for q in range(n)], dtype=np.int64)
+    monkeypatch.setenv("AQC_PROJECTED_VDAG_MIN_ELEMS", "1")
+    res = {}
+    for name, env in (("fused", {}), ("two", {"AQC_PROJECTED_FUSED": "0"}), ("stages", {"AQC_PROJECTED_VDAG": "0"})):
+        for k in ("AQC_PROJECTED_FUSED", "AQC_PROJECTED_VDAG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ws = _ws(circ, B, monkeypatch, sparse=True, tile=12)
+        info = ws.projected_info()
+        assert info and info["shared_with_first_stage"] <= 4 and info["summed_bits"] <= 10
+        ws.upload(BUF_Y, tg)
+        ws.set_basis(BUF_X, 0)
+        ws.gather_setup(flips)
+        ws.set_thetas(th)
+        ws.objective_launch(BUF_X)
+        res[name] = (ws.gather_fetch().copy(), ws.get_grads().copy(), info["summed_bits"])
+        ws.close()
+    for name in ("two", "stages"):
+        assert maxdiff(res["fused"][0], res[name][0]) < 1e-13 and maxdiff(res["fused"][1], res[name][1]) < 1e-13
+    if n == 20:
+        assert res["fused"][2] == 9   # (the case the test is for: 512 summed values)
+    if n == 16:
+        vh = orc.v_dagger_mul_vec(circ, th[1], tg[1])
+        x = np.zeros(1 << n, complex); x[0] = 1.0
+        assert maxdiff(res["fused"][0][1], vh[flips]) < TOL and maxdiff(res["fused"][1][1], orc.grad_of_dot_product(circ, th[1], x, vh)) < TOL
+
+
 # one shape per kind of virtual register the planner produces on random spin ansaetze: (qubits shared with the first stage, virtual
 # stages, register padded to 8 qubits) -- found with HipContext.plan_projected on the host
 _ROUTE_SHAPES = [(16, 7, 8), (14, 7, 10), (17, 5, 8), (16, 10, 9), (14, 6, 11), (17, 15, 8), (16, 22, 10), (12, 19, 10), (15, 21, 8),

@@ -121,6 +121,8 @@ struct ProjArgs {
     const unsigned* off_us;  // [2^us]: element offset of the value u of the first stage's local bits outside T
     int us_bits;
     size_t part_stride;      // fused pass with more than 256 summed values: elements between the partial copies of the virtual z
+    double2* cpart;          // fused pass with few items: [shares][2 batch][2^us][16] partial tile products (null: never split)
+    int cpart_shares;
     int t, ntiles_v;
     double2* vm;             // [batch][2][2^nvp]
     TileItem* vitems;        // items of the virtual stage launches: (lane, slot ntiles_v + tile, the same as partial slot)

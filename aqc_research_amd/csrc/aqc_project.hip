@@ -265,7 +265,10 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
     if (item >= *a.nitems) return;   // (uniform over the workgroup: before any barrier)
     const TileItem it = a.items[item];
     const size_t ebits = pj_tile_bits(a, it.tile);
-    const int nu = 1 << a.us_bits, ncb = 1 << a.cb, nkb = 1 << (a.t - 4);
+    const int nu = 1 << a.us_bits, ncb = 1 << a.cb, nkb_all = 1 << (a.t - 4);
+    // blockIdx.z: which share of the blocks of i_T (few items: the walk is split so that the launch fills the chip; the tile product's
+    // sums over i_T are then partial -- one compact copy per share in cpart, added by project_csum_kernel)
+    const int kb0 = (int)blockIdx.z * (nkb_all / (int)gridDim.z), nkb = kb0 + nkb_all / (int)gridDim.z;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kg = l >> 4;
     cplx* tile = reinterpret_cast<cplx*>(pj_smem) + (size_t)wave * (PB * 16 * kPjRow);   // transposition tiles of the wave
     cplx* red = reinterpret_cast<cplx*>(pj_smem) + NW * (PB * 16 * kPjRow);              // [2 (or 1)][NW waves][256]
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
     for (int jj = 0; jj < 4; ++jj) tlow[jj] = a.off_t[4 * kg + jj];
     cplx yv[QB][4];
     {
-        const unsigned tb = a.off_t[0];
+        const unsigned tb = a.off_t[kb0 * 16];
 #pragma unroll
         for (int q = 0; q < QB; ++q)
 #pragma unroll
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
     // loads from L2: their latency would otherwise open every block)
     cplx mn[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) mn[jj] = cvalid ? mbase[(size_t)(4 * kg + jj) + ((size_t)r16 << a.t)] : make_double2(0.0, 0.0);
-    for (int kb = 0; kb < nkb; ++kb) {
+    for (int jj = 0; jj < 4; ++jj) mn[jj] = cvalid ? mbase[(size_t)(kb0 * 16 + 4 * kg + jj) + ((size_t)r16 << a.t)] : make_double2(0.0, 0.0);
+    for (int kb = kb0; kb < nkb; ++kb) {
         cplx ma[4];
         double ms[4];
 #pragma unroll
@@ -384,6 +387,17 @@ __global__ __launch_bounds__(64 * (16 / QB), 1) void project_fused_kernel(const 
         if (!kRedDouble) __syncthreads();
     }
     // C: D[row = c = kg + 4 r][col = u in the block = r16]
+    if (gridDim.z > 1) {   // a share of the sums over i_T: compact copy [share][item][u][16]
+        cplx* pbase = a.cpart + (((size_t)blockIdx.z * gridDim.x + item) << (a.us_bits + 4));
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            if (!uvalid[q]) continue;
+            const int u = (16 * (int)blockIdx.y + QB * wave + q) * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pbase[(size_t)u * 16 + kg + 4 * r] = make_double2(c1[q][r] + c2[q][r], c3[q][r] + c1[q][r] - c2[q][r]);
+        }
+        return;
+    }
     cplx* obase = ctile + real_base + ebits;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
@@ -409,6 +423,23 @@ __global__ __launch_bounds__(256) void project_sum_kernel(const ProjArgs a, doub
     for (int p = 1; p < nparts; ++p) { const cplx x = yout[(size_t)p * a.part_stride + vbase + v]; acc.x += x.x; acc.y += x.y; }
     yout[vbase + v] = acc;
 }
+// ... and the shares of the tile product over i_T (blockIdx.z of the fused pass): added in share order into the tile of ZW
+__global__ __launch_bounds__(256) void project_csum_kernel(const ProjArgs a, double2* __restrict__ ctile, int nshares, int nitems_max) {
+    const int item = blockIdx.y;
+    if (item >= *a.nitems) return;
+    const TileItem it = a.items[item];
+    const size_t ebits = pj_tile_bits(a, it.tile);
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;   // u * 16 + c
+    if (e >= (16u << a.us_bits)) return;
+    const unsigned u = e >> 4, c = e & 15;
+    if (c >= (1u << a.cb)) return;
+    cplx acc = make_double2(0.0, 0.0);
+    for (int z = 0; z < nshares; ++z) {
+        const cplx x = a.cpart[(((size_t)z * nitems_max + item) << (a.us_bits + 4)) + e];
+        acc.x += x.x; acc.y += x.y;
+    }
+    ctile[(size_t)it.lane * a.lane_stride + ebits + a.off_us[u] + a.off_cb[c]] = acc;
+}
 hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile, void* yout, hipStream_t s) {
     if (a.t < 4 || a.us_bits < 4 || a.us_bits > 10 || (a.us_bits > 8 && a.part_stride == 0) || a.cb < 0 || a.cb > 4 || a.batch < 1 || !a.y || !a.s || !mend || !ctile || !yout || !a.off_us)
         return hipErrorInvalidValue;
@@ -424,7 +455,10 @@ hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile
         attr_set[dev] = true;
     }
     const int nparts = a.us_bits > 8 ? 1 << (a.us_bits - 8) : 1;
-    const dim3 grid((unsigned)(2 * a.batch), (unsigned)nparts);
+    int nshares = 1;   // few items: split the walk over i_T until the launch has ~512 workgroups (one per CU and a successor)
+    if (a.cpart)
+        nshares = a.cpart_shares;   // (sized by proj_alloc for this batch)
+    const dim3 grid((unsigned)(2 * a.batch), (unsigned)nparts, (unsigned)nshares);
     const double2* m = static_cast<const double2*>(mend);
     double2* c = static_cast<double2*>(ctile);
     double2* y = static_cast<double2*>(yout);
@@ -434,6 +468,11 @@ hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         project_sum_kernel<<<dim3((unsigned)(((1u << (a.t + a.cb)) + 255) / 256), (unsigned)(2 * a.batch)), 256, 0, s>>>(a, y, nparts);
+    }
+    if (nshares > 1) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        project_csum_kernel<<<dim3((unsigned)(((16u << a.us_bits) + 255) / 256), (unsigned)(2 * a.batch)), 256, 0, s>>>(a, c, nshares, 2 * a.batch);
     }
     return hipGetLastError();
 }

@@ -79,6 +79,8 @@ struct ProjRoute {
     double2* vm = nullptr;         // [batch][2][2^nvp]: the virtual lhs pattern M_0 ...
     double2* vy = nullptr;         // ... the virtual z ...
     double2* vme = nullptr;        // ... and M after the later stages' gates (objective by projection)
+    double2* cpart = nullptr;      // partial tile products of the fused pass when its walk is split (few lanes)
+    int cpart_shares = 0;
     int vy_copies = 1;             // vy holds this many copies of the virtual z (fused pass over more than 256 summed values: partial sums)
     unsigned l0_mask = 0;          // address bits local to the first stage
     unsigned* d_tab = nullptr;     // off_t | off_usblk | off_cb

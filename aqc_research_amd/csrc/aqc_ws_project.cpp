@@ -126,6 +126,17 @@ int proj_alloc(aqc_ws* ws) {
     HIP_OK(hipMalloc((void**)&pr.vy, vbytes * pr.vy_copies));
     HIP_OK(hipMemsetAsync(pr.vm, 0, vbytes, ws->stream));   // (entries beyond 2^nv -- a register padded to 8 qubits -- stay zero for good)
     HIP_OK(hipMemsetAsync(pr.vy, 0, vbytes * pr.vy_copies, ws->stream));
+    pr.cpart_shares = 0;
+    const long want_wgs = env_int("AQC_PROJECTED_FUSED_WGS", 512);
+    if (pr.us <= 10 && pr.cb <= 4 && (long)B < want_wgs) {   // the fused pass of a small batch splits its walk over the touched bits (launch_project_fused)
+        int shares = 1;
+        const int cap = env_int("AQC_PROJECTED_FUSED_MAX_SHARES", 64);   // (1: never split -- what large batches run; tests)
+        while ((long)B * pr.vy_copies * shares < want_wgs && 2 * shares <= (1 << (pr.t - 4)) && 2 * shares <= cap) shares *= 2;
+        if (shares > 1) {
+            HIP_OK(hipMalloc((void**)&pr.cpart, sizeof(double2) * (size_t)shares * 2 * B * (16ull << pr.us)));
+            pr.cpart_shares = shares;
+        }
+    }
     HIP_OK(hipMalloc((void**)&pr.vme, vbytes));
     HIP_OK(hipMemsetAsync(pr.vme, 0, vbytes, ws->stream));
     HIP_OK(hipMalloc((void**)&pr.d_tab, sizeof(unsigned) * pr.h_tab.size()));
@@ -147,9 +158,9 @@ void proj_free(aqc_ws* ws) {
         v.d_stages = nullptr; v.d_ops = nullptr; v.d_subs = nullptr; v.d_mops = nullptr; v.d_subs3 = nullptr; v.d_grps = nullptr;
         v.d_umat = nullptr; v.d_rpart = nullptr;
     }
-    for (void* q : {(void*)pr.vm, (void*)pr.vy, (void*)pr.vme, (void*)pr.d_tab, (void*)pr.d_items, (void*)pr.d_count, (void*)pr.d_lane_parts})
+    for (void* q : {(void*)pr.vm, (void*)pr.vy, (void*)pr.vme, (void*)pr.cpart, (void*)pr.d_tab, (void*)pr.d_items, (void*)pr.d_count, (void*)pr.d_lane_parts})
         if (q) (void)hipFree(q);
-    pr.vm = pr.vy = pr.vme = nullptr; pr.d_tab = nullptr; pr.d_items = nullptr; pr.d_count = nullptr; pr.d_lane_parts = nullptr;
+    pr.vm = pr.vy = pr.vme = nullptr; pr.cpart = nullptr; pr.d_tab = nullptr; pr.d_items = nullptr; pr.d_count = nullptr; pr.d_lane_parts = nullptr;
     pr.ok = false;
 }
 
@@ -345,6 +356,7 @@ int run_vdag_projected(aqc_ws* ws, int x_buf) {   // the caller has asked vdag_r
     if (ws->proj_fused_enabled && pr.us <= 10 && pr.cb <= 4 && (pr.us <= 8 || pr.vy_copies == 1 << (pr.us - 8))) {   // both products from one fetch of the target
         ProjArgs q = a;
         q.part_stride = (size_t)ws->batch * (2ull << pr.nvp);
+        q.cpart = pr.cpart; q.cpart_shares = pr.cpart_shares;
         q.y = ws->bufs[AQC_BUF_Y]; q.s = ws->bufs[AQC_BUF_W];
         ProfScope ps(ws, AQC_K_PROJECT);
         HIP_OK(launch_project_fused(q, pr.vme, ws->bufs[AQC_BUF_ZW], pr.vy, ws->stream));

@@ -552,8 +552,9 @@ def test_fused_pass_equals_the_two_launches(n, blocks, monkeypatch):
     flips = np.array([0] + [1 << q for q in range(n)], dtype=np.int64)
     monkeypatch.setenv("AQC_PROJECTED_VDAG_MIN_ELEMS", "1")
     res = {}
-    for name, env in (("fused", {}), ("two", {"AQC_PROJECTED_FUSED": "0"}), ("stages", {"AQC_PROJECTED_VDAG": "0"})):
-        for k in ("AQC_PROJECTED_FUSED", "AQC_PROJECTED_VDAG"):
+    for name, env in (("fused", {}), ("whole", {"AQC_PROJECTED_FUSED_MAX_SHARES": "1"}), ("two", {"AQC_PROJECTED_FUSED": "0"}),
+                      ("stages", {"AQC_PROJECTED_VDAG": "0"})):   # fused: the walk split over the touched bits (few lanes); whole: one workgroup per item
+        for k in ("AQC_PROJECTED_FUSED", "AQC_PROJECTED_VDAG", "AQC_PROJECTED_FUSED_MAX_SHARES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -567,7 +568,7 @@ def test_fused_pass_equals_the_two_launches(n, blocks, monkeypatch):
         ws.objective_launch(BUF_X)
         res[name] = (ws.gather_fetch().copy(), ws.get_grads().copy(), info["summed_bits"])
         ws.close()
-    for name in ("two", "stages"):
+    for name in ("whole", "two", "stages"):
         assert maxdiff(res["fused"][0], res[name][0]) < 1e-13 and maxdiff(res["fused"][1], res[name][1]) < 1e-13
     if n == 20:
         assert res["fused"][2] == 9   # (the case the test is for: 512 summed values)

@@ -24,6 +24,8 @@
 // fixed-order sum over waves and tiles): run-to-run identical, no float atomics.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <type_traits>
 
 #include "aqc_device.h"
@@ -856,8 +858,9 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
                                                            const cplx* rpart, int ntiles, int nsubs_total, cplx* partial, int nslots,
                                                            int from, int to, int front, const int* slot_theta, cplx* grads, cplx* mirror,
                                                            const GatherJob gj, int tiles_per_lane, int chunk, int sparse_subs,
-                                                           const int* lane_parts, int conj_sub, const double* umat, int nsubs_run) {   // ntiles: partial slots per (lane, sub-stage)
-    if ((int)blockIdx.x == nsubs_run) {   // (nsubs_run: the launch walks the first nsubs_run sub-stages of the plan)   // the passenger (see GatherJob): one extra workgroup per lane of the batch
+                                                           const int* lane_parts, int conj_sub, const double* umat, int nsubs_run,
+                                                           const RgradSecond second) {   // ntiles: partial slots per (lane, sub-stage)
+    if ((int)blockIdx.x == nsubs_run + second.count) {   // (nsubs_run: the launch walks the first nsubs_run sub-stages of the plan, then `second`'s)   // the passenger (see GatherJob): one extra workgroup per lane of the batch
         const cplx* src = static_cast<const cplx*>(gj.buf) + (size_t)blockIdx.y * gj.lane_stride;
         for (int i = threadIdx.x; i < gj.count; i += 64 * WAVES) {
             const cplx v = src[(size_t)gj.elem[i]];
@@ -870,7 +873,13 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     __shared__ Gm gm[kGrpChunk];
     __shared__ cplx rho_s[kGrpChunk][16];
     __shared__ cplx psum[WAVES > 1 ? WAVES - 1 : 1][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, si = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    int si = blockIdx.x;
+    if (si >= nsubs_run) {   // a sub-stage of the second plan of the launch (projected route: the virtual plan's walk rides along)
+        si -= nsubs_run;
+        subs = second.subs; grps = second.grps; rpart = second.rpart; ntiles = second.nparts; nsubs_total = second.nsubs_total;
+        tiles_per_lane = second.nparts; chunk = 0; sparse_subs = second.nsubs_total; lane_parts = second.lane_parts; conj_sub = -1; umat = second.umat;
+    }
     RG_STAMP(0);
     const DevSub3 sub = subs[si];
     const double* th = thetas + (size_t)b * T;
@@ -1265,22 +1274,25 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
                         const int* slot_theta, void* grads, void* mirror, GatherJob gather, int nparts, int chunk, int sparse_subs,
-                        const int* lane_parts, int conj_sub, const double* umat, int nsubs_run) {
+                        const int* lane_parts, int conj_sub, const double* umat, int nsubs_run, const RgradSecond* second_plan) {
     if (nsubs_total < 1) return hipSuccess;
     if (nsubs_run < 0 || nsubs_run > nsubs_total) nsubs_run = nsubs_total;
-    const int extra = gather.count > 0 && gather.buf ? 1 : 0;
+    RgradSecond second;
+    memset(&second, 0, sizeof second);
+    if (second_plan) second = *second_plan;
+    const int extra = (gather.count > 0 && gather.buf ? 1 : 0) + second.count;
     if (nsubs_run + extra < 1) return hipSuccess;
     const int tiles_per_lane = ntiles;
     if (nparts <= 0) nparts = ntiles;
     ntiles = nparts;   // slots per (lane, sub-stage); the kernels derive the number in use from (tiles_per_lane, chunk)
-    if (nparts >= 32)
+    if (nparts >= 32 && second.count == 0)
         rgrad_kernel<4><<<dim3(nsubs_run + extra, batch), 256, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                   nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat, nsubs_run);
+                                                                  static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat, nsubs_run, second);
     else
         rgrad_kernel<1><<<dim3(nsubs_run + extra, batch), 64, 0, s>>>(subs, grps, entangler, thetas, T, static_cast<const cplx*>(rpart), ntiles,
                                                                  nsubs_total, static_cast<cplx*>(partial), nslots, from, to, front, slot_theta,
-                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat, nsubs_run);
+                                                                 static_cast<cplx*>(grads), static_cast<cplx*>(mirror), gather, tiles_per_lane, chunk, sparse_subs, lane_parts, conj_sub, umat, nsubs_run, second);
     return hipGetLastError();
 }
 

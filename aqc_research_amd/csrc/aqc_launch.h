@@ -147,6 +147,14 @@ hipError_t launch_ubuild(const UJob* jobs, int njobs, const double* thetas, int 
 struct GatherJob {           // optional passenger of the gradient walk: out[lane][i] = buf[lane][elem[i]] (+ pinned host copy)
     const void* buf; size_t lane_stride; const long long* elem; int count; void* out; void* mirror;
 };
+struct RgradSecond {         // a second plan whose gradient walk rides in the same launch (projected route: the virtual sweep plan); all of its
+    const DevSub3* subs;     // sub-stages hold lane_parts[lane] partials (item-list launches), none is R-only
+    const DevGrp* grps;
+    const double2* rpart;
+    const int* lane_parts;
+    const double* umat;
+    int nparts, nsubs_total, count;   // partial slots per (lane, sub-stage); sub-stages of the plan; how many of them walk here (0: none)
+};
 hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, const double* thetas, int T, const void* rpart,
                         int ntiles, int nsubs_total, void* partial, int nslots, int from, int to, int front, int batch, hipStream_t s,
                         const int* slot_theta = nullptr, void* grads = nullptr, void* mirror = nullptr,
@@ -154,7 +162,8 @@ hipError_t launch_rgrad(const DevSub3* subs, const DevGrp* grps, int entangler, 
                         int nparts = 0, int chunk = 0,   // partial-R slots per (lane, sub-stage) and the persistent sweep's chunk
                         int sparse_subs = 0, const int* lane_parts = nullptr,   // the first sparse_subs sub-stages hold lane_parts[lane] partials (item-list launch)
                         int conj_sub = -1, const double* umat = nullptr,        // sub-stage whose R arrives as Z W^H of its INPUTS: R <- U R U^H first (umat: the plan's operands)
-                        int nsubs_run = -1);                                    // walk the first nsubs_run sub-stages only (-1: all)
+                        int nsubs_run = -1,                                     // walk the first nsubs_run sub-stages only (-1: all)
+                        const RgradSecond* second_plan = nullptr);
 // Tile lists on the device (aqc_ws_sweep.cpp).  Per lane, the tiles of `stage` that hold the elements supp[lane][0 .. per_lane)
 // (the support of the lane's sparse lhs state; -1 = none; may be null) and extra[0 .. nextra) (the same for every lane: the
 // registered gather set; may be null), each tile once, in that order -> item list (lane-major, slot = position inside the lane),

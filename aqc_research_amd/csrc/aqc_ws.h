@@ -292,7 +292,7 @@ int proj_alloc(aqc_ws* ws);                 // its device side (plan tables, buf
 void proj_free(aqc_ws* ws);
 bool sweep_route_projected(const aqc_ws* ws, bool sparse);
 int run_projected_stages(aqc_ws* ws);       // projection + the virtual stage launches (after the sweep's first stage)
-int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_layer);
+aqc::RgradSecond projected_rgrad_plan(aqc_ws* ws);   // the virtual plan's gradient walk, to ride in the real plan's launch
 bool vdag_route_projected(aqc_ws* ws, int x_buf);   // the objective's V^H by two passes over y instead of its stages (host-known single basis state)
 int run_vdag_projected(aqc_ws* ws, int x_buf);      // Y -> Z on the lhs tiles, the virtual z for the sweep that follows
 int proj_fix_amplitudes(aqc_ws* ws, int x_buf);     // after the gather: the amplitudes outside the lhs tiles, from the virtual z

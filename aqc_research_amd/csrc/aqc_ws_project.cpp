@@ -258,16 +258,16 @@ int run_projected_stages(aqc_ws* ws) {
     return 0;
 }
 
-// the gradient entries of the virtual plan's gate groups (the real plan's walk stops after its first stage)
-int run_projected_rgrad(aqc_ws* ws, int block_from, int block_to, int front_layer) {
+// the gradient entries of the virtual plan's gate groups: its walk rides in the launch of the real plan's (which stops after its first stage)
+RgradSecond projected_rgrad_plan(aqc_ws* ws) {
     ProjRoute& pr = ws->proj;
-    const Program& prog = ws->ctx->prog;
     DevPlan& v = pr.vsw;
-    const int nsubs = (int)v.h_subs3.size(), ntiles = 2 * pr.ntiles_v;
-    HIP_OK(launch_rgrad(v.d_subs3, v.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), v.d_rpart, ntiles, nsubs, ws->d_partial, ws->nslots,
-                        block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream, ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads,
-                        ws->mirror_grads, GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr}, ntiles, 0, nsubs, pr.d_lane_parts, -1, v.d_umat));
-    return 0;
+    RgradSecond r;
+    memset(&r, 0, sizeof r);
+    r.subs = v.d_subs3; r.grps = v.d_grps; r.rpart = v.d_rpart; r.lane_parts = pr.d_lane_parts; r.umat = v.d_umat;
+    r.nparts = 2 * pr.ntiles_v;
+    r.nsubs_total = r.count = (int)v.h_subs3.size();
+    return r;
 }
 
 // ---- the objective's V^H by projection ------------------------------------------------------------------------------------------

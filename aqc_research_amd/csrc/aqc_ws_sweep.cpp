@@ -476,7 +476,8 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
         if (projected && run_projected_stages(ws)) return 1;
         sweep_state_after(ws, sparse, false);
         ProfScope ps(ws, AQC_K_FINALIZE);
-        if (projected && run_projected_rgrad(ws, block_from, block_to, front_layer)) return 1;
+        RgradSecond vwalk;   // projected route: the virtual plan's walk in the same launch (two launches: 54 + 54 us at the headline, one: ~70)
+        if (projected) vwalk = projected_rgrad_plan(ws);
         HIP_OK(launch_rgrad(p.d_subs3, p.d_grps, prog.entangler, ws->d_thetas, prog.num_thetas(), p.d_rpart, p.ntiles, nsubs, ws->d_partial,
                             ws->nslots, block_from, block_to, front_layer ? 1 : 0, ws->batch, ws->stream,
                             ws->grads_direct ? ws->d_slot_theta : nullptr, ws->d_grads, ws->mirror_grads,
@@ -484,7 +485,7 @@ int grad_from_impl(aqc_ws* ws, int x_buf, int block_from, int block_to, int fron
                                              : GatherJob{nullptr, 0, nullptr, 0, nullptr, nullptr},
                             sweep3_nparts(p.ntiles, ws->batch, p.k), sweep3_chunk(p.ntiles, ws->batch, p.k),
                             sparse ? p.h_stages[0].nsubs : 0, sparse ? ws->d_sw_lane_parts : nullptr, r_only_sub, p.d_umat,
-                            projected ? p.h_stages[0].nsubs : -1));
+                            projected ? p.h_stages[0].nsubs : -1, projected ? &vwalk : nullptr));
 #ifdef AQC_TUNING
         if (env_int("AQC_STAMPS", 0) != 0) { HIP_OK(hipStreamSynchronize(ws->stream)); rgrad_print_stamps(nsubs); }
 #endif

@@ -132,7 +132,8 @@ struct ProjArgs {
 };
 hipError_t launch_project_init(const ProjArgs& a, hipStream_t s);
 hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile, void* yout, hipStream_t s);   // both products of the objective by projection, one fetch of y
-hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, hipStream_t s);
+hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, const void* z,
+                               hipStream_t s);   // the whole gather of an evaluation by projection: inside the lhs tile from z, outside from the virtual z
 hipError_t launch_project(const ProjArgs& a, hipStream_t s);
 struct UJob {               // one 16 x 16 unitary to build: sub-stage `index` of a plan with `nsubs` sub-stages
     const DevSub3* sub;

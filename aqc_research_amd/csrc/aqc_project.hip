@@ -481,31 +481,44 @@ hipError_t launch_project_fused(const ProjArgs& a, const void* mend, void* ctile
 // bits (flip states on the other bits): with the virtual z, Y_0 = (later stages)^H proj(y), of an lhs state that is ONE basis state with
 // coefficient 1,  <g|V^H y> = sum_c Y_0[(c on the shared bits, g on the touched bits outside the first stage), c].
 __global__ __launch_bounds__(64) void project_amps_kernel(const ProjArgs a, const long long* gather, int ngather, const long long* supp, double2* small,
-                                                          const double2* vy) {
+                                                          const double2* vy, const double2* z) {
+    // (the whole registered gather of such an evaluation: indices inside the lane's tile are read from Z, where V^H's last stage has just
+    // put them; four lanes share the sum over c of an index outside it)
     const int b = blockIdx.x;
     const long long e = supp[2 * (size_t)b];
     if (e < 0) return;
     unsigned fmask = 0;
     for (int i = 0; i < a.nub0; ++i) fmask |= 1u << a.ubits0[i];
     const cplx* y0 = vy + (((size_t)b * 2) << a.nvp);
-    const int ncb = 1 << a.cb;
-    for (int i = threadIdx.x; i < ngather; i += 64) {
-        const unsigned g = (unsigned)gather[i];
-        if ((((unsigned)e ^ g) & fmask) == 0) continue;   // inside the lane's tile: the gather has read it from Z
-        unsigned it_g = 0;   // the entry's index on the touched bits outside the first stage: g's
-        for (int j = 0; j < a.t; ++j)
-            if (g & a.tf_mask & a.off_t[1u << j]) it_g |= 1u << j;
+    const int ncb = 1 << a.cb, part = threadIdx.x & 3;
+    for (int base = 0; base < ngather; base += 16) {
+        const int i = base + (int)(threadIdx.x >> 2);
         double re = 0.0, im = 0.0;
-        for (int c = 0; c < ncb; ++c) {   // ... and on the shared ones: c (it_of_c: the T index with those bits = c, the others 0)
-            const cplx v = y0[(a.it_of_c[c] | it_g) + ((size_t)c << a.t)];
-            re += v.x; im += v.y;
+        bool inside = false;
+        unsigned g = 0;
+        if (i < ngather) {
+            g = (unsigned)gather[i];
+            inside = (((unsigned)e ^ g) & fmask) == 0;
+            if (!inside) {
+                unsigned it_g = 0;   // the entry's index on the touched bits outside the first stage: g's
+                for (int j = 0; j < a.t; ++j)
+                    if (g & a.tf_mask & a.off_t[1u << j]) it_g |= 1u << j;
+                for (int c = part; c < ncb; c += 4) {   // ... and on the shared ones: c (it_of_c: the T index with those bits = c, the others 0)
+                    const cplx v = y0[(a.it_of_c[c] | it_g) + ((size_t)c << a.t)];
+                    re += v.x; im += v.y;
+                }
+            }
         }
-        small[(size_t)b * ngather + i] = make_double2(re, im);
+        re += __shfl_xor(re, 1, 64); im += __shfl_xor(im, 1, 64);
+        re += __shfl_xor(re, 2, 64); im += __shfl_xor(im, 2, 64);
+        if (i < ngather && part == 0) small[(size_t)b * ngather + i] = inside ? z[(size_t)b * a.lane_stride + g] : make_double2(re, im);
     }
 }
-hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, hipStream_t s) {
-    if (!gather || ngather < 1 || !supp || !small || !vy) return hipErrorInvalidValue;
-    project_amps_kernel<<<dim3((unsigned)a.batch), 64, 0, s>>>(a, gather, ngather, supp, static_cast<double2*>(small), static_cast<const double2*>(vy));
+hipError_t launch_project_amps(const ProjArgs& a, const long long* gather, int ngather, const long long* supp, void* small, const void* vy, const void* z,
+                               hipStream_t s) {
+    if (!gather || ngather < 1 || !supp || !small || !vy || !z) return hipErrorInvalidValue;
+    project_amps_kernel<<<dim3((unsigned)a.batch), 64, 0, s>>>(a, gather, ngather, supp, static_cast<double2*>(small), static_cast<const double2*>(vy),
+                                                               static_cast<const double2*>(z));
     return hipGetLastError();
 }
 

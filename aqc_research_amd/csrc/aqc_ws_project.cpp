@@ -415,9 +415,8 @@ int proj_fix_amplitudes(aqc_ws* ws, int x_buf) {
     ProjRoute& pr = ws->proj;
     if (results_guard(ws)) return 1;
     ProfScope ps(ws, AQC_K_MISC);
-    HIP_OK(launch_gather(ws->bufs[AQC_BUF_Z], ws->lane_elems, ws->d_index, ws->gather_count, ws->batch, ws->d_small, ws->stream, nullptr));
     ProjArgs a = proj_args(ws);
-    HIP_OK(launch_project_amps(a, ws->d_index, ws->gather_count, ws->d_combo_prev[x_buf], ws->d_small, pr.vy, ws->stream));
+    HIP_OK(launch_project_amps(a, ws->d_index, ws->gather_count, ws->d_combo_prev[x_buf], ws->d_small, pr.vy, ws->bufs[AQC_BUF_Z], ws->stream));
     return 0;
 }
 

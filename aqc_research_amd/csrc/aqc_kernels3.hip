@@ -872,7 +872,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     __shared__ cplx R[16 * 17];    // R[j * 17 + i] = sum_c z_c[j] conj(w_c[i]); rows padded: column walks hit 16 different banks
     __shared__ Gm gm[kGrpChunk];
     __shared__ cplx rho_s[kGrpChunk][16];
-    __shared__ cplx psum[WAVES > 1 ? WAVES - 1 : 1][256];
+    __shared__ cplx psum[WAVES > 1 ? WAVES - 1 : 1][WAVES > 1 ? 256 : 1];   // (one wave: no partial sums to hand over -- 4 KB less, 13 workgroups per CU instead of 10)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
     int si = blockIdx.x;
     if (si >= nsubs_run) {   // a sub-stage of the second plan of the launch (projected route: the virtual plan's walk rides along)
@@ -926,8 +926,8 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
     }
     if (si == conj_sub) {   // this sub-stage's R was taken from its INPUTS (sweep_mfma_kernel, r_only): R_end = U R U^H with the sub-stage's U,
                             // read back from the operand planes the stage kernels use (u0 = Re U, u1 = Im U - Re U; entry [s][l] = U[l % 16][4 s + l / 16])
-        cplx* const Us = &rho_s[0][0];   // (16 x 16 each, in arrays the walk has not started to use / the tile sum is done with:
-        cplx* const Ts = &psum[0][0];    // no extra LDS -- a dozen of these workgroups share a CU)
+        cplx* const Us = &rho_s[0][0];   // (16 x 16, in an array the walk has not started to use; T = U R passes through registers back into
+                                         // R's own storage: no extra LDS -- a dozen of these workgroups share a CU)
         const double* up = umat + ((size_t)b * nsubs_total + si) * 12 * 64;
         __syncthreads();
 #pragma unroll
@@ -937,6 +937,7 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
         }
         __syncthreads();
         const int i0 = lane & 15, j0 = lane >> 4;   // this lane: entries (j0 + 4 m, i0)
+        cplx acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {               // T = U R
             const int j = j0 + 4 * m;
@@ -945,19 +946,25 @@ __global__ __launch_bounds__(64 * WAVES) void rgrad_kernel(const DevSub3* subs, 
                 const cplx u = Us[j * 16 + k], r = R[k * 17 + i0];
                 re += u.x * r.x - u.y * r.y; im += u.x * r.y + u.y * r.x;
             }
-            Ts[j * 16 + i0] = make_double2(re, im);
+            acc[m] = make_double2(re, im);
         }
+        __syncthreads();                            // (every entry of R has been read)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) R[(j0 + 4 * m) * 17 + i0] = acc[m];
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < 4; ++m) {               // R = T U^H
             const int j = j0 + 4 * m;
             double re = 0.0, im = 0.0;
             for (int k = 0; k < 16; ++k) {
-                const cplx t = Ts[j * 16 + k], u = Us[i0 * 16 + k];
+                const cplx t = R[j * 17 + k], u = Us[i0 * 16 + k];
                 re += t.x * u.x + t.y * u.y; im += t.y * u.x - t.x * u.y;
             }
-            R[j * 17 + i0] = make_double2(re, im);
+            acc[m] = make_double2(re, im);
         }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) R[(j0 + 4 * m) * 17 + i0] = acc[m];
         __syncthreads();
     }
     RG_STAMP(1);
